@@ -1,0 +1,204 @@
+// C ABI entry points of libbaler_amd.so (see include/baler_amd.h).  gfx950 only.
+#include <cstring>
+
+#include "bamd_internal.hpp"
+#include "fused.hpp"
+
+namespace bamd {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+int DevBuf::ensure(size_t need) {
+    if (need <= bytes) return BAMD_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    // round up so that slowly growing batches do not reallocate every call
+    size_t want = (need + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+        p = nullptr;
+        return BAMD_ERR_ALLOC;
+    }
+    bytes = want;
+    return BAMD_OK;
+}
+
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+}  // namespace bamd
+
+using namespace bamd;
+
+extern "C" {
+
+int bamd_abi_version(void) { return BAMD_ABI_VERSION; }
+
+const char *bamd_last_error(void) { return g_err.c_str(); }
+
+int bamd_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+        return BAMD_ERR_NO_DEVICE;
+    }
+    return n;
+}
+
+int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle **out) {
+    BAMD_REQUIRE(dims && out, "null argument");
+    BAMD_REQUIRE(n_layers >= 2 && n_layers % 2 == 0, "n_layers must be even and >= 2");
+    BAMD_REQUIRE(mode == BAMD_MODE_F32 || mode == BAMD_MODE_F64 || mode == BAMD_MODE_BF16, "unknown mode");
+    for (int l = 0; l <= n_layers; ++l) BAMD_REQUIRE(dims[l] > 0, "layer widths must be positive");
+    int ndev = bamd_device_count();
+    if (ndev <= 0) {
+        if (ndev == 0) set_error("no HIP device visible");
+        return BAMD_ERR_NO_DEVICE;
+    }
+    BAMD_REQUIRE(device >= 0 && device < ndev, "device ordinal out of range");
+    BAMD_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BAMD_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("libbaler_amd is built for gfx950 only; device is ") + prop.gcnArchName);
+        return BAMD_ERR_NO_DEVICE;
+    }
+    bamd_handle *h = new bamd_handle();
+    h->L = n_layers;
+    h->mode = mode;
+    h->device = device;
+    h->dims.assign(dims, dims + n_layers + 1);
+    h->esize = mode == BAMD_MODE_F64 ? 8 : 4;
+    int64_t off = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        h->w_off.push_back(off);
+        off += (int64_t)dims[l + 1] * dims[l];
+        h->b_off.push_back(off);
+        off += dims[l + 1];
+        h->sum_dims += dims[l + 1];
+    }
+    h->nparams = off;
+    for (int l = 0; l <= n_layers; ++l) h->max_dim = dims[l] > h->max_dim ? dims[l] : h->max_dim;
+    int rc = h->params.ensure((size_t)(h->nparams + 1) * h->esize);
+    if (rc) { delete h; return rc; }
+    rc = fused_setup(h);
+    if (rc) { bamd_destroy(h); return rc; }
+    *out = h;
+    return BAMD_OK;
+}
+
+void bamd_destroy(bamd_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    h->params.release();
+    h->packed.release();
+    h->work.release();
+    h->slabs.release();
+    h->lossp.release();
+    delete h;
+}
+
+int64_t bamd_param_count(const bamd_handle *h) { return h ? h->nparams : 0; }
+int bamd_mode_of(const bamd_handle *h) { return h ? h->mode : BAMD_ERR_INVALID; }
+
+int bamd_load_params(bamd_handle *h, const void *params, int dtype, void *stream) {
+    BAMD_REQUIRE(h && params, "null argument");
+    BAMD_REQUIRE(dtype == BAMD_F32 || dtype == BAMD_F64, "bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_convert(params, dtype, h->params.p, h->esize == 8 ? BAMD_F64 : BAMD_F32, h->nparams, s);
+    if (rc) return rc;
+    h->params_loaded = true;
+    return fused_pack(h, s);
+}
+
+int bamd_minmax(const void *x, int dtype, int64_t n_rows, int n_cols, double *features, void *stream) {
+    return launch_minmax(x, dtype, n_rows, n_cols, features, (hipStream_t)stream);
+}
+
+int bamd_normalize(const void *x, int dtype, int64_t n_rows, int n_cols, const double *features, void *out,
+                   int out_dtype, void *stream) {
+    return launch_normalize(x, dtype, n_rows, n_cols, features, out, out_dtype, (hipStream_t)stream);
+}
+
+int bamd_renormalize(const void *x, int dtype, int64_t n_rows, int n_cols, const double *features,
+                     const uint8_t *int_mask, double *out, void *stream) {
+    return launch_renormalize(x, dtype, n_rows, n_cols, features, int_mask, out, (hipStream_t)stream);
+}
+
+#define BAMD_CHECK_MODEL(h)                                                        \
+    BAMD_REQUIRE(h, "null handle");                                                \
+    BAMD_REQUIRE((h)->params_loaded, "bamd_load_params() has not been called");
+
+int bamd_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features, void *z,
+                int z_dtype, void *stream) {
+    BAMD_CHECK_MODEL(h);
+    BAMD_REQUIRE(x && z && n_rows >= 0, "bad arguments");
+    if (n_rows == 0) return BAMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (h->fused_ok) return fused_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
+    return generic_forward(h, x, x_dtype, n_rows, features, 0, h->L / 2, z, z_dtype, nullptr, nullptr, s);
+}
+
+int bamd_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n_rows, const double *features,
+                const uint8_t *int_mask, void *out, int out_dtype, void *stream) {
+    BAMD_CHECK_MODEL(h);
+    BAMD_REQUIRE(z && out && n_rows >= 0, "bad arguments");
+    if (n_rows == 0) return BAMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (h->fused_ok) return fused_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);
+    return generic_forward(h, z, z_dtype, n_rows, nullptr, h->L / 2, h->L, out, out_dtype, features, int_mask, s);
+}
+
+int bamd_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features,
+                      void *recon, int recon_dtype, double *loss_sum, void *stream) {
+    BAMD_CHECK_MODEL(h);
+    BAMD_REQUIRE(x && loss_sum && n_rows > 0, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (h->fused_ok) return fused_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
+    return generic_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
+}
+
+int bamd_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features,
+                 void *grads, void *stream) {
+    BAMD_CHECK_MODEL(h);
+    BAMD_REQUIRE(grads && n_rows >= 0 && (x || n_rows == 0), "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rows == 0) {  // an empty shard of a global batch contributes a zero gradient and zero loss
+        BAMD_HIP(hipMemsetAsync(grads, 0, (size_t)(h->nparams + 1) * h->esize, s));
+        return BAMD_OK;
+    }
+    if (h->fused_ok) return fused_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
+    return generic_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
+}
+
+int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, void *v, const bamd_adam *hp,
+                   double *loss_accum, void *stream) {
+    BAMD_CHECK_MODEL(h);
+    BAMD_REQUIRE(params && grads && m && v && hp, "null argument");
+    BAMD_REQUIRE(hp->step >= 1, "step must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, s);
+    if (rc) return rc;
+    return fused_pack(h, s);
+}
+
+int bamd_emd_rows(const void *x, const void *recon, int dtype, int64_t n_rows, int n_cols, double *out,
+                  void *stream) {
+    return launch_emd_rows(x, recon, dtype, n_rows, n_cols, out, (hipStream_t)stream);
+}
+
+int bamd_activation_means(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features,
+                          double *out, int max_nodes, void *stream) {
+    BAMD_CHECK_MODEL(h);
+    BAMD_REQUIRE(x && out && n_rows > 0, "bad arguments");
+    return generic_activation_means(h, x, x_dtype, n_rows, features, out, max_nodes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// Internal declarations shared by the translation units of libbaler_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/baler_amd.h"
+
+namespace bamd {
+
+constexpr float kSlope = 0.01f;  // F.leaky_relu default negative_slope (models.py:142-150)
+
+void set_error(const std::string &msg);
+
+#define BAMD_HIP(call)                                                                      \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            bamd::set_error(std::string(#call) + ": " + hipGetErrorString(e_));             \
+            return BAMD_ERR_HIP;                                                            \
+        }                                                                                   \
+    } while (0)
+
+#define BAMD_REQUIRE(cond, msg)                                                             \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            bamd::set_error(std::string(__func__) + ": " + (msg));                          \
+            return BAMD_ERR_INVALID;                                                        \
+        }                                                                                   \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);  // grow-only; returns bamd_status
+    void release();
+};
+
+}  // namespace bamd
+
+struct bamd_handle {
+    int L = 0;
+    int mode = 0;
+    int device = 0;
+    std::vector<int> dims;          // L+1
+    std::vector<int64_t> w_off;     // offset of W_l in the flat vector
+    std::vector<int64_t> b_off;     // offset of b_l
+    int64_t nparams = 0;
+    int sum_dims = 0;               // sum of dims[1..L]
+    int max_dim = 0;
+    size_t esize = 4;               // sizeof parameter/compute scalar (4 or 8)
+
+    bamd::DevBuf params;            // flat copy of the parameters in the compute type
+    bamd::DevBuf packed;            // MFMA-fragment-packed weights for the fused kernels
+    bamd::DevBuf work;              // activation workspace (generic path)
+    bamd::DevBuf slabs;             // per-workgroup partial gradients
+    bamd::DevBuf lossp;             // partial loss sums (double)
+    bool params_loaded = false;
+    bool fused_ok = false;          // shape is served by the fused register-chained kernels
+
+    bool has_act(int l) const { return !(l == L / 2 - 1 || l == L - 1); }
+};
+
+namespace bamd {
+
+// ---- elementwise.hip ----------------------------------------------------------------------------
+int launch_minmax(const void *x, int dtype, int64_t n, int c, double *features, hipStream_t s);
+int launch_normalize(const void *x, int dtype, int64_t n, int c, const double *features, void *out,
+                     int out_dtype, hipStream_t s);
+int launch_renormalize(const void *x, int dtype, int64_t n, int c, const double *features,
+                       const uint8_t *int_mask, double *out, hipStream_t s);
+int launch_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t count,
+                   hipStream_t s);
+int launch_emd_rows(const void *x, const void *recon, int dtype, int64_t n, int c, double *out,
+                    hipStream_t s);
+int launch_adam(void *params, void *params_copy, const void *grads, void *m, void *v, int64_t np,
+                size_t esize, const bamd_adam &hp, double *loss_accum, hipStream_t s);
+
+// ---- generic.hip (layer-by-layer MFMA path, any dims) -------------------------------------------
+int generic_forward(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                    int l0, int l1, void *out, int out_dtype, const double *renorm,
+                    const uint8_t *int_mask, hipStream_t s);
+int generic_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n,
+                         const double *features, void *recon, int recon_dtype, double *loss_sum,
+                         hipStream_t s);
+int generic_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                    void *grads, hipStream_t s);
+int generic_activation_means(bamd_handle *h, const void *x, int x_dtype, int64_t n,
+                             const double *features, double *out, int max_nodes, hipStream_t s);
+
+}  // namespace bamd

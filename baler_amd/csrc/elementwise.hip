@@ -1,0 +1,274 @@
+// HBM-bound helper kernels either side of the autoencoder: column min/max, (un)normalisation,
+// dtype conversion, the per-row EMD metric and the fused Adam step.  gfx950 only.
+#include "bamd_internal.hpp"
+
+namespace bamd {
+
+template <typename T>
+__device__ __forceinline__ double ld(const void *p, int64_t i) {
+    return (double)reinterpret_cast<const T *>(p)[i];
+}
+
+// ---- column min/max -----------------------------------------------------------------------------
+// data_processing.find_minmax (data_processing.py:113-130).  Rows are contiguous, so a workgroup
+// reads R = 256/tcols whole rows per pass (one coalesced segment) and every thread keeps the running
+// min/max of ONE column.  Algorithmic traffic: n*c*sizeof(T) bytes read once.
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_partial(const T *__restrict__ x, int64_t n, int c,
+                                                      int tcols, double *__restrict__ part) {
+    const int R = 256 / tcols;
+    const int lc = threadIdx.x % tcols, lr = threadIdx.x / tcols;
+    const int col = blockIdx.y * tcols + lc;
+    double mn = INFINITY, mx = -INFINITY;
+    if (lr < R && col < c) {
+        for (int64_t r = (int64_t)blockIdx.x * R + lr; r < n; r += (int64_t)gridDim.x * R) {
+            double v = (double)x[r * c + col];
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        }
+    }
+    __shared__ double smn[256], smx[256];
+    smn[threadIdx.x] = mn;
+    smx[threadIdx.x] = mx;
+    __syncthreads();
+    if (lr == 0 && col < c) {
+        for (int k = 1; k < R; ++k) {
+            double a = smn[k * tcols + lc], b = smx[k * tcols + lc];
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        part[((int64_t)blockIdx.x * 2 + 0) * c + col] = mn;
+        part[((int64_t)blockIdx.x * 2 + 1) * c + col] = mx;
+    }
+}
+
+__global__ void minmax_final(const double *__restrict__ part, int nblk, int c,
+                             double *__restrict__ features) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double mn = INFINITY, mx = -INFINITY;
+    for (int b = 0; b < nblk; ++b) {
+        double a = part[((int64_t)b * 2 + 0) * c + col], d = part[((int64_t)b * 2 + 1) * c + col];
+        mn = a < mn ? a : mn;
+        mx = d > mx ? d : mx;
+    }
+    features[col] = mn;
+    features[c + col] = mx - mn;
+}
+
+static DevBuf g_minmax_scratch;
+
+int launch_minmax(const void *x, int dtype, int64_t n, int c, double *features, hipStream_t s) {
+    BAMD_REQUIRE(x && features && n > 0 && c > 0, "bad arguments");
+    const int tcols = c < 256 ? c : 256;
+    const int R = 256 / tcols;
+    int64_t want = (n + R - 1) / R;
+    int nblk = (int)(want < 1024 ? want : 1024);
+    int ncb = (c + tcols - 1) / tcols;
+    int rc = g_minmax_scratch.ensure((size_t)nblk * 2 * c * sizeof(double));
+    if (rc) return rc;
+    double *part = (double *)g_minmax_scratch.p;
+    dim3 grid(nblk, ncb);
+    if (dtype == BAMD_F64)
+        hipLaunchKernelGGL(minmax_partial<double>, grid, dim3(256), 0, s, (const double *)x, n, c,
+                           tcols, part);
+    else
+        hipLaunchKernelGGL(minmax_partial<float>, grid, dim3(256), 0, s, (const float *)x, n, c,
+                           tcols, part);
+    hipLaunchKernelGGL(minmax_final, dim3((c + 255) / 256), dim3(256), 0, s, part, nblk, c, features);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+// ---- normalise / renormalise / convert ----------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void normalize_k(const TI *__restrict__ x, int64_t count, int c,
+                            const double *__restrict__ f, TO *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int col = (int)(i % c);
+        // (x - min) / (max - min) in float64, exactly as data_processing.py:147-152
+        out[i] = (TO)(((double)x[i] - f[col]) / f[c + col]);
+    }
+}
+
+template <typename TI>
+__global__ void renormalize_k(const TI *__restrict__ x, int64_t count, int c,
+                              const double *__restrict__ f, const uint8_t *__restrict__ mask,
+                              double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int col = (int)(i % c);
+        // norm*range + min with two roundings (numpy, data_processing.py:203): no FMA contraction
+        double v = __dadd_rn(__dmul_rn((double)x[i], f[c + col]), f[col]);
+        if (mask && mask[col]) v = trunc(v);  // astype(int) written back to float64 (baler.py:431)
+        out[i] = v;
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void convert_k(const TI *__restrict__ x, TO *__restrict__ out, int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (TO)x[i];
+}
+
+static inline int ew_grid(int64_t count) {
+    int64_t b = (count + 255) / 256;
+    return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
+}
+
+int launch_normalize(const void *x, int dtype, int64_t n, int c, const double *f, void *out,
+                     int out_dtype, hipStream_t s) {
+    BAMD_REQUIRE(x && f && out && n >= 0 && c > 0, "bad arguments");
+    int64_t count = n * c;
+    if (count == 0) return BAMD_OK;
+    dim3 g(ew_grid(count)), b(256);
+    if (dtype == BAMD_F64 && out_dtype == BAMD_F64)
+        hipLaunchKernelGGL((normalize_k<double, double>), g, b, 0, s, (const double *)x, count, c, f, (double *)out);
+    else if (dtype == BAMD_F64)
+        hipLaunchKernelGGL((normalize_k<double, float>), g, b, 0, s, (const double *)x, count, c, f, (float *)out);
+    else if (out_dtype == BAMD_F64)
+        hipLaunchKernelGGL((normalize_k<float, double>), g, b, 0, s, (const float *)x, count, c, f, (double *)out);
+    else
+        hipLaunchKernelGGL((normalize_k<float, float>), g, b, 0, s, (const float *)x, count, c, f, (float *)out);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+int launch_renormalize(const void *x, int dtype, int64_t n, int c, const double *f,
+                       const uint8_t *mask, double *out, hipStream_t s) {
+    BAMD_REQUIRE(x && f && out && n >= 0 && c > 0, "bad arguments");
+    int64_t count = n * c;
+    if (count == 0) return BAMD_OK;
+    dim3 g(ew_grid(count)), b(256);
+    if (dtype == BAMD_F64)
+        hipLaunchKernelGGL(renormalize_k<double>, g, b, 0, s, (const double *)x, count, c, f, mask, out);
+    else
+        hipLaunchKernelGGL(renormalize_k<float>, g, b, 0, s, (const float *)x, count, c, f, mask, out);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+int launch_convert(const void *src, int sd, void *dst, int dd, int64_t count, hipStream_t s) {
+    if (count == 0) return BAMD_OK;
+    dim3 g(ew_grid(count)), b(256);
+    if (sd == BAMD_F64 && dd == BAMD_F64)
+        hipLaunchKernelGGL((convert_k<double, double>), g, b, 0, s, (const double *)src, (double *)dst, count);
+    else if (sd == BAMD_F64)
+        hipLaunchKernelGGL((convert_k<double, float>), g, b, 0, s, (const double *)src, (float *)dst, count);
+    else if (dd == BAMD_F64)
+        hipLaunchKernelGGL((convert_k<float, double>), g, b, 0, s, (const float *)src, (double *)dst, count);
+    else
+        hipLaunchKernelGGL((convert_k<float, float>), g, b, 0, s, (const float *)src, (float *)dst, count);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+// ---- per-row EMD (utils.py:112-119) -------------------------------------------------------------
+// wasserstein_distance of two equal-size, unit-weight samples = mean |sorted(a) - sorted(b)|.
+// One thread per row, insertion sort of <= 64 values; two-stage fixed-order sum (deterministic).
+template <typename T>
+__global__ void __launch_bounds__(256) emd_partial(const T *__restrict__ x, const T *__restrict__ r,
+                                                   int64_t n, int c, double *__restrict__ part) {
+    double acc = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n;
+         row += (int64_t)gridDim.x * blockDim.x) {
+        double a[64], b[64];
+        for (int k = 0; k < c; ++k) {
+            double va = (double)x[row * c + k], vb = (double)r[row * c + k];
+            int i = k;
+            while (i > 0 && a[i - 1] > va) { a[i] = a[i - 1]; --i; }
+            a[i] = va;
+            i = k;
+            while (i > 0 && b[i - 1] > vb) { b[i] = b[i - 1]; --i; }
+            b[i] = vb;
+        }
+        double sacc = 0.0;
+        for (int k = 0; k < c; ++k) sacc += fabs(a[k] - b[k]);
+        acc += sacc / (double)c;
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+__global__ void sum_partials_k(const double *__restrict__ part, int n, double *__restrict__ out,
+                               double scale, int accumulate) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double sacc = 0.0;
+        for (int i = 0; i < n; ++i) sacc += part[i];
+        sacc *= scale;
+        *out = accumulate ? *out + sacc : sacc;
+    }
+}
+
+static DevBuf g_emd_scratch;
+
+int launch_emd_rows(const void *x, const void *r, int dtype, int64_t n, int c, double *out,
+                    hipStream_t s) {
+    BAMD_REQUIRE(x && r && out && n > 0 && c > 0 && c <= 64, "bad arguments (n_cols must be <= 64)");
+    int nblk = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+    int rc = g_emd_scratch.ensure(sizeof(double) * nblk);
+    if (rc) return rc;
+    double *part = (double *)g_emd_scratch.p;
+    if (dtype == BAMD_F64)
+        hipLaunchKernelGGL(emd_partial<double>, dim3(nblk), dim3(256), 0, s, (const double *)x, (const double *)r, n, c, part);
+    else
+        hipLaunchKernelGGL(emd_partial<float>, dim3(nblk), dim3(256), 0, s, (const float *)x, (const float *)r, n, c, part);
+    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(64), 0, s, part, nblk, out, 1.0, 0);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+// ---- fused Adam ---------------------------------------------------------------------------------
+// torch.optim.Adam single-tensor step (training.py:266; torch/optim/adam.py _single_tensor_adam) over
+// ONE flat buffer: p, g, m, v are read once and p, m, v written once (28 B/param in fp32).  The
+// per-element arithmetic runs in float64 and is rounded to the storage type once, so the fp32 mode
+// differs from the fp64 reference by storage rounding only.  zero_grad needs no work: the next
+// bamd_fwd_bwd overwrites the gradient buffer.
+template <typename T>
+__global__ void __launch_bounds__(256) adam_k(T *__restrict__ p, T *__restrict__ pcopy,
+                                              const T *__restrict__ g, T *__restrict__ m,
+                                              T *__restrict__ v, int64_t np, double b1, double b2,
+                                              double eps, double step_size, double bc2_sqrt,
+                                              double *loss_accum) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) {
+        double gi = (double)g[i];
+        double mi = (double)m[i], vi = (double)v[i];
+        mi = mi + (gi - mi) * (1.0 - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+        vi = vi * b2 + (1.0 - b2) * gi * gi;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+        double denom = sqrt(vi) / bc2_sqrt + eps;
+        double pi = (double)p[i] - step_size * (mi / denom);
+        m[i] = (T)mi;
+        v[i] = (T)vi;
+        p[i] = (T)pi;
+        if (pcopy) pcopy[i] = (T)pi;
+    }
+    if (loss_accum && i == 0) *loss_accum += (double)g[np];
+}
+
+int launch_adam(void *params, void *pcopy, const void *grads, void *m, void *v, int64_t np,
+                size_t esize, const bamd_adam &hp, double *loss_accum, hipStream_t s) {
+    double bc1 = 1.0 - pow(hp.beta1, (double)hp.step);
+    double bc2 = 1.0 - pow(hp.beta2, (double)hp.step);
+    double step_size = hp.lr / bc1;
+    double bc2_sqrt = sqrt(bc2);
+    dim3 g((unsigned)((np + 255) / 256)), b(256);
+    if (esize == 8)
+        hipLaunchKernelGGL(adam_k<double>, g, b, 0, s, (double *)params, (double *)pcopy, (const double *)grads,
+                           (double *)m, (double *)v, np, hp.beta1, hp.beta2, hp.eps, step_size, bc2_sqrt, loss_accum);
+    else
+        hipLaunchKernelGGL(adam_k<float>, g, b, 0, s, (float *)params, (float *)pcopy, (const float *)grads,
+                           (float *)m, (float *)v, np, hp.beta1, hp.beta2, hp.eps, step_size, bc2_sqrt, loss_accum);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+}  // namespace bamd

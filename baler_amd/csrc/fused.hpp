@@ -1,0 +1,16 @@
+// Fused register-chained kernels for narrow autoencoders (fused.hip).
+#pragma once
+#include "bamd_internal.hpp"
+
+namespace bamd {
+int fused_setup(bamd_handle *h);                 // decides h->fused_ok, allocates the packed weights
+int fused_pack(bamd_handle *h, hipStream_t s);   // h->params -> h->packed (no-op when !fused_ok)
+int fused_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z,
+                 int z_dtype, hipStream_t s);
+int fused_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features,
+                 const uint8_t *int_mask, void *out, int out_dtype, hipStream_t s);
+int fused_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                       void *recon, int recon_dtype, double *loss_sum, hipStream_t s);
+int fused_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
+                  hipStream_t s);
+}  // namespace bamd

@@ -1,0 +1,436 @@
+// Generic layer-by-layer path: any layer widths (CFD_dense_AE(2500,25), the 512-column encoder ...),
+// fp32 (v_mfma_f32_16x16x4_f32) or fp64 (v_mfma_f64_16x16x4_f64).  One LDS-tiled MFMA GEMM kernel
+// serves the three products of a Linear layer through operand descriptors and fused epilogues:
+//   forward   Y  = lrelu(X W^T + b)                      (aten::addmm + aten::leaky_relu)
+//   input grad dZ_prev = (dZ W) * lrelu'(Y_prev)          (aten::mm + aten::leaky_relu_backward)
+//   weight grad [dW | db] = dZ^T [X | 1]                  (aten::mm + aten::sum), split over row
+//              ranges into per-split slabs that are summed in a fixed order (deterministic).
+// The fused register-chained kernels in fused.hip are the fast path for narrow models; this path is
+// the general fallback and the independent cross-check for them.  gfx950 only.
+#include "bamd_internal.hpp"
+
+namespace bamd {
+
+template <typename T> struct MF;
+template <> struct MF<float> {
+    using v4 = __attribute__((ext_vector_type(4))) float;
+    static __device__ __forceinline__ v4 mma(float a, float b, v4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // C/D map of the f32 16x16 forms: col = lane&15, row = (lane>>4)*4 + reg
+    static __device__ __forceinline__ int crow(int reg, int lane) { return (lane >> 4) * 4 + reg; }
+};
+template <> struct MF<double> {
+    using v4 = __attribute__((ext_vector_type(4))) double;
+    static __device__ __forceinline__ v4 mma(double a, double b, v4 c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // f64 16x16x4 uses its own map: col = lane&15, row = (lane>>4) + 4*reg
+    static __device__ __forceinline__ int crow(int reg, int lane) { return (lane >> 4) + 4 * reg; }
+};
+
+// element(o, k) of a GEMM operand: p[o*s_o + k*s_k] inside [0,n_o) x [k_lo,k_hi), else 0;
+// outer index == ones_o yields 1 (the appended ones-column that turns db into a GEMM column).
+template <typename T> struct Opnd {
+    const T *p;
+    int64_t s_o, s_k, n_o, ones_o;
+    __device__ __forceinline__ T get(int64_t o, int64_t k, int64_t k_hi) const {
+        if (k >= k_hi) return (T)0;
+        if (o < n_o) return p[o * s_o + k * s_k];
+        if (o == ones_o) return (T)1;
+        return (T)0;
+    }
+};
+
+enum { EPI_FWD = 0, EPI_DX = 1, EPI_DW = 2 };
+
+template <typename T> struct Epi {
+    T *out;            // FWD/DX: output matrix
+    int64_t ld;        // its leading dimension
+    int64_t n_rows, n_cols;
+    const T *bias;     // FWD
+    int act;           // FWD: apply leaky relu
+    const T *ymask;    // DX: post-activation output of the previous layer (sign = pre-activation sign)
+    int64_t ld_mask;
+    T *gw, *gb;        // DW: slab bases of this layer's dW and db
+    int64_t kin;       // DW: in-features (column kin of the product is db)
+    int64_t slab_stride;
+    int64_t rows_per_split;
+};
+
+template <typename T, int EPI, bool A_KFAST, bool B_KFAST>
+__global__ void __launch_bounds__(256) gemm_k(Opnd<T> A, Opnd<T> B, int64_t kred, Epi<T> e) {
+    using v4 = typename MF<T>::v4;
+    __shared__ __attribute__((aligned(16))) T As[64][20];
+    __shared__ __attribute__((aligned(16))) T Bs[64][20];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
+    int64_t k_lo = 0, k_hi = kred;
+    if (EPI == EPI_DW) {
+        k_lo = (int64_t)blockIdx.z * e.rows_per_split;
+        k_hi = k_lo + e.rows_per_split < kred ? k_lo + e.rows_per_split : kred;
+    }
+    v4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4){0, 0, 0, 0};
+
+    for (int64_t k0 = k_lo; k0 < k_hi; k0 += 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int idx = tid + r * 256;
+            int oa = A_KFAST ? (idx >> 4) : (idx & 63), ka = A_KFAST ? (idx & 15) : (idx >> 6);
+            As[oa][ka] = A.get(i0 + oa, k0 + ka, k_hi);
+            int ob = B_KFAST ? (idx >> 4) : (idx & 63), kb = B_KFAST ? (idx & 15) : (idx >> 6);
+            Bs[ob][kb] = B.get(j0 + ob, k0 + kb, k_hi);
+        }
+        __syncthreads();
+        // lane (o = lane&15, g = lane>>4) takes k = 4g..4g+3 of the 16-deep chunk for the four
+        // MFMA steps; A and B use the same k permutation, so the sum over k is unchanged.
+        T a4[2][4], b4[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a4[t][r] = As[wr * 32 + t * 16 + (lane & 15)][4 * (lane >> 4) + r];
+                b4[t][r] = Bs[wc * 32 + t * 16 + (lane & 15)][4 * (lane >> 4) + r];
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = MF<T>::mma(a4[mt][r], b4[nt][r], acc[mt][nt]);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                int64_t row = i0 + wr * 32 + mt * 16 + MF<T>::crow(reg, lane);
+                int64_t col = j0 + wc * 32 + nt * 16 + (lane & 15);
+                T val = acc[mt][nt][reg];
+                if (EPI == EPI_FWD) {
+                    if (row < e.n_rows && col < e.n_cols) {
+                        val += e.bias[col];
+                        if (e.act) val = val > (T)0 ? val : val * (T)kSlope;
+                        e.out[row * e.ld + col] = val;
+                    }
+                } else if (EPI == EPI_DX) {
+                    if (row < e.n_rows && col < e.n_cols) {
+                        if (e.ymask) val = e.ymask[row * e.ld_mask + col] > (T)0 ? val : val * (T)kSlope;
+                        e.out[row * e.ld + col] = val;
+                    }
+                } else {
+                    int64_t so = (int64_t)blockIdx.z * e.slab_stride;
+                    if (row < e.n_rows) {
+                        if (col < e.kin) e.gw[so + row * e.kin + col] = val;
+                        else if (col == e.kin) e.gb[so + row] = val;
+                    }
+                }
+            }
+}
+
+// dZ_L = 2 (R - X)/C and per-block partial sums of (R - X)^2 (utils.py:195-199 and its autograd).
+template <typename T>
+__global__ void __launch_bounds__(256) loss_grad_k(const T *__restrict__ r, const T *__restrict__ x,
+                                                   int64_t count, double inv_c, T *__restrict__ dz,
+                                                   double *__restrict__ part) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        T d = r[i] - x[i];
+        acc += (double)d * (double)d;
+        if (dz) dz[i] = (T)(2.0 * (double)d * inv_c);
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+template <typename TO>
+__global__ void loss_final_k(const double *__restrict__ part, int n, double scale, TO *dst,
+                             int accumulate) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += part[i];
+        s *= scale;
+        *dst = accumulate ? (TO)((double)*dst + s) : (TO)s;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) reduce_slabs_k(const T *__restrict__ slabs, int nslab,
+                                                      int64_t np, int64_t stride, T *__restrict__ g,
+                                                      int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    T s = accumulate ? g[i] : (T)0;
+    for (int k = 0; k < nslab; ++k) s += slabs[(int64_t)k * stride + i];
+    g[i] = s;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) colmean_k(const T *__restrict__ y, int64_t n, int c,
+                                                 double *__restrict__ out) {
+    // mean over rows of column blockIdx.x (fixed-order tree; diagnostics only)
+    int col = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t r = threadIdx.x; r < n; r += blockDim.x) acc += (double)y[r * c + col];
+    __shared__ double sh[256];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[col] = sh[0] / (double)n;
+}
+
+__global__ void fill_nan_k(double *p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = NAN;
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+template <typename T> struct Work {
+    T *x0;
+    std::vector<T *> y;  // y[l] = output of layer l-1 (y[0] = x0)
+    T *dza, *dzb;
+    int64_t chunk;
+};
+
+template <typename T>
+static int carve(bamd_handle *h, int64_t n, bool need_grad, Work<T> &wk) {
+    int64_t per_row = h->dims[0] + h->sum_dims + (need_grad ? 2 * h->max_dim : 0);
+    int64_t chunk = (int64_t)(1u << 28) / (per_row * (int64_t)sizeof(T));
+    chunk = chunk < 1024 ? 1024 : chunk;
+    chunk = chunk > (1 << 20) ? (1 << 20) : chunk;
+    chunk &= ~(int64_t)63;
+    if (chunk > n) chunk = n;
+    int rc = h->work.ensure((size_t)(per_row * chunk) * sizeof(T));
+    if (rc) return rc;
+    T *p = (T *)h->work.p;
+    wk.chunk = chunk;
+    wk.y.assign(h->L + 1, nullptr);
+    for (int l = 0; l <= h->L; ++l) {
+        wk.y[l] = p;
+        p += chunk * h->dims[l];
+    }
+    wk.x0 = wk.y[0];
+    wk.dza = need_grad ? p : nullptr;
+    wk.dzb = need_grad ? p + chunk * h->max_dim : nullptr;
+    return BAMD_OK;
+}
+
+template <typename T>
+static int stage_input(bamd_handle *h, const void *x, int x_dtype, int64_t row0, int64_t rows, int width,
+                       const double *features, T *dst, hipStream_t s) {
+    size_t es = x_dtype == BAMD_F64 ? 8 : 4;
+    const char *src = (const char *)x + (size_t)row0 * width * es;
+    int td = sizeof(T) == 8 ? BAMD_F64 : BAMD_F32;
+    if (features) return launch_normalize(src, x_dtype, rows, width, features, dst, td, s);
+    return launch_convert(src, x_dtype, dst, td, rows * width, s);
+}
+
+template <typename T>
+static void launch_fwd_layer(bamd_handle *h, int l, const T *xin, T *yout, int64_t rows, hipStream_t s) {
+    const T *P = (const T *)h->params.p;
+    int K = h->dims[l], N = h->dims[l + 1];
+    Opnd<T> A{xin, K, 1, rows, -1};
+    Opnd<T> B{P + h->w_off[l], K, 1, N, -1};
+    Epi<T> e{};
+    e.out = yout; e.ld = N; e.n_rows = rows; e.n_cols = N;
+    e.bias = P + h->b_off[l]; e.act = h->has_act(l) ? 1 : 0;
+    dim3 grid((N + 63) / 64, (unsigned)((rows + 63) / 64), 1);
+    hipLaunchKernelGGL((gemm_k<T, EPI_FWD, true, true>), grid, dim3(256), 0, s, A, B, (int64_t)K, e);
+}
+
+template <typename T>
+static int forward_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                     int l0, int l1, void *out, int out_dtype, const double *renorm,
+                     const uint8_t *int_mask, hipStream_t s) {
+    Work<T> wk;
+    int rc = carve<T>(h, n, false, wk);
+    if (rc) return rc;
+    int td = sizeof(T) == 8 ? BAMD_F64 : BAMD_F32;
+    int win = h->dims[l0], wout = h->dims[l1];
+    size_t oes = out_dtype == BAMD_F64 ? 8 : 4;
+    for (int64_t r0 = 0; r0 < n; r0 += wk.chunk) {
+        int64_t rows = n - r0 < wk.chunk ? n - r0 : wk.chunk;
+        rc = stage_input<T>(h, x, x_dtype, r0, rows, win, features, wk.y[l0], s);
+        if (rc) return rc;
+        for (int l = l0; l < l1; ++l) launch_fwd_layer<T>(h, l, wk.y[l], wk.y[l + 1], rows, s);
+        char *dst = (char *)out + (size_t)r0 * wout * oes;
+        if (renorm) {
+            if (out_dtype != BAMD_F64) { set_error("decode with features needs a float64 output"); return BAMD_ERR_INVALID; }
+            rc = launch_renormalize(wk.y[l1], td, rows, wout, renorm, int_mask, (double *)dst, s);
+        } else {
+            rc = launch_convert(wk.y[l1], td, dst, out_dtype, rows * wout, s);
+        }
+        if (rc) return rc;
+    }
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+int generic_forward(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                    int l0, int l1, void *out, int out_dtype, const double *renorm,
+                    const uint8_t *int_mask, hipStream_t s) {
+    if (h->esize == 8) return forward_T<double>(h, x, x_dtype, n, features, l0, l1, out, out_dtype, renorm, int_mask, s);
+    return forward_T<float>(h, x, x_dtype, n, features, l0, l1, out, out_dtype, renorm, int_mask, s);
+}
+
+template <typename T>
+static int forward_loss_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                          void *recon, int recon_dtype, double *loss_sum, hipStream_t s) {
+    Work<T> wk;
+    int rc = carve<T>(h, n, false, wk);
+    if (rc) return rc;
+    int td = sizeof(T) == 8 ? BAMD_F64 : BAMD_F32;
+    int c = h->dims[0];
+    rc = h->lossp.ensure(sizeof(double) * 1024);
+    if (rc) return rc;
+    size_t oes = recon_dtype == BAMD_F64 ? 8 : 4;
+    int chunk_i = 0;
+    for (int64_t r0 = 0; r0 < n; r0 += wk.chunk, ++chunk_i) {
+        int64_t rows = n - r0 < wk.chunk ? n - r0 : wk.chunk;
+        rc = stage_input<T>(h, x, x_dtype, r0, rows, c, features, wk.x0, s);
+        if (rc) return rc;
+        for (int l = 0; l < h->L; ++l) launch_fwd_layer<T>(h, l, wk.y[l], wk.y[l + 1], rows, s);
+        int64_t count = rows * c;
+        int nblk = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
+        hipLaunchKernelGGL(loss_grad_k<T>, dim3(nblk), dim3(256), 0, s, wk.y[h->L], wk.x0, count, 1.0 / c,
+                           (T *)nullptr, (double *)h->lossp.p);
+        hipLaunchKernelGGL(loss_final_k<double>, dim3(1), dim3(64), 0, s, (const double *)h->lossp.p, nblk,
+                           1.0 / c, loss_sum, chunk_i > 0 ? 1 : 0);
+        if (recon) {
+            rc = launch_convert(wk.y[h->L], td, (char *)recon + (size_t)r0 * c * oes, recon_dtype, count, s);
+            if (rc) return rc;
+        }
+    }
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+int generic_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                         void *recon, int recon_dtype, double *loss_sum, hipStream_t s) {
+    if (h->esize == 8) return forward_loss_T<double>(h, x, x_dtype, n, features, recon, recon_dtype, loss_sum, s);
+    return forward_loss_T<float>(h, x, x_dtype, n, features, recon, recon_dtype, loss_sum, s);
+}
+
+template <typename T>
+static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                     void *grads_v, hipStream_t s) {
+    Work<T> wk;
+    int rc = carve<T>(h, n, true, wk);
+    if (rc) return rc;
+    const T *P = (const T *)h->params.p;
+    T *grads = (T *)grads_v;
+    int c = h->dims[0];
+    const int64_t np = h->nparams;
+    // number of row splits of the weight-gradient product (slab memory bounded to ~256 MB)
+    int64_t max_split = (int64_t)(1u << 28) / (np * (int64_t)sizeof(T));
+    max_split = max_split < 1 ? 1 : (max_split > 64 ? 64 : max_split);
+    rc = h->lossp.ensure(sizeof(double) * 1024);
+    if (rc) return rc;
+    int chunk_i = 0;
+    for (int64_t r0 = 0; r0 < n; r0 += wk.chunk, ++chunk_i) {
+        int64_t rows = n - r0 < wk.chunk ? n - r0 : wk.chunk;
+        int64_t nsplit = (rows + 255) / 256;
+        nsplit = nsplit > max_split ? max_split : nsplit;
+        int64_t rps = ((rows + nsplit - 1) / nsplit + 15) & ~(int64_t)15;
+        nsplit = (rows + rps - 1) / rps;
+        rc = h->slabs.ensure((size_t)(nsplit * np) * sizeof(T));
+        if (rc) return rc;
+        T *slabs = (T *)h->slabs.p;
+        rc = stage_input<T>(h, x, x_dtype, r0, rows, c, features, wk.x0, s);
+        if (rc) return rc;
+        for (int l = 0; l < h->L; ++l) launch_fwd_layer<T>(h, l, wk.y[l], wk.y[l + 1], rows, s);
+        int64_t count = rows * c;
+        int nblk = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
+        T *dz = wk.dza, *dz_next = wk.dzb;
+        hipLaunchKernelGGL(loss_grad_k<T>, dim3(nblk), dim3(256), 0, s, wk.y[h->L], wk.x0, count, 1.0 / c, dz,
+                           (double *)h->lossp.p);
+        hipLaunchKernelGGL(loss_final_k<T>, dim3(1), dim3(64), 0, s, (const double *)h->lossp.p, nblk, 1.0 / c,
+                           grads + np, chunk_i > 0 ? 1 : 0);
+        for (int l = h->L - 1; l >= 0; --l) {
+            int K = h->dims[l], N = h->dims[l + 1];
+            // [dW | db] = dZ^T [X | 1], reduced over this chunk's rows in nsplit fixed slabs
+            {
+                Opnd<T> A{dz, 1, N, N, -1};
+                Opnd<T> B{wk.y[l], 1, K, K, K};
+                Epi<T> e{};
+                e.n_rows = N; e.kin = K; e.gw = slabs + h->w_off[l]; e.gb = slabs + h->b_off[l];
+                e.slab_stride = np; e.rows_per_split = rps;
+                dim3 grid((K + 1 + 63) / 64, (N + 63) / 64, (unsigned)nsplit);
+                hipLaunchKernelGGL((gemm_k<T, EPI_DW, false, false>), grid, dim3(256), 0, s, A, B, rows, e);
+            }
+            if (l > 0) {
+                // dZ_{l-1} = (dZ_l W_l) * lrelu'(Y_{l-1})
+                Opnd<T> A{dz, N, 1, rows, -1};
+                Opnd<T> B{P + h->w_off[l], 1, K, K, -1};
+                Epi<T> e{};
+                e.out = dz_next; e.ld = K; e.n_rows = rows; e.n_cols = K;
+                e.ymask = h->has_act(l - 1) ? wk.y[l] : nullptr; e.ld_mask = K;
+                dim3 grid((K + 63) / 64, (unsigned)((rows + 63) / 64), 1);
+                hipLaunchKernelGGL((gemm_k<T, EPI_DX, true, false>), grid, dim3(256), 0, s, A, B, (int64_t)N, e);
+                T *t = dz; dz = dz_next; dz_next = t;
+            }
+        }
+        hipLaunchKernelGGL(reduce_slabs_k<T>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, slabs,
+                           (int)nsplit, np, np, grads, chunk_i > 0 ? 1 : 0);
+    }
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+int generic_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                    void *grads, hipStream_t s) {
+    if (h->esize == 8) return fwd_bwd_T<double>(h, x, x_dtype, n, features, grads, s);
+    return fwd_bwd_T<float>(h, x, x_dtype, n, features, grads, s);
+}
+
+template <typename T>
+static int act_means_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                       double *out, int max_nodes, hipStream_t s) {
+    Work<T> wk;
+    int rc = carve<T>(h, n, false, wk);
+    if (rc) return rc;
+    if (wk.chunk < n) { set_error("activation_means: batch larger than one workspace chunk"); return BAMD_ERR_UNSUPPORTED; }
+    int nact = h->L - 2;
+    hipLaunchKernelGGL(fill_nan_k, dim3((nact * max_nodes + 255) / 256), dim3(256), 0, s, out, nact * max_nodes);
+    rc = stage_input<T>(h, x, x_dtype, 0, n, h->dims[0], features, wk.x0, s);
+    if (rc) return rc;
+    int r = 0;
+    for (int l = 0; l < h->L; ++l) {
+        launch_fwd_layer<T>(h, l, wk.y[l], wk.y[l + 1], n, s);
+        if (h->has_act(l)) {
+            if (h->dims[l + 1] > max_nodes) { set_error("activation_means: max_nodes too small"); return BAMD_ERR_INVALID; }
+            hipLaunchKernelGGL(colmean_k<T>, dim3(h->dims[l + 1]), dim3(256), 0, s, wk.y[l + 1], n, h->dims[l + 1],
+                               out + (int64_t)r * max_nodes);
+            ++r;
+        }
+    }
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+int generic_activation_means(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
+                             double *out, int max_nodes, hipStream_t s) {
+    if (h->esize == 8) return act_means_T<double>(h, x, x_dtype, n, features, out, max_nodes, s);
+    return act_means_T<float>(h, x, x_dtype, n, features, out, max_nodes, s);
+}
+
+}  // namespace bamd

@@ -1,0 +1,121 @@
+"""Normalisation, model load/save (mirror of ``baler/modules/data_processing.py`` for the hot path).
+
+The numeric functions run as device kernels behind the C ABI; they accept numpy arrays (uploaded,
+result downloaded -- the reference's signature) or device tensors (result stays on device, which is
+what the CLI path uses so the dataset crosses PCIe once).
+"""
+from typing import List
+
+import numpy as np
+import torch
+
+from .. import native
+from . import models
+
+
+def _device():
+    native.require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev(a):
+    """-> (2-D contiguous device tensor f32/f64, was_numpy, original_shape)."""
+    was_np = not isinstance(a, torch.Tensor)
+    t = torch.as_tensor(np.asarray(a)) if was_np else a
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(torch.float64)
+    shape = tuple(t.shape)
+    if t.dim() == 1:
+        t = t.reshape(-1, 1)
+    elif t.dim() > 2:
+        t = t.reshape(t.shape[0], -1)
+    if not t.is_cuda:
+        t = t.to(_device())
+    return t.contiguous(), was_np, shape
+
+
+def convert_to_blocks_util(blocks, data):
+    """reference data_processing.py:26-34: reshape to (-1, blocks[1], blocks[2])."""
+    print("Converted Dataset to Blocks of Size - ", blocks, " from original ", tuple(data.shape))
+    total = int(np.prod(tuple(data.shape)))
+    return data.reshape(total // (blocks[1] * blocks[2]), blocks[1], blocks[2])
+
+
+def save_model(model, model_path: str) -> None:
+    """reference data_processing.py:37-47: torch.save(state_dict) -- same keys, shapes and dtypes."""
+    torch.save(model.state_dict(), model_path)
+
+
+def initialise_model(model_name: str):
+    """reference data_processing.py:76-86: look the class up by name."""
+    try:
+        return getattr(models, model_name)
+    except AttributeError as e:
+        raise AttributeError(
+            f"baler_amd provides the dense models {('AE', 'CFD_dense_AE')}; got {model_name!r}") from e
+
+
+def load_model(model_object, model_path: str, n_features: int, z_dim: int):
+    """reference data_processing.py:89-110 (load_state_dict(strict=False) onto the device)."""
+    model = model_object(n_features, z_dim)
+    model.to(_device())
+    model.load_state_dict(torch.load(str(model_path), map_location="cpu"), strict=False)
+    return model
+
+
+def find_minmax(data):
+    """reference data_processing.py:113-130: [min ; max-min] over axis 0 (device reduction kernel)."""
+    t, was_np, shape = _to_dev(data)
+    feats = native.minmax(t)
+    if len(shape) > 2:
+        feats = feats.reshape((2,) + tuple(shape[1:]))
+    elif len(shape) == 1:
+        feats = feats.reshape(2)
+    return feats.cpu().numpy() if was_np else feats
+
+
+def normalize(data, custom_norm: bool):
+    """reference data_processing.py:133-153 applied the way helper.normalize applies it
+    (np.apply_along_axis over axis 0, helper.py:261-274): per-column (x-min)/(max-min) with min/max
+    taken from the data itself; identity if custom_norm."""
+    if custom_norm:
+        return np.array(data) if not isinstance(data, torch.Tensor) else data
+    t, was_np, shape = _to_dev(data)
+    feats = native.minmax(t)
+    out = native.normalize(t, feats, torch.float64).reshape(shape)
+    return out.cpu().numpy() if was_np else out
+
+
+def split(data, test_size: float, random_state: int):
+    """sklearn train_test_split(data, test_size, random_state) (helper.py:315-317) restated:
+    permutation of RandomState(random_state); test = first ceil(test_size*n), train = the rest."""
+    n = data.shape[0]
+    n_test = int(np.ceil(test_size * n))
+    n_train = int(np.floor((1.0 - test_size) * n))
+    perm = np.random.RandomState(random_state).permutation(n)
+    tr, te = perm[n_test:n_test + n_train], perm[:n_test]
+    if isinstance(data, torch.Tensor):
+        tri = torch.as_tensor(tr, device=data.device)
+        tei = torch.as_tensor(te, device=data.device)
+        return data.index_select(0, tri).contiguous(), data.index_select(0, tei).contiguous()
+    return data[tr], data[te]
+
+
+def renormalize_std(input_data, true_min: float, feature_range: float):
+    """reference data_processing.py:171-185."""
+    return renormalize_func(np.asarray(input_data, dtype=np.float64).reshape(-1, 1), [true_min],
+                            [feature_range]).reshape(-1)
+
+
+def renormalize_func(norm_data, min_list: List, range_list: List, int_mask=None):
+    """reference data_processing.py:188-203: norm*range + min (float64), optional fused truncation of
+    the integer columns (baler.py:426-435)."""
+    t, was_np, shape = _to_dev(norm_data)
+    feats = torch.as_tensor(np.stack([np.asarray(min_list, dtype=np.float64).reshape(-1),
+                                      np.asarray(range_list, dtype=np.float64).reshape(-1)]),
+                            device=t.device).contiguous()
+    mask = None
+    if int_mask is not None:
+        mask = torch.as_tensor(np.asarray(int_mask, dtype=np.uint8), device=t.device).contiguous()
+    out = native.renormalize(t, feats, mask).reshape(shape)
+    return out.cpu().numpy() if was_np else out

@@ -1,0 +1,217 @@
+"""Training loop (mirror of ``baler/modules/training.py``: fit / validate / train).
+
+Same epoch semantics as the reference: the whole normalised dataset resident on the device
+(training.py:230-231), sequential batches of ``batch_size`` rows, no shuffling, partial last batch
+kept and weighted equally in the epoch mean (training.py:97-99), Adam with torch defaults
+(training.py:266), ReduceLROnPlateau / EarlyStopping between epochs (training.py:269-323).
+
+What differs is how a step executes: ONE native ``bamd_fwd_bwd`` (forward + loss + backward, fused
+HIP/MFMA kernels) and ONE native ``bamd_adam_step`` per batch, the running loss accumulated ON THE
+DEVICE and read once per epoch (the reference syncs with ``loss.item()`` every step,
+training.py:97).  Under ``torch.distributed`` (one process per GPU, RCCL) every global batch is split
+into contiguous row slices, one per rank, and the flat ``[grads | loss]`` buffer is SUM-all-reduced
+between the two native calls; every rank then applies the identical Adam step.
+"""
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from .. import dist as bdist
+from . import helper, utils
+
+
+class Adam:
+    """Flat-buffer Adam state (torch.optim.Adam defaults, reference training.py:266).  Exposes
+    ``param_groups`` so the reference-style LRScheduler can drive ``lr``."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        flat = model.flat
+        self.param_groups = [{"lr": float(lr), "betas": betas, "eps": eps}]
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.grads = torch.zeros_like(flat)       # [grads (nparams) | batch loss (1)]
+        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=flat.device)
+        self.step_count = 0
+
+    def zero_grad(self):
+        """No work: bamd_fwd_bwd overwrites the gradient buffer (reference training.py:68)."""
+
+    def train_step(self, handle, batch, world=1):
+        """forward+loss+backward -> [all-reduce] -> Adam, all asynchronous on the current stream."""
+        handle.fwd_bwd(batch, self.grads)
+        if world > 1:
+            bdist.allreduce_sum(self.grads)
+        self.step_count += 1
+        g = self.param_groups[0]
+        handle.adam_step(self.model.flat, self.grads, self.m, self.v, self.step_count, g["lr"],
+                         g["betas"][0], g["betas"][1], g["eps"], loss_accum=self.loss_accum)
+
+
+def _batches(n_rows, bs):
+    return [(s, min(s + bs, n_rows)) for s in range(0, n_rows, bs)]
+
+
+def _rank_slice(lo, hi, rank, world):
+    """Contiguous slice of global batch [lo,hi) owned by `rank` (sizes differ by at most one row)."""
+    n = hi - lo
+    base, rem = divmod(n, world)
+    a = lo + rank * base + min(rank, rem)
+    return a, a + base + (1 if rank < rem else 0)
+
+
+def fit(config, model, train_dl, model_children, regular_param, optimizer, latent_dim, RHO, l1,
+        n_dimensions):
+    """One epoch (reference training.py:31-101).  ``train_dl`` is a ``(device tensor, batch_size)``
+    pair -- the native loop slices the resident tensor instead of going through a DataLoader.
+    Returns (epoch_loss, last batch loss, 0, model) like the reference."""
+    print("### Beginning Training")
+    model.train()
+    data, bs = train_dl
+    rank, world = bdist.rank_world()
+    h = model.handle()
+    optimizer.loss_accum.zero_()
+    spans = _batches(data.shape[0], bs)
+    for lo, hi in spans:
+        a, b = _rank_slice(lo, hi, rank, world) if world > 1 else (lo, hi)
+        optimizer.train_step(h, data[a:b], world)
+    # one device->host read per epoch (the reference does one per step)
+    last = float(optimizer.grads[model.nparams].item())
+    epoch_loss = float(optimizer.loss_accum.item()) / len(spans)
+    model._dirty = False  # the native Adam updated model.flat AND the handle's packed copy
+    print(f"# Finished. Training Loss: {last:.6f}")
+    return epoch_loss, last, 0, model
+
+
+def validate(model, test_dl, model_children, reg_param):
+    """reference training.py:104-137: mean over batches of the batch loss, no gradients."""
+    print("### Beginning Validating")
+    model.eval()
+    data, bs = test_dl
+    rank, world = bdist.rank_world()
+    h = model.handle()
+    spans = _batches(data.shape[0], bs)
+    losses = torch.zeros(len(spans), dtype=torch.float64, device=data.device)
+    for i, (lo, hi) in enumerate(spans):
+        a, b = _rank_slice(lo, hi, rank, world) if world > 1 else (lo, hi)
+        if b > a:
+            h.forward_loss(data[a:b], want_recon=False, loss_out=losses[i:i + 1])
+    if world > 1:
+        bdist.allreduce_sum(losses)
+    host = losses.cpu().numpy()
+    epoch_loss = float(host.sum() / len(spans))
+    print(f"# Finished. Validation Loss: {host[-1]:.6f}")
+    return epoch_loss
+
+
+def _to_device_dataset(arr, config, device):
+    """reference training.py:194-231: 1-D data float64 (n, c); 2-D dense data float32 (n, h*w)."""
+    t = arr if isinstance(arr, torch.Tensor) else torch.as_tensor(np.asarray(arr))
+    if config.data_dimension == 2:
+        if getattr(config, "model_type", None) != "dense":
+            raise NotImplementedError("baler_amd covers the dense models; convolutional models are out of scope")
+        t = t.to(torch.float32).reshape(t.shape[0], -1)
+    elif config.data_dimension == 1:
+        t = t.to(torch.float64)
+    return t.to(device).contiguous()
+
+
+def train(model, variables, train_data, test_data, project_path, config):
+    """reference training.py:150-348 (same artefacts: loss_data.npy, activations.npy, model_{epoch}.pt)."""
+    if config.deterministic_algorithm:
+        random.seed(0)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        # the native kernels are bitwise deterministic by construction (fixed-order reductions)
+
+    test_size = config.test_size
+    bs = config.batch_size
+    epochs = config.epochs
+    device = helper.get_device()
+    model = model.to(device)
+    model_children = list(model.children())
+
+    train_ds = _to_device_dataset(train_data, config, device)
+    valid_ds = train_ds if test_data is train_data else _to_device_dataset(test_data, config, device)
+    train_dl, valid_dl = (train_ds, bs), (valid_ds, bs)
+
+    optimizer = Adam(model, lr=config.lr)
+    if config.early_stopping:
+        early_stopping = utils.EarlyStopping(patience=config.early_stopping_patience,
+                                             min_delta=config.min_delta)
+    if config.lr_scheduler:
+        lr_scheduler = utils.LRScheduler(optimizer=optimizer, patience=config.lr_scheduler_patience)
+
+    train_loss, val_loss = [], []
+    start = time.time()
+    rank, world = bdist.rank_world()
+    want_acts = bool(getattr(config, "activation_extraction", False))
+    trained_model = model
+
+    for epoch in range(epochs):
+        print(f"Epoch {epoch + 1} of {epochs}")
+        train_epoch_loss, _, _, trained_model = _fit_with_capture(
+            config, model, train_dl, model_children, optimizer, want_acts)
+        train_loss.append(train_epoch_loss)
+
+        if test_size:
+            val_epoch_loss = validate(model=trained_model, test_dl=valid_dl, model_children=model_children,
+                                      reg_param=config.reg_param)
+        else:
+            val_epoch_loss = train_epoch_loss
+        val_loss.append(val_epoch_loss)
+
+        if config.lr_scheduler:
+            lr_scheduler(val_epoch_loss)
+        if config.early_stopping:
+            early_stopping(val_epoch_loss)
+            if early_stopping.early_stop:
+                break
+        if config.intermittent_model_saving and rank == 0:
+            if epoch % config.intermittent_saving_patience == 0:
+                helper.model_saver(model, os.path.join(project_path, f"model_{epoch}.pt"))
+
+    end = time.time()
+    if rank == 0:
+        if want_acts:
+            acts = model.get_activations().get("means")
+            if acts is not None:
+                np.save(os.path.join(project_path, "activations.npy"), acts.cpu().numpy())
+        print(f"{(end - start) / 60:.3} minutes")
+        np.save(os.path.join(project_path, "loss_data.npy"), np.array([train_loss, val_loss]))
+    return trained_model
+
+
+def _fit_with_capture(config, model, train_dl, model_children, optimizer, want_acts):
+    """fit(), plus the activation snapshot of the epoch's last batch taken with the weights that batch
+    sees (i.e. before its optimiser step), as the reference's forward hooks do."""
+    if not want_acts:
+        return fit(config, model, train_dl, model_children, getattr(config, "reg_param", 0.0), optimizer,
+                   getattr(config, "latent_space_size", None), getattr(config, "RHO", None),
+                   getattr(config, "l1", None), config.data_dimension)
+    data, bs = train_dl
+    spans = _batches(data.shape[0], bs)
+    if len(spans) == 1:
+        model.capture_activations(data[spans[0][0]:spans[0][1]])
+        return fit(config, model, train_dl, model_children, config.reg_param, optimizer,
+                   getattr(config, "latent_space_size", None), config.RHO, config.l1, config.data_dimension)
+    # all batches but the last, then capture, then the last batch
+    print("### Beginning Training")
+    model.train()
+    rank, world = bdist.rank_world()
+    h = model.handle()
+    optimizer.loss_accum.zero_()
+    for i, (lo, hi) in enumerate(spans):
+        if i == len(spans) - 1:
+            model._dirty = False
+            model.capture_activations(data[lo:hi])
+        a, b = _rank_slice(lo, hi, rank, world) if world > 1 else (lo, hi)
+        optimizer.train_step(h, data[a:b], world)
+    last = float(optimizer.grads[model.nparams].item())
+    epoch_loss = float(optimizer.loss_accum.item()) / len(spans)
+    model._dirty = False
+    print(f"# Finished. Training Loss: {last:.6f}")
+    return epoch_loss, last, 0, model

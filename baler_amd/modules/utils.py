@@ -1,0 +1,84 @@
+"""Loss helpers and per-epoch controllers (mirror of ``baler/modules/utils.py`` for the hot path).
+
+* ``mse_sum_loss_l1``  -- reference utils.py:176-211; only ``validate=True`` is ever used by the
+  reference's training loop (training.py:83-89), and that is what is implemented.
+* ``emd_rows``         -- the EMD term of reference utils.py:112-119 as a device kernel.
+* ``EarlyStopping``    -- reference utils.py:248-282.
+* ``LRScheduler``      -- reference utils.py:285-323 (= ReduceLROnPlateau(mode="min", factor, patience,
+  min_lr) with torch defaults threshold=1e-4 'rel', cooldown=0, eps=1e-8), written out on the host so
+  it has no dependency on a torch optimizer; it accepts any object with ``param_groups``.
+"""
+import math
+
+import torch
+
+from .. import native
+
+factor = 0.5
+min_lr = 1e-6
+
+
+def mse_sum_loss_l1(model_children, true_data, reconstructed_data, reg_param, validate):
+    """sum((recon - x)^2) / n_columns on device; returns (loss, 0, 0) like the reference."""
+    if not validate:
+        raise NotImplementedError(
+            "mse_sum_loss_l1(validate=False) is never reached from the reference CLI (training.py:83-89)")
+    x = true_data.reshape(true_data.shape[0], -1).contiguous()
+    r = reconstructed_data.reshape(x.shape).contiguous()
+    d = (r - x).to(torch.float64)
+    return (d * d).sum() / x.shape[1], 0, 0
+
+
+def emd_rows(true_data, reconstructed_data):
+    """Sum over rows of the 1-D Wasserstein distance between a row's columns (device kernel)."""
+    return native.emd_rows(true_data.contiguous(), reconstructed_data.contiguous())
+
+
+class EarlyStopping:
+    def __init__(self, patience: int, min_delta: float):
+        self.patience = patience
+        self.min_delta = min_delta
+        self.counter = 0
+        self.best_loss = None
+        self.early_stop = False
+
+    def __call__(self, train_loss):
+        if self.best_loss is None:
+            self.best_loss = train_loss
+        elif self.best_loss - train_loss > self.min_delta:
+            self.best_loss = train_loss
+            self.counter = 0
+        elif self.best_loss - train_loss < self.min_delta:
+            # equality (best - loss == min_delta) changes nothing, exactly like the reference
+            self.counter += 1
+            print(f"Early stopping counter {self.counter} of {self.patience}")
+            if self.counter >= self.patience:
+                print("Early Stopping")
+                self.early_stop = True
+
+
+class LRScheduler:
+    def __init__(self, optimizer, patience, min_lr=min_lr, factor=factor):
+        self.optimizer = optimizer
+        self.patience = patience
+        self.min_lr = min_lr
+        self.factor = factor
+        self.threshold = 1e-4
+        self.eps = 1e-8
+        self.best = math.inf
+        self.num_bad_epochs = 0
+
+    def __call__(self, train_loss):
+        current = float(train_loss)
+        if current < self.best * (1.0 - self.threshold):
+            self.best = current
+            self.num_bad_epochs = 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            for group in self.optimizer.param_groups:
+                old = float(group["lr"])
+                new = max(old * self.factor, self.min_lr)
+                if old - new > self.eps:
+                    group["lr"] = new
+            self.num_bad_epochs = 0

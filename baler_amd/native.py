@@ -1,0 +1,241 @@
+"""ctypes binding of libbaler_amd.so (include/baler_amd.h).
+
+PyTorch is used only as the owner of device memory and of the current HIP stream; every call
+below passes raw device pointers (``tensor.data_ptr()``) across the C ABI.  There is NO CPU or
+PyTorch fallback: if the library is missing, fails to load, or no gfx950 device is present, the
+calls raise ``NativeError``.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbaler_amd.so")
+
+F32, F64 = 0, 1
+MODE_F32, MODE_F64, MODE_BF16 = 0, 1, 2
+MODE_NAMES = {"fp32": MODE_F32, "f32": MODE_F32, "fp64": MODE_F64, "f64": MODE_F64, "bf16": MODE_BF16}
+
+# every symbol include/baler_amd.h declares (tests check that the library exports all of them)
+SYMBOLS = (
+    "bamd_abi_version", "bamd_last_error", "bamd_device_count", "bamd_create", "bamd_destroy",
+    "bamd_param_count", "bamd_mode_of", "bamd_load_params", "bamd_minmax", "bamd_normalize",
+    "bamd_renormalize", "bamd_encode", "bamd_decode", "bamd_forward_loss", "bamd_fwd_bwd",
+    "bamd_adam_step", "bamd_emd_rows", "bamd_activation_means",
+)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class AdamHP(ctypes.Structure):
+    _fields_ = [("step", ctypes.c_int64), ("lr", ctypes.c_double), ("beta1", ctypes.c_double),
+                ("beta2", ctypes.c_double), ("eps", ctypes.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libbaler_amd.so (built in-tree by ``make -C baler_amd/csrc`` / ``__graft_entry__.build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} is missing: build it with `make -C baler_amd/csrc` "
+                          "(there is no CPU fallback for the hot path)")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i64, ci, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
+    L.bamd_abi_version.restype = ci
+    L.bamd_last_error.restype = ctypes.c_char_p
+    L.bamd_device_count.restype = ci
+    L.bamd_create.argtypes = [ctypes.POINTER(ci), ci, ci, ci, ctypes.POINTER(vp)]
+    L.bamd_destroy.argtypes = [vp]
+    L.bamd_destroy.restype = None
+    L.bamd_param_count.argtypes = [vp]
+    L.bamd_param_count.restype = i64
+    L.bamd_mode_of.argtypes = [vp]
+    L.bamd_load_params.argtypes = [vp, vp, ci, vp]
+    L.bamd_minmax.argtypes = [vp, ci, i64, ci, vp, vp]
+    L.bamd_normalize.argtypes = [vp, ci, i64, ci, vp, vp, ci, vp]
+    L.bamd_renormalize.argtypes = [vp, ci, i64, ci, vp, vp, vp, vp]
+    L.bamd_encode.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp]
+    L.bamd_decode.argtypes = [vp, vp, ci, i64, vp, vp, vp, ci, vp]
+    L.bamd_forward_loss.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp, vp]
+    L.bamd_fwd_bwd.argtypes = [vp, vp, ci, i64, vp, vp, vp]
+    L.bamd_adam_step.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, vp]
+    L.bamd_emd_rows.argtypes = [vp, vp, ci, i64, ci, vp, vp]
+    L.bamd_activation_means.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp]
+    for name in SYMBOLS:
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().bamd_last_error().decode(errors="replace")
+        raise NativeError(f"{what} failed (status {rc}): {msg}")
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float64:
+        return F64
+    raise NativeError(f"unsupported tensor dtype {t.dtype}")
+
+
+def _dev_tensor(t):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise NativeError("expected a CUDA/HIP tensor (the hot path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise NativeError("expected a contiguous tensor")
+    return t
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def require_gpu():
+    n = lib().bamd_device_count()
+    if n <= 0 or not torch.cuda.is_available():
+        raise NativeError("no MI355X (gfx950) device visible: the baler_amd hot path has no CPU fallback")
+    return n
+
+
+# ---- handle-free kernels --------------------------------------------------------------------------
+def minmax(x):
+    """data_processing.find_minmax on device: x (n, c) f32/f64 -> (2, c) f64 [min ; max-min]."""
+    x = _dev_tensor(x)
+    n, c = x.shape
+    out = torch.empty((2, c), dtype=torch.float64, device=x.device)
+    _check(lib().bamd_minmax(_ptr(x), _dt(x), n, c, _ptr(out), _stream()), "bamd_minmax")
+    return out
+
+
+def normalize(x, features, out_dtype=torch.float64):
+    x = _dev_tensor(x)
+    features = _dev_tensor(features)
+    n, c = x.shape
+    out = torch.empty((n, c), dtype=out_dtype, device=x.device)
+    _check(lib().bamd_normalize(_ptr(x), _dt(x), n, c, _ptr(features), _ptr(out), _dt(out), _stream()),
+           "bamd_normalize")
+    return out
+
+
+def renormalize(x, features, int_mask=None):
+    x = _dev_tensor(x)
+    n, c = x.shape
+    out = torch.empty((n, c), dtype=torch.float64, device=x.device)
+    _check(lib().bamd_renormalize(_ptr(x), _dt(x), n, c, _ptr(features), _ptr(int_mask), _ptr(out),
+                                  _stream()), "bamd_renormalize")
+    return out
+
+
+def emd_rows(x, recon):
+    x = _dev_tensor(x)
+    recon = _dev_tensor(recon)
+    if x.dtype != recon.dtype or x.shape != recon.shape:
+        raise NativeError("emd_rows: x and recon must have the same dtype and shape")
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    _check(lib().bamd_emd_rows(_ptr(x), _ptr(recon), _dt(x), x.shape[0], x.shape[1], _ptr(out), _stream()),
+           "bamd_emd_rows")
+    return out
+
+
+# ---- model handle ---------------------------------------------------------------------------------
+class Handle:
+    """Owns a bamd_handle*; parameters and optimiser state stay in caller-owned torch tensors."""
+
+    def __init__(self, dims, mode="fp32", device=None):
+        require_gpu()
+        self.dims = [int(d) for d in dims]
+        self.mode = MODE_NAMES[mode] if isinstance(mode, str) else int(mode)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        arr = (ctypes.c_int * len(self.dims))(*self.dims)
+        h = ctypes.c_void_p()
+        _check(lib().bamd_create(arr, len(self.dims) - 1, self.mode, self.device.index, ctypes.byref(h)),
+               "bamd_create")
+        self._h = h
+        self.nparams = int(lib().bamd_param_count(h))
+        self.param_dtype = torch.float64 if self.mode == MODE_F64 else torch.float32
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bamd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def z_dim(self):
+        return self.dims[(len(self.dims) - 1) // 2]
+
+    def load_params(self, flat):
+        flat = _dev_tensor(flat)
+        if flat.numel() < self.nparams:
+            raise NativeError("parameter vector too short")
+        _check(lib().bamd_load_params(self._h, _ptr(flat), _dt(flat), _stream()), "bamd_load_params")
+
+    def encode(self, x, features=None, out_dtype=None):
+        x = _dev_tensor(x)
+        out = torch.empty((x.shape[0], self.z_dim), dtype=out_dtype or x.dtype, device=x.device)
+        _check(lib().bamd_encode(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(out), _dt(out),
+                                 _stream()), "bamd_encode")
+        return out
+
+    def decode(self, z, features=None, int_mask=None, out_dtype=None):
+        z = _dev_tensor(z)
+        out = torch.empty((z.shape[0], self.dims[-1]), dtype=out_dtype or z.dtype, device=z.device)
+        _check(lib().bamd_decode(self._h, _ptr(z), _dt(z), z.shape[0], _ptr(features), _ptr(int_mask),
+                                 _ptr(out), _dt(out), _stream()), "bamd_decode")
+        return out
+
+    def forward_loss(self, x, features=None, want_recon=True, loss_out=None):
+        x = _dev_tensor(x)
+        recon = torch.empty_like(x) if want_recon else None
+        loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float64, device=x.device)
+        _check(lib().bamd_forward_loss(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(recon),
+                                       _dt(recon) if recon is not None else F32, _ptr(loss), _stream()),
+               "bamd_forward_loss")
+        return recon, loss
+
+    def fwd_bwd(self, x, grads, features=None):
+        x = _dev_tensor(x)
+        grads = _dev_tensor(grads)
+        if grads.dtype != self.param_dtype or grads.numel() < self.nparams + 1:
+            raise NativeError("grads must hold param_count+1 elements of the handle's parameter type")
+        _check(lib().bamd_fwd_bwd(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(grads), _stream()),
+               "bamd_fwd_bwd")
+
+    def adam_step(self, params, grads, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, loss_accum=None):
+        for t in (params, grads, m, v):
+            _dev_tensor(t)
+            if t.dtype != self.param_dtype:
+                raise NativeError("optimizer tensors must have the handle's parameter type")
+        hp = AdamHP(int(step), float(lr), float(beta1), float(beta2), float(eps))
+        _check(lib().bamd_adam_step(self._h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), ctypes.byref(hp),
+                                    _ptr(loss_accum), _stream()), "bamd_adam_step")
+
+    def activation_means(self, x, features=None, max_nodes=200):
+        x = _dev_tensor(x)
+        out = torch.empty((len(self.dims) - 3, max_nodes), dtype=torch.float64, device=x.device)
+        _check(lib().bamd_activation_means(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(out),
+                                           max_nodes, _stream()), "bamd_activation_means")
+        return out

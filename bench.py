@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- rows/sec of the Baler dense-AE hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): CMS 24-column AE 24->200->100->50->15->50->100->200->24,
+1,000,000 synthetic CMS-like rows per GPU resident in HBM (float64, min-max normalised, as
+training.train keeps them).  One "step" = one pass of the training hot path over that batch:
+forward + sum-of-squares loss + backward over the rank's 1M rows, ONE RCCL sum-all-reduce of the flat
+[grads | loss] buffer (N > 1), one fused Adam step.  Weak scaling: rows per GPU fixed, global batch =
+N x 1M rows.  `value` = N * rows * K / time (max over ranks, barrier + synchronize on both sides).
+
+Extra keys on the same JSON line: encode / decode rows/s (same resident rows), the strict reference
+batching regime (batch_size 512, sequential steps, latency-bound), `roofline` for the dominant kernel
+(HIP events on the launch stream, inside the timed region) and `cpu_baseline` (the plain-PyTorch fp64
+restatement of the reference loops, timed on this box's host cores; N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+# algorithmic (unpadded) work per row of AE(24,15): SURVEY.md section 8(d) / BASELINE.md section 4
+FLOP_TRAIN_ROW = 357_000
+FLOP_ENCODE_ROW = 61_100
+PEAK_TFLOPS = {"fp32": 157.3, "fp64": 78.6, "bf16": 2500.0}
+DTYPE_NAME = {"fp32": "f32", "fp64": "f64", "bf16": "bf16"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000, help="rows per GPU")
+    ap.add_argument("--mode", default=os.environ.get("BALER_AMD_MODE", "fp32"), choices=["fp32", "fp64", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip encode/decode/bs512 side measurements")
+    ap.add_argument("--cpu-rows", type=int, default=400_000)
+    return ap.parse_args()
+
+
+def timed(fn, steps, world, dev):
+    """barrier + synchronize, K calls, synchronize + barrier; returns max-over-ranks seconds."""
+    import torch.distributed as td
+    if world > 1:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        td.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(rows):
+    """The reference's loops restated in plain PyTorch fp64 (oracle/torch_ref.py, bit-identical to the
+    imported reference in the authoring container): training.fit with DataLoader + loss.item() per step,
+    batch 512; helper.compress's encode loop.  Bounded sample of the same synthetic workload."""
+    from baler_amd import synth
+    from oracle import c_oracle as orc
+    from oracle import torch_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    data = orc.normalize(synth.cms_rows(rows))
+    model = torch_ref.load_flat(torch_ref.DenseAE(24, 15), orc.formula_params(orc.ae_dims(24, 15), 7))
+    dl = torch_ref.make_loader(data, 512)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    torch_ref.fit_epoch(model, opt, torch_ref.make_loader(data[:20480], 512))  # warm-up
+    t0 = time.perf_counter()
+    torch_ref.fit_epoch(model, opt, dl)
+    t_train = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    torch_ref.compress_loop(model, data[:rows // 2], 512)
+    t_enc = time.perf_counter() - t0
+    return {
+        "value": rows / t_train, "unit": "rows/s", "cores": cores, "kind": "port",
+        "encode_rows_per_s": (rows // 2) / t_enc,
+        "sample": f"{rows} rows x 24 cols, 1 epoch of training.fit at batch_size 512 through DataLoader "
+                  f"(fp64, torch {torch.__version__}, {cores} threads); encode loop of helper.compress on "
+                  f"{rows // 2} rows",
+    }
+
+
+def main():
+    a = parse()
+    from baler_amd import dist as bdist
+    from baler_amd import native, synth
+    from baler_amd.modules import models
+
+    rank, world, local = bdist.init_from_env()
+    if world != a.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    native.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---- resident synthetic rows: generated per rank (counter based), normalised on the device -------
+    raw = torch.as_tensor(synth.cms_rows(a.rows, row0=rank * a.rows)).to(dev)
+    feats = native.minmax(raw)
+    x = native.normalize(raw, feats, torch.float64)
+    del raw
+
+    torch.manual_seed(0)
+    model = models.AE(24, 15, mode=a.mode).to(dev)
+    h = model.handle()
+    flat = model.flat
+    grads, m, v = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
+    loss_acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    state = {"t": 0}
+    ev = []  # (start, end) HIP events around the dominant kernel call, on the launch stream
+
+    def train_step(record=False):
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        h.fwd_bwd(x, grads)
+        if record:
+            e1.record()
+            ev.append((e0, e1))
+        if world > 1:
+            bdist.allreduce_sum(grads)
+        state["t"] += 1
+        h.adam_step(flat, grads, m, v, state["t"], 1e-3, loss_accum=loss_acc)
+
+    for _ in range(a.warmup):
+        train_step()
+    dt = timed(lambda: train_step(True), a.steps, world, dev)
+    rows_total = world * a.rows * a.steps
+    value = rows_total / dt
+    k_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    final_loss = float(grads[-1].item())
+
+    out = {
+        "metric": "rows/sec (train) + rows/sec (encode), CMS 24-col AE at 1/2/4/8 GPUs",
+        "value": value, "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE_NAME[a.mode], "data": "synthetic",
+        "config": {
+            "workload": f"CMS 24-col AE(24,15) train step (fwd+loss+bwd+Adam), {a.rows} synthetic rows per GPU "
+                        f"resident in HBM as float64, one optimizer step per pass (global batch = n_gpus x {a.rows}), "
+                        f"{a.mode} MFMA, random-init weights",
+            "rows_per_gpu": a.rows, "n_cols": 24, "latent": 15, "parallelism": f"dp{world}",
+            "compute_mode": a.mode,
+        },
+        "train_rows_per_s": value, "last_batch_loss": final_loss,
+    }
+
+    achieved = FLOP_TRAIN_ROW * a.rows / (k_ms * 1e-3) / 1e12
+    out["roofline"] = {
+        "bound": "mfma", "kernel": "bamd_fwd_bwd (forward+loss+backward of one batch)",
+        "achieved": achieved, "peak": PEAK_TFLOPS[a.mode], "unit": "TFLOP/s",
+        "frac": achieved / PEAK_TFLOPS[a.mode], "traffic": None,
+        "launch_ms": k_ms, "algorithmic_flop_per_row": FLOP_TRAIN_ROW, "rows_per_launch": a.rows,
+    }
+
+    if not a.no_extras:
+        # encode / decode passes over the same resident rows (no collectives: rows shard naturally)
+        z = h.encode(x)
+        t_enc = timed(lambda: h.encode(x), max(3, a.steps // 2), world, dev)
+        n_enc = max(3, a.steps // 2)
+        out["encode_rows_per_s"] = world * a.rows * n_enc / t_enc
+        t_dec = timed(lambda: h.decode(z), n_enc, world, dev)
+        out["decode_rows_per_s"] = world * a.rows * n_enc / t_dec
+        out["encode_tflops"] = FLOP_ENCODE_ROW * a.rows * n_enc / t_enc / 1e12
+        # strict reference batching: global batch 512 x n_gpus... kept at 512 rows per GPU, sequential steps
+        nb = 400
+        def bs512_pass():
+            for i in range(nb):
+                h.fwd_bwd(x[i * 512:(i + 1) * 512], grads)
+                if world > 1:
+                    bdist.allreduce_sum(grads)
+                state["t"] += 1
+                h.adam_step(flat, grads, m, v, state["t"], 1e-3, loss_accum=loss_acc)
+        bs512_pass()
+        t512 = timed(bs512_pass, 1, world, dev)
+        out["train_bs512_rows_per_s"] = world * 512 * nb / t512
+        out["train_bs512_us_per_step"] = 1e6 * t512 / nb
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_rows)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as td
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/*
+ * baler_amd.h -- C ABI of libbaler_amd.so, the MI355X (gfx950) hot path of Baler's dense
+ * autoencoder: train (forward + sum-of-squares loss + backward + Adam), encode (compress) and
+ * decode (decompress), plus the per-column min-max (un)normalisation either side of it.
+ *
+ * The reference (baler-collaboration/baler @ 2024_10_08) has NO native/FFI boundary for this path:
+ * the path sits behind Python call surfaces.  Each entry point below names
+ * the reference interface it replaces (file:line, relative to the reference checkout); the Python
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative bamd_status; no exceptions cross the ABI;
+ *    bamd_last_error() returns a message for the calling thread's last failure;
+ *  - the CALLER owns every device buffer passed in (dataset, params, grads, Adam m/v, outputs);
+ *    the library borrows the pointers for the duration of the call and owns only its handle
+ *    (layer descriptor, MFMA-fragment-packed weight copy, partial-gradient slabs, activation
+ *    workspace);
+ *  - all work is enqueued asynchronously on the hipStream_t passed as `stream` (void*; NULL =
+ *    the default stream); nothing synchronises the host;
+ *  - one handle per (model, device); a handle is not thread-safe;
+ *  - parameter vectors are FLAT in Baler's state-dict order: for each layer l, W_l[out][in]
+ *    row-major then b_l[out] (models.py:128-136; the key order of model.pt);
+ *  - rows are independent: multi-GPU = one process and one handle per GPU, rows sharded by the
+ *    caller; the only exchange is a SUM all-reduce of the flat gradient buffer between
+ *    bamd_fwd_bwd() and bamd_adam_step() (done by the caller with RCCL).
+ */
+#ifndef BALER_AMD_H
+#define BALER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BAMD_ABI_VERSION 1
+
+typedef struct bamd_handle bamd_handle;
+
+typedef enum bamd_status {
+    BAMD_OK = 0,
+    BAMD_ERR_INVALID = -1,     /* bad argument (null pointer, unsupported dtype/shape ...) */
+    BAMD_ERR_NO_DEVICE = -2,   /* no HIP device / wrong architecture */
+    BAMD_ERR_HIP = -3,         /* a HIP runtime call failed; see bamd_last_error() */
+    BAMD_ERR_ALLOC = -4,       /* device allocation failed */
+    BAMD_ERR_UNSUPPORTED = -5  /* feature not available in this compute mode */
+} bamd_status;
+
+/* element type of a caller buffer */
+typedef enum bamd_dtype { BAMD_F32 = 0, BAMD_F64 = 1 } bamd_dtype;
+
+/* arithmetic the Linear layers run in.  F32 = v_mfma_f32_16x16x4_f32 (exact fp32, the parity mode:
+ * outputs within 1e-5 rel. of the fp64 reference).  F64 = v_mfma_f64_16x16x4_f64 (long-horizon
+ * training parity).  BF16 = v_mfma_f32_*_bf16 with fp32 accumulate and fp32 master weights
+ * (throughput mode, ~1e-2 on outputs). */
+typedef enum bamd_mode { BAMD_MODE_F32 = 0, BAMD_MODE_F64 = 1, BAMD_MODE_BF16 = 2 } bamd_mode;
+
+/* Adam hyper-parameters of one step (torch.optim.Adam defaults are beta1=.9 beta2=.999 eps=1e-8). */
+typedef struct bamd_adam {
+    int64_t step;   /* t AFTER the increment (first step = 1) */
+    double lr;      /* current learning rate (host-side ReduceLROnPlateau feeds this) */
+    double beta1, beta2, eps;
+} bamd_adam;
+
+int bamd_abi_version(void);
+const char *bamd_last_error(void);
+/* number of visible HIP devices, or a negative bamd_status */
+int bamd_device_count(void);
+
+/* ---- model handle ------------------------------------------------------------------------------
+ * Replaces: models.AE.__init__ / models.CFD_dense_AE.__init__ (models.py:122-139, 192-209) and
+ * data_processing.initialise_model/load_model (data_processing.py:76-110).
+ * dims has n_layers+1 entries (n_features, 200, 100, 50, z, 50, 100, 200, n_features for the
+ * reference topologies; any even n_layers >= 2 is accepted).  LeakyReLU(0.01) follows every layer
+ * except the last encoder layer and the last decoder layer (models.py:141-152). */
+int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle **out);
+void bamd_destroy(bamd_handle *h);
+int64_t bamd_param_count(const bamd_handle *h);
+int bamd_mode_of(const bamd_handle *h);
+
+/* (Re)build the handle's MFMA-fragment-packed weight copy from the caller's flat parameter vector
+ * (device pointer; dtype F32 or F64).  Call after loading a checkpoint or changing params outside
+ * bamd_adam_step().  Replaces: model.load_state_dict (data_processing.py:105-110). */
+int bamd_load_params(bamd_handle *h, const void *params, int dtype, void *stream);
+
+/* ---- normalisation -----------------------------------------------------------------------------
+ * Replaces: data_processing.find_minmax (data_processing.py:113-130).  features = [min ; max-min],
+ * (2, n_cols) float64, device memory. */
+int bamd_minmax(const void *x, int dtype, int64_t n_rows, int n_cols, double *features,
+                void *stream);
+/* Replaces: helper.normalize -> data_processing.normalize (helper.py:261-274,
+ * data_processing.py:133-153): out = (x - min)/(max - min) per column, evaluated in float64 and
+ * rounded to out_dtype. */
+int bamd_normalize(const void *x, int dtype, int64_t n_rows, int n_cols, const double *features,
+                   void *out, int out_dtype, void *stream);
+/* Replaces: data_processing.renormalize_func (data_processing.py:188-203) + the per-column
+ * astype cast at baler.py:426-435: out = x*range + min (float64), then truncation toward zero for
+ * columns with int_mask[c] != 0 (int_mask may be NULL; it is a DEVICE pointer of n_cols bytes). */
+int bamd_renormalize(const void *x, int dtype, int64_t n_rows, int n_cols, const double *features,
+                     const uint8_t *int_mask, double *out, void *stream);
+
+/* ---- inference ---------------------------------------------------------------------------------
+ * Replaces: AE.encode (models.py:141-145) as driven by helper.compress's loop (helper.py:583-611).
+ * x: (n_rows, n_features) row-major, x_dtype.  If features != NULL the rows are min-max normalised
+ * on load with features = [min ; range] (device, float64) -- the fused form of helper.py:500-504.
+ * z: (n_rows, z_dim) row-major, z_dtype. */
+int bamd_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features,
+                void *z, int z_dtype, void *stream);
+/* Replaces: AE.decode (models.py:147-152) as driven by helper.decompress (helper.py:700-723), with
+ * the optional un-normalise + int-column truncation epilogue of baler.py:420-435 fused in when
+ * features != NULL (int_mask may still be NULL). */
+int bamd_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n_rows, const double *features,
+                const uint8_t *int_mask, void *out, int out_dtype, void *stream);
+/* Replaces: AE.forward (models.py:154-156) + utils.mse_sum_loss_l1(validate=True)
+ * (utils.py:195-211) as used by training.validate (training.py:104-137).
+ * recon may be NULL.  *loss_sum (device, float64) is OVERWRITTEN with sum((recon-x)^2)/n_features
+ * of this batch. */
+int bamd_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows,
+                      const double *features, void *recon, int recon_dtype, double *loss_sum,
+                      void *stream);
+
+/* ---- training ----------------------------------------------------------------------------------
+ * Replaces: one iteration of training.fit's loop body up to loss.backward() (training.py:64-92):
+ * zero_grad, forward, loss = sum((r-x)^2)/n_features, backward.
+ * grads: device buffer of bamd_param_count()+1 elements of the handle's parameter type (float for
+ * MODE_F32/BF16, double for MODE_F64); it is OVERWRITTEN with the gradient of this batch in
+ * state-dict order, and element [param_count] receives the batch loss.  Summation order is fixed
+ * (no float atomics): results are bitwise reproducible run to run.
+ * Data-parallel use: each rank passes its slice of the global batch, then SUM-all-reduces the
+ * whole buffer (the loss is a row sum, so the global-batch gradient is the sum of shard gradients). */
+int bamd_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features,
+                 void *grads, void *stream);
+/* Replaces: torch.optim.Adam.step + zero_grad (training.py:68,95,266) on the flat buffers, and
+ * refreshes the handle's packed weight copy.  params/m/v/grads: device, handle parameter type.
+ * If loss_accum != NULL (device, float64): *loss_accum += grads[param_count]  (the running_loss of
+ * training.py:97 without the per-step host sync). */
+int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, void *v,
+                   const bamd_adam *hp, double *loss_accum, void *stream);
+
+/* ---- diagnostics -------------------------------------------------------------------------------
+ * Replaces: the EMD term of utils.mse_loss_emd_l1 (utils.py:112-119): sum over rows of the 1-D
+ * Wasserstein distance between the row's column values of x and recon.  *out (device, float64)
+ * is overwritten.  Forward-only metric; n_cols <= 64. */
+int bamd_emd_rows(const void *x, const void *recon, int dtype, int64_t n_rows, int n_cols,
+                  double *out, void *stream);
+/* Replaces: activation extraction (models.py:160-183, diagnostics.py:10-47): mean over the batch of
+ * leaky_relu(pre-activation) for every activated layer; out is (n_layers-2, max_nodes) float64
+ * device memory, padded with NaN. */
+int bamd_activation_means(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows,
+                          const double *features, double *out, int max_nodes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BALER_AMD_H */

@@ -1,0 +1,344 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the
+same seeded inputs and against the golden vectors generated from the imported reference.
+
+Tolerances (BASELINE.json north_star: 1e-5 relative fp32 tolerance vs the fp64 reference):
+  fp32 mode  rel-L2 <= 1e-5 on encode/decode/forward/loss/gradients/first Adam steps
+  fp64 mode  rel-L2 <= 1e-11 (summation order differs from the scalar oracle), loss curve 1e-9
+  integer/exact work (min/max, normalise in fp64, truncation)  bit-exact
+"""
+import numpy as np
+import pytest
+import torch
+
+from baler_amd import native, synth
+from oracle import c_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-5
+TOL64 = 1e-11
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def make_handle(dims, flat, mode):
+    h = native.Handle(dims, mode)
+    p = dev(np.concatenate([flat, [0.0]]), torch.float64 if mode == "fp64" else torch.float32)
+    h.load_params(p)
+    return h, p
+
+
+@pytest.fixture(scope="module")
+def data10k():
+    return orc.normalize(synth.cms_rows(10000))
+
+
+# ---- normalisation --------------------------------------------------------------------------------
+def test_minmax_normalize_bit_exact(golden):
+    g = golden("g1_normalize.npz")
+    raw = dev(g["raw"])
+    feats = native.minmax(raw)
+    assert np.array_equal(feats.cpu().numpy(), g["features"])
+    normed = native.normalize(raw, feats, torch.float64)
+    assert np.array_equal(normed.cpu().numpy(), g["normalized"])
+    ren = native.renormalize(normed, feats)
+    assert np.array_equal(ren.cpu().numpy(), g["renormalized"])
+
+
+@pytest.mark.parametrize("data,expected", [
+    ([[1, 2, 3], [4, 5, 6], [7, 8, 9]], [[1, 2, 3], [6, 6, 6]]),
+    ([[-1, -2, -3], [-4, -5, -6], [-7, -8, -9]], [[-7, -8, -9], [6, 6, 6]]),
+    ([[0, 0, 0], [1, 1, 1], [2, 2, 2]], [[0, 0, 0], [2, 2, 2]]),
+])
+def test_find_minmax_reference_vectors(data, expected):
+    # reference tests/test_data_processing.py:52-67, through the product's data_processing mirror
+    from baler_amd.modules import data_processing
+    out = data_processing.find_minmax(np.array(data, dtype=np.float64))
+    assert np.array_equal(out, np.array(expected, dtype=np.float64))
+
+
+def test_normalize_renormalize_reference_vectors():
+    # reference tests/test_data_processing.py:70-121
+    from baler_amd.modules import data_processing
+    out = data_processing.normalize(np.array([1.0, 2.0, 3.0, 4.0, 5.0]), False)
+    np.testing.assert_almost_equal(out, [0.0, 0.25, 0.5, 0.75, 1.0])
+    assert np.array_equal(data_processing.normalize(np.array([1, 2, 3, 4, 5]), True), [1, 2, 3, 4, 5])
+    r = data_processing.renormalize_std(np.array([0.1, 0.2, 0.3, 0.4, 0.5]), 1, 2)
+    np.testing.assert_array_equal(r, np.array([1.2, 1.4, 1.6, 1.8, 2.0]))
+    data = np.array([[-1, 2], [-0.5, 6], [0, 10], [1, 18]], dtype=float)
+    normed = (data - data.min(0)) / (data.max(0) - data.min(0))
+    np.testing.assert_array_equal(data_processing.renormalize_func(normed, [-1, 2], [2, 16]), data)
+
+
+def test_minmax_large_and_wide():
+    x = synth.cms_rows(200_003)
+    feats = native.minmax(dev(x)).cpu().numpy()
+    assert np.array_equal(feats[0], x.min(0)) and np.array_equal(feats[1], x.max(0) - x.min(0))
+    w = synth.wide_rows(777, 2500)
+    fw = native.minmax(dev(w)).cpu().numpy()
+    assert np.array_equal(fw[0], w.min(0)) and np.array_equal(fw[1], w.max(0) - w.min(0))
+    f32 = native.minmax(dev(x, torch.float32)).cpu().numpy()
+    x32 = x.astype(np.float32).astype(np.float64)
+    assert np.array_equal(f32[0], x32.min(0))
+
+
+# ---- encode / decode / loss -----------------------------------------------------------------------
+@pytest.mark.parametrize("mode,tol", [("fp32", TOL32), ("fp64", TOL64)])
+def test_encode_decode_forward_golden(golden, mode, tol):
+    g = golden("g2_ae24_io.npz")
+    dims = orc.ae_dims(24, 15)
+    h, _ = make_handle(dims, orc.formula_params(dims, int(g["seed"])), mode)
+    x = dev(g["x"])
+    z = h.encode(x)
+    assert z.dtype == torch.float64 and rel(z.cpu().numpy(), g["z"]) < tol
+    dec = h.decode(dev(g["z"]))
+    assert rel(dec.cpu().numpy(), g["decoded"]) < tol
+    recon, loss = h.forward_loss(x)
+    assert rel(recon.cpu().numpy(), g["forward"]) < tol
+    assert abs(loss.item() - g["loss"]) < tol * abs(g["loss"])
+    # fp32 I/O gives the same numbers to fp32 precision
+    z32 = h.encode(dev(g["x"], torch.float32))
+    assert z32.dtype == torch.float32 and rel(z32.cpu().numpy(), g["z"]) < TOL32
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 65, 511, 1000])
+def test_encode_ragged_sizes(n, data10k):
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 21)
+    h, _ = make_handle(dims, flat, "fp32")
+    x = data10k[:n]
+    assert rel(h.encode(dev(x)).cpu().numpy(), orc.encode(dims, flat, x)) < TOL32
+    z = orc.encode(dims, flat, x)
+    assert rel(h.decode(dev(z)).cpu().numpy(), orc.decode(dims, flat, z)) < TOL32
+
+
+def test_encode_empty():
+    dims = orc.ae_dims(24, 15)
+    h, _ = make_handle(dims, orc.formula_params(dims, 21), "fp32")
+    z = h.encode(torch.empty((0, 24), dtype=torch.float64, device="cuda"))
+    assert tuple(z.shape) == (0, 15)
+
+
+def test_encode_fused_normalisation(data10k):
+    """encode(raw, features) == encode(normalize(raw)) -- the fused form of helper.py:500-504."""
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 22)
+    h, _ = make_handle(dims, flat, "fp32")
+    raw = synth.cms_rows(4096)
+    feats = native.minmax(dev(raw))
+    z = h.encode(dev(raw), features=feats)
+    want = orc.encode(dims, flat, orc.normalize(raw))
+    assert rel(z.cpu().numpy(), want) < TOL32
+
+
+def test_decode_renorm_and_int_cast(golden):
+    g = golden("g8_decompress.npz")
+    dims = orc.ae_dims(24, 15)
+    h, _ = make_handle(dims, orc.formula_params(dims, int(g["seed"])), "fp64")
+    nf = dev(g["normalization_features"])
+    mask = torch.as_tensor(g["int_mask"].astype(np.uint8)).cuda()
+    pre = h.decode(dev(g["z"]), features=nf)
+    assert rel(pre.cpu().numpy(), g["pre_cast"]) < TOL64
+    post = h.decode(dev(g["z"]), features=nf, int_mask=mask).cpu().numpy()
+    # truncation flips by one where the pre-cast value sits within tolerance of an integer
+    near_int = np.abs(g["pre_cast"] - np.round(g["pre_cast"])) < 1e-9 * np.maximum(1, np.abs(g["pre_cast"]))
+    ok = (post == g["post_cast"]) | near_int
+    assert ok.all()
+    cols = g["int_mask"].astype(bool)
+    assert np.array_equal(post[:, cols], np.trunc(post[:, cols]))
+    # fp32 mode: compare before the cast at 1e-5
+    h32, _ = make_handle(dims, orc.formula_params(dims, int(g["seed"])), "fp32")
+    pre32 = h32.decode(dev(g["z"]), features=nf)
+    assert rel(pre32.cpu().numpy(), g["pre_cast"]) < TOL32
+    # the standalone renormalise kernel is exact given the same decoded input
+    post2 = native.renormalize(dev(g["decoded"]), nf, mask).cpu().numpy()
+    assert np.array_equal(post2, g["post_cast"])
+
+
+# ---- gradients / Adam -----------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,tol", [("fp32", TOL32), ("fp64", TOL64)])
+def test_gradients_golden(golden, data10k, mode, tol):
+    g = golden("g5_ae24_grads.npz")
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, int(g["seed"]))
+    h, p = make_handle(dims, flat, mode)
+    x = data10k[int(g["row0"]):int(g["row0"]) + int(g["n_rows"])]
+    grads = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), grads)
+    gh = grads.cpu().numpy().astype(np.float64)
+    assert abs(gh[-1] - g["loss"]) < tol * abs(g["loss"])
+    assert rel(gh[:-1][g["sample_idx"]], g["sample_val"]) < tol
+    norms, off = [], 0
+    for l in range(8):
+        for n in (dims[l + 1] * dims[l], dims[l + 1]):
+            norms.append(np.linalg.norm(gh[off:off + n]))
+            off += n
+    assert rel(norms, g["tensor_l2"]) < tol
+    # full vector against the oracle on the same inputs, per tensor
+    _, go = orc.fwd_bwd(dims, flat, x)
+    off = 0
+    for l in range(8):
+        for n in (dims[l + 1] * dims[l], dims[l + 1]):
+            assert rel(gh[off:off + n], go[off:off + n]) < tol, (l, n)
+            off += n
+    # bitwise reproducible run to run (fixed-order reductions)
+    grads2 = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), grads2)
+    assert torch.equal(grads, grads2)
+
+
+@pytest.mark.parametrize("n", [1, 7, 100, 272, 513, 4099])
+def test_gradients_ragged(n, data10k):
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 31)
+    h, p = make_handle(dims, flat, "fp32")
+    grads = torch.zeros_like(p)
+    h.fwd_bwd(dev(data10k[:n]), grads)
+    lo, go = orc.fwd_bwd(dims, flat, data10k[:n])
+    gh = grads.cpu().numpy().astype(np.float64)
+    assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
+
+
+def test_empty_shard_gives_zero_grad():
+    dims = orc.ae_dims(24, 15)
+    h, p = make_handle(dims, orc.formula_params(dims, 31), "fp32")
+    grads = torch.ones_like(p)
+    h.fwd_bwd(torch.empty((0, 24), dtype=torch.float64, device="cuda"), grads)
+    assert float(grads.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", TOL32), ("fp64", 1e-10)])
+def test_adam_trajectory_golden(golden, data10k, mode, tol):
+    g = golden("g6_ae24_adam.npz")
+    dims = orc.ae_dims(24, 15)
+    h, p = make_handle(dims, orc.formula_params(dims, int(g["seed"])), mode)
+    m, v, grads = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+    acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for step in range(1, 13):
+        lr = 1e-3 if step < 11 else 5e-4
+        h.fwd_bwd(dev(data10k[(step - 1) * 512: step * 512]), grads)
+        h.adam_step(p, grads, m, v, step, lr, loss_accum=acc)
+        assert abs(float(grads[-1]) - g["losses"][step - 1]) < tol * g["losses"][step - 1]
+        if step in (1, 2, 3, 10, 12):
+            ph = p.cpu().numpy().astype(np.float64)[:-1]
+            assert rel(ph[g["sample_idx"]], g[f"p{step}"]) < tol, step
+    assert abs(acc.item() - g["losses"].sum()) < tol * g["losses"].sum()
+
+
+def test_big_batch_dp_equivalent(golden):
+    """3 steps at batch 4096 == what an 8 x 512 data-parallel step must equal;
+    also: the gradient of a batch is the SUM of the gradients of its row shards."""
+    g = golden("g12_dp_bs4096.npz")
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, int(g["seed"]))
+    data = orc.normalize(synth.cms_rows(int(g["n_rows"])))
+    h, p = make_handle(dims, flat, "fp32")
+    m, v, grads = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+    shard_sum = torch.zeros_like(p)
+    tmp = torch.zeros_like(p)
+    for s in range(3):
+        xb = dev(data[s * 4096:(s + 1) * 4096])
+        if s == 0:
+            for r in range(8):
+                h.fwd_bwd(xb[r * 512:(r + 1) * 512], tmp)
+                shard_sum += tmp
+        h.fwd_bwd(xb, grads)
+        if s == 0:
+            assert rel(shard_sum.cpu().numpy(), grads.cpu().numpy()) < 1e-6
+        assert abs(float(grads[-1]) - g["losses"][s]) < TOL32 * g["losses"][s]
+        h.adam_step(p, grads, m, v, s + 1, 1e-3)
+    assert rel(p.cpu().numpy().astype(np.float64)[:-1][g["sample_idx"]], g["sample"]) < TOL32
+
+
+# ---- diagnostics ----------------------------------------------------------------------------------
+def test_activation_means_golden(golden, data10k):
+    g = golden("g9_activations.npz")
+    dims = orc.ae_dims(24, 15)
+    h, _ = make_handle(dims, orc.formula_params(dims, int(g["seed"])), "fp32")
+    a = h.activation_means(dev(data10k[:int(g["n_rows"])])).cpu().numpy()
+    assert a.shape == (6, 200)
+    assert np.array_equal(np.isnan(a), np.isnan(g["activations"]))
+    assert rel(np.nan_to_num(a), np.nan_to_num(g["activations"])) < TOL32
+
+
+def test_emd_golden(golden):
+    g = golden("g10_emd.npz")
+    out = native.emd_rows(dev(g["x"]), dev(g["recon"]))
+    assert abs(out.item() - g["emd"]) < 1e-12 * abs(g["emd"])
+
+
+# ---- other configs --------------------------------------------------------------------------------
+def test_cfd_dense_golden(golden):
+    g = golden("g11_cfd_dense.npz")
+    dims = orc.ae_dims(2500, 25)
+    flat = orc.formula_params(dims, int(g["seed"]))
+    h, p = make_handle(dims, flat, "fp32")
+    x = dev(synth.cfd_field(int(g["n_frames"])).reshape(-1, 2500), torch.float32)
+    z = h.encode(x)
+    assert rel(z.cpu().numpy(), g["z"]) < TOL32
+    dec = h.decode(dev(g["z"], torch.float32)).cpu().numpy()
+    assert rel(dec[:, :64], g["decoded_head"]) < TOL32
+    assert rel(dec.astype(np.float64).sum(axis=1), g["decoded_rowsum"]) < TOL32
+    grads = torch.zeros_like(p)
+    h.fwd_bwd(x, grads)
+    gh = grads.cpu().numpy().astype(np.float64)
+    assert abs(gh[-1] - g["loss"]) < 1e-4 * abs(g["loss"])  # the reference itself is fp32 here
+    norms, off = [], 0
+    for l in range(8):
+        for n in (dims[l + 1] * dims[l], dims[l + 1]):
+            norms.append(np.linalg.norm(gh[off:off + n]))
+            off += n
+    assert rel(norms, g["grad_tensor_l2"]) < 1e-4
+
+
+def test_wide_512_encoder_vs_oracle():
+    dims = orc.ae_dims(512, 6)
+    flat = orc.formula_params(dims, 41)
+    h, _ = make_handle(dims, flat, "fp32")
+    x = synth.wide_rows(300, 512)
+    assert rel(h.encode(dev(x, torch.float32)).cpu().numpy(), orc.encode(dims, flat, x)) < TOL32
+
+
+# ---- size-independent properties at BASELINE.json's full single-GPU size --------------------------
+def test_full_size_properties():
+    n = 1_000_000
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 51)
+    h, p = make_handle(dims, flat, "fp32")
+    raw = dev(synth.cms_rows(n))
+    feats = native.minmax(raw)
+    x = native.normalize(raw, feats, torch.float32)
+    # (1) encode is row-independent: whole == concatenation of ragged pieces, bit for bit
+    z = h.encode(x)
+    cut = 333_331
+    z2 = torch.cat([h.encode(x[:cut]), h.encode(x[cut:])])
+    assert torch.equal(z, z2)
+    # (2) deterministic
+    assert torch.equal(z, h.encode(x))
+    # (3) sampled rows against the oracle
+    idx = np.random.default_rng(0).choice(n, size=256, replace=False)
+    xs = x[torch.as_tensor(idx).cuda()].cpu().numpy().astype(np.float64)
+    assert rel(z[torch.as_tensor(idx).cuda()].cpu().numpy(), orc.encode(dims, flat, xs)) < TOL32
+    # (4) loss and gradient are additive over row shards
+    g_full, g_a, g_b = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+    h.fwd_bwd(x, g_full)
+    h.fwd_bwd(x[:cut], g_a)
+    h.fwd_bwd(x[cut:], g_b)
+    assert rel((g_a + g_b).cpu().numpy(), g_full.cpu().numpy()) < 1e-5
+    # (5) forward loss equals the loss slot of fwd_bwd
+    _, l = h.forward_loss(x, want_recon=False)
+    assert abs(l.item() - float(g_full[-1])) < 1e-5 * l.item()
+    # (6) decode(encode(x)) == forward(x)
+    recon, _ = h.forward_loss(x[:4096])
+    assert rel(h.decode(h.encode(x[:4096])).cpu().numpy(), recon.cpu().numpy()) < 1e-6
