@@ -139,7 +139,7 @@ int bamd_renormalize(const void *x, int dtype, int64_t n_rows, int n_cols, const
 int bamd_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features, void *z,
                 int z_dtype, void *stream) {
     BAMD_CHECK_MODEL(h);
-    BAMD_REQUIRE(x && z && n_rows >= 0, "bad arguments");
+    BAMD_REQUIRE(n_rows >= 0 && ((x && z) || n_rows == 0), "bad arguments");
     if (n_rows == 0) return BAMD_OK;
     hipStream_t s = (hipStream_t)stream;
     if (h->fused_ok) return fused_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
@@ -149,7 +149,7 @@ int bamd_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, cons
 int bamd_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n_rows, const double *features,
                 const uint8_t *int_mask, void *out, int out_dtype, void *stream) {
     BAMD_CHECK_MODEL(h);
-    BAMD_REQUIRE(z && out && n_rows >= 0, "bad arguments");
+    BAMD_REQUIRE(n_rows >= 0 && ((z && out) || n_rows == 0), "bad arguments");
     if (n_rows == 0) return BAMD_OK;
     hipStream_t s = (hipStream_t)stream;
     if (h->fused_ok) return fused_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);

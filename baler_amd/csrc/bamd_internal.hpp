@@ -11,7 +11,7 @@
 
 namespace bamd {
 
-constexpr float kSlope = 0.01f;  // F.leaky_relu default negative_slope (models.py:142-150)
+constexpr double kSlope = 0.01;  // F.leaky_relu default negative_slope (models.py:142-150); cast to T at use
 
 void set_error(const std::string &msg);
 
