@@ -97,6 +97,7 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
 void bamd_destroy(bamd_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    fused_teardown(h);
     h->params.release();
     h->packed.release();
     h->work.release();

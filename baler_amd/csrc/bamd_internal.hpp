@@ -60,6 +60,7 @@ struct bamd_handle {
     bamd::DevBuf lossp;             // partial loss sums (double)
     bool params_loaded = false;
     bool fused_ok = false;          // shape is served by the fused register-chained kernels
+    void *fused_state = nullptr;    // index maps of the fused path (fused.hip)
 
     bool has_act(int l) const { return !(l == L / 2 - 1 || l == L - 1); }
 };
