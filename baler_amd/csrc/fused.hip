@@ -15,9 +15,10 @@
 //
 // Training adds, per layer, the weight-gradient product  [dW | db] = dZ^T [X | 1]  reduced over the
 // workgroup's 64 rows: the four waves write their dZ^T / X^T tiles into a [slot][row] LDS image, and the
-// (n-tile, k-tile) outputs are dealt round-robin to the waves, accumulated into a PRIVATE per-workgroup
-// slab in fragment order (plain 16-byte loads/stores, no atomics).  A second kernel sums the slabs in a
-// fixed order into the canonical state-dict layout: bitwise reproducible.
+// (n-tile, k-tile) outputs are dealt round-robin to the waves, which keep them in MFMA accumulators for
+// the whole persistent loop.  At the end every workgroup stores its tiles once into a PRIVATE slab in
+// fragment order (plain 16-byte stores, no atomics) and a small kernel sums the slabs in a fixed order
+// into the canonical state-dict layout: bitwise reproducible.
 #include "fused.hpp"
 
 #include <cstdlib>
@@ -42,7 +43,6 @@ __host__ __device__ constexpr int slot_feature(int d, int t, int g, int r) {
 }
 
 constexpr int kQS = 68;        // LDS row stride (floats) of the [slot][row] images: 64 rows + 4 pad
-constexpr int kQRows = 208;    // 13 tiles
 constexpr int kRowsPerWG = 64;
 
 // ---- compile-time description of AE(F, Z): 8 layers F-200-100-50-Z-50-100-200-F -----------------------
@@ -52,17 +52,23 @@ template <int F, int Z> struct Net {
         return i == 0 ? F : i == 1 ? 200 : i == 2 ? 100 : i == 3 ? 50 : i == 4 ? Z : i == 5 ? 50 : i == 6 ? 100 : i == 7 ? 200 : F;
     }
     __host__ __device__ static constexpr bool act(int l) { return !(l == 3 || l == 7); }
-    // packed buffer (float4 units): [Wf of all layers | Wb of all layers | bias frags of all layers]
+    // packed buffer (float4 units):
+    //   [ Wf(0..7) | Wb(7,6,..,1) | bias frags | E: Wf(0..2) Wb(3,2,1) ]   (+ slack for the ring's pad reads)
+    // Wf = forward fragments, Wb = transposed fragments for the input-gradient chain, packed in the order
+    // the kernels consume them so that every kernel walks ONE linear stream.  Region E duplicates the
+    // encoder's fragments for the encoder-gradient kernel (forward 0..2 then backward 3..1).
     __host__ __device__ static constexpr int wcount(int l) { return tiles(dim(l)) * tiles(dim(l + 1)) * 64; }
     __host__ __device__ static constexpr int wf_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += wcount(j); return s; }
-    // transposed (backward) fragments, packed in consumption order: layer 7, 6, ..., 1 (layer 0 last, unused)
     __host__ __device__ static constexpr int wb_off(int l) { int s = wf_off(L); for (int j = L - 1; j > l; --j) s += wcount(j); return s; }
-    __host__ __device__ static constexpr int bf_off(int l) { int s = 2 * wf_off(L); for (int j = 0; j < l; ++j) s += tiles(dim(j + 1)) * 4; return s; }
-    __host__ __device__ static constexpr int packed_f4() { return bf_off(L); }
+    __host__ __device__ static constexpr int bf_off(int l) { int s = wb_off(0); for (int j = 0; j < l; ++j) s += tiles(dim(j + 1)) * 4; return s; }
+    __host__ __device__ static constexpr int e_off() { return (bf_off(L) + 63) / 64 * 64; }
+    __host__ __device__ static constexpr int ef_off(int l) { return e_off() + wf_off(l); }                       // l = 0..2
+    __host__ __device__ static constexpr int eb_off(int l) { int s = e_off() + wf_off(3); for (int j = 3; j > l; --j) s += wcount(j); return s; }  // l = 3..1
+    __host__ __device__ static constexpr int packed_f4() { return eb_off(0) + 16 * 64; }
     // weight-gradient tiles of layer l: tiles(N) x tiles(K + 1) (the extra slot carries db)
     __host__ __device__ static constexpr int dw_tiles(int l) { return tiles(dim(l + 1)) * tiles(dim(l) + 1); }
     __host__ __device__ static constexpr int slab_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += dw_tiles(j); return s; }
-    __host__ __device__ static constexpr int slab_f4() { return (slab_off(L) + 1) * 64 + 4; }  // + dummy tile + loss slot
+    __host__ __device__ static constexpr int slab_f4() { return slab_off(L) * 64 + 4; }  // + loss slot (16 B)
     // canonical (state-dict) offsets
     __host__ __device__ static constexpr int w_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += dim(j + 1) * dim(j) + dim(j + 1); return s; }
     __host__ __device__ static constexpr int b_off(int l) { return w_off(l) + dim(l + 1) * dim(l); }
@@ -105,20 +111,25 @@ __device__ __forceinline__ void ring_tail(Ring &ring, gv4p stream, int lane) {
 // stream fragments BASE .. BASE + tiles(KD)*NT - 1 in [q][t] order (component r = step r of k-tile q).
 template <int KD, int NT, int BASE, int TOTAL>
 __device__ __forceinline__ void chain_gemm(const v4 (&in)[tiles(KD)], v4 (&out)[NT], Ring &ring, gv4p stream, int lane) {
+    // v_mfma_f32_16x16x4_f32 issues every 32 cycles but a DEPENDENT accumulate needs 40: consecutive
+    // fragments (different output tiles) are walked in pairs with their MFMA steps interleaved, so each
+    // wave alternates between two independent accumulators and the pipe stays back-to-back at one wave
+    // per SIMD.
+    constexpr int NF = tiles(KD) * NT;
 #pragma unroll
-    for (int q = 0; q < tiles(KD); ++q) {
+    for (int f = 0; f < NF; f += 2) {
+        const int q0 = f / NT, t0 = f % NT;
+        const bool two = f + 1 < NF;
+        const int q1 = two ? (f + 1) / NT : q0, t1 = two ? (f + 1) % NT : t0;
+        const int s0 = (BASE + f) % kRing, s1 = (BASE + f + 1) % kRing;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            constexpr int dummy = 0;
-            const int G = BASE + q * NT + t;
-            const int sl = G % kRing;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < tile_steps(KD, q)) out[t] = mfma(ring.slot[sl][r], in[q][r], out[t]);
-            ring.slot[sl] = stream[((G + kRing) % pad_total(TOTAL)) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
-            (void)dummy;
+        for (int r = 0; r < 4; ++r) {
+            if (r < tile_steps(KD, q0)) out[t0] = mfma(ring.slot[s0][r], in[q0][r], out[t0]);
+            if (two && r < tile_steps(KD, q1)) out[t1] = mfma(ring.slot[s1][r], in[q1][r], out[t1]);
         }
+        ring.slot[s0] = stream[((BASE + f + kRing) % pad_total(TOTAL)) * 64 + lane];
+        if (two) ring.slot[s1] = stream[((BASE + f + 1 + kRing) % pad_total(TOTAL)) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -176,11 +187,17 @@ template <class N> struct StreamForward {  // forward fragments of layers 0..7
     static constexpr int total = N::wf_off(8) / 64;
     static constexpr int start_f4 = 0;
 };
-template <class N> struct StreamTrain {    // forward 0..7 then backward 7..1 (packed in that order)
+template <class N> struct StreamTrainDec {  // decoder-gradient kernel: forward 0..7 then backward 7,6,5,4
     static constexpr int fwd_base(int l) { return N::wf_off(l) / 64; }
-    static constexpr int bwd_base(int l) { return (N::wb_off(l)) / 64; }
-    static constexpr int total = N::wb_off(0) / 64;   // layer 0 needs no input gradient
+    static constexpr int bwd_base(int l) { return N::wb_off(l) / 64; }
+    static constexpr int total = N::wb_off(3) / 64;
     static constexpr int start_f4 = 0;
+};
+template <class N> struct StreamTrainEnc {  // encoder-gradient kernel: forward 0..2 then backward 3,2,1 (region E)
+    static constexpr int fwd_base(int l) { return (N::ef_off(l) - N::e_off()) / 64; }
+    static constexpr int bwd_base(int l) { return (N::eb_off(l) - N::e_off()) / 64; }
+    static constexpr int total = (N::eb_off(0) - N::e_off()) / 64;
+    static constexpr int start_f4 = N::e_off();
 };
 
 // ---- row I/O in slot order ------------------------------------------------------------------------------
@@ -312,7 +329,17 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
     }
 }
 
-// ---- training kernel ----------------------------------------------------------------------------------
+// ---- training kernels ---------------------------------------------------------------------------------
+// The autoencoder's bottleneck is the natural checkpoint: training runs as TWO launches over the same
+// rows.  The decoder-gradient kernel runs the whole forward, the loss, the decoder's backward chain and
+// accumulates the decoder's weight gradients; it hands dL/dz (15 floats per row) to the encoder-gradient
+// kernel, which recomputes the cheap encoder forward, runs the encoder's backward chain and accumulates
+// the encoder's weight gradients.  Each kernel therefore stashes only half of the activations in
+// registers (~100 per lane) and keeps its half of the weight-gradient tiles (38 per wave = 152
+// registers per lane) in accumulators for its WHOLE persistent loop: no partial-gradient traffic at all
+// inside the loop; one 150-KB slab store per workgroup at the end.  Cost: the encoder forward is
+// computed twice (+16 % MFMAs).  HBM traffic per row: x twice + dL/dz once each way (~0.5 KB).
+//
 // LDS image helpers: rows = feature slots (16t + 4g + r), columns = the workgroup's 64 batch rows.
 template <int NT>
 __device__ __forceinline__ void q_write(float *__restrict__ q, const v4 (&a)[NT], int lane, int wave) {
@@ -339,136 +366,140 @@ __device__ __forceinline__ void q_write_x(float *__restrict__ q, const v4 (&a)[t
         }
 }
 
-// [dW | db] tiles of layer l: D[n-slot][k-slot] = sum over the workgroup's 64 rows of dZ^T[n][m] X^T[k][m].
-// Tiles are dealt round-robin to the 4 waves; every wave runs the same static schedule (the surplus
-// tile of a short wave recomputes the last tile into a dummy slab tile), LDS fragment reads of tile i+1
-// are issued before the MFMAs of tile i, and the old slab tile is added AFTER the MFMA chain so its load
-// latency hides behind it.
+template <class N, int l> struct DW {
+    static constexpr int NT = tiles(N::dim(l + 1)), KT = tiles(N::dim(l) + 1), TOT = NT * KT, T = (TOT + 3) / 4;
+    static constexpr int rows_x = 16 * KT, rows_dz = 16 * NT;   // image rows
+};
+
+// [dW | db] tiles of layer l: D[n-slot][k-slot] += sum over the workgroup's 64 rows of dZ^T[n][m] X^T[k][m].
+// Tiles are dealt round-robin to the 4 waves (tile idx = wave + 4*it lives in acc[it] for the whole
+// kernel); every wave runs the same static schedule (the surplus tile of a short wave recomputes the last
+// tile into an accumulator that is never stored).  LDS fragment reads run DEPTH-1 steps ahead of the MFMAs.
 template <class N, int l>
-__device__ __forceinline__ void dw_phase(const float *__restrict__ qdz, const float *__restrict__ qx, v4 *__restrict__ slab,
-                                         bool accumulate, int lane, int wave) {
-    constexpr int NT = tiles(N::dim(l + 1)), KT = tiles(N::dim(l) + 1), TOT = NT * KT, T = (TOT + 3) / 4;
-    constexpr int U = 4 * T, DEPTH = 3;            // (tile, 16-row group) steps; LDS fragment lookahead
+__device__ __forceinline__ void dw_phase(const float *__restrict__ qdz, const float *__restrict__ qx,
+                                         v4 (&acc)[DW<N, l>::T], int lane, int wave) {
+    using D = DW<N, l>;
+    // step u = (tile pair p, 16-row group s): the two tiles of a pair are independent accumulators whose
+    // MFMAs alternate (see chain_gemm); LDS fragment reads run one step ahead of the MFMAs.
+    constexpr int NP = (D::T + 1) / 2, U = 4 * NP;
     const int g = lane >> 4, i = lane & 15;
-    v4 fa[DEPTH], fb[DEPTH];
-    auto lds_frags = [&](int u, v4 &a, v4 &b) {
-        int idx = wave + 4 * (u >> 2);
-        idx = idx < TOT ? idx : TOT - 1;
-        const int kt = idx / NT, nt = idx - kt * NT;
-        a = *(const v4 *)(qdz + (16 * nt + i) * kQS + 4 * g + 16 * (u & 3));
-        b = *(const v4 *)(qx + (16 * kt + i) * kQS + 4 * g + 16 * (u & 3));
-    };
+    v4 fa[2][2], fb[2][2];   // [buffer][tile of the pair]
+    auto lds_frags = [&](int u, v4 (&a)[2], v4 (&b)[2]) {
 #pragma unroll
-    for (int u = 0; u < DEPTH - 1; ++u) lds_frags(u, fa[u], fb[u]);
-    v4 acc, old;
-    v4 *dst = nullptr;
+        for (int h = 0; h < 2; ++h) {
+            const int it = 2 * (u >> 2) + h;
+            if (it < D::T) {
+                int idx = wave + 4 * it;
+                idx = idx < D::TOT ? idx : D::TOT - 1;
+                const int kt = idx / D::NT, nt = idx - kt * D::NT;
+                a[h] = *(const v4 *)(qdz + (16 * nt + i) * kQS + 4 * g + 16 * (u & 3));
+                b[h] = *(const v4 *)(qx + (16 * kt + i) * kQS + 4 * g + 16 * (u & 3));
+            }
+        }
+    };
+    lds_frags(0, fa[0], fb[0]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        if ((u & 3) == 0) {
-            const int idx = wave + 4 * (u >> 2);
-            // dead surplus tile -> dummy tile at the end of the slab (index slab_off(L))
-            dst = slab + (idx < TOT ? N::slab_off(l) + idx : N::slab_off(N::L)) * 64 + lane;
-            old = *dst;
-            acc = (v4){0.f, 0.f, 0.f, 0.f};
-        }
-        if (u + DEPTH - 1 < U) lds_frags(u + DEPTH - 1, fa[(u + DEPTH - 1) % DEPTH], fb[(u + DEPTH - 1) % DEPTH]);
+        if (u + 1 < U) lds_frags(u + 1, fa[(u + 1) & 1], fb[(u + 1) & 1]);
+        const int it0 = 2 * (u >> 2), it1 = it0 + 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma(fa[u % DEPTH][r], fb[u % DEPTH][r], acc);
-        if ((u & 3) == 3) {
-            if (accumulate) acc += old;
-            *dst = acc;
+        for (int r = 0; r < 4; ++r) {
+            acc[it0] = mfma(fa[u & 1][0][r], fb[u & 1][0][r], acc[it0]);
+            if (it1 < D::T) acc[it1] = mfma(fa[u & 1][1][r], fb[u & 1][1][r], acc[it1]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 template <class N, int l>
-__device__ __forceinline__ void layer_grads(const float *qdz, const float *qx, v4 *slab, bool accumulate, int lane, int wave) {
-    // (callers run the dX chain between the image writes and this function's first barrier)
-    __syncthreads();
-    dw_phase<N, l>(qdz, qx, slab, accumulate, lane, wave);
-    __syncthreads();
+__device__ __forceinline__ void dw_flush(v4 *__restrict__ slab, const v4 (&acc)[DW<N, l>::T], int lane, int wave) {
+#pragma unroll
+    for (int it = 0; it < DW<N, l>::T; ++it) {
+        const int idx = wave + 4 * it;
+        if (idx < DW<N, l>::TOT) slab[(N::slab_off(l) + idx) * 64 + lane] = acc[it];
+    }
 }
 
+// Image buffers alternate between two LDS regions (A: 240 slot rows, B: 320 slot rows) so that the next
+// layer's image writes never touch what a slower wave is still reading: ONE barrier per layer.
+constexpr int kImgA = 240, kImgB = 320;
+
 template <int F, int Z>
-__global__ void __launch_bounds__(256) train_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64,
-                                                    int64_t n, const double *__restrict__ feats, v4 *__restrict__ slabs) {
+__global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64,
+                                                        int64_t n, const double *__restrict__ feats, v4 *__restrict__ slabs,
+                                                        v4 *__restrict__ dz_out) {
     using N = Net<F, Z>;
-    using S = StreamTrain<N>;
+    using S = StreamTrainDec<N>;
+    static_assert(DW<N, 7>::rows_x + DW<N, 7>::rows_dz <= kImgA && DW<N, 6>::rows_x + DW<N, 6>::rows_dz <= kImgB &&
+                  DW<N, 5>::rows_x + DW<N, 5>::rows_dz <= kImgA && DW<N, 4>::rows_x + DW<N, 4>::rows_dz <= kImgB, "image buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *qx = lds, *qdz = lds + kQRows * kQS;
-    v4 *bias_lds = (v4 *)(lds + 2 * kQRows * kQS);
+    float *imgA = lds, *imgB = lds + kImgA * kQS;
+    v4 *bias_lds = (v4 *)(lds + (kImgA + kImgB) * kQS);
     stage_bias<N>(bias_lds, packed);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     v4 *slab = slabs + (int64_t)blockIdx.x * N::slab_f4();
     const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
-    gv4p stream = (gv4p)packed;
+    gv4p stream = (gv4p)packed + S::start_f4;
     double lacc = 0.0;
-    bool accumulate = false;
+    v4 g7[DW<N, 7>::T], g6[DW<N, 6>::T], g5[DW<N, 5>::T], g4[DW<N, 4>::T];
+    zero_tiles(g7); zero_tiles(g6); zero_tiles(g5); zero_tiles(g4);
     Ring ring;
     ring_prime<S::total>(ring, stream, lane);
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        // keep the weight loads AND the per-tile LDS address arithmetic inside the loop: both are loop
+        // invariant, and LICM would hoist hundreds of registers' worth of them (-> scratch spills)
+        asm volatile("" : "+s"(stream), "+s"(wave), "+v"(lane));
         const int64_t row = grp * kRowsPerWG + 16 * wave + (lane & 15);
         const bool valid = row < n;
-        asm volatile("" : "+s"(stream));  // keep the weight loads inside the loop (see infer_kernel)
-        // ---- forward, keeping every layer input (the stash) in registers
-        v4 a0[tiles(F)], a1[13], a2[7], a3[4], a4[tiles(Z)], a5[4], a6[7], a7[13];
-        v4 d8[tiles(F)];
-        load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
-        fwd_layer<N, S, 0>(a0, a1, ring, stream, bias_lds, lane);
-        fwd_layer<N, S, 1>(a1, a2, ring, stream, bias_lds, lane);
-        fwd_layer<N, S, 2>(a2, a3, ring, stream, bias_lds, lane);
-        fwd_layer<N, S, 3>(a3, a4, ring, stream, bias_lds, lane);
-        fwd_layer<N, S, 4>(a4, a5, ring, stream, bias_lds, lane);
-        fwd_layer<N, S, 5>(a5, a6, ring, stream, bias_lds, lane);
-        fwd_layer<N, S, 6>(a6, a7, ring, stream, bias_lds, lane);
-        fwd_layer<N, S, 7>(a7, d8, ring, stream, bias_lds, lane);
-        // ---- loss and dL/drecon = 2 (r - x)/C  (utils.py:195-199); invalid rows contribute nothing
+        v4 a4[tiles(Z)], a5[4], a6[7], a7[13], d8[tiles(F)];
+        {
+            v4 a0[tiles(F)], a1[13], a2[7], a3[4];
+            load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
+            fwd_layer<N, S, 0>(a0, a1, ring, stream, bias_lds, lane);
+            fwd_layer<N, S, 1>(a1, a2, ring, stream, bias_lds, lane);
+            fwd_layer<N, S, 2>(a2, a3, ring, stream, bias_lds, lane);
+            fwd_layer<N, S, 3>(a3, a4, ring, stream, bias_lds, lane);
+            fwd_layer<N, S, 4>(a4, a5, ring, stream, bias_lds, lane);
+            fwd_layer<N, S, 5>(a5, a6, ring, stream, bias_lds, lane);
+            fwd_layer<N, S, 6>(a6, a7, ring, stream, bias_lds, lane);
+            fwd_layer<N, S, 7>(a7, d8, ring, stream, bias_lds, lane);
+            // loss and dL/drecon = 2 (r - x)/C  (utils.py:195-199); invalid rows contribute nothing
 #pragma unroll
-        for (int t = 0; t < tiles(F); ++t)
+            for (int t = 0; t < tiles(F); ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float d = d8[t][r] - a0[t][r];
-                const bool live = valid && slot_feature(F, t, lane >> 4, r) >= 0;
-                if (live) lacc += (double)d * (double)d;
-                d8[t][r] = live ? d * (2.0f / (float)F) : 0.f;
-            }
-        // ---- backward: layer 8 .. 1.  Image writes, then the dX chain (registers only), then the
-        //      workgroup-wide weight-gradient tiles between two barriers.
-        v4 d7[13], d6[7], d5[4], d4[tiles(Z)], d3[4], d2[7], d1[13];
-        q_write(qdz, d8, lane, wave); q_write_x<200>(qx, a7, lane, wave);
+                for (int r = 0; r < 4; ++r) {
+                    float d = d8[t][r] - a0[t][r];
+                    const bool live = valid && slot_feature(F, t, lane >> 4, r) >= 0;
+                    if (live) lacc += (double)d * (double)d;
+                    d8[t][r] = live ? d * (2.0f / (float)F) : 0.f;
+                }
+        }
+        // decoder backward: per layer, image writes -> dX chain (registers only) -> barrier -> dW tiles
+        v4 d7[13], d6[7], d5[4], d4[tiles(Z)];
+        q_write_x<200>(imgA, a7, lane, wave); q_write(imgA + DW<N, 7>::rows_x * kQS, d8, lane, wave);
         bwd_layer<N, S, 7>(d8, d7, ring, stream, lane); lrelu_bwd(d7, a7);
-        layer_grads<N, 7>(qdz, qx, slab, accumulate, lane, wave);
+        __syncthreads();
+        dw_phase<N, 7>(imgA + DW<N, 7>::rows_x * kQS, imgA, g7, lane, wave);
 
-        q_write(qdz, d7, lane, wave); q_write_x<100>(qx, a6, lane, wave);
+        q_write_x<100>(imgB, a6, lane, wave); q_write(imgB + DW<N, 6>::rows_x * kQS, d7, lane, wave);
         bwd_layer<N, S, 6>(d7, d6, ring, stream, lane); lrelu_bwd(d6, a6);
-        layer_grads<N, 6>(qdz, qx, slab, accumulate, lane, wave);
+        __syncthreads();
+        dw_phase<N, 6>(imgB + DW<N, 6>::rows_x * kQS, imgB, g6, lane, wave);
 
-        q_write(qdz, d6, lane, wave); q_write_x<50>(qx, a5, lane, wave);
+        q_write_x<50>(imgA, a5, lane, wave); q_write(imgA + DW<N, 5>::rows_x * kQS, d6, lane, wave);
         bwd_layer<N, S, 5>(d6, d5, ring, stream, lane); lrelu_bwd(d5, a5);
-        layer_grads<N, 5>(qdz, qx, slab, accumulate, lane, wave);
+        __syncthreads();
+        dw_phase<N, 5>(imgA + DW<N, 5>::rows_x * kQS, imgA, g5, lane, wave);
 
-        q_write(qdz, d5, lane, wave); q_write_x<Z>(qx, a4, lane, wave);
-        bwd_layer<N, S, 4>(d5, d4, ring, stream, lane);            // en4 has no activation
-        layer_grads<N, 4>(qdz, qx, slab, accumulate, lane, wave);
-
-        q_write(qdz, d4, lane, wave); q_write_x<50>(qx, a3, lane, wave);
-        bwd_layer<N, S, 3>(d4, d3, ring, stream, lane); lrelu_bwd(d3, a3);
-        layer_grads<N, 3>(qdz, qx, slab, accumulate, lane, wave);
-
-        q_write(qdz, d3, lane, wave); q_write_x<100>(qx, a2, lane, wave);
-        bwd_layer<N, S, 2>(d3, d2, ring, stream, lane); lrelu_bwd(d2, a2);
-        layer_grads<N, 2>(qdz, qx, slab, accumulate, lane, wave);
-
-        q_write(qdz, d2, lane, wave); q_write_x<200>(qx, a1, lane, wave);
-        bwd_layer<N, S, 1>(d2, d1, ring, stream, lane); lrelu_bwd(d1, a1);
-        layer_grads<N, 1>(qdz, qx, slab, accumulate, lane, wave);
-
-        q_write(qdz, d1, lane, wave); q_write_x<F>(qx, a0, lane, wave);
-        layer_grads<N, 0>(qdz, qx, slab, accumulate, lane, wave);
+        q_write_x<Z>(imgB, a4, lane, wave); q_write(imgB + DW<N, 4>::rows_x * kQS, d5, lane, wave);
+        bwd_layer<N, S, 4>(d5, d4, ring, stream, lane);            // en4 has no activation: dL/dz
+        if (valid) dz_out[row * 4 + (lane >> 4)] = d4[0];           // 16 slots per row, slot order
+        __syncthreads();
+        dw_phase<N, 4>(imgB + DW<N, 4>::rows_x * kQS, imgB, g4, lane, wave);
         ring_tail<S::total>(ring, stream, lane);
-        accumulate = true;
     }
+    dw_flush<N, 7>(slab, g7, lane, wave); dw_flush<N, 6>(slab, g6, lane, wave);
+    dw_flush<N, 5>(slab, g5, lane, wave); dw_flush<N, 4>(slab, g4, lane, wave);
     // per-workgroup loss partial (fixed-order tree)
     __syncthreads();
     double *sh = (double *)lds;
@@ -478,7 +509,64 @@ __global__ void __launch_bounds__(256) train_kernel(const v4 *packed, const void
         if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *(double *)(slab + (N::slab_off(N::L) + 1) * 64) = sh[0];
+    if (threadIdx.x == 0) *(double *)(slab + N::slab_off(N::L) * 64) = sh[0];
+}
+
+template <int F, int Z>
+__global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64,
+                                                        int64_t n, const double *__restrict__ feats, v4 *__restrict__ slabs,
+                                                        const v4 *__restrict__ dz_in) {
+    using N = Net<F, Z>;
+    using S = StreamTrainEnc<N>;
+    static_assert(Z <= 16, "dL/dz hand-off is one tile per row");
+    static_assert(DW<N, 3>::rows_x + DW<N, 3>::rows_dz <= kImgB && DW<N, 2>::rows_x + DW<N, 2>::rows_dz <= kImgA &&
+                  DW<N, 1>::rows_x + DW<N, 1>::rows_dz <= kImgB && DW<N, 0>::rows_x + DW<N, 0>::rows_dz <= kImgA, "image buffers");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *imgA = lds, *imgB = lds + kImgA * kQS;   // layers 3,1 -> B ; layers 2,0 -> A : one barrier per layer
+    v4 *bias_lds = (v4 *)(lds + (kImgA + kImgB) * kQS);
+    stage_bias<N>(bias_lds, packed);
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    v4 *slab = slabs + (int64_t)blockIdx.x * N::slab_f4();
+    const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
+    gv4p stream = (gv4p)packed + S::start_f4;
+    v4 g3[DW<N, 3>::T], g2[DW<N, 2>::T], g1[DW<N, 1>::T], g0[DW<N, 0>::T];
+    zero_tiles(g3); zero_tiles(g2); zero_tiles(g1); zero_tiles(g0);
+    Ring ring;
+    ring_prime<S::total>(ring, stream, lane);
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        asm volatile("" : "+s"(stream), "+s"(wave), "+v"(lane));   // see train_dec_kernel
+        const int64_t row = grp * kRowsPerWG + 16 * wave + (lane & 15);
+        const bool valid = row < n;
+        v4 a0[tiles(F)], a1[13], a2[7], a3[4], d4[tiles(Z)];
+        load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
+        d4[0] = valid ? dz_in[row * 4 + (lane >> 4)] : (v4){0.f, 0.f, 0.f, 0.f};
+        fwd_layer<N, S, 0>(a0, a1, ring, stream, bias_lds, lane);
+        fwd_layer<N, S, 1>(a1, a2, ring, stream, bias_lds, lane);
+        fwd_layer<N, S, 2>(a2, a3, ring, stream, bias_lds, lane);
+        // (z itself is not needed again: en4's weight gradient uses a3 and dL/dz)
+        v4 d3[4], d2[7], d1[13];
+        q_write_x<50>(imgB, a3, lane, wave); q_write(imgB + DW<N, 3>::rows_x * kQS, d4, lane, wave);
+        bwd_layer<N, S, 3>(d4, d3, ring, stream, lane); lrelu_bwd(d3, a3);
+        __syncthreads();
+        dw_phase<N, 3>(imgB + DW<N, 3>::rows_x * kQS, imgB, g3, lane, wave);
+
+        q_write_x<100>(imgA, a2, lane, wave); q_write(imgA + DW<N, 2>::rows_x * kQS, d3, lane, wave);
+        bwd_layer<N, S, 2>(d3, d2, ring, stream, lane); lrelu_bwd(d2, a2);
+        __syncthreads();
+        dw_phase<N, 2>(imgA + DW<N, 2>::rows_x * kQS, imgA, g2, lane, wave);
+
+        q_write_x<200>(imgB, a1, lane, wave); q_write(imgB + DW<N, 1>::rows_x * kQS, d2, lane, wave);
+        bwd_layer<N, S, 1>(d2, d1, ring, stream, lane); lrelu_bwd(d1, a1);
+        __syncthreads();
+        dw_phase<N, 1>(imgB + DW<N, 1>::rows_x * kQS, imgB, g1, lane, wave);
+
+        q_write_x<F>(imgA, a0, lane, wave); q_write(imgA + DW<N, 0>::rows_x * kQS, d1, lane, wave);
+        __syncthreads();
+        dw_phase<N, 0>(imgA + DW<N, 0>::rows_x * kQS, imgA, g0, lane, wave);
+        ring_tail<S::total>(ring, stream, lane);
+    }
+    dw_flush<N, 3>(slab, g3, lane, wave); dw_flush<N, 2>(slab, g2, lane, wave);
+    dw_flush<N, 1>(slab, g1, lane, wave); dw_flush<N, 0>(slab, g0, lane, wave);
 }
 
 // grads[p] = sum over workgroup slabs (fixed order) of slab[map[p]];  grads[np] = sum of loss partials / C
@@ -520,6 +608,7 @@ __global__ void sum_loss_k(const double *__restrict__ part, int n, double scale,
 struct FusedState {
     DevBuf pack_src;   // int per packed float: canonical parameter index or -1
     DevBuf slab_map;   // int per canonical parameter: float offset inside a slab
+    DevBuf dz;         // dL/dz hand-off between the two training kernels: 16 floats per row
     int packed_floats = 0;
     int nwg_max = 256;
 };
@@ -541,8 +630,8 @@ static int build_maps(bamd_handle *h, FusedState *st) {
                         if (nf >= 0 && kf >= 0)
                             src[((size_t)N::wf_off(l) + (q * NT + t) * 64 + lane) * 4 + r] = N::w_off(l) + nf * K + kf;
                     }
-        // backward frags: [tq][tk][lane].comp[r] = W[n(tq, g, r)][k(tk, i)]
-        for (int tq = 0; tq < NT; ++tq)
+        // backward frags (layers 1..7): [tq][tk][lane].comp[r] = W[n(tq, g, r)][k(tk, i)]
+        for (int tq = 0; tq < NT && l >= 1; ++tq)
             for (int tk = 0; tk < KT; ++tk)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int r = 0; r < 4; ++r) {
@@ -577,6 +666,11 @@ static int build_maps(bamd_handle *h, FusedState *st) {
                         }
                     }
     }
+    // region E: copies of Wf(0..2) and Wb(3,2,1) in the encoder-gradient kernel's consumption order
+    for (int l = 0; l < 3; ++l)
+        for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::ef_off(l) * 4 + i] = src[(size_t)N::wf_off(l) * 4 + i];
+    for (int l = 3; l >= 1; --l)
+        for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::eb_off(l) * 4 + i] = src[(size_t)N::wb_off(l) * 4 + i];
     for (int v : smap)
         if (v < 0) { set_error("fused: incomplete slab map"); return BAMD_ERR_INVALID; }
     st->packed_floats = (int)src.size();
@@ -592,7 +686,7 @@ static int build_maps(bamd_handle *h, FusedState *st) {
 
 constexpr int kF = 24, kZ = 15;   // the instantiated shape: CMS example, compression_ratio 1.6
 using CMS = Net<kF, kZ>;
-constexpr int kTrainLds = 2 * kQRows * kQS * (int)sizeof(float) + (CMS::bf_off(CMS::L) - CMS::bf_off(0)) * 16;
+constexpr int kTrainLds = (kImgA + kImgB) * kQS * (int)sizeof(float) + (CMS::bf_off(CMS::L) - CMS::bf_off(0)) * 16;
 
 static bool shape_is_cms(const bamd_handle *h) {
     if (h->L != 8 || h->mode != BAMD_MODE_F32) return false;
@@ -614,7 +708,9 @@ int fused_setup(bamd_handle *h) {
     h->fused_state = st;
     int rc = build_maps<kF, kZ>(h, st);
     if (rc) return rc;
-    BAMD_HIP(hipFuncSetAttribute((const void *)train_kernel<kF, kZ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    BAMD_HIP(hipFuncSetAttribute((const void *)train_dec_kernel<kF, kZ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 kTrainLds));
+    BAMD_HIP(hipFuncSetAttribute((const void *)train_enc_kernel<kF, kZ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  kTrainLds));
     h->fused_ok = true;
     return BAMD_OK;
@@ -625,6 +721,7 @@ void fused_teardown(bamd_handle *h) {
     if (!st) return;
     st->pack_src.release();
     st->slab_map.release();
+    st->dz.release();
     delete st;
     h->fused_state = nullptr;
 }
@@ -680,12 +777,16 @@ int fused_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const d
     const size_t slab_bytes = (size_t)CMS::slab_f4() * 16;
     int rc = h->slabs.ensure(slab_bytes * (size_t)grid);
     if (rc) return rc;
+    rc = st->dz.ensure((size_t)n * 64);
+    if (rc) return rc;
     const int lds_bytes = kTrainLds;
-    hipLaunchKernelGGL((train_kernel<kF, kZ>), dim3(grid), dim3(256), lds_bytes, s, (const v4 *)h->packed.p, x,
-                       x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p);
+    hipLaunchKernelGGL((train_dec_kernel<kF, kZ>), dim3(grid), dim3(256), lds_bytes, s, (const v4 *)h->packed.p, x,
+                       x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (v4 *)st->dz.p);
+    hipLaunchKernelGGL((train_enc_kernel<kF, kZ>), dim3(grid), dim3(256), lds_bytes, s, (const v4 *)h->packed.p, x,
+                       x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (const v4 *)st->dz.p);
     const int np = CMS::nparams();
     hipLaunchKernelGGL(reduce_slabs_map_k<float>, dim3((np + 1 + 255) / 256), dim3(256), 0, s, (const float *)h->slabs.p,
-                       grid, (int64_t)CMS::slab_f4() * 4, (const int *)st->slab_map.p, np, (CMS::slab_off(CMS::L) + 1) * 64 * 4,
+                       grid, (int64_t)CMS::slab_f4() * 4, (const int *)st->slab_map.p, np, CMS::slab_off(CMS::L) * 64 * 4,
                        1.0 / kF, (float *)grads);
     BAMD_HIP(hipGetLastError());
     return BAMD_OK;
