@@ -83,7 +83,24 @@ __device__ __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_am
 // has fed its MFMAs, its ring slot is refilled with fragment G + P (wrapping to the next iteration), so
 // every L2 access has P*4 MFMAs (~2 us) to land.  sched_barrier(0) pins that order; hipcc inserts the
 // counted s_waitcnt vmcnt(P-1) itself.
-typedef const v4 __attribute__((address_space(1))) *gv4p;
+// Loads go through a buffer resource: ONE per-lane offset VGPR (lane*16) serves every fragment, the
+// fragment index is an SGPR offset (s_mov), so the ring costs no address arithmetic and no address
+// registers (flat/global loads made hipcc rebuild a 64-bit address per load in registers that aliased
+// in-flight ring slots, which forced s_waitcnt vmcnt(0) in the middle of the pipeline).
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;   // lane * 16
+};
+__device__ __forceinline__ WStream make_stream(const v4 *base, int bytes, int lane) {
+    WStream ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, bytes, 0x00020000);
+    ws.voff = lane * 16;
+    return ws;
+}
+__device__ __forceinline__ v4 frag(const WStream &ws, int idx) {
+    return __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
+}
 constexpr int kRing = 8;
 struct Ring { v4 slot[kRing]; };
 
@@ -93,24 +110,24 @@ struct Ring { v4 slot[kRing]; };
 __host__ __device__ constexpr int pad_total(int t) { return (t + kRing - 1) / kRing * kRing; }
 
 template <int TOTAL>
-__device__ __forceinline__ void ring_prime(Ring &ring, gv4p stream, int lane) {
+__device__ __forceinline__ void ring_prime(Ring &ring, const WStream &ws) {
     static_assert(TOTAL >= kRing, "stream shorter than the ring");
 #pragma unroll
-    for (int i = 0; i < kRing; ++i) ring.slot[i] = stream[i * 64 + lane];
+    for (int i = 0; i < kRing; ++i) ring.slot[i] = frag(ws, i);
 }
 // end of an iteration: step over the pad fragments, refilling their slots for the next iteration
 template <int TOTAL>
-__device__ __forceinline__ void ring_tail(Ring &ring, gv4p stream, int lane) {
+__device__ __forceinline__ void ring_tail(Ring &ring, const WStream &ws) {
 #pragma unroll
     for (int G = TOTAL; G < pad_total(TOTAL); ++G)
-        ring.slot[G % kRing] = stream[((G + kRing) % pad_total(TOTAL)) * 64 + lane];
+        ring.slot[G % kRing] = frag(ws, (G + kRing) % pad_total(TOTAL));
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // out^T tiles += frags . in^T tiles;  KD = reduction dimension (size of `in`); this layer's fragments are
 // stream fragments BASE .. BASE + tiles(KD)*NT - 1 in [q][t] order (component r = step r of k-tile q).
 template <int KD, int NT, int BASE, int TOTAL>
-__device__ __forceinline__ void chain_gemm(const v4 (&in)[tiles(KD)], v4 (&out)[NT], Ring &ring, gv4p stream, int lane) {
+__device__ __forceinline__ void chain_gemm(const v4 (&in)[tiles(KD)], v4 (&out)[NT], Ring &ring, const WStream &ws) {
     // v_mfma_f32_16x16x4_f32 issues every 32 cycles but a DEPENDENT accumulate needs 40: consecutive
     // fragments (different output tiles) are walked in pairs with their MFMA steps interleaved, so each
     // wave alternates between two independent accumulators and the pipe stays back-to-back at one wave
@@ -127,8 +144,8 @@ __device__ __forceinline__ void chain_gemm(const v4 (&in)[tiles(KD)], v4 (&out)[
             if (r < tile_steps(KD, q0)) out[t0] = mfma(ring.slot[s0][r], in[q0][r], out[t0]);
             if (two && r < tile_steps(KD, q1)) out[t1] = mfma(ring.slot[s1][r], in[q1][r], out[t1]);
         }
-        ring.slot[s0] = stream[((BASE + f + kRing) % pad_total(TOTAL)) * 64 + lane];
-        if (two) ring.slot[s1] = stream[((BASE + f + 1 + kRing) % pad_total(TOTAL)) * 64 + lane];
+        ring.slot[s0] = frag(ws, (BASE + f + kRing) % pad_total(TOTAL));
+        if (two) ring.slot[s1] = frag(ws, (BASE + f + 1 + kRing) % pad_total(TOTAL));
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -158,17 +175,17 @@ template <int NT> __device__ __forceinline__ void lrelu_bwd(v4 (&d)[NT], const v
 // one Linear layer of the forward chain.  S = stream description (frag base of every layer, total)
 template <class N, class S, int l>
 __device__ __forceinline__ void fwd_layer(const v4 (&in)[tiles(N::dim(l))], v4 (&out)[tiles(N::dim(l + 1))],
-                                          Ring &ring, gv4p stream, const v4 *bias_lds, int lane) {
+                                          Ring &ring, const WStream &ws, const v4 *bias_lds, int lane) {
     init_bias(out, bias_lds + (N::bf_off(l) - N::bf_off(0)), lane);
-    chain_gemm<N::dim(l), tiles(N::dim(l + 1)), S::fwd_base(l), S::total>(in, out, ring, stream, lane);
+    chain_gemm<N::dim(l), tiles(N::dim(l + 1)), S::fwd_base(l), S::total>(in, out, ring, ws);
     if (N::act(l)) lrelu(out);
 }
 // dY_{l-1}^T = W_l^T dZ_l^T
 template <class N, class S, int l>
 __device__ __forceinline__ void bwd_layer(const v4 (&dz)[tiles(N::dim(l + 1))], v4 (&dx)[tiles(N::dim(l))],
-                                          Ring &ring, gv4p stream, int lane) {
+                                          Ring &ring, const WStream &ws) {
     zero_tiles(dx);
-    chain_gemm<N::dim(l + 1), tiles(N::dim(l)), S::bwd_base(l), S::total>(dz, dx, ring, stream, lane);
+    chain_gemm<N::dim(l + 1), tiles(N::dim(l)), S::bwd_base(l), S::total>(dz, dx, ring, ws);
 }
 
 // stream descriptions: which layers' fragments a kernel iteration walks, in order
@@ -204,24 +221,43 @@ template <class N> struct StreamTrainEnc {  // encoder-gradient kernel: forward 
 template <int D>
 __device__ __forceinline__ void load_rows(v4 (&a)[tiles(D)], const void *x, int is_f64, int64_t row, bool valid,
                                           int lane, const double *__restrict__ feats) {
+    // all loads of the tile are issued back to back (one exec region), conversions afterwards
+    constexpr int NS = tiles(D) * 4;
     const int g = lane >> 4;
+    double v[NS];
 #pragma unroll
-    for (int t = 0; t < tiles(D); ++t)
+    for (int s = 0; s < NS; ++s) v[s] = 0.0;
+    if (valid) {
+        if (is_f64) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = slot_feature(D, t, g, r);
-            float v = 0.f;
-            if (valid && f >= 0) {
-                const int64_t i = row * D + f;
-                if (feats) {
-                    double d = is_f64 ? ((const double *)x)[i] : (double)((const float *)x)[i];
-                    v = (float)((d - feats[f]) / feats[D + f]);   // (x - min)/(max - min) in float64
-                } else {
-                    v = is_f64 ? (float)((const double *)x)[i] : ((const float *)x)[i];
-                }
+            for (int s = 0; s < NS; ++s) {
+                const int f = slot_feature(D, s >> 2, g, s & 3);
+                if (f >= 0) v[s] = ((const double *)x)[row * D + f];
             }
-            a[t][r] = v;
+        } else {
+            float w[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int f = slot_feature(D, s >> 2, g, s & 3);
+                w[s] = f >= 0 ? ((const float *)x)[row * D + f] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) v[s] = (double)w[s];
         }
+        if (feats) {
+            double mn[NS], rg[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int f = slot_feature(D, s >> 2, g, s & 3);
+                mn[s] = f >= 0 ? feats[f] : 0.0;
+                rg[s] = f >= 0 ? feats[D + f] : 1.0;
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) v[s] = (v[s] - mn[s]) / rg[s];   // (x - min)/(max - min) in float64
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s >> 2][s & 3] = (float)v[s];
 }
 
 template <int D>
@@ -270,31 +306,31 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
     stage_bias<N>(bias_lds, packed);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t ntile = (n + 15) / 16;
-    gv4p stream = (gv4p)packed + S::start_f4;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, threadIdx.x & 63);
     double lacc = 0.0;
     Ring ring;
-    ring_prime<S::total>(ring, stream, lane);
+    ring_prime<S::total>(ring, ws);
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
         const int64_t row = tile * 16 + (lane & 15);
         const bool valid = row < n;
         // keep the weight loads INSIDE the loop: without this LICM hoists all of them (loop-invariant
         // addresses) and spills the whole model to scratch
-        asm volatile("" : "+s"(stream));
+        asm volatile("" : "+v"(ws.voff));
         if (KIND == K_ENCODE || KIND == K_FORWARD) {
             v4 a0[tiles(F)], a1[13], a2[7], a3[4], a4[tiles(Z)];
             load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
-            fwd_layer<N, S, 0>(a0, a1, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 1>(a1, a2, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 2>(a2, a3, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 3>(a3, a4, ring, stream, bias_lds, lane);
+            fwd_layer<N, S, 0>(a0, a1, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
             if (KIND == K_ENCODE) {
                 store_rows<Z>(a4, out, out_f64, row, valid, lane, nullptr, nullptr);
             } else {
                 v4 a5[4], a6[7], a7[13], a8[tiles(F)];
-                fwd_layer<N, S, 4>(a4, a5, ring, stream, bias_lds, lane);
-                fwd_layer<N, S, 5>(a5, a6, ring, stream, bias_lds, lane);
-                fwd_layer<N, S, 6>(a6, a7, ring, stream, bias_lds, lane);
-                fwd_layer<N, S, 7>(a7, a8, ring, stream, bias_lds, lane);
+                fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
+                fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
+                fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
+                fwd_layer<N, S, 7>(a7, a8, ring, ws, bias_lds, lane);
                 if (out) store_rows<F>(a8, out, out_f64, row, valid, lane, nullptr, nullptr);
                 if (valid) {
 #pragma unroll
@@ -310,13 +346,13 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
         } else {
             v4 a4[tiles(Z)], a5[4], a6[7], a7[13], a8[tiles(F)];
             load_rows<Z>(a4, xin, in_f64, row, valid, lane, nullptr);
-            fwd_layer<N, S, 4>(a4, a5, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 5>(a5, a6, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 6>(a6, a7, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 7>(a7, a8, ring, stream, bias_lds, lane);
+            fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 7>(a7, a8, ring, ws, bias_lds, lane);
             store_rows<F>(a8, out, out_f64, row, valid, lane, feats, imask);
         }
-        ring_tail<S::total>(ring, stream, lane);
+        ring_tail<S::total>(ring, ws);
     }
     if (KIND == K_FORWARD) {
         sh[threadIdx.x] = lacc;
@@ -439,30 +475,30 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     v4 *slab = slabs + (int64_t)blockIdx.x * N::slab_f4();
     const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
-    gv4p stream = (gv4p)packed + S::start_f4;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, threadIdx.x & 63);
     double lacc = 0.0;
     v4 g7[DW<N, 7>::T], g6[DW<N, 6>::T], g5[DW<N, 5>::T], g4[DW<N, 4>::T];
     zero_tiles(g7); zero_tiles(g6); zero_tiles(g5); zero_tiles(g4);
     Ring ring;
-    ring_prime<S::total>(ring, stream, lane);
+    ring_prime<S::total>(ring, ws);
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         // keep the weight loads AND the per-tile LDS address arithmetic inside the loop: both are loop
         // invariant, and LICM would hoist hundreds of registers' worth of them (-> scratch spills)
-        asm volatile("" : "+s"(stream), "+s"(wave), "+v"(lane));
+        asm volatile("" : "+v"(ws.voff), "+s"(wave), "+v"(lane));
         const int64_t row = grp * kRowsPerWG + 16 * wave + (lane & 15);
         const bool valid = row < n;
         v4 a4[tiles(Z)], a5[4], a6[7], a7[13], d8[tiles(F)];
         {
             v4 a0[tiles(F)], a1[13], a2[7], a3[4];
             load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
-            fwd_layer<N, S, 0>(a0, a1, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 1>(a1, a2, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 2>(a2, a3, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 3>(a3, a4, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 4>(a4, a5, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 5>(a5, a6, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 6>(a6, a7, ring, stream, bias_lds, lane);
-            fwd_layer<N, S, 7>(a7, d8, ring, stream, bias_lds, lane);
+            fwd_layer<N, S, 0>(a0, a1, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 7>(a7, d8, ring, ws, bias_lds, lane);
             // loss and dL/drecon = 2 (r - x)/C  (utils.py:195-199); invalid rows contribute nothing
 #pragma unroll
             for (int t = 0; t < tiles(F); ++t)
@@ -477,26 +513,26 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
         // decoder backward: per layer, image writes -> dX chain (registers only) -> barrier -> dW tiles
         v4 d7[13], d6[7], d5[4], d4[tiles(Z)];
         q_write_x<200>(imgA, a7, lane, wave); q_write(imgA + DW<N, 7>::rows_x * kQS, d8, lane, wave);
-        bwd_layer<N, S, 7>(d8, d7, ring, stream, lane); lrelu_bwd(d7, a7);
+        bwd_layer<N, S, 7>(d8, d7, ring, ws); lrelu_bwd(d7, a7);
         __syncthreads();
         dw_phase<N, 7>(imgA + DW<N, 7>::rows_x * kQS, imgA, g7, lane, wave);
 
         q_write_x<100>(imgB, a6, lane, wave); q_write(imgB + DW<N, 6>::rows_x * kQS, d7, lane, wave);
-        bwd_layer<N, S, 6>(d7, d6, ring, stream, lane); lrelu_bwd(d6, a6);
+        bwd_layer<N, S, 6>(d7, d6, ring, ws); lrelu_bwd(d6, a6);
         __syncthreads();
         dw_phase<N, 6>(imgB + DW<N, 6>::rows_x * kQS, imgB, g6, lane, wave);
 
         q_write_x<50>(imgA, a5, lane, wave); q_write(imgA + DW<N, 5>::rows_x * kQS, d6, lane, wave);
-        bwd_layer<N, S, 5>(d6, d5, ring, stream, lane); lrelu_bwd(d5, a5);
+        bwd_layer<N, S, 5>(d6, d5, ring, ws); lrelu_bwd(d5, a5);
         __syncthreads();
         dw_phase<N, 5>(imgA + DW<N, 5>::rows_x * kQS, imgA, g5, lane, wave);
 
         q_write_x<Z>(imgB, a4, lane, wave); q_write(imgB + DW<N, 4>::rows_x * kQS, d5, lane, wave);
-        bwd_layer<N, S, 4>(d5, d4, ring, stream, lane);            // en4 has no activation: dL/dz
+        bwd_layer<N, S, 4>(d5, d4, ring, ws);            // en4 has no activation: dL/dz
         if (valid) dz_out[row * 4 + (lane >> 4)] = d4[0];           // 16 slots per row, slot order
         __syncthreads();
         dw_phase<N, 4>(imgB + DW<N, 4>::rows_x * kQS, imgB, g4, lane, wave);
-        ring_tail<S::total>(ring, stream, lane);
+        ring_tail<S::total>(ring, ws);
     }
     dw_flush<N, 7>(slab, g7, lane, wave); dw_flush<N, 6>(slab, g6, lane, wave);
     dw_flush<N, 5>(slab, g5, lane, wave); dw_flush<N, 4>(slab, g4, lane, wave);
@@ -528,42 +564,42 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     v4 *slab = slabs + (int64_t)blockIdx.x * N::slab_f4();
     const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
-    gv4p stream = (gv4p)packed + S::start_f4;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, threadIdx.x & 63);
     v4 g3[DW<N, 3>::T], g2[DW<N, 2>::T], g1[DW<N, 1>::T], g0[DW<N, 0>::T];
     zero_tiles(g3); zero_tiles(g2); zero_tiles(g1); zero_tiles(g0);
     Ring ring;
-    ring_prime<S::total>(ring, stream, lane);
+    ring_prime<S::total>(ring, ws);
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        asm volatile("" : "+s"(stream), "+s"(wave), "+v"(lane));   // see train_dec_kernel
+        asm volatile("" : "+v"(ws.voff), "+s"(wave), "+v"(lane));   // see train_dec_kernel
         const int64_t row = grp * kRowsPerWG + 16 * wave + (lane & 15);
         const bool valid = row < n;
         v4 a0[tiles(F)], a1[13], a2[7], a3[4], d4[tiles(Z)];
         load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
         d4[0] = valid ? dz_in[row * 4 + (lane >> 4)] : (v4){0.f, 0.f, 0.f, 0.f};
-        fwd_layer<N, S, 0>(a0, a1, ring, stream, bias_lds, lane);
-        fwd_layer<N, S, 1>(a1, a2, ring, stream, bias_lds, lane);
-        fwd_layer<N, S, 2>(a2, a3, ring, stream, bias_lds, lane);
+        fwd_layer<N, S, 0>(a0, a1, ring, ws, bias_lds, lane);
+        fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
+        fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
         // (z itself is not needed again: en4's weight gradient uses a3 and dL/dz)
         v4 d3[4], d2[7], d1[13];
         q_write_x<50>(imgB, a3, lane, wave); q_write(imgB + DW<N, 3>::rows_x * kQS, d4, lane, wave);
-        bwd_layer<N, S, 3>(d4, d3, ring, stream, lane); lrelu_bwd(d3, a3);
+        bwd_layer<N, S, 3>(d4, d3, ring, ws); lrelu_bwd(d3, a3);
         __syncthreads();
         dw_phase<N, 3>(imgB + DW<N, 3>::rows_x * kQS, imgB, g3, lane, wave);
 
         q_write_x<100>(imgA, a2, lane, wave); q_write(imgA + DW<N, 2>::rows_x * kQS, d3, lane, wave);
-        bwd_layer<N, S, 2>(d3, d2, ring, stream, lane); lrelu_bwd(d2, a2);
+        bwd_layer<N, S, 2>(d3, d2, ring, ws); lrelu_bwd(d2, a2);
         __syncthreads();
         dw_phase<N, 2>(imgA + DW<N, 2>::rows_x * kQS, imgA, g2, lane, wave);
 
         q_write_x<200>(imgB, a1, lane, wave); q_write(imgB + DW<N, 1>::rows_x * kQS, d2, lane, wave);
-        bwd_layer<N, S, 1>(d2, d1, ring, stream, lane); lrelu_bwd(d1, a1);
+        bwd_layer<N, S, 1>(d2, d1, ring, ws); lrelu_bwd(d1, a1);
         __syncthreads();
         dw_phase<N, 1>(imgB + DW<N, 1>::rows_x * kQS, imgB, g1, lane, wave);
 
         q_write_x<F>(imgA, a0, lane, wave); q_write(imgA + DW<N, 0>::rows_x * kQS, d1, lane, wave);
         __syncthreads();
         dw_phase<N, 0>(imgA + DW<N, 0>::rows_x * kQS, imgA, g0, lane, wave);
-        ring_tail<S::total>(ring, stream, lane);
+        ring_tail<S::total>(ring, ws);
     }
     dw_flush<N, 3>(slab, g3, lane, wave); dw_flush<N, 2>(slab, g2, lane, wave);
     dw_flush<N, 1>(slab, g1, lane, wave); dw_flush<N, 0>(slab, g0, lane, wave);
