@@ -56,6 +56,10 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
     BAMD_REQUIRE(dims && out, "null argument");
     BAMD_REQUIRE(n_layers >= 2 && n_layers % 2 == 0, "n_layers must be even and >= 2");
     BAMD_REQUIRE(mode == BAMD_MODE_F32 || mode == BAMD_MODE_F64 || mode == BAMD_MODE_BF16, "unknown mode");
+    if (mode == BAMD_MODE_BF16) {
+        set_error("BAMD_MODE_BF16 (throughput mode, ~3e-3 relative error) is not implemented yet; use BAMD_MODE_F32");
+        return BAMD_ERR_UNSUPPORTED;
+    }
     for (int l = 0; l <= n_layers; ++l) BAMD_REQUIRE(dims[l] > 0, "layer widths must be positive");
     int ndev = bamd_device_count();
     if (ndev <= 0) {

@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=1_000_000, help="rows per GPU")
-    ap.add_argument("--mode", default=os.environ.get("BALER_AMD_MODE", "fp32"), choices=["fp32", "fp64", "bf16"])
+    ap.add_argument("--mode", default=os.environ.get("BALER_AMD_MODE", "fp32"), choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip encode/decode/bs512 side measurements")
     ap.add_argument("--cpu-rows", type=int, default=400_000)
