@@ -159,6 +159,9 @@ template <int NT> __device__ __forceinline__ void zero_tiles(v4 (&out)[NT]) {
     for (int t = 0; t < NT; ++t) out[t] = (v4){0.f, 0.f, 0.f, 0.f};
 }
 template <int NT> __device__ __forceinline__ void lrelu(v4 (&a)[NT]) {
+#ifdef BAMD_ABLATE_LRELU
+    return;
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -166,6 +169,9 @@ template <int NT> __device__ __forceinline__ void lrelu(v4 (&a)[NT]) {
 }
 // dZ = dY * lrelu'(pre) ; sign(pre) == sign(post-activation y)
 template <int NT> __device__ __forceinline__ void lrelu_bwd(v4 (&d)[NT], const v4 (&y)[NT]) {
+#ifdef BAMD_ABLATE_LRELU
+    return;
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -227,6 +233,9 @@ __device__ __forceinline__ void load_rows(v4 (&a)[tiles(D)], const void *x, int 
     double v[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) v[s] = 0.0;
+#ifdef BAMD_ABLATE_XLOAD
+    valid = false;
+#endif
     if (valid) {
         if (is_f64) {
 #pragma unroll
@@ -379,6 +388,9 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
 // LDS image helpers: rows = feature slots (16t + 4g + r), columns = the workgroup's 64 batch rows.
 template <int NT>
 __device__ __forceinline__ void q_write(float *__restrict__ q, const v4 (&a)[NT], int lane, int wave) {
+#ifdef BAMD_ABLATE_QWRITE
+    return;
+#endif
     const int col = 16 * wave + (lane & 15), g = lane >> 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -389,6 +401,9 @@ __device__ __forceinline__ void q_write(float *__restrict__ q, const v4 (&a)[NT]
 template <int D>
 __device__ __forceinline__ void q_write_x(float *__restrict__ q, const v4 (&a)[tiles(D)], int lane, int wave) {
     static_assert(D % 16 != 0, "ones slot lives in the partial last tile");
+#ifdef BAMD_ABLATE_QWRITE
+    return;
+#endif
     constexpr int T = tiles(D) - 1, V = D - 16 * T;      // partial tile, V valid slots; ones slot idx = V
     constexpr int R1 = V / 4, G1 = V % 4;
     const int col = 16 * wave + (lane & 15), g = lane >> 4;
@@ -415,6 +430,9 @@ template <class N, int l>
 __device__ __forceinline__ void dw_phase(const float *__restrict__ qdz, const float *__restrict__ qx,
                                          v4 (&acc)[DW<N, l>::T], int lane, int wave) {
     using D = DW<N, l>;
+#ifdef BAMD_ABLATE_DW
+    return;
+#endif
     // step u = (tile pair p, 16-row group s): the two tiles of a pair are independent accumulators whose
     // MFMAs alternate (see chain_gemm); LDS fragment reads run one step ahead of the MFMAs.
     constexpr int NP = (D::T + 1) / 2, U = 4 * NP;

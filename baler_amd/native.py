@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbaler_amd.so")
+LIB_PATH = os.environ.get("BALER_AMD_LIB", os.path.join(_HERE, "libbaler_amd.so"))  # override: kernel A/B experiments
 
 F32, F64 = 0, 1
 MODE_F32, MODE_F64, MODE_BF16 = 0, 1, 2

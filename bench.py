@@ -189,10 +189,21 @@ def main():
     }
 
     achieved = FLOP_TRAIN_ROW * a.rows / (k_ms * 1e-3) / 1e12
+    # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
+    # separate runs, gfx950 x2 read correction), summarised under profiles/; counters cannot be read in-process
+    traffic = None
+    try:
+        with open(os.path.join(REPO, "profiles", "r1_pmc_summary.json")) as f:
+            pm = json.load(f)
+        if pm.get("rows") == a.rows and a.mode == "fp32":
+            traffic = pm["fwd_bwd_hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     out["roofline"] = {
-        "bound": "mfma", "kernel": "bamd_fwd_bwd (forward+loss+backward of one batch)",
+        "bound": "mfma",
+        "kernel": "bamd_fwd_bwd = train_dec_kernel + train_enc_kernel (+ 0.1 ms slab reduction)",
         "achieved": achieved, "peak": PEAK_TFLOPS[a.mode], "unit": "TFLOP/s",
-        "frac": achieved / PEAK_TFLOPS[a.mode], "traffic": None,
+        "frac": achieved / PEAK_TFLOPS[a.mode], "traffic": traffic,
         "launch_ms": k_ms, "algorithmic_flop_per_row": FLOP_TRAIN_ROW, "rows_per_launch": a.rows,
     }
 
