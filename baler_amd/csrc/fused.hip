@@ -165,7 +165,7 @@ template <int NT> __device__ __forceinline__ void lrelu(v4 (&a)[NT]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[t][r] = a[t][r] > 0.f ? a[t][r] : a[t][r] * 0.01f;
+        for (int r = 0; r < 4; ++r) a[t][r] = fmaxf(a[t][r], a[t][r] * 0.01f);   // == x > 0 ? x : 0.01 x
 }
 // dZ = dY * lrelu'(pre) ; sign(pre) == sign(post-activation y)
 template <int NT> __device__ __forceinline__ void lrelu_bwd(v4 (&d)[NT], const v4 (&y)[NT]) {
@@ -224,15 +224,16 @@ template <class N> struct StreamTrainEnc {  // encoder-gradient kernel: forward 
 };
 
 // ---- row I/O in slot order ------------------------------------------------------------------------------
+// Row loads are split in two so that the training kernels can issue the NEXT row group's loads before a
+// long MFMA phase and convert them after it (the HBM latency of the first touch of a row is ~2 us).
+template <int D> struct RawRows { double v[tiles(D) * 4]; };
+
 template <int D>
-__device__ __forceinline__ void load_rows(v4 (&a)[tiles(D)], const void *x, int is_f64, int64_t row, bool valid,
-                                          int lane, const double *__restrict__ feats) {
-    // all loads of the tile are issued back to back (one exec region), conversions afterwards
+__device__ __forceinline__ void load_rows_issue(RawRows<D> &raw, const void *x, int is_f64, int64_t row, bool valid, int lane) {
     constexpr int NS = tiles(D) * 4;
     const int g = lane >> 4;
-    double v[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) v[s] = 0.0;
+    for (int s = 0; s < NS; ++s) raw.v[s] = 0.0;
 #ifdef BAMD_ABLATE_XLOAD
     valid = false;
 #endif
@@ -241,7 +242,7 @@ __device__ __forceinline__ void load_rows(v4 (&a)[tiles(D)], const void *x, int 
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int f = slot_feature(D, s >> 2, g, s & 3);
-                if (f >= 0) v[s] = ((const double *)x)[row * D + f];
+                if (f >= 0) raw.v[s] = ((const double *)x)[row * D + f];
             }
         } else {
             float w[NS];
@@ -251,22 +252,37 @@ __device__ __forceinline__ void load_rows(v4 (&a)[tiles(D)], const void *x, int 
                 w[s] = f >= 0 ? ((const float *)x)[row * D + f] : 0.f;
             }
 #pragma unroll
-            for (int s = 0; s < NS; ++s) v[s] = (double)w[s];
-        }
-        if (feats) {
-            double mn[NS], rg[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int f = slot_feature(D, s >> 2, g, s & 3);
-                mn[s] = f >= 0 ? feats[f] : 0.0;
-                rg[s] = f >= 0 ? feats[D + f] : 1.0;
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) v[s] = (v[s] - mn[s]) / rg[s];   // (x - min)/(max - min) in float64
+            for (int s = 0; s < NS; ++s) raw.v[s] = (double)w[s];
         }
     }
+}
+
+template <int D>
+__device__ __forceinline__ void load_rows_finish(v4 (&a)[tiles(D)], RawRows<D> &raw, bool valid, int lane,
+                                                 const double *__restrict__ feats) {
+    constexpr int NS = tiles(D) * 4;
+    const int g = lane >> 4;
+    if (feats && valid) {
+        double mn[NS], rg[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) a[s >> 2][s & 3] = (float)v[s];
+        for (int s = 0; s < NS; ++s) {
+            const int f = slot_feature(D, s >> 2, g, s & 3);
+            mn[s] = f >= 0 ? feats[f] : 0.0;
+            rg[s] = f >= 0 ? feats[D + f] : 1.0;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) raw.v[s] = (raw.v[s] - mn[s]) / rg[s];   // (x - min)/(max - min) in float64
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s >> 2][s & 3] = (float)raw.v[s];
+}
+
+template <int D>
+__device__ __forceinline__ void load_rows(v4 (&a)[tiles(D)], const void *x, int is_f64, int64_t row, bool valid,
+                                          int lane, const double *__restrict__ feats) {
+    RawRows<D> raw;
+    load_rows_issue<D>(raw, x, is_f64, row, valid, lane);
+    load_rows_finish<D>(a, raw, valid, lane, feats);
 }
 
 template <int D>
@@ -499,16 +515,25 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
     zero_tiles(g7); zero_tiles(g6); zero_tiles(g5); zero_tiles(g4);
     Ring ring;
     ring_prime<S::total>(ring, ws);
+    v4 a0n[tiles(F)];   // next row group's input, loaded one iteration ahead (software pipeline)
+    {
+        const int64_t row0 = (int64_t)blockIdx.x * kRowsPerWG + 16 * wave + (lane & 15);
+        load_rows<F>(a0n, xin, in_f64, row0, row0 < n, lane, feats);
+    }
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         // keep the weight loads AND the per-tile LDS address arithmetic inside the loop: both are loop
         // invariant, and LICM would hoist hundreds of registers' worth of them (-> scratch spills)
         asm volatile("" : "+v"(ws.voff), "+s"(wave), "+v"(lane));
         const int64_t row = grp * kRowsPerWG + 16 * wave + (lane & 15);
         const bool valid = row < n;
+        const int64_t row_next = row + (int64_t)gridDim.x * kRowsPerWG;
+        const bool valid_next = row_next < n;
+        RawRows<F> xraw;
         v4 a4[tiles(Z)], a5[4], a6[7], a7[13], d8[tiles(F)];
         {
             v4 a0[tiles(F)], a1[13], a2[7], a3[4];
-            load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
+#pragma unroll
+            for (int t = 0; t < tiles(F); ++t) a0[t] = a0n[t];
             fwd_layer<N, S, 0>(a0, a1, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
@@ -538,7 +563,9 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
         q_write_x<100>(imgB, a6, lane, wave); q_write(imgB + DW<N, 6>::rows_x * kQS, d7, lane, wave);
         bwd_layer<N, S, 6>(d7, d6, ring, ws); lrelu_bwd(d6, a6);
         __syncthreads();
+        load_rows_issue<F>(xraw, xin, in_f64, row_next, valid_next, lane);   // lands during the longest dW phase
         dw_phase<N, 6>(imgB + DW<N, 6>::rows_x * kQS, imgB, g6, lane, wave);
+        load_rows_finish<F>(a0n, xraw, valid_next, lane, feats);
 
         q_write_x<50>(imgA, a5, lane, wave); q_write(imgA + DW<N, 5>::rows_x * kQS, d6, lane, wave);
         bwd_layer<N, S, 5>(d6, d5, ring, ws); lrelu_bwd(d5, a5);
@@ -587,13 +614,22 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
     zero_tiles(g3); zero_tiles(g2); zero_tiles(g1); zero_tiles(g0);
     Ring ring;
     ring_prime<S::total>(ring, ws);
+    v4 a0n[tiles(F)], d4n;   // next row group's inputs, loaded one iteration ahead (software pipeline)
+    {
+        const int64_t row0 = (int64_t)blockIdx.x * kRowsPerWG + 16 * wave + (lane & 15);
+        load_rows<F>(a0n, xin, in_f64, row0, row0 < n, lane, feats);
+        d4n = row0 < n ? dz_in[row0 * 4 + (lane >> 4)] : (v4){0.f, 0.f, 0.f, 0.f};
+    }
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         asm volatile("" : "+v"(ws.voff), "+s"(wave), "+v"(lane));   // see train_dec_kernel
         const int64_t row = grp * kRowsPerWG + 16 * wave + (lane & 15);
-        const bool valid = row < n;
+        const int64_t row_next = row + (int64_t)gridDim.x * kRowsPerWG;
+        const bool valid_next = row_next < n;
+        RawRows<F> xraw;
         v4 a0[tiles(F)], a1[13], a2[7], a3[4], d4[tiles(Z)];
-        load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
-        d4[0] = valid ? dz_in[row * 4 + (lane >> 4)] : (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < tiles(F); ++t) a0[t] = a0n[t];
+        d4[0] = d4n;
         fwd_layer<N, S, 0>(a0, a1, ring, ws, bias_lds, lane);
         fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
         fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
@@ -612,7 +648,11 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
         q_write_x<200>(imgB, a1, lane, wave); q_write(imgB + DW<N, 1>::rows_x * kQS, d2, lane, wave);
         bwd_layer<N, S, 1>(d2, d1, ring, ws); lrelu_bwd(d1, a1);
         __syncthreads();
+        load_rows_issue<F>(xraw, xin, in_f64, row_next, valid_next, lane);   // lands during the longest dW phase
+        v4 dzraw = valid_next ? dz_in[row_next * 4 + (lane >> 4)] : (v4){0.f, 0.f, 0.f, 0.f};
         dw_phase<N, 1>(imgB + DW<N, 1>::rows_x * kQS, imgB, g1, lane, wave);
+        load_rows_finish<F>(a0n, xraw, valid_next, lane, feats);
+        d4n = dzraw;
 
         q_write_x<F>(imgA, a0, lane, wave); q_write(imgA + DW<N, 0>::rows_x * kQS, d1, lane, wave);
         __syncthreads();
