@@ -101,3 +101,159 @@ def test_cli_train_compress_decompress(workspace, golden, monkeypatch, compute_m
         data = orc.normalize(synth.cms_rows(10000))
         z = orc.encode(orc.ae_dims(24, 15), final, data)
         assert rel(comp["data"], z) < 1e-5
+
+
+def _reset_config():
+    """helper.Config is a class mutated in place (like the reference's, helper.py:92-93): attributes of an
+    earlier project (e.g. the CMS type_list) would leak into the next one within this test process."""
+    from baler_amd.modules import helper
+    for k in [k for k in vars(helper.Config) if not k.startswith("__")]:
+        delattr(helper.Config, k)
+
+
+def _write_project(tmp_path, monkeypatch, workspace, project, config_body, data, names):
+    _reset_config()
+    ws = tmp_path / "workspaces"
+    proj = ws / workspace / project
+    for d in ("config", "output/compressed_output", "output/decompressed_output", "output/plotting",
+              "output/training"):
+        os.makedirs(proj / d, exist_ok=True)
+    os.makedirs(ws / workspace / "data", exist_ok=True)
+    (ws / "__init__.py").write_text("")
+    (proj / "config" / f"{project}_config.py").write_text(config_body)
+    np.savez(ws / workspace / "data" / f"{project}.npz", data=data, names=names)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.syspath_prepend(str(tmp_path))
+    for k in [k for k in sys.modules if k == "workspaces" or k.startswith("workspaces.")]:
+        del sys.modules[k]
+    return proj / "output"
+
+
+_SPLIT_CONFIG = '''
+def set_config(c):
+    c.input_path = "workspaces/W/data/P.npz"
+    c.data_dimension = 1
+    c.compression_ratio = 1.6
+    c.apply_normalization = True
+    c.custom_norm = False
+    c.model_name = "AE"
+    c.epochs = 3
+    c.lr = 0.001
+    c.batch_size = 512
+    c.test_size = 0.2
+    c.early_stopping = True
+    c.early_stopping_patience = 100
+    c.min_delta = 0
+    c.lr_scheduler = True
+    c.lr_scheduler_patience = 50
+    c.deterministic_algorithm = True
+    c.reg_param = 0.001
+    c.RHO = 0.05
+    c.l1 = True
+    c.activation_extraction = False
+    c.intermittent_model_saving = True
+    c.intermittent_saving_patience = 2
+    c.separate_model_saving = False
+    c.extra_compression = True
+    c.save_error_bounded_deltas = False
+    c.error_bounded_requirement = 10
+    c.convert_to_blocks = False
+'''
+
+
+def test_cli_validation_split(tmp_path, monkeypatch):
+    """test_size != 0: sklearn-style split (random_state=1), validate loop, intermittent saving,
+    extra_compression -- against the CPU oracle replaying the same run (SURVEY section 8(f) row 2)."""
+    from baler_amd import baler
+    from baler_amd.modules import helper, models
+    from oracle import host_logic
+    raw = synth.cms_rows(6000, row0=20000)
+    out = _write_project(tmp_path, monkeypatch, "W", "P", _SPLIT_CONFIG, raw, synth.CMS_NAMES)
+    models.set_default_mode("fp64")
+    init = orc.formula_params(orc.ae_dims(24, 15), 77)
+    monkeypatch.setattr(helper, "model_init",
+                        lambda name: (lambda n_features, z_dim: getattr(models, name)(n_features, z_dim).load_flat(init)))
+    baler.main(["--project", "W", "P", "--mode", "train"])
+    loss = np.load(out / "training" / "loss_data.npy")
+    assert loss.shape == (2, 3)
+    data = orc.normalize(raw)
+    tr, te = host_logic.split_indices(6000, 0.2)
+    st = orc.FitState(orc.ae_dims(24, 15), init)
+    want = []
+    for ep in range(3):
+        el, _ = orc.fit_epoch(st, data[tr], 512, 1e-3)
+        want.append((el, orc.validate_epoch(st.dims, st.params, data[te], 512)))
+    assert rel(loss[0], [w[0] for w in want]) < 1e-9
+    assert rel(loss[1], [w[1] for w in want]) < 1e-9
+    assert os.path.exists(out / "training" / "model_0.pt") and os.path.exists(out / "training" / "model_2.pt")
+    baler.main(["--project", "W", "P", "--mode", "compress"])
+    baler.main(["--project", "W", "P", "--mode", "decompress"])
+    comp = np.load(out / "compressed_output" / "compressed.npz")      # savez_compressed
+    assert rel(comp["data"], orc.encode(st.dims, st.params, data)) < 1e-9
+    dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
+    nf = orc.find_minmax(raw)
+    assert rel(dec, orc.renormalize(orc.decode(st.dims, st.params, comp["data"]), nf[0], nf[1])) < 1e-9
+    models.set_default_mode("fp32")
+
+
+_CFD_CONFIG = '''
+def set_config(c):
+    c.input_path = "workspaces/CFD/data/anim.npz"
+    c.compression_ratio = 100
+    c.epochs = 3
+    c.early_stopping = False
+    c.early_stopping_patience = 100
+    c.min_delta = 0
+    c.lr_scheduler = True
+    c.lr_scheduler_patience = 50
+    c.model_name = "CFD_dense_AE"
+    c.model_type = "dense"
+    c.custom_norm = True
+    c.l1 = True
+    c.reg_param = 0.001
+    c.RHO = 0.05
+    c.lr = 0.001
+    c.batch_size = 6000
+    c.test_size = 0
+    c.data_dimension = 2
+    c.apply_normalization = False
+    c.extra_compression = False
+    c.intermittent_model_saving = False
+    c.intermittent_saving_patience = 100
+    c.activation_extraction = False
+    c.deterministic_algorithm = False
+    c.save_error_bounded_deltas = False
+    c.error_bounded_requirement = 1
+    c.convert_to_blocks = False
+    c.separate_model_saving = False
+'''
+
+
+def test_cli_cfd_dense_2d(tmp_path, monkeypatch):
+    """The reference's working CFD config (CFD_project_animation: CFD_dense_AE(2500,25), 2-D data flattened to
+    (N, 2500) float32, one 60-row batch) end to end on the generic layer-wise MFMA path."""
+    from baler_amd import baler
+    from baler_amd.modules import helper, models
+    field = synth.cfd_field(60)
+    out = _write_project(tmp_path, monkeypatch, "CFD", "anim", _CFD_CONFIG, field, np.array([]))
+    models.set_default_mode("fp32")
+    dims = orc.ae_dims(2500, 25)
+    init = orc.formula_params(dims, 78)
+    monkeypatch.setattr(helper, "model_init",
+                        lambda name: (lambda n_features, z_dim: getattr(models, name)(n_features, z_dim).load_flat(init)))
+    for mode in ("train", "compress", "decompress"):
+        baler.main(["--project", "CFD", "anim", "--mode", mode])
+    loss = np.load(out / "training" / "loss_data.npy")
+    x = field.astype(np.float32).astype(np.float64).reshape(60, 2500)
+    st = orc.FitState(dims, init.astype(np.float32).astype(np.float64))
+    want = [orc.fit_epoch(st, x, 6000, 1e-3)[0] for _ in range(3)]
+    assert rel(loss[0], want) < 1e-4          # the reference model itself is float32 here
+    sd = torch.load(out / "compressed_output" / "model.pt")
+    assert sd["en1.weight"].dtype == torch.float32 and tuple(sd["en1.weight"].shape) == (200, 2500)
+    comp = np.load(out / "compressed_output" / "compressed.npz")
+    assert comp["data"].shape == (60, 25) and comp["data"].dtype == np.float32
+    final = np.concatenate([v.numpy().ravel().astype(np.float64) for v in sd.values()])
+    assert rel(comp["data"], orc.encode(dims, final, x)) < 1e-5
+    dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
+    assert dec.shape == (60, 50, 50) and dec.dtype == np.float32
+    assert rel(dec.reshape(60, 2500), orc.decode(dims, final, comp["data"].astype(np.float64))) < 1e-5
