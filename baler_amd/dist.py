@@ -26,6 +26,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: several ranks may share one GPU (BALER_AMD_FORCE_DEVICE) over gloo (BALER_AMD_DIST_BACKEND)
+    # so that the multi-rank code path can be exercised on a single-GPU box; RCCL itself needs one GPU per rank
+    if "BALER_AMD_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["BALER_AMD_FORCE_DEVICE"])
+    backend = backend or os.environ.get("BALER_AMD_DIST_BACKEND")
     if world > 1 and not is_dist():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -36,6 +41,8 @@ def init_from_env(backend=None):
             td.init_process_group(backend, rank=rank, world_size=world,
                                   device_id=torch.device("cuda", local))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local)
             td.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
 
