@@ -699,7 +699,9 @@ __global__ void sum_loss_k(const double *__restrict__ part, int n, double scale,
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
+struct FusedOps;
 struct FusedState {
+    const FusedOps *ops = nullptr;
     DevBuf pack_src;   // int per packed float: canonical parameter index or -1
     DevBuf slab_map;   // int per canonical parameter: float offset inside a slab
     DevBuf dz;         // dL/dz hand-off between the two training kernels: 16 floats per row
@@ -778,34 +780,118 @@ static int build_maps(bamd_handle *h, FusedState *st) {
     return rc;
 }
 
-constexpr int kF = 24, kZ = 15;   // the instantiated shape: CMS example, compression_ratio 1.6
-using CMS = Net<kF, kZ>;
-constexpr int kTrainLds = (kImgA + kImgB) * kQS * (int)sizeof(float) + (CMS::bf_off(CMS::L) - CMS::bf_off(0)) * 16;
+constexpr int kBiasF4 = Net<24, 15>::bf_off(8) - Net<24, 15>::bf_off(0);   // 51 tiles x 4 lane groups for every Z <= 16
+constexpr int kTrainLds = (kImgA + kImgB) * kQS * (int)sizeof(float) + kBiasF4 * 16;
 
-static bool shape_is_cms(const bamd_handle *h) {
-    if (h->L != 8 || h->mode != BAMD_MODE_F32) return false;
-    for (int i = 0; i <= 8; ++i)
-        if (h->dims[i] != CMS::dim(i)) return false;
-    return true;
-}
+// entry points of one instantiated shape
+struct FusedOps {
+    int (*setup)(bamd_handle *, FusedState *);
+    int (*encode)(bamd_handle *, const void *, int, int64_t, const double *, void *, int, hipStream_t);
+    int (*decode)(bamd_handle *, const void *, int, int64_t, const double *, const uint8_t *, void *, int, hipStream_t);
+    int (*forward_loss)(bamd_handle *, const void *, int, int64_t, const double *, void *, int, double *, hipStream_t);
+    int (*fwd_bwd)(bamd_handle *, const void *, int, int64_t, const double *, void *, hipStream_t);
+};
 
 static FusedState *state_of(bamd_handle *h) { return (FusedState *)h->fused_state; }
+
+static int infer_grid(int64_t n) {
+    int64_t wg = ((n + 15) / 16 + 3) / 4;
+    return (int)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg));
+}
+
+template <int F, int Z> struct Impl {
+    using N = Net<F, Z>;
+    static_assert(N::bf_off(8) - N::bf_off(0) == kBiasF4, "bias fragment count");
+
+    static bool matches(const bamd_handle *h) {
+        if (h->L != 8) return false;
+        for (int i = 0; i <= 8; ++i)
+            if (h->dims[i] != N::dim(i)) return false;
+        return true;
+    }
+    static int setup(bamd_handle *h, FusedState *st) {
+        int rc = build_maps<F, Z>(h, st);
+        if (rc) return rc;
+        BAMD_HIP(hipFuncSetAttribute((const void *)train_dec_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
+        BAMD_HIP(hipFuncSetAttribute((const void *)train_enc_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
+        return BAMD_OK;
+    }
+    static int encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
+                      hipStream_t s) {
+        hipLaunchKernelGGL((infer_kernel<F, Z, K_ENCODE>), dim3(infer_grid(n)), dim3(256), 0, s, (const v4 *)h->packed.p, x,
+                           x_dtype == BAMD_F64, n, features, z, z_dtype == BAMD_F64, (const uint8_t *)nullptr, (double *)nullptr);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features, const uint8_t *int_mask,
+                      void *out, int out_dtype, hipStream_t s) {
+        hipLaunchKernelGGL((infer_kernel<F, Z, K_DECODE>), dim3(infer_grid(n)), dim3(256), 0, s, (const v4 *)h->packed.p, z,
+                           z_dtype == BAMD_F64, n, features, out, out_dtype == BAMD_F64, int_mask, (double *)nullptr);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *recon,
+                            int recon_dtype, double *loss_sum, hipStream_t s) {
+        int grid = infer_grid(n);
+        int rc = h->lossp.ensure(sizeof(double) * 1024);
+        if (rc) return rc;
+        hipLaunchKernelGGL((infer_kernel<F, Z, K_FORWARD>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x,
+                           x_dtype == BAMD_F64, n, features, recon, recon_dtype == BAMD_F64, (const uint8_t *)nullptr,
+                           (double *)h->lossp.p);
+        hipLaunchKernelGGL(sum_loss_k, dim3(1), dim3(64), 0, s, (const double *)h->lossp.p, grid, 1.0 / F, loss_sum);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
+                       hipStream_t s) {
+        FusedState *st = state_of(h);
+        int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
+        int grid = (int)(ngroups < st->nwg_max ? ngroups : st->nwg_max);
+        int rc = h->slabs.ensure((size_t)N::slab_f4() * 16 * (size_t)grid);
+        if (rc) return rc;
+        rc = st->dz.ensure((size_t)n * 64);
+        if (rc) return rc;
+        hipLaunchKernelGGL((train_dec_kernel<F, Z>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
+                           x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (v4 *)st->dz.p);
+        hipLaunchKernelGGL((train_enc_kernel<F, Z>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
+                           x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (const v4 *)st->dz.p);
+        const int np = N::nparams();
+        hipLaunchKernelGGL(reduce_slabs_map_k<float>, dim3((np + 1 + 255) / 256), dim3(256), 0, s, (const float *)h->slabs.p,
+                           grid, (int64_t)N::slab_f4() * 4, (const int *)st->slab_map.p, np, N::slab_off(N::L) * 64 * 4,
+                           1.0 / F, (float *)grads);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static const FusedOps *ops() {
+        static const FusedOps o = {setup, encode, decode, forward_loss, fwd_bwd};
+        return &o;
+    }
+};
+
+// Instantiated shapes: the CMS 24-column model at the usual compression ratios
+// (latent = ceil(24 / ratio): 1.6 -> 15, 2 -> 12, 3 -> 8, 4 -> 6).  Anything else runs on generic.hip.
+static const FusedOps *find_ops(const bamd_handle *h) {
+    if (h->mode != BAMD_MODE_F32) return nullptr;
+    if (Impl<24, 15>::matches(h)) return Impl<24, 15>::ops();
+    if (Impl<24, 12>::matches(h)) return Impl<24, 12>::ops();
+    if (Impl<24, 8>::matches(h)) return Impl<24, 8>::ops();
+    if (Impl<24, 6>::matches(h)) return Impl<24, 6>::ops();
+    return nullptr;
+}
 
 }  // namespace
 
 int fused_setup(bamd_handle *h) {
     h->fused_ok = false;
-    if (!shape_is_cms(h)) return BAMD_OK;
+    const FusedOps *ops = find_ops(h);
+    if (!ops) return BAMD_OK;
     const char *env = getenv("BALER_AMD_FORCE_GENERIC");
     if (env && env[0] == '1') return BAMD_OK;
     FusedState *st = new FusedState();
+    st->ops = ops;
     h->fused_state = st;
-    int rc = build_maps<kF, kZ>(h, st);
+    int rc = ops->setup(h, st);
     if (rc) return rc;
-    BAMD_HIP(hipFuncSetAttribute((const void *)train_dec_kernel<kF, kZ>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 kTrainLds));
-    BAMD_HIP(hipFuncSetAttribute((const void *)train_enc_kernel<kF, kZ>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 kTrainLds));
     h->fused_ok = true;
     return BAMD_OK;
 }
@@ -829,61 +915,21 @@ int fused_pack(bamd_handle *h, hipStream_t s) {
     return BAMD_OK;
 }
 
-static int infer_grid(int64_t n) {
-    int64_t wg = ((n + 15) / 16 + 3) / 4;
-    return (int)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg));
-}
-
 int fused_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
                  hipStream_t s) {
-    hipLaunchKernelGGL((infer_kernel<kF, kZ, K_ENCODE>), dim3(infer_grid(n)), dim3(256), 0, s, (const v4 *)h->packed.p, x,
-                       x_dtype == BAMD_F64, n, features, z, z_dtype == BAMD_F64, (const uint8_t *)nullptr, (double *)nullptr);
-    BAMD_HIP(hipGetLastError());
-    return BAMD_OK;
+    return state_of(h)->ops->encode(h, x, x_dtype, n, features, z, z_dtype, s);
 }
-
 int fused_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features, const uint8_t *int_mask,
                  void *out, int out_dtype, hipStream_t s) {
-    hipLaunchKernelGGL((infer_kernel<kF, kZ, K_DECODE>), dim3(infer_grid(n)), dim3(256), 0, s, (const v4 *)h->packed.p, z,
-                       z_dtype == BAMD_F64, n, features, out, out_dtype == BAMD_F64, int_mask, (double *)nullptr);
-    BAMD_HIP(hipGetLastError());
-    return BAMD_OK;
+    return state_of(h)->ops->decode(h, z, z_dtype, n, features, int_mask, out, out_dtype, s);
 }
-
 int fused_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *recon,
                        int recon_dtype, double *loss_sum, hipStream_t s) {
-    int grid = infer_grid(n);
-    int rc = h->lossp.ensure(sizeof(double) * 1024);
-    if (rc) return rc;
-    hipLaunchKernelGGL((infer_kernel<kF, kZ, K_FORWARD>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x,
-                       x_dtype == BAMD_F64, n, features, recon, recon_dtype == BAMD_F64, (const uint8_t *)nullptr,
-                       (double *)h->lossp.p);
-    hipLaunchKernelGGL(sum_loss_k, dim3(1), dim3(64), 0, s, (const double *)h->lossp.p, grid, 1.0 / kF, loss_sum);
-    BAMD_HIP(hipGetLastError());
-    return BAMD_OK;
+    return state_of(h)->ops->forward_loss(h, x, x_dtype, n, features, recon, recon_dtype, loss_sum, s);
 }
-
 int fused_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
                   hipStream_t s) {
-    FusedState *st = state_of(h);
-    int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
-    int grid = (int)(ngroups < st->nwg_max ? ngroups : st->nwg_max);
-    const size_t slab_bytes = (size_t)CMS::slab_f4() * 16;
-    int rc = h->slabs.ensure(slab_bytes * (size_t)grid);
-    if (rc) return rc;
-    rc = st->dz.ensure((size_t)n * 64);
-    if (rc) return rc;
-    const int lds_bytes = kTrainLds;
-    hipLaunchKernelGGL((train_dec_kernel<kF, kZ>), dim3(grid), dim3(256), lds_bytes, s, (const v4 *)h->packed.p, x,
-                       x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (v4 *)st->dz.p);
-    hipLaunchKernelGGL((train_enc_kernel<kF, kZ>), dim3(grid), dim3(256), lds_bytes, s, (const v4 *)h->packed.p, x,
-                       x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (const v4 *)st->dz.p);
-    const int np = CMS::nparams();
-    hipLaunchKernelGGL(reduce_slabs_map_k<float>, dim3((np + 1 + 255) / 256), dim3(256), 0, s, (const float *)h->slabs.p,
-                       grid, (int64_t)CMS::slab_f4() * 4, (const int *)st->slab_map.p, np, CMS::slab_off(CMS::L) * 64 * 4,
-                       1.0 / kF, (float *)grads);
-    BAMD_HIP(hipGetLastError());
-    return BAMD_OK;
+    return state_of(h)->ops->fwd_bwd(h, x, x_dtype, n, features, grads, s);
 }
 
 }  // namespace bamd
