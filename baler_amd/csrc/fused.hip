@@ -919,14 +919,22 @@ __global__ void __launch_bounds__(256) lat_train_kernel(const v4 *packed, const 
 #undef LAT_BIAS
     // ---------------- weight gradients: [dW | db] tiles over this tile's 16 rows, straight to the slab ----------------
     auto dw_layer = [&](int slab_off, int nt_count, int tot, const float *imz, const float *imx) {
-        for (int idx = wave; idx < tot; idx += 4) {
+        // fragment reads of tile idx+4 are issued before the MFMAs of tile idx (LDS latency hidden)
+        auto fetch = [&](int idx, v4 &a, v4 &b) {
+            idx = idx < tot ? idx : tot - 1;
             const int kt = idx / nt_count, nt = idx - kt * nt_count;
-            const v4 a = *(const v4 *)(imz + (16 * nt + (lane & 15)) * kLS + 4 * g);
-            const v4 b = *(const v4 *)(imx + (16 * kt + (lane & 15)) * kLS + 4 * g);
+            a = *(const v4 *)(imz + (16 * nt + (lane & 15)) * kLS + 4 * g);
+            b = *(const v4 *)(imx + (16 * kt + (lane & 15)) * kLS + 4 * g);
+        };
+        v4 a, b, an, bn;
+        fetch(wave, a, b);
+        for (int idx = wave; idx < tot; idx += 4) {
+            fetch(idx + 4, an, bn);
             v4 acc = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = mfma(a[r], b[r], acc);
             slab[(slab_off + idx) * 64 + lane] = acc;
+            a = an; b = bn;
         }
     };
 #pragma unroll
@@ -944,20 +952,26 @@ __global__ void __launch_bounds__(256) lat_train_kernel(const v4 *packed, const 
     if (threadIdx.x == 0) *(double *)(slab + N::slab_off(N::L) * 64) = sh[0];
 }
 
-// grads[p] = sum over workgroup slabs (fixed order) of slab[map[p]];  grads[np] = sum of loss partials / C
+// Slab reduction in SLAB order: thread i sums float4 i of every workgroup slab (fully coalesced 16-byte
+// loads, fixed order => bitwise reproducible) and scatters the four sums to their canonical (state-dict)
+// positions through the inverse map (-1 = padding).  grads[np] = sum of the loss partials / C.
 template <typename T>
-__global__ void __launch_bounds__(256) reduce_slabs_map_k(const float *__restrict__ slabs, int nslab, int64_t slab_floats,
-                                                          const int *__restrict__ map, int np, int loss_float_off,
-                                                          double inv_c, T *__restrict__ grads) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < np) {
-        const int src = map[p];
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += slabs[(int64_t)k * slab_floats + src];
-        grads[p] = (T)s;
-    } else if (p == np) {
+__global__ void __launch_bounds__(256) reduce_slabs_k(const v4 *__restrict__ slabs, int nslab, int slab_f4, int tile_f4,
+                                                      const int *__restrict__ inv_map, int np, double inv_c,
+                                                      T *__restrict__ grads) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tile_f4) {
+        v4 s = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int k = 0; k < nslab; ++k) s += slabs[(int64_t)k * slab_f4 + i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int p = inv_map[4 * i + c];
+            if (p >= 0) grads[p] = (T)s[c];
+        }
+    } else if (i == tile_f4) {
         double s = 0.0;
-        for (int k = 0; k < nslab; ++k) s += *(const double *)(slabs + (int64_t)k * slab_floats + loss_float_off);
+        for (int k = 0; k < nslab; ++k) s += *(const double *)(slabs + (int64_t)k * slab_f4 + tile_f4);
         grads[np] = (T)(s * inv_c);
     }
 }
@@ -984,7 +998,7 @@ struct FusedOps;
 struct FusedState {
     const FusedOps *ops = nullptr;
     DevBuf pack_src;   // int per packed float: canonical parameter index or -1
-    DevBuf slab_map;   // int per canonical parameter: float offset inside a slab
+    DevBuf slab_map;   // int per slab float: canonical parameter index or -1 (padding)
     DevBuf dz;         // dL/dz hand-off between the two training kernels: 16 floats per row
     int packed_floats = 0;
     int nwg_max = 256;
@@ -1051,6 +1065,9 @@ static int build_maps(bamd_handle *h, FusedState *st) {
         for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::eb_off(l) * 4 + i] = src[(size_t)N::wb_off(l) * 4 + i];
     for (int v : smap)
         if (v < 0) { set_error("fused: incomplete slab map"); return BAMD_ERR_INVALID; }
+    std::vector<int> inv((size_t)N::slab_off(N::L) * 64 * 4, -1);   // slab float -> canonical parameter
+    for (int p = 0; p < N::nparams(); ++p) inv[smap[p]] = p;
+    smap.swap(inv);
     st->packed_floats = (int)src.size();
     int rc = st->pack_src.ensure(src.size() * sizeof(int));
     if (rc) return rc;
@@ -1137,9 +1154,9 @@ template <int F, int Z> struct Impl {
             if (rc) return rc;
             hipLaunchKernelGGL((lat_train_kernel<F, Z>), dim3(grid), dim3(256), Lat<N>::lds_bytes, s, (const v4 *)h->packed.p,
                                x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p);
-            hipLaunchKernelGGL(reduce_slabs_map_k<float>, dim3((np + 1 + 255) / 256), dim3(256), 0, s,
-                               (const float *)h->slabs.p, grid, (int64_t)N::slab_f4() * 4, (const int *)st->slab_map.p, np,
-                               N::slab_off(N::L) * 64 * 4, 1.0 / F, (float *)grads);
+            hipLaunchKernelGGL(reduce_slabs_k<float>, dim3((N::slab_off(N::L) * 64 + 1 + 255) / 256), dim3(256), 0, s,
+                               (const v4 *)h->slabs.p, grid, N::slab_f4(), N::slab_off(N::L) * 64, (const int *)st->slab_map.p,
+                               np, 1.0 / F, (float *)grads);
             BAMD_HIP(hipGetLastError());
             return BAMD_OK;
         }
@@ -1153,8 +1170,8 @@ template <int F, int Z> struct Impl {
                            x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (v4 *)st->dz.p);
         hipLaunchKernelGGL((train_enc_kernel<F, Z>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
                            x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (const v4 *)st->dz.p);
-        hipLaunchKernelGGL(reduce_slabs_map_k<float>, dim3((np + 1 + 255) / 256), dim3(256), 0, s, (const float *)h->slabs.p,
-                           grid, (int64_t)N::slab_f4() * 4, (const int *)st->slab_map.p, np, N::slab_off(N::L) * 64 * 4,
+        hipLaunchKernelGGL(reduce_slabs_k<float>, dim3((N::slab_off(N::L) * 64 + 1 + 255) / 256), dim3(256), 0, s,
+                           (const v4 *)h->slabs.p, grid, N::slab_f4(), N::slab_off(N::L) * 64, (const int *)st->slab_map.p, np,
                            1.0 / F, (float *)grads);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
