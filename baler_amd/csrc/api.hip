@@ -189,9 +189,10 @@ int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, voi
     BAMD_REQUIRE(params && grads && m && v && hp, "null argument");
     BAMD_REQUIRE(hp->step >= 1, "step must be >= 1");
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, s);
-    if (rc) return rc;
-    return fused_pack(h, s);
+    const int *sc_off = nullptr, *sc_idx = nullptr;
+    void *packed = nullptr;
+    fused_scatter(h, &sc_off, &sc_idx, &packed);   // Adam also refreshes the packed weight copy (one launch)
+    return launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, sc_off, sc_idx, packed, s);
 }
 
 int bamd_emd_rows(const void *x, const void *recon, int dtype, int64_t n_rows, int n_cols, double *out,

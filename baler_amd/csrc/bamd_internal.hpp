@@ -78,7 +78,8 @@ int launch_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int
 int launch_emd_rows(const void *x, const void *recon, int dtype, int64_t n, int c, double *out,
                     hipStream_t s);
 int launch_adam(void *params, void *params_copy, const void *grads, void *m, void *v, int64_t np,
-                size_t esize, const bamd_adam &hp, double *loss_accum, hipStream_t s);
+                size_t esize, const bamd_adam &hp, double *loss_accum, const int *sc_off, const int *sc_idx,
+                void *packed, hipStream_t s);
 
 // ---- generic.hip (layer-by-layer MFMA path, any dims) -------------------------------------------
 int generic_forward(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,

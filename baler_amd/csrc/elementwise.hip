@@ -237,7 +237,8 @@ __global__ void __launch_bounds__(256) adam_k(T *__restrict__ p, T *__restrict__
                                               const T *__restrict__ g, T *__restrict__ m,
                                               T *__restrict__ v, int64_t np, double b1, double b2,
                                               double eps, double step_size, double bc2_sqrt,
-                                              double *loss_accum) {
+                                              double *loss_accum, const int *__restrict__ sc_off,
+                                              const int *__restrict__ sc_idx, T *__restrict__ packed) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < np) {
         double gi = (double)g[i];
@@ -250,12 +251,15 @@ __global__ void __launch_bounds__(256) adam_k(T *__restrict__ p, T *__restrict__
         v[i] = (T)vi;
         p[i] = (T)pi;
         if (pcopy) pcopy[i] = (T)pi;
+        if (packed)   // refresh every copy of this parameter in the MFMA-fragment-packed buffer (fused pack)
+            for (int k = sc_off[i]; k < sc_off[i + 1]; ++k) packed[sc_idx[k]] = (T)pi;
     }
     if (loss_accum && i == 0) *loss_accum += (double)g[np];
 }
 
 int launch_adam(void *params, void *pcopy, const void *grads, void *m, void *v, int64_t np,
-                size_t esize, const bamd_adam &hp, double *loss_accum, hipStream_t s) {
+                size_t esize, const bamd_adam &hp, double *loss_accum, const int *sc_off, const int *sc_idx,
+                void *packed, hipStream_t s) {
     double bc1 = 1.0 - pow(hp.beta1, (double)hp.step);
     double bc2 = 1.0 - pow(hp.beta2, (double)hp.step);
     double step_size = hp.lr / bc1;
@@ -263,10 +267,10 @@ int launch_adam(void *params, void *pcopy, const void *grads, void *m, void *v, 
     dim3 g((unsigned)((np + 255) / 256)), b(256);
     if (esize == 8)
         hipLaunchKernelGGL(adam_k<double>, g, b, 0, s, (double *)params, (double *)pcopy, (const double *)grads,
-                           (double *)m, (double *)v, np, hp.beta1, hp.beta2, hp.eps, step_size, bc2_sqrt, loss_accum);
+                           (double *)m, (double *)v, np, hp.beta1, hp.beta2, hp.eps, step_size, bc2_sqrt, loss_accum, sc_off, sc_idx, (double *)packed);
     else
         hipLaunchKernelGGL(adam_k<float>, g, b, 0, s, (float *)params, (float *)pcopy, (const float *)grads,
-                           (float *)m, (float *)v, np, hp.beta1, hp.beta2, hp.eps, step_size, bc2_sqrt, loss_accum);
+                           (float *)m, (float *)v, np, hp.beta1, hp.beta2, hp.eps, step_size, bc2_sqrt, loss_accum, sc_off, sc_idx, (float *)packed);
     BAMD_HIP(hipGetLastError());
     return BAMD_OK;
 }

@@ -1000,6 +1000,7 @@ struct FusedState {
     DevBuf pack_src;   // int per packed float: canonical parameter index or -1
     DevBuf slab_map;   // int per slab float: canonical parameter index or -1 (padding)
     DevBuf dz;         // dL/dz hand-off between the two training kernels: 16 floats per row
+    DevBuf sc_off, sc_idx;   // CSR parameter -> packed float positions (fused Adam + pack)
     int packed_floats = 0;
     int nwg_max = 256;
     int64_t latency_max_rows = 4096;   // <= this many rows: lat_train_kernel (BALER_AMD_LATENCY_ROWS overrides)
@@ -1068,6 +1069,20 @@ static int build_maps(bamd_handle *h, FusedState *st) {
     std::vector<int> inv((size_t)N::slab_off(N::L) * 64 * 4, -1);   // slab float -> canonical parameter
     for (int p = 0; p < N::nparams(); ++p) inv[smap[p]] = p;
     smap.swap(inv);
+    {   // inverse of the pack map: for every parameter the list of packed positions that hold a copy of it
+        std::vector<int> off((size_t)N::nparams() + 1, 0), idx;
+        for (int v : src) if (v >= 0) off[v + 1]++;
+        for (int p = 0; p < N::nparams(); ++p) off[p + 1] += off[p];
+        idx.resize(off[N::nparams()]);
+        std::vector<int> cur(off.begin(), off.end() - 1);
+        for (size_t i = 0; i < src.size(); ++i) if (src[i] >= 0) idx[cur[src[i]]++] = (int)i;
+        int rc2 = st->sc_off.ensure(off.size() * sizeof(int));
+        if (rc2) return rc2;
+        rc2 = st->sc_idx.ensure(idx.size() * sizeof(int));
+        if (rc2) return rc2;
+        BAMD_HIP(hipMemcpy(st->sc_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+        BAMD_HIP(hipMemcpy(st->sc_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     st->packed_floats = (int)src.size();
     int rc = st->pack_src.ensure(src.size() * sizeof(int));
     if (rc) return rc;
@@ -1217,8 +1232,19 @@ void fused_teardown(bamd_handle *h) {
     st->pack_src.release();
     st->slab_map.release();
     st->dz.release();
+    st->sc_off.release();
+    st->sc_idx.release();
     delete st;
     h->fused_state = nullptr;
+}
+
+void fused_scatter(bamd_handle *h, const int **sc_off, const int **sc_idx, void **packed) {
+    *sc_off = nullptr; *sc_idx = nullptr; *packed = nullptr;
+    if (!h->fused_ok) return;
+    FusedState *st = state_of(h);
+    *sc_off = (const int *)st->sc_off.p;
+    *sc_idx = (const int *)st->sc_idx.p;
+    *packed = h->packed.p;
 }
 
 int fused_pack(bamd_handle *h, hipStream_t s) {

@@ -6,6 +6,8 @@ namespace bamd {
 int fused_setup(bamd_handle *h);                 // decides h->fused_ok, allocates the packed weights
 int fused_pack(bamd_handle *h, hipStream_t s);   // h->params -> h->packed (no-op when !fused_ok)
 void fused_teardown(bamd_handle *h);
+// scatter lists (CSR over parameters) into h->packed for the fused Adam+pack kernel; all null when !fused_ok
+void fused_scatter(bamd_handle *h, const int **sc_off, const int **sc_idx, void **packed);
 int fused_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z,
                  int z_dtype, hipStream_t s);
 int fused_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features,
