@@ -285,12 +285,63 @@ __device__ __forceinline__ void load_rows(v4 (&a)[tiles(D)], const void *x, int 
     load_rows_finish<D>(a, raw, valid, lane, feats);
 }
 
+// Wide rows (D > 64, e.g. the 512-column table): tile by tile, 16/32-byte vector loads for full tiles
+// (4 consecutive features per lane), no fp64 staging array.
+template <int D>
+__device__ __forceinline__ void load_rows_wide(v4 (&a)[tiles(D)], const void *x, int is_f64, int64_t row, bool valid,
+                                               int lane, const double *__restrict__ feats) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < tiles(D); ++t) {
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        if (valid) {
+            if (D - 16 * t >= 16) {
+                const int64_t i = row * D + 16 * t + 4 * g;
+                if (is_f64) {
+                    const double2 lo = *(const double2 *)((const double *)x + i), hi = *(const double2 *)((const double *)x + i + 2);
+                    v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+                } else {
+                    const float4 w = *(const float4 *)((const float *)x + i);
+                    v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = slot_feature(D, t, g, r);
+                    if (f >= 0) v[r] = is_f64 ? ((const double *)x)[row * D + f] : (double)((const float *)x)[row * D + f];
+                }
+            }
+            if (feats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = slot_feature(D, t, g, r);
+                    if (f >= 0) v[r] = (v[r] - feats[f]) / feats[D + f];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[t][r] = (float)v[r];
+    }
+}
+
 template <int D>
 __device__ __forceinline__ void store_rows(const v4 (&a)[tiles(D)], void *out, int is_f64, int64_t row, bool valid,
                                            int lane, const double *__restrict__ renorm, const uint8_t *__restrict__ imask) {
     const int g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < tiles(D); ++t)
+    for (int t = 0; t < tiles(D); ++t) {
+        if (D > 64 && D - 16 * t >= 16 && !renorm) {   // wide rows: one 16/32-byte store per full tile
+            if (valid) {
+                const int64_t i = row * D + 16 * t + 4 * g;
+                if (is_f64) {
+                    *(double2 *)((double *)out + i) = make_double2((double)a[t][0], (double)a[t][1]);
+                    *(double2 *)((double *)out + i + 2) = make_double2((double)a[t][2], (double)a[t][3]);
+                } else {
+                    *(float4 *)((float *)out + i) = make_float4(a[t][0], a[t][1], a[t][2], a[t][3]);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = slot_feature(D, t, g, r);
@@ -306,6 +357,7 @@ __device__ __forceinline__ void store_rows(const v4 (&a)[tiles(D)], void *out, i
                 }
             }
         }
+    }
 }
 
 // ---- inference kernels: every wave streams 16-row tiles on its own ---------------------------------------
@@ -343,7 +395,8 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
         asm volatile("" : "+v"(ws.voff));
         if (KIND == K_ENCODE || KIND == K_FORWARD) {
             v4 a0[tiles(F)], a1[13], a2[7], a3[4], a4[tiles(Z)];
-            load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
+            if (F > 64) load_rows_wide<F>(a0, xin, in_f64, row, valid, lane, feats);
+            else load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
             fwd_layer<N, S, 0>(a0, a1, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
@@ -1006,7 +1059,7 @@ struct FusedState {
     int64_t latency_max_rows = 4096;   // <= this many rows: lat_train_kernel (BALER_AMD_LATENCY_ROWS overrides)
 };
 
-template <int F, int Z>
+template <int F, int Z, bool TRAIN>
 static int build_maps(bamd_handle *h, FusedState *st) {
     using N = Net<F, Z>;
     std::vector<int> src((size_t)N::packed_f4() * 4, -1);
@@ -1040,6 +1093,7 @@ static int build_maps(bamd_handle *h, FusedState *st) {
                     int nf = slot_feature(NN, t, g, r);
                     if (nf >= 0) src[((size_t)N::bf_off(l) + t * 4 + g) * 4 + r] = N::b_off(l) + nf;
                 }
+        if (!TRAIN) continue;
         // slab map: tile idx = kt*NT + nt; lane (j = lane & 15 -> k slot row 16kt + j), reg r -> n slot row 4g + r
         const int KTp = tiles(K + 1);
         const int T1 = tiles(K) - 1, V = K - 16 * T1, ones_row = 16 * T1 + 4 * (V % 4) + (V / 4);
@@ -1064,11 +1118,13 @@ static int build_maps(bamd_handle *h, FusedState *st) {
         for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::ef_off(l) * 4 + i] = src[(size_t)N::wf_off(l) * 4 + i];
     for (int l = 3; l >= 1; --l)
         for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::eb_off(l) * 4 + i] = src[(size_t)N::wb_off(l) * 4 + i];
-    for (int v : smap)
-        if (v < 0) { set_error("fused: incomplete slab map"); return BAMD_ERR_INVALID; }
-    std::vector<int> inv((size_t)N::slab_off(N::L) * 64 * 4, -1);   // slab float -> canonical parameter
-    for (int p = 0; p < N::nparams(); ++p) inv[smap[p]] = p;
-    smap.swap(inv);
+    if (TRAIN) {
+        for (int v : smap)
+            if (v < 0) { set_error("fused: incomplete slab map"); return BAMD_ERR_INVALID; }
+        std::vector<int> inv((size_t)N::slab_off(N::L) * 64 * 4, -1);   // slab float -> canonical parameter
+        for (int p = 0; p < N::nparams(); ++p) inv[smap[p]] = p;
+        smap.swap(inv);
+    }
     {   // inverse of the pack map: for every parameter the list of packed positions that hold a copy of it
         std::vector<int> off((size_t)N::nparams() + 1, 0), idx;
         for (int v : src) if (v >= 0) off[v + 1]++;
@@ -1115,8 +1171,6 @@ static int infer_grid(int64_t n) {
 
 template <int F, int Z> struct Impl {
     using N = Net<F, Z>;
-    static_assert(N::bf_off(8) - N::bf_off(0) == kBiasF4, "bias fragment count");
-
     static bool matches(const bamd_handle *h) {
         if (h->L != 8) return false;
         for (int i = 0; i <= 8; ++i)
@@ -1124,7 +1178,8 @@ template <int F, int Z> struct Impl {
         return true;
     }
     static int setup(bamd_handle *h, FusedState *st) {
-        int rc = build_maps<F, Z>(h, st);
+        static_assert(N::bf_off(8) - N::bf_off(0) == kBiasF4, "bias fragment count");
+        int rc = build_maps<F, Z, true>(h, st);
         if (rc) return rc;
         BAMD_HIP(hipFuncSetAttribute((const void *)train_dec_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
         BAMD_HIP(hipFuncSetAttribute((const void *)train_enc_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
@@ -1197,6 +1252,24 @@ template <int F, int Z> struct Impl {
     }
 };
 
+// Encode-only instantiation for wide tables (the 512-column config, BASELINE.json configs[4]): encode on the
+// register chain; decode, training and forward_loss on the generic layer-wise path (the weight-gradient accumulators of a wide first
+// layer do not fit the register file).
+template <int F, int Z> struct ImplInfer {
+    using N = Net<F, Z>;
+    static bool matches(const bamd_handle *h) {
+        if (h->L != 8) return false;
+        for (int i = 0; i <= 8; ++i)
+            if (h->dims[i] != N::dim(i)) return false;
+        return true;
+    }
+    static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, false>(h, st); }
+    static const FusedOps *ops() {
+        static const FusedOps o = {setup, Impl<F, Z>::encode, nullptr, nullptr, nullptr};
+        return &o;
+    }
+};
+
 // Instantiated shapes: the CMS 24-column model at the usual compression ratios
 // (latent = ceil(24 / ratio): 1.6 -> 15, 2 -> 12, 3 -> 8, 4 -> 6).  Anything else runs on generic.hip.
 static const FusedOps *find_ops(const bamd_handle *h) {
@@ -1205,6 +1278,7 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     if (Impl<24, 12>::matches(h)) return Impl<24, 12>::ops();
     if (Impl<24, 8>::matches(h)) return Impl<24, 8>::ops();
     if (Impl<24, 6>::matches(h)) return Impl<24, 6>::ops();
+    if (ImplInfer<512, 6>::matches(h)) return ImplInfer<512, 6>::ops();
     return nullptr;
 }
 
@@ -1262,14 +1336,18 @@ int fused_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const do
 }
 int fused_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features, const uint8_t *int_mask,
                  void *out, int out_dtype, hipStream_t s) {
+    if (!state_of(h)->ops->decode)
+        return generic_forward(h, z, z_dtype, n, nullptr, h->L / 2, h->L, out, out_dtype, features, int_mask, s);
     return state_of(h)->ops->decode(h, z, z_dtype, n, features, int_mask, out, out_dtype, s);
 }
 int fused_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *recon,
                        int recon_dtype, double *loss_sum, hipStream_t s) {
+    if (!state_of(h)->ops->forward_loss) return generic_forward_loss(h, x, x_dtype, n, features, recon, recon_dtype, loss_sum, s);
     return state_of(h)->ops->forward_loss(h, x, x_dtype, n, features, recon, recon_dtype, loss_sum, s);
 }
 int fused_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
                   hipStream_t s) {
+    if (!state_of(h)->ops->fwd_bwd) return generic_fwd_bwd(h, x, x_dtype, n, features, grads, s);
     return state_of(h)->ops->fwd_bwd(h, x, x_dtype, n, features, grads, s);
 }
 

@@ -370,3 +370,25 @@ def test_other_latent_sizes_fused(z, data10k):
     finally:
         del os.environ["BALER_AMD_FORCE_GENERIC"]
     assert rel(gg.cpu().numpy(), grads.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_wide_512_fused_encode_ragged(dtype):
+    """Encode of the 512-column model runs on the fused register chain (vector row loads); decode/train on the
+    generic path: both against the oracle, ragged row count, fp32 and fp64 rows, fused normalisation."""
+    dims = orc.ae_dims(512, 6)
+    flat = orc.formula_params(dims, 42)
+    h, p = make_handle(dims, flat, "fp32")
+    raw = synth.wide_rows(1003, 512) * 3.0 + 1.0
+    xn = orc.normalize(raw)
+    z = h.encode(dev(xn, dtype))
+    assert rel(z.cpu().numpy(), orc.encode(dims, flat, xn)) < TOL32
+    feats = native.minmax(dev(raw, dtype))
+    z2 = h.encode(dev(raw, dtype), features=feats)
+    assert rel(z2.cpu().numpy(), orc.encode(dims, flat, xn)) < (TOL32 if dtype == torch.float64 else 1e-4)
+    zz = orc.encode(dims, flat, xn)
+    assert rel(h.decode(dev(zz, dtype)).cpu().numpy(), orc.decode(dims, flat, zz)) < TOL32
+    grads = torch.zeros_like(p)
+    h.fwd_bwd(dev(xn[:200], dtype), grads)
+    lo, go = orc.fwd_bwd(dims, flat, xn[:200])
+    assert rel(grads.cpu().numpy().astype(np.float64)[:-1], go) < TOL32
