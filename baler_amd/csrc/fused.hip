@@ -102,6 +102,9 @@ __device__ __forceinline__ v4 frag(const WStream &ws, int idx) {
     return __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
 }
 constexpr int kRing = 8;
+#ifndef BAMD_CHAIN_WAYS
+#define BAMD_CHAIN_WAYS 2
+#endif
 struct Ring { v4 slot[kRing]; };
 
 // The stream is walked cyclically (iteration after iteration), so its length is padded to a multiple of
@@ -133,19 +136,23 @@ __device__ __forceinline__ void chain_gemm(const v4 (&in)[tiles(KD)], v4 (&out)[
     // wave alternates between two independent accumulators and the pipe stays back-to-back at one wave
     // per SIMD.
     constexpr int NF = tiles(KD) * NT;
+    constexpr int W = BAMD_CHAIN_WAYS;   // fragments whose MFMA steps are interleaved (independent accumulators)
 #pragma unroll
-    for (int f = 0; f < NF; f += 2) {
-        const int q0 = f / NT, t0 = f % NT;
-        const bool two = f + 1 < NF;
-        const int q1 = two ? (f + 1) / NT : q0, t1 = two ? (f + 1) % NT : t0;
-        const int s0 = (BASE + f) % kRing, s1 = (BASE + f + 1) % kRing;
+    for (int f = 0; f < NF; f += W) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (r < tile_steps(KD, q0)) out[t0] = mfma(ring.slot[s0][r], in[q0][r], out[t0]);
-            if (two && r < tile_steps(KD, q1)) out[t1] = mfma(ring.slot[s1][r], in[q1][r], out[t1]);
-        }
-        ring.slot[s0] = frag(ws, (BASE + f + kRing) % pad_total(TOTAL));
-        if (two) ring.slot[s1] = frag(ws, (BASE + f + 1 + kRing) % pad_total(TOTAL));
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+                if (f + j < NF && r < tile_steps(KD, (f + j) / NT))
+                    out[(f + j) % NT] = mfma(ring.slot[(BASE + f + j) % kRing][r], in[(f + j) / NT][r], out[(f + j) % NT]);
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#ifdef BAMD_ABLATE_HALF_LOADS
+            if (f + j < NF && ((f + j) & 1) == 0)
+#else
+            if (f + j < NF)
+#endif
+                ring.slot[(BASE + f + j) % kRing] = frag(ws, (BASE + f + j + kRing) % pad_total(TOTAL));
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -165,7 +172,8 @@ template <int NT> __device__ __forceinline__ void lrelu(v4 (&a)[NT]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[t][r] = fmaxf(a[t][r], a[t][r] * 0.01f);   // == x > 0 ? x : 0.01 x
+        for (int r = 0; r < 4; ++r)   // x > 0 ? x : 0.01 x == max(x, 0.01 x) == med3(x, 0.01 x, +inf): v_mul + v_med3, and
+            a[t][r] = __builtin_amdgcn_fmed3f(a[t][r], a[t][r] * 0.01f, __builtin_inff());   // no canonicalising v_max (fmaxf adds one)
 }
 // dZ = dY * lrelu'(pre) ; sign(pre) == sign(post-activation y)
 template <int NT> __device__ __forceinline__ void lrelu_bwd(v4 (&d)[NT], const v4 (&y)[NT]) {
@@ -1189,7 +1197,9 @@ template <int F, int Z> struct Impl {
     }
     static int encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
                       hipStream_t s) {
-        hipLaunchKernelGGL((infer_kernel<F, Z, K_ENCODE>), dim3(infer_grid(n)), dim3(256), 0, s, (const v4 *)h->packed.p, x,
+        static const int extra_lds = getenv("BALER_AMD_INFER_LDS") ? atoi(getenv("BALER_AMD_INFER_LDS")) : 0;   // occupancy experiments
+        if (extra_lds) (void)hipFuncSetAttribute((const void *)infer_kernel<F, Z, K_ENCODE>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+        hipLaunchKernelGGL((infer_kernel<F, Z, K_ENCODE>), dim3(infer_grid(n)), dim3(256), extra_lds, s, (const v4 *)h->packed.p, x,
                            x_dtype == BAMD_F64, n, features, z, z_dtype == BAMD_F64, (const uint8_t *)nullptr, (double *)nullptr);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
