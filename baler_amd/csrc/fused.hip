@@ -173,7 +173,7 @@ template <int NT> __device__ __forceinline__ void lrelu(v4 (&a)[NT]) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)   // x > 0 ? x : 0.01 x == max(x, 0.01 x) == med3(x, 0.01 x, +inf): v_mul + v_med3, and
-            a[t][r] = __builtin_amdgcn_fmed3f(a[t][r], a[t][r] * 0.01f, __builtin_inff());   // no canonicalising v_max (fmaxf adds one)
+            a[t][r] = __builtin_amdgcn_fmed3f(a[t][r], a[t][r] * 0.01f, 3.402823466e38f);   // (FLT_MAX, not inf: hipcc folds med3(x,y,inf) back into canonicalise + v_max)
 }
 // dZ = dY * lrelu'(pre) ; sign(pre) == sign(post-activation y)
 template <int NT> __device__ __forceinline__ void lrelu_bwd(v4 (&d)[NT], const v4 (&y)[NT]) {
