@@ -9,6 +9,8 @@
 // the general fallback and the independent cross-check for them.  gfx950 only.
 #include "bamd_internal.hpp"
 
+#include <cstdlib>
+
 namespace bamd {
 
 template <typename T> struct MF;
@@ -57,6 +59,28 @@ template <typename T> struct Epi {
     int64_t slab_stride;
     int64_t rows_per_split;
 };
+
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue(const Epi<T> &e, int64_t row, int64_t col, T val) {
+    if (EPI == EPI_FWD) {
+        if (row < e.n_rows && col < e.n_cols) {
+            val += e.bias[col];
+            if (e.act) val = val > (T)0 ? val : val * (T)kSlope;
+            e.out[row * e.ld + col] = val;
+        }
+    } else if (EPI == EPI_DX) {
+        if (row < e.n_rows && col < e.n_cols) {
+            if (e.ymask) val = e.ymask[row * e.ld_mask + col] > (T)0 ? val : val * (T)kSlope;
+            e.out[row * e.ld + col] = val;
+        }
+    } else {
+        const int64_t so = (int64_t)blockIdx.z * e.slab_stride;
+        if (row < e.n_rows) {
+            if (col < e.kin) e.gw[so + row * e.kin + col] = val;
+            else if (col == e.kin) e.gb[so + row] = val;
+        }
+    }
+}
 
 template <typename T, int EPI, bool A_KFAST, bool B_KFAST>
 __global__ void __launch_bounds__(256) gemm_k(Opnd<T> A, Opnd<T> B, int64_t kred, Epi<T> e) {
@@ -112,29 +136,127 @@ __global__ void __launch_bounds__(256) gemm_k(Opnd<T> A, Opnd<T> B, int64_t kred
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                int64_t row = i0 + wr * 32 + mt * 16 + MF<T>::crow(reg, lane);
-                int64_t col = j0 + wc * 32 + nt * 16 + (lane & 15);
-                T val = acc[mt][nt][reg];
-                if (EPI == EPI_FWD) {
-                    if (row < e.n_rows && col < e.n_cols) {
-                        val += e.bias[col];
-                        if (e.act) val = val > (T)0 ? val : val * (T)kSlope;
-                        e.out[row * e.ld + col] = val;
-                    }
-                } else if (EPI == EPI_DX) {
-                    if (row < e.n_rows && col < e.n_cols) {
-                        if (e.ymask) val = e.ymask[row * e.ld_mask + col] > (T)0 ? val : val * (T)kSlope;
-                        e.out[row * e.ld + col] = val;
-                    }
-                } else {
-                    int64_t so = (int64_t)blockIdx.z * e.slab_stride;
-                    if (row < e.n_rows) {
-                        if (col < e.kin) e.gw[so + row * e.kin + col] = val;
-                        else if (col == e.kin) e.gb[so + row] = val;
-                    }
-                }
+            for (int reg = 0; reg < 4; ++reg)
+                epilogue<T, EPI>(e, i0 + wr * 32 + mt * 16 + MF<T>::crow(reg, lane), j0 + wc * 32 + nt * 16 + (lane & 15),
+                                 acc[mt][nt][reg]);
+}
+
+// 128 x 128 x 16 tile, 2 x 2 waves of 4 x 4 MFMA tiles each, double-buffered LDS with register staging: the global
+// loads of chunk c+1 are in flight while chunk c feeds 64 MFMAs per wave (8 ds_read_b128 per 64 MFMAs), one barrier per
+// chunk.  Used when both outer dimensions are >= 96 (the wide layers of CFD_dense_AE / the 512-column model, their
+// input- and weight-gradient products); 16-wide sub-tiles entirely outside the matrix are skipped.
+template <typename T, int EPI, bool A_KFAST, bool B_KFAST>
+__global__ void __launch_bounds__(256) gemm_big_k(Opnd<T> A, Opnd<T> B, int64_t kred, Epi<T> e) {
+    using v4 = typename MF<T>::v4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T(*As)[128][20] = (T(*)[128][20])smem_raw;                       // [2][128][20]
+    T(*Bs)[128][20] = (T(*)[128][20])(smem_raw + 2 * 128 * 20 * sizeof(T));
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int64_t i0 = (int64_t)blockIdx.y * 128, j0 = (int64_t)blockIdx.x * 128;
+    int64_t k_lo = 0, k_hi = kred;
+    if (EPI == EPI_DW) {
+        k_lo = (int64_t)blockIdx.z * e.rows_per_split;
+        k_hi = k_lo + e.rows_per_split < kred ? k_lo + e.rows_per_split : kred;
+    }
+    const int64_t na = (A.ones_o >= 0 ? A.ones_o + 1 : A.n_o), nb = (B.ones_o >= 0 ? B.ones_o + 1 : B.n_o);
+    bool live_m[4], live_n[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        live_m[t] = i0 + wr * 64 + 16 * t < na;
+        live_n[t] = j0 + wc * 64 + 16 * t < nb;
+    }
+    v4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4){0, 0, 0, 0};
+    // Staging registers: 8 elements of A and 8 of B per thread per chunk.  Fast path (interior tile, full chunk, 4-element
+    // aligned rows): two vector loads per operand -- K-fast operands take 4 consecutive k of one row, K-slow operands
+    // (outer index contiguous) take 4 consecutive rows of one k; otherwise bounds-checked scalar loads.
+    T ra[8], rb[8];
+    const bool vecA = (i0 + 128 <= A.n_o) && ((A_KFAST ? A.s_o : A.s_k) % 4 == 0) && (((uintptr_t)A.p) % (4 * sizeof(T)) == 0) &&
+                      (A_KFAST ? A.s_k == 1 : A.s_o == 1);
+    const bool vecB = (j0 + 128 <= B.n_o) && ((B_KFAST ? B.s_o : B.s_k) % 4 == 0) && (((uintptr_t)B.p) % (4 * sizeof(T)) == 0) &&
+                      (B_KFAST ? B.s_k == 1 : B.s_o == 1);
+    auto gload_one = [&](const Opnd<T> &X, bool KF, bool vec, int64_t o0, int64_t k0, T (&reg)[8]) {
+        if (vec && k0 + 16 <= k_hi && (KF ? (k0 % 4 == 0) : true)) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                v4 v;
+                if (KF) v = *(const v4 *)(X.p + (o0 + (tid >> 2) + 64 * h) * X.s_o + k0 + 4 * (tid & 3));
+                else v = *(const v4 *)(X.p + (o0 + 4 * (tid & 31)) + (k0 + (tid >> 5) + 8 * h) * X.s_k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) reg[4 * h + j] = v[j];
             }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t o = KF ? o0 + (tid >> 2) + 64 * h : o0 + 4 * (tid & 31) + j;
+                    const int64_t k = KF ? k0 + 4 * (tid & 3) + j : k0 + (tid >> 5) + 8 * h;
+                    reg[4 * h + j] = X.get(o, k, k_hi);
+                }
+        }
+    };
+    auto gload = [&](int64_t k0) {
+        gload_one(A, A_KFAST, vecA, i0, k0, ra);
+        gload_one(B, B_KFAST, vecB, j0, k0, rb);
+    };
+    auto lstore_one = [&](T (*S)[20], bool KF, const T (&reg)[8]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (KF) {
+                v4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = reg[4 * h + j];
+                *(v4 *)&S[(tid >> 2) + 64 * h][4 * (tid & 3)] = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) S[4 * (tid & 31) + j][(tid >> 5) + 8 * h] = reg[4 * h + j];
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        lstore_one(As[buf], A_KFAST, ra);
+        lstore_one(Bs[buf], B_KFAST, rb);
+    };
+    if (k_lo < k_hi) {
+        gload(k_lo);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t k0 = k_lo; k0 < k_hi; k0 += 16, buf ^= 1) {
+        const bool more = k0 + 16 < k_hi;
+        if (more) gload(k0 + 16);
+        T a4[4][4], b4[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a4[t][r] = As[buf][wr * 64 + t * 16 + (lane & 15)][4 * (lane >> 4) + r];
+                b4[t][r] = Bs[buf][wc * 64 + t * 16 + (lane & 15)][4 * (lane >> 4) + r];
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    if (live_m[mt] && live_n[nt]) acc[mt][nt] = MF<T>::mma(a4[mt][r], b4[nt][r], acc[mt][nt]);
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                epilogue<T, EPI>(e, i0 + wr * 64 + mt * 16 + MF<T>::crow(reg, lane), j0 + wc * 64 + nt * 16 + (lane & 15),
+                                 acc[mt][nt][reg]);
 }
 
 // dZ_L = 2 (R - X)/C and per-block partial sums of (R - X)^2 (utils.py:195-199 and its autograd).
@@ -160,12 +282,20 @@ __global__ void __launch_bounds__(256) loss_grad_k(const T *__restrict__ r, cons
 }
 
 template <typename TO>
-__global__ void loss_final_k(const double *__restrict__ part, int n, double scale, TO *dst,
-                             int accumulate) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += part[i];
-        s *= scale;
+__global__ void __launch_bounds__(256) loss_final_k(const double *__restrict__ part, int n, double scale, TO *dst,
+                                                    int accumulate) {
+    // fixed-order tree over <= 1024 partials (one block)
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        s = sh[0] * scale;
         *dst = accumulate ? (TO)((double)*dst + s) : (TO)s;
     }
 }
@@ -203,6 +333,25 @@ __global__ void fill_nan_k(double *p, int n) {
     if (i < n) p[i] = NAN;
 }
 
+// pick the tile: 128 x 128 (double-buffered) when both outer extents are large enough, else 64 x 64
+template <typename T, int EPI, bool AK, bool BK>
+static void launch_gemm(const Opnd<T> &A, const Opnd<T> &B, int64_t kred, const Epi<T> &e, int64_t outer_a, int64_t outer_b,
+                        unsigned nz, hipStream_t s) {
+    if (outer_a >= 96 && outer_b >= 96) {
+        const int lds = 4 * 128 * 20 * (int)sizeof(T);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)gemm_big_k<T, EPI, AK, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_set = true;
+        }
+        dim3 grid((unsigned)((outer_b + 127) / 128), (unsigned)((outer_a + 127) / 128), nz);
+        hipLaunchKernelGGL((gemm_big_k<T, EPI, AK, BK>), grid, dim3(256), lds, s, A, B, kred, e);
+    } else {
+        dim3 grid((unsigned)((outer_b + 63) / 64), (unsigned)((outer_a + 63) / 64), nz);
+        hipLaunchKernelGGL((gemm_k<T, EPI, AK, BK>), grid, dim3(256), 0, s, A, B, kred, e);
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 template <typename T> struct Work {
     T *x0;
@@ -214,7 +363,10 @@ template <typename T> struct Work {
 template <typename T>
 static int carve(bamd_handle *h, int64_t n, bool need_grad, Work<T> &wk) {
     int64_t per_row = h->dims[0] + h->sum_dims + (need_grad ? 2 * h->max_dim : 0);
-    int64_t chunk = (int64_t)(1u << 28) / (per_row * (int64_t)sizeof(T));
+    // activation workspace budget: large enough that one chunk fills the chip even for wide models
+    // (CFD_dense_AE: 42 KB of activations per row); 288 GB of HBM per GPU make 4 GB a small price
+    static const int64_t budget = getenv("BALER_AMD_WORKSPACE_MB") ? atoll(getenv("BALER_AMD_WORKSPACE_MB")) << 20 : ((int64_t)4 << 30);
+    int64_t chunk = budget / (per_row * (int64_t)sizeof(T));
     chunk = chunk < 1024 ? 1024 : chunk;
     chunk = chunk > (1 << 20) ? (1 << 20) : chunk;
     chunk &= ~(int64_t)63;
@@ -253,8 +405,7 @@ static void launch_fwd_layer(bamd_handle *h, int l, const T *xin, T *yout, int64
     Epi<T> e{};
     e.out = yout; e.ld = N; e.n_rows = rows; e.n_cols = N;
     e.bias = P + h->b_off[l]; e.act = h->has_act(l) ? 1 : 0;
-    dim3 grid((N + 63) / 64, (unsigned)((rows + 63) / 64), 1);
-    hipLaunchKernelGGL((gemm_k<T, EPI_FWD, true, true>), grid, dim3(256), 0, s, A, B, (int64_t)K, e);
+    launch_gemm<T, EPI_FWD, true, true>(A, B, (int64_t)K, e, rows, N, 1, s);
 }
 
 template <typename T>
@@ -313,7 +464,7 @@ static int forward_loss_T(bamd_handle *h, const void *x, int x_dtype, int64_t n,
         int nblk = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
         hipLaunchKernelGGL(loss_grad_k<T>, dim3(nblk), dim3(256), 0, s, wk.y[h->L], wk.x0, count, 1.0 / c,
                            (T *)nullptr, (double *)h->lossp.p);
-        hipLaunchKernelGGL(loss_final_k<double>, dim3(1), dim3(64), 0, s, (const double *)h->lossp.p, nblk,
+        hipLaunchKernelGGL(loss_final_k<double>, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk,
                            1.0 / c, loss_sum, chunk_i > 0 ? 1 : 0);
         if (recon) {
             rc = launch_convert(wk.y[h->L], td, (char *)recon + (size_t)r0 * c * oes, recon_dtype, count, s);
@@ -363,7 +514,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
         T *dz = wk.dza, *dz_next = wk.dzb;
         hipLaunchKernelGGL(loss_grad_k<T>, dim3(nblk), dim3(256), 0, s, wk.y[h->L], wk.x0, count, 1.0 / c, dz,
                            (double *)h->lossp.p);
-        hipLaunchKernelGGL(loss_final_k<T>, dim3(1), dim3(64), 0, s, (const double *)h->lossp.p, nblk, 1.0 / c,
+        hipLaunchKernelGGL(loss_final_k<T>, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk, 1.0 / c,
                            grads + np, chunk_i > 0 ? 1 : 0);
         for (int l = h->L - 1; l >= 0; --l) {
             int K = h->dims[l], N = h->dims[l + 1];
@@ -374,8 +525,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 Epi<T> e{};
                 e.n_rows = N; e.kin = K; e.gw = slabs + h->w_off[l]; e.gb = slabs + h->b_off[l];
                 e.slab_stride = np; e.rows_per_split = rps;
-                dim3 grid((K + 1 + 63) / 64, (N + 63) / 64, (unsigned)nsplit);
-                hipLaunchKernelGGL((gemm_k<T, EPI_DW, false, false>), grid, dim3(256), 0, s, A, B, rows, e);
+                launch_gemm<T, EPI_DW, false, false>(A, B, rows, e, N, K + 1, (unsigned)nsplit, s);
             }
             if (l > 0) {
                 // dZ_{l-1} = (dZ_l W_l) * lrelu'(Y_{l-1})
@@ -384,8 +534,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 Epi<T> e{};
                 e.out = dz_next; e.ld = K; e.n_rows = rows; e.n_cols = K;
                 e.ymask = h->has_act(l - 1) ? wk.y[l] : nullptr; e.ld_mask = K;
-                dim3 grid((K + 63) / 64, (unsigned)((rows + 63) / 64), 1);
-                hipLaunchKernelGGL((gemm_k<T, EPI_DX, true, false>), grid, dim3(256), 0, s, A, B, (int64_t)N, e);
+                launch_gemm<T, EPI_DX, true, false>(A, B, (int64_t)N, e, rows, K, 1, s);
                 T *t = dz; dz = dz_next; dz_next = t;
             }
         }
