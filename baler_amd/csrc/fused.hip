@@ -45,6 +45,15 @@ __host__ __device__ constexpr int slot_feature(int d, int t, int g, int r) {
 constexpr int kQS = 68;        // LDS row stride (floats) of the [slot][row] images: 64 rows + 4 pad
 constexpr int kRowsPerWG = 64;
 
+// Which layer the training pair is cut at: the decoder-gradient kernel back-propagates layers 7..kSplit, the
+// encoder-gradient kernel layers kSplit-1..0 (recomputing the forward of layers 0..kSplit-2).  4 = cut at the
+// bottleneck (16-float hand-off per row, encoder forward recomputed); 2 = cut after en2 (112-float hand-off, only
+// en1 recomputed, 481 registers in the first kernel): measured 3.59 ms vs 3.91 ms per 1M rows, so 2 is the default.
+#ifndef BAMD_SPLIT
+#define BAMD_SPLIT 2
+#endif
+constexpr int kSplit = BAMD_SPLIT;
+
 // ---- compile-time description of AE(F, Z): 8 layers F-200-100-50-Z-50-100-200-F -----------------------
 template <int F, int Z> struct Net {
     static constexpr int L = 8;
@@ -63,7 +72,7 @@ template <int F, int Z> struct Net {
     __host__ __device__ static constexpr int bf_off(int l) { int s = wb_off(0); for (int j = 0; j < l; ++j) s += tiles(dim(j + 1)) * 4; return s; }
     __host__ __device__ static constexpr int e_off() { return (bf_off(L) + 63) / 64 * 64; }
     __host__ __device__ static constexpr int ef_off(int l) { return e_off() + wf_off(l); }                       // l = 0..2
-    __host__ __device__ static constexpr int eb_off(int l) { int s = e_off() + wf_off(3); for (int j = 3; j > l; --j) s += wcount(j); return s; }  // l = 3..1
+    __host__ __device__ static constexpr int eb_off(int l) { int s = e_off() + wf_off(kSplit - 1); for (int j = kSplit - 1; j > l; --j) s += wcount(j); return s; }  // l = kSplit-1..1
     __host__ __device__ static constexpr int packed_f4() { return eb_off(0) + 16 * 64; }
     // weight-gradient tiles of layer l: tiles(N) x tiles(K + 1) (the extra slot carries db)
     __host__ __device__ static constexpr int dw_tiles(int l) { return tiles(dim(l + 1)) * tiles(dim(l) + 1); }
@@ -221,7 +230,7 @@ template <class N> struct StreamForward {  // forward fragments of layers 0..7
 template <class N> struct StreamTrainDec {  // decoder-gradient kernel: forward 0..7 then backward 7,6,5,4
     static constexpr int fwd_base(int l) { return N::wf_off(l) / 64; }
     static constexpr int bwd_base(int l) { return N::wb_off(l) / 64; }
-    static constexpr int total = N::wb_off(3) / 64;
+    static constexpr int total = N::wb_off(kSplit - 1) / 64;
     static constexpr int start_f4 = 0;
 };
 template <class N> struct StreamTrainEnc {  // encoder-gradient kernel: forward 0..2 then backward 3,2,1 (region E)
@@ -452,15 +461,15 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
 }
 
 // ---- training kernels ---------------------------------------------------------------------------------
-// The autoencoder's bottleneck is the natural checkpoint: training runs as TWO launches over the same
-// rows.  The decoder-gradient kernel runs the whole forward, the loss, the decoder's backward chain and
-// accumulates the decoder's weight gradients; it hands dL/dz (15 floats per row) to the encoder-gradient
-// kernel, which recomputes the cheap encoder forward, runs the encoder's backward chain and accumulates
-// the encoder's weight gradients.  Each kernel therefore stashes only half of the activations in
-// registers (~100 per lane) and keeps its half of the weight-gradient tiles (38 per wave = 152
-// registers per lane) in accumulators for its WHOLE persistent loop: no partial-gradient traffic at all
-// inside the loop; one 150-KB slab store per workgroup at the end.  Cost: the encoder forward is
-// computed twice (+16 % MFMAs).  HBM traffic per row: x twice + dL/dz once each way (~0.5 KB).
+// Activations + weight-gradient accumulators of the whole model do not fit one CU (register file 512 KB + LDS
+// 160 KB), so training runs as TWO launches over the same rows, cut at layer kSplit.  The first
+// ("decoder-gradient") kernel runs the whole forward, the loss and the backward chain of layers 7..kSplit,
+// accumulating their weight gradients; it hands dL/d(pre-activation of layer kSplit-1) to the second
+// ("encoder-gradient") kernel, which recomputes the forward of layers 0..kSplit-2, back-propagates layers
+// kSplit-1..0 and accumulates their weight gradients.  Each kernel keeps its share of the weight-gradient tiles
+// in MFMA accumulators for its WHOLE persistent loop: no partial-gradient traffic inside the loop; one slab store
+// per workgroup at the end.  kSplit = 4 cuts at the bottleneck (16 floats per row handed off, encoder forward
+// recomputed: +16 % MFMAs); kSplit = 2 (default) cuts after en2 (112 floats per row, only en1 recomputed: +2 %).
 //
 // LDS image helpers: rows = feature slots (16t + 4g + r), columns = the workgroup's 64 batch rows.
 template <int NT>
@@ -574,6 +583,10 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
     double lacc = 0.0;
     v4 g7[DW<N, 7>::T], g6[DW<N, 6>::T], g5[DW<N, 5>::T], g4[DW<N, 4>::T];
     zero_tiles(g7); zero_tiles(g6); zero_tiles(g5); zero_tiles(g4);
+#if BAMD_SPLIT == 2
+    v4 g3[DW<N, 3>::T], g2[DW<N, 2>::T];
+    zero_tiles(g3); zero_tiles(g2);
+#endif
     Ring ring;
     ring_prime<S::total>(ring, ws);
     v4 a0n[tiles(F)];   // next row group's input, loaded one iteration ahead (software pipeline)
@@ -591,8 +604,15 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
         const bool valid_next = row_next < n;
         RawRows<F> xraw;
         v4 a4[tiles(Z)], a5[4], a6[7], a7[13], d8[tiles(F)];
+#if BAMD_SPLIT == 2
+        v4 a2[7], a3[4];
+#endif
         {
+#if BAMD_SPLIT == 2
+            v4 a0[tiles(F)], a1[13];
+#else
             v4 a0[tiles(F)], a1[13], a2[7], a3[4];
+#endif
 #pragma unroll
             for (int t = 0; t < tiles(F); ++t) a0[t] = a0n[t];
             fwd_layer<N, S, 0>(a0, a1, ring, ws, bias_lds, lane);
@@ -635,13 +655,34 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
 
         q_write_x<Z>(imgB, a4, lane, wave); q_write(imgB + DW<N, 4>::rows_x * kQS, d5, lane, wave);
         bwd_layer<N, S, 4>(d5, d4, ring, ws);            // en4 has no activation: dL/dz
+#if BAMD_SPLIT == 4
         if (valid) dz_out[row * 4 + (lane >> 4)] = d4[0];           // 16 slots per row, slot order
+#endif
         __syncthreads();
         dw_phase<N, 4>(imgB + DW<N, 4>::rows_x * kQS, imgB, g4, lane, wave);
+#if BAMD_SPLIT == 2
+        v4 d3[4], d2[7];
+        q_write_x<50>(imgA, a3, lane, wave); q_write(imgA + DW<N, 3>::rows_x * kQS, d4, lane, wave);
+        bwd_layer<N, S, 3>(d4, d3, ring, ws); lrelu_bwd(d3, a3);
+        __syncthreads();
+        dw_phase<N, 3>(imgA + DW<N, 3>::rows_x * kQS, imgA, g3, lane, wave);
+
+        q_write_x<100>(imgB, a2, lane, wave); q_write(imgB + DW<N, 2>::rows_x * kQS, d3, lane, wave);
+        bwd_layer<N, S, 2>(d3, d2, ring, ws); lrelu_bwd(d2, a2);
+        if (valid) {                                                   // dZ_1 hand-off: 7 tiles per row, slot order
+#pragma unroll
+            for (int t = 0; t < 7; ++t) dz_out[(row * 7 + t) * 4 + (lane >> 4)] = d2[t];
+        }
+        __syncthreads();
+        dw_phase<N, 2>(imgB + DW<N, 2>::rows_x * kQS, imgB, g2, lane, wave);
+#endif
         ring_tail<S::total>(ring, ws);
     }
     dw_flush<N, 7>(slab, g7, lane, wave); dw_flush<N, 6>(slab, g6, lane, wave);
     dw_flush<N, 5>(slab, g5, lane, wave); dw_flush<N, 4>(slab, g4, lane, wave);
+#if BAMD_SPLIT == 2
+    dw_flush<N, 3>(slab, g3, lane, wave); dw_flush<N, 2>(slab, g2, lane, wave);
+#endif
     // per-workgroup loss partial (fixed-order tree)
     __syncthreads();
     double *sh = (double *)lds;
@@ -654,6 +695,64 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
     if (threadIdx.x == 0) *(double *)(slab + N::slab_off(N::L) * 64) = sh[0];
 }
 
+#if BAMD_SPLIT == 2
+// Encoder-gradient kernel, cut after en2: recomputes only en1's forward, receives dZ_1 (7 tiles per row).
+template <int F, int Z>
+__global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64,
+                                                        int64_t n, const double *__restrict__ feats, v4 *__restrict__ slabs,
+                                                        const v4 *__restrict__ dz_in) {
+    using N = Net<F, Z>;
+    using S = StreamTrainEnc<N>;
+    static_assert(DW<N, 1>::rows_x + DW<N, 1>::rows_dz <= kImgB && DW<N, 0>::rows_x + DW<N, 0>::rows_dz <= kImgA, "image buffers");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *imgA = lds, *imgB = lds + kImgA * kQS;
+    v4 *bias_lds = (v4 *)(lds + (kImgA + kImgB) * kQS);
+    stage_bias<N>(bias_lds, packed);
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    v4 *slab = slabs + (int64_t)blockIdx.x * N::slab_f4();
+    const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, threadIdx.x & 63);
+    v4 g1[DW<N, 1>::T], g0[DW<N, 0>::T];
+    zero_tiles(g1); zero_tiles(g0);
+    Ring ring;
+    ring_prime<S::total>(ring, ws);
+    v4 a0n[tiles(F)], d2n[7];   // next row group's inputs, loaded one iteration ahead (software pipeline)
+    {
+        const int64_t row0 = (int64_t)blockIdx.x * kRowsPerWG + 16 * wave + (lane & 15);
+        load_rows<F>(a0n, xin, in_f64, row0, row0 < n, lane, feats);
+#pragma unroll
+        for (int t = 0; t < 7; ++t) d2n[t] = row0 < n ? dz_in[(row0 * 7 + t) * 4 + (lane >> 4)] : (v4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        asm volatile("" : "+v"(ws.voff), "+s"(wave), "+v"(lane));   // see train_dec_kernel
+        const int64_t row = grp * kRowsPerWG + 16 * wave + (lane & 15);
+        const int64_t row_next = row + (int64_t)gridDim.x * kRowsPerWG;
+        const bool valid_next = row_next < n;
+        RawRows<F> xraw;
+        v4 a0[tiles(F)], a1[13], d2[7], d1[13];
+#pragma unroll
+        for (int t = 0; t < tiles(F); ++t) a0[t] = a0n[t];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) d2[t] = d2n[t];
+        fwd_layer<N, S, 0>(a0, a1, ring, ws, bias_lds, lane);
+
+        q_write_x<200>(imgB, a1, lane, wave); q_write(imgB + DW<N, 1>::rows_x * kQS, d2, lane, wave);
+        bwd_layer<N, S, 1>(d2, d1, ring, ws); lrelu_bwd(d1, a1);
+        __syncthreads();
+        load_rows_issue<F>(xraw, xin, in_f64, row_next, valid_next, lane);   // lands during the long dW phase
+#pragma unroll
+        for (int t = 0; t < 7; ++t) d2n[t] = valid_next ? dz_in[(row_next * 7 + t) * 4 + (lane >> 4)] : (v4){0.f, 0.f, 0.f, 0.f};
+        dw_phase<N, 1>(imgB + DW<N, 1>::rows_x * kQS, imgB, g1, lane, wave);
+        load_rows_finish<F>(a0n, xraw, valid_next, lane, feats);
+
+        q_write_x<F>(imgA, a0, lane, wave); q_write(imgA + DW<N, 0>::rows_x * kQS, d1, lane, wave);
+        __syncthreads();
+        dw_phase<N, 0>(imgA + DW<N, 0>::rows_x * kQS, imgA, g0, lane, wave);
+        ring_tail<S::total>(ring, ws);
+    }
+    dw_flush<N, 1>(slab, g1, lane, wave); dw_flush<N, 0>(slab, g0, lane, wave);
+}
+#else
 template <int F, int Z>
 __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64,
                                                         int64_t n, const double *__restrict__ feats, v4 *__restrict__ slabs,
@@ -723,6 +822,8 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
     dw_flush<N, 3>(slab, g3, lane, wave); dw_flush<N, 2>(slab, g2, lane, wave);
     dw_flush<N, 1>(slab, g1, lane, wave); dw_flush<N, 0>(slab, g0, lane, wave);
 }
+
+#endif
 
 // ---- latency kernel for small batches (the reference's batch_size = 512 regime) ----------------------------
 // The throughput kernels give a whole 16-row chain to ONE wave: a 512-row batch occupies 32 waves for ~55 us
@@ -1122,9 +1223,9 @@ static int build_maps(bamd_handle *h, FusedState *st) {
                     }
     }
     // region E: copies of Wf(0..2) and Wb(3,2,1) in the encoder-gradient kernel's consumption order
-    for (int l = 0; l < 3; ++l)
+    for (int l = 0; l < kSplit - 1; ++l)
         for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::ef_off(l) * 4 + i] = src[(size_t)N::wf_off(l) * 4 + i];
-    for (int l = 3; l >= 1; --l)
+    for (int l = kSplit - 1; l >= 1; --l)
         for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::eb_off(l) * 4 + i] = src[(size_t)N::wb_off(l) * 4 + i];
     if (TRAIN) {
         for (int v : smap)
@@ -1244,7 +1345,7 @@ template <int F, int Z> struct Impl {
         int grid = (int)(ngroups < st->nwg_max ? ngroups : st->nwg_max);
         int rc = h->slabs.ensure((size_t)N::slab_f4() * 16 * (size_t)grid);
         if (rc) return rc;
-        rc = st->dz.ensure((size_t)n * 64);
+        rc = st->dz.ensure((size_t)n * (kSplit == 2 ? 7 * 64 : 64));
         if (rc) return rc;
         hipLaunchKernelGGL((train_dec_kernel<F, Z>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
                            x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (v4 *)st->dz.p);
