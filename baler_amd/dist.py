@@ -54,6 +54,13 @@ def allreduce_sum(t):
     return t
 
 
+def broadcast(t, src=0):
+    """Broadcast a tensor from `src` (initial parameters: every rank constructs its own randomly initialised model)."""
+    if is_dist() and td.get_world_size() > 1:
+        td.broadcast(t, src=src)
+    return t
+
+
 def barrier():
     if is_dist():
         td.barrier()

@@ -133,6 +133,10 @@ def train(model, variables, train_data, test_data, project_path, config):
     device = helper.get_device()
     model = model.to(device)
     model_children = list(model.children())
+    # data parallel: the reference builds the model from an unseeded RNG (baler.py:158-160), so every rank holds
+    # different initial weights -- rank 0's are broadcast once, after which the replicated Adam keeps ranks identical
+    bdist.broadcast(model.flat, src=0)
+    model.mark_params_changed()
 
     train_ds = _to_device_dataset(train_data, config, device)
     valid_ds = train_ds if test_data is train_data else _to_device_dataset(test_data, config, device)

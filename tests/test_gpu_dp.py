@@ -35,7 +35,9 @@ c.data_dimension = 1; c.activation_extraction = False; c.intermittent_model_savi
 c.intermittent_saving_patience = 100
 out = os.environ["OUT"] + f"/rank{rank}"
 os.makedirs(out, exist_ok=True)
-model = models.AE(24, 15, mode=os.environ.get("MODE", "fp64")).load_flat(init)
+model = models.AE(24, 15, mode=os.environ.get("MODE", "fp64"))
+if rank == 0:
+    model.load_flat(init)   # only rank 0 holds the intended initial weights: train() must broadcast them
 training.train(model, 24, data, data, out, c)
 flat = model.flat.cpu().numpy().astype(np.float64)[:-1]
 np.save(os.environ["OUT"] + f"/params_rank{rank}.npy", flat)
