@@ -116,6 +116,7 @@ int bamd_mode_of(const bamd_handle *h) { return h ? h->mode : BAMD_ERR_INVALID; 
 int bamd_load_params(bamd_handle *h, const void *params, int dtype, void *stream) {
     BAMD_REQUIRE(h && params, "null argument");
     BAMD_REQUIRE(dtype == BAMD_F32 || dtype == BAMD_F64, "bad dtype");
+    BAMD_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_convert(params, dtype, h->params.p, h->esize == 8 ? BAMD_F64 : BAMD_F32, h->nparams, s);
     if (rc) return rc;
@@ -139,7 +140,8 @@ int bamd_renormalize(const void *x, int dtype, int64_t n_rows, int n_cols, const
 
 #define BAMD_CHECK_MODEL(h)                                                        \
     BAMD_REQUIRE(h, "null handle");                                                \
-    BAMD_REQUIRE((h)->params_loaded, "bamd_load_params() has not been called");
+    BAMD_REQUIRE((h)->params_loaded, "bamd_load_params() has not been called");    \
+    BAMD_HIP(hipSetDevice((h)->device)); /* the handle's buffers live on its device */
 
 int bamd_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features, void *z,
                 int z_dtype, void *stream) {

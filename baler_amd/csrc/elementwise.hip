@@ -56,7 +56,14 @@ __global__ void minmax_final(const double *__restrict__ part, int nblk, int c,
     features[c + col] = mx - mn;
 }
 
-static DevBuf g_minmax_scratch;
+// handle-free kernels keep one grow-only scratch buffer per (device, purpose); calls on one device are expected from
+// one host thread at a time (the scratch is reused, not per-stream)
+static DevBuf &scratch_for(int purpose) {
+    static DevBuf bufs[2][64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return bufs[purpose][dev & 63];
+}
 
 int launch_minmax(const void *x, int dtype, int64_t n, int c, double *features, hipStream_t s) {
     BAMD_REQUIRE(x && features && n > 0 && c > 0, "bad arguments");
@@ -65,9 +72,10 @@ int launch_minmax(const void *x, int dtype, int64_t n, int c, double *features, 
     int64_t want = (n + R - 1) / R;
     int nblk = (int)(want < 1024 ? want : 1024);
     int ncb = (c + tcols - 1) / tcols;
-    int rc = g_minmax_scratch.ensure((size_t)nblk * 2 * c * sizeof(double));
+    DevBuf &scratch = scratch_for(0);
+    int rc = scratch.ensure((size_t)nblk * 2 * c * sizeof(double));
     if (rc) return rc;
-    double *part = (double *)g_minmax_scratch.p;
+    double *part = (double *)scratch.p;
     dim3 grid(nblk, ncb);
     if (dtype == BAMD_F64)
         hipLaunchKernelGGL(minmax_partial<double>, grid, dim3(256), 0, s, (const double *)x, n, c,
@@ -208,15 +216,15 @@ __global__ void sum_partials_k(const double *__restrict__ part, int n, double *_
     }
 }
 
-static DevBuf g_emd_scratch;
 
 int launch_emd_rows(const void *x, const void *r, int dtype, int64_t n, int c, double *out,
                     hipStream_t s) {
     BAMD_REQUIRE(x && r && out && n > 0 && c > 0 && c <= 64, "bad arguments (n_cols must be <= 64)");
     int nblk = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
-    int rc = g_emd_scratch.ensure(sizeof(double) * nblk);
+    DevBuf &scratch = scratch_for(1);
+    int rc = scratch.ensure(sizeof(double) * nblk);
     if (rc) return rc;
-    double *part = (double *)g_emd_scratch.p;
+    double *part = (double *)scratch.p;
     if (dtype == BAMD_F64)
         hipLaunchKernelGGL(emd_partial<double>, dim3(nblk), dim3(256), 0, s, (const double *)x, (const double *)r, n, c, part);
     else

@@ -392,3 +392,27 @@ def test_wide_512_fused_encode_ragged(dtype):
     h.fwd_bwd(dev(xn[:200], dtype), grads)
     lo, go = orc.fwd_bwd(dims, flat, xn[:200])
     assert rel(grads.cpu().numpy().astype(np.float64)[:-1], go) < TOL32
+
+
+def test_abi_error_paths():
+    """Errors are negative statuses with a message, never exceptions across the ABI."""
+    import ctypes
+    L = native.lib()
+    h = ctypes.c_void_p()
+    dims = (ctypes.c_int * 9)(24, 200, 100, 50, 15, 50, 100, 200, 24)
+    assert L.bamd_create(dims, 7, 0, 0, ctypes.byref(h)) == -1 and b"even" in L.bamd_last_error()
+    assert L.bamd_create(dims, 8, 9, 0, ctypes.byref(h)) == -1
+    assert L.bamd_create(dims, 8, native.MODE_BF16, 0, ctypes.byref(h)) == -5 and b"BF16" in L.bamd_last_error()
+    assert L.bamd_create(dims, 8, 0, 99, ctypes.byref(h)) == -1
+    bad = (ctypes.c_int * 9)(24, 200, 0, 50, 15, 50, 100, 200, 24)
+    assert L.bamd_create(bad, 8, 0, 0, ctypes.byref(h)) == -1
+    assert L.bamd_create(dims, 8, 0, 0, ctypes.byref(h)) == 0
+    x = torch.zeros((4, 24), dtype=torch.float32, device="cuda")
+    z = torch.zeros((4, 15), dtype=torch.float32, device="cuda")
+    rc = L.bamd_encode(h, ctypes.c_void_p(x.data_ptr()), 0, 4, None, ctypes.c_void_p(z.data_ptr()), 0, None)
+    assert rc == -1 and b"bamd_load_params" in L.bamd_last_error()      # parameters not loaded yet
+    L.bamd_destroy(h)
+    with pytest.raises(native.NativeError):
+        native.Handle(orc.ae_dims(24, 15), "bf16")
+    with pytest.raises(native.NativeError):
+        make_handle(orc.ae_dims(24, 15), orc.formula_params(orc.ae_dims(24, 15), 1), "fp32")[0].encode(torch.zeros(4, 24))
