@@ -107,6 +107,7 @@ void bamd_destroy(bamd_handle *h) {
     h->work.release();
     h->slabs.release();
     h->lossp.release();
+    h->gscratch.release();
     delete h;
 }
 
@@ -195,6 +196,26 @@ int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, voi
     void *packed = nullptr;
     fused_scatter(h, &sc_off, &sc_idx, &packed);   // Adam also refreshes the packed weight copy (one launch)
     return launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, sc_off, sc_idx, packed, s);
+}
+
+int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features, void *params,
+                    void *grads, void *m, void *v, const bamd_adam *hp, double *loss_accum, void *stream) {
+    BAMD_CHECK_MODEL(h);
+    BAMD_REQUIRE(params && m && v && hp && n_rows >= 0 && (x || n_rows == 0), "bad arguments");
+    BAMD_REQUIRE(hp->step >= 1, "step must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rows > 0) {
+        int rc = fused_train_step(h, x, x_dtype, n_rows, features, grads, params, m, v, *hp, loss_accum, s);
+        if (rc != BAMD_ERR_UNSUPPORTED) return rc;
+    }
+    if (!grads) {
+        int rc = h->gscratch.ensure((size_t)(h->nparams + 1) * h->esize);
+        if (rc) return rc;
+        grads = h->gscratch.p;
+    }
+    int rc = bamd_fwd_bwd(h, x, x_dtype, n_rows, features, grads, stream);
+    if (rc) return rc;
+    return bamd_adam_step(h, params, grads, m, v, hp, loss_accum, stream);
 }
 
 int bamd_emd_rows(const void *x, const void *recon, int dtype, int64_t n_rows, int n_cols, double *out,

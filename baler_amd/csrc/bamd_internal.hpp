@@ -58,6 +58,7 @@ struct bamd_handle {
     bamd::DevBuf work;              // activation workspace (generic path)
     bamd::DevBuf slabs;             // per-workgroup partial gradients
     bamd::DevBuf lossp;             // partial loss sums (double)
+    bamd::DevBuf gscratch;          // gradient buffer of bamd_train_step() when the caller passes none
     bool params_loaded = false;
     bool fused_ok = false;          // shape is served by the fused register-chained kernels
     void *fused_state = nullptr;    // index maps of the fused path (fused.hip)

@@ -21,8 +21,10 @@
 // into the canonical state-dict layout: bitwise reproducible.
 #include "fused.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace bamd {
 namespace {
@@ -1099,9 +1101,11 @@ __global__ void __launch_bounds__(256) lat_train_kernel(const v4 *packed, const 
             a = an; b = bn;
         }
     };
+#ifndef BAMD_ABLATE_LATDW
 #pragma unroll
     for (int l = 0; l < N::L; ++l)
         dw_layer(N::slab_off(l), tiles(N::dim(l + 1)), N::dw_tiles(l), img + LT::z_off(l) * kLS, img + LT::x_off(l) * kLS);
+#endif
     // loss partial of this tile
     __syncthreads();
     double *sh = (double *)lds;
@@ -1112,6 +1116,407 @@ __global__ void __launch_bounds__(256) lat_train_kernel(const v4 *packed, const 
         __syncthreads();
     }
     if (threadIdx.x == 0) *(double *)(slab + N::slab_off(N::L) * 64) = sh[0];
+}
+
+// ---- small-batch path, second generation: chain kernel + weight-gradient tile kernel ----------------------
+// lat_train_kernel is bound by two things a profile shows: (1) its 8-deep fragment ring keeps 8 KiB per wave in
+// flight while every step's first touch of the (just re-packed) weights comes from HBM/Infinity Cache (~1 us):
+// 145 KiB per wave / 8 KiB x 1 us = 18 us of the 28; (2) every workgroup forms the full [dW | db] of its 16 rows
+// with 4-step MFMAs and writes a 247-KiB slab that a second kernel reads back (10 us + 6 us).
+//   lat2_chain_kernel: same register/LDS-exchange chain, W waves per workgroup, but the fragments of WHOLE layers
+//     are requested two layers ahead (up to 49 fragments = 196 registers in flight per wave), and the X^T / dZ^T
+//     images go to global memory ([16-row block][slot][16 rows], 104 KiB per block) instead of LDS.
+//   lat2_dw_kernel: one workgroup per weight-gradient TILE (298 of them: the whole chip, not 32 CUs), contracting
+//     over ALL rows of the batch (fixed order: wave w takes blocks w, w+4, ..; then waves 0..3), optionally fused
+//     with the Adam update of exactly those 256 parameters and the refresh of their packed copies.
+constexpr int kImgStride = 16;   // floats per slot in the global images (= rows per block)
+
+#ifdef BAMD_LAT_TRACE   // debug build: shader-clock stamps of workgroup 0 at every layer boundary (tools/lat_trace.py)
+__device__ unsigned long long g_lat_trace[64];
+#define LAT_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lat_trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LAT_T(i) do {} while (0)
+#endif
+
+// The 15 chain GEMMs of one training step as ONE fragment sequence per wave (forward layers 0..7, then the
+// transposed fragments of layers 7..1): a register ring of D fragments runs D fragments AHEAD of the MFMAs across
+// layer boundaries, one refill per consumed fragment, so the loads are spread between the MFMAs.  (Requesting whole
+// layers at once stalls the wave: a 1-KiB fragment load occupies the CU's 64 B/clk L1 path for 16 cycles and a
+// wave issues in order, so 28 loads x 4 waves in a row = 1800 cycles before the first MFMA of the layer.)
+template <class N, int W, int D_> struct LatSeq {
+    static constexpr int D = D_, Wv = W, NG = 15;
+    __host__ __device__ static constexpr int layer(int g) { return g < 8 ? g : 15 - g; }              // 0..7, 7..1
+    __host__ __device__ static constexpr int kd(int g) { return g < 8 ? N::dim(g) : N::dim(layer(g) + 1); }
+    __host__ __device__ static constexpr int nt(int g) { return tiles(g < 8 ? N::dim(g + 1) : N::dim(layer(g))); }
+    __host__ __device__ static constexpr int base(int g) { return (g < 8 ? N::wf_off(g) : N::wb_off(layer(g))) / 64; }
+    __host__ __device__ static constexpr int nl(int g) { return (nt(g) + W - 1) / W; }
+    __host__ __device__ static constexpr int nf(int g) { return tiles(kd(g)) * nl(g); }
+    __host__ __device__ static constexpr int start(int g) { int s = 0; for (int j = 0; j < g; ++j) s += nf(j); return s; }
+    static constexpr int total = start(NG);
+    __host__ __device__ static constexpr int gemm_of(int G) { int g = 0; for (int j = 1; j < NG; ++j) if (G >= start(j)) g = j; return g; }
+};
+// (every index below is a template constant: with loop variables hipcc left the ring in scratch memory)
+template <class SQ, int G>
+__device__ __forceinline__ void seq_issue(v4 (&slot)[SQ::D], const WStream &ws, int wave) {
+    if constexpr (G < SQ::total) {
+        constexpr int g = SQ::gemm_of(G), f = G - SQ::start(g), NL = SQ::nl(g), q = f / NL, i = f % NL, NT = SQ::nt(g);
+        int t = wave + SQ::Wv * i;
+        t = t < NT ? t : NT - 1;
+        slot[G % SQ::D] = frag_rt(ws, SQ::base(g) + q * NT + t);
+    }
+}
+template <class SQ, int... G>
+__device__ __forceinline__ void seq_prologue(v4 (&slot)[SQ::D], const WStream &ws, int wave, std::integer_sequence<int, G...>) {
+    (seq_issue<SQ, G>(slot, ws, wave), ...);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// fragments f and f+1 of GEMM g feed two interleaved accumulators; each consumed fragment is replaced by the one D ahead
+template <class SQ, int g, int f>
+__device__ __forceinline__ void seq_pair(const v4 (&in)[tiles(SQ::kd(g))], v4 (&out)[SQ::nl(g)], v4 (&slot)[SQ::D],
+                                         const WStream &ws, int wave) {
+    constexpr int NL = SQ::nl(g), NF = SQ::nf(g), S0 = SQ::start(g), KD = SQ::kd(g);
+    constexpr bool two = f + 1 < NF;
+    constexpr int q0 = f / NL, i0 = f % NL, q1 = two ? (f + 1) / NL : q0, i1 = two ? (f + 1) % NL : i0;
+    constexpr int s0 = (S0 + f) % SQ::D, s1 = (S0 + f + (two ? 1 : 0)) % SQ::D;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r < tile_steps(KD, q0)) out[i0] = mfma(slot[s0][r], in[q0][r], out[i0]);
+        if (two && r < tile_steps(KD, q1)) out[i1] = mfma(slot[s1][r], in[q1][r], out[i1]);
+    }
+    seq_issue<SQ, S0 + f + SQ::D>(slot, ws, wave);
+    if constexpr (two) seq_issue<SQ, S0 + f + 1 + SQ::D>(slot, ws, wave);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class SQ, int g, int... P>
+__device__ __forceinline__ void seq_mm_impl(const v4 (&in)[tiles(SQ::kd(g))], v4 (&out)[SQ::nl(g)], v4 (&slot)[SQ::D],
+                                            const WStream &ws, int wave, std::integer_sequence<int, P...>) {
+    (seq_pair<SQ, g, 2 * P>(in, out, slot, ws, wave), ...);
+}
+// GEMM g of the sequence: out[i] += frags(q, tile wave + W i) . in[q]
+template <class SQ, int g>
+__device__ __forceinline__ void seq_mm(const v4 (&in)[tiles(SQ::kd(g))], v4 (&out)[SQ::nl(g)], v4 (&slot)[SQ::D], const WStream &ws,
+                                       int wave) {
+    seq_mm_impl<SQ, g>(in, out, slot, ws, wave, std::make_integer_sequence<int, (SQ::nf(g) + 1) / 2>{});
+}
+// own tiles -> LDS exchange buffer (C layout) and -> the global [slot][16 rows] image through a buffer resource
+// (per-lane offset once, slot offsets as SGPR/immediate: no address arithmetic per store).  Measured: 16-byte stores
+// of C-layout tiles save 0.3 us here but cost lat2_dw_kernel 1.2 us of transposing 4-byte loads.
+template <int D, bool ONES, int W>
+__device__ __forceinline__ void lat2_publish(v4 *xch, __amdgpu_buffer_rsrc_t irs, int slot0, const v4 (&loc)[(tiles(D) + W - 1) / W],
+                                             int lane, int wave) {
+    constexpr int NT = tiles(D), NL = (NT + W - 1) / W;
+    constexpr int T1 = tiles(D) - 1, V = D - 16 * T1, R1 = V / 4, G1 = V % 4;
+    const int g = lane >> 4, col = lane & 15;
+    const int voff = (4 * g * kImgStride + col) * 4;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int t = wave + W * i;
+        if (t < NT) {
+            if (xch) xch[t * 64 + lane] = loc[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = loc[i][r];
+                if (ONES && t == T1 && r == R1 && g == G1) v = 1.0f;      // the ones slot that carries db
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), irs, voff + r * kImgStride * 4,
+                                                      (slot0 + 16 * t) * kImgStride * 4, 0);
+            }
+        }
+    }
+}
+
+template <int F, int Z, int W>
+__global__ void __launch_bounds__(64 * W) lat2_chain_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
+                                                            const double *__restrict__ feats, float *__restrict__ imgs,
+                                                            double *__restrict__ loss_part) {
+    using N = Net<F, Z>;
+    using LT = Lat<N>;
+    constexpr int kImgFloats = LT::z_off(N::L) * kImgStride;
+    __shared__ __attribute__((aligned(16))) v4 xch_lds[2 * LT::xch_f4 + (N::bf_off(N::L) - N::bf_off(0))];
+    __shared__ double loss_lds[W];
+    v4 *xchA = xch_lds, *xchB = xchA + LT::xch_f4, *bias_lds = xchB + LT::xch_f4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    WStream ws = make_stream(packed, N::packed_f4() * 16, lane);
+    constexpr int TF = tiles(F), TZ = tiles(Z);
+    static_assert(TF <= 4 && TZ == 1, "input / latent tiles");
+    LAT_T(0);
+    // the rows first (layer 0 waits for them), then the ring's first D fragments queue up behind them
+    const int64_t row = (int64_t)blockIdx.x * 16 + (lane & 15);
+    const bool valid = row < n;
+    RawRows<F> xraw;
+    load_rows_issue<F>(xraw, xin, in_f64, row, valid, lane);
+    using SQ = LatSeq<N, W, (W == 4 ? 32 : 24)>;
+    v4 ring[SQ::D];
+    constexpr int kNB = N::bf_off(N::L) - N::bf_off(0), kBV = (kNB + 64 * W - 1) / (64 * W);
+    v4 bv[kBV];                                   // bias fragments: requested with the rows, not after them
+#pragma unroll
+    for (int k = 0; k < kBV; ++k) {
+        const int idx = (int)threadIdx.x + k * 64 * W;
+        bv[k] = idx < kNB ? packed[N::bf_off(0) + idx] : (v4){0.f, 0.f, 0.f, 0.f};
+    }
+    seq_prologue<SQ>(ring, ws, wave, std::make_integer_sequence<int, SQ::D>{});
+    v4 a0[TF];
+    load_rows_finish<F>(a0, xraw, valid, lane, feats);
+#pragma unroll
+    for (int k = 0; k < kBV; ++k) {
+        const int idx = (int)threadIdx.x + k * 64 * W;
+        if (idx < kNB) bias_lds[idx] = bv[k];
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void *)(imgs + (int64_t)blockIdx.x * kImgFloats), 0,
+                                                                         kImgFloats * 4, 0x00020000);
+#define LAT2_BIAS(loc, l, NTl)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < (NTl + W - 1) / W; ++i) {                                      \
+        int t_ = wave + W * i; t_ = t_ < NTl ? t_ : NTl - 1;                                             \
+        loc[i] = bias_lds[(N::bf_off(l) - N::bf_off(0)) + t_ * 4 + g];                                   \
+    }
+    LAT_T(1);
+    constexpr int L13 = (13 + W - 1) / W, L7 = (7 + W - 1) / W, L4 = (4 + W - 1) / W, LF = (TF + W - 1) / W;
+    // ---------------- forward ----------------
+    {   // X image of layer 0 (= the input): every wave holds all of a0, wave t publishes tile t
+        v4 own[LF];
+#pragma unroll
+        for (int i = 0; i < LF; ++i) own[i] = a0[(wave + W * i) < TF ? (wave + W * i) : TF - 1];
+        lat2_publish<F, true, W>(nullptr, irs, LT::x_off(0), own, lane, wave);
+    }
+    v4 s1[L13], s2[L7], s3[L4], s4[1], s5[L4], s6[L7], s7[L13], o8[LF];
+    LAT2_BIAS(s1, 0, 13) seq_mm<SQ, 0>(a0, s1, ring, ws, wave); lrelu(s1);
+    lat2_publish<200, true, W>(xchA, irs, LT::x_off(1), s1, lane, wave);
+    __syncthreads();
+    LAT_T(2);
+    {
+        v4 a1[13]; lat_collect(xchA, a1, lane);
+        LAT2_BIAS(s2, 1, 7) seq_mm<SQ, 1>(a1, s2, ring, ws, wave); lrelu(s2);
+    }
+    lat2_publish<100, true, W>(xchB, irs, LT::x_off(2), s2, lane, wave);
+    __syncthreads();
+    LAT_T(3);
+    {
+        v4 a2[7]; lat_collect(xchB, a2, lane);
+        LAT2_BIAS(s3, 2, 4) seq_mm<SQ, 2>(a2, s3, ring, ws, wave); lrelu(s3);
+    }
+    lat2_publish<50, true, W>(xchA, irs, LT::x_off(3), s3, lane, wave);
+    __syncthreads();
+    LAT_T(4);
+    {
+        v4 a3[4]; lat_collect(xchA, a3, lane);
+        LAT2_BIAS(s4, 3, TZ) seq_mm<SQ, 3>(a3, s4, ring, ws, wave);                       // en4: no activation
+    }
+    lat2_publish<Z, true, W>(xchB, irs, LT::x_off(4), s4, lane, wave);
+    __syncthreads();
+    LAT_T(5);
+    {
+        v4 a4[TZ]; lat_collect(xchB, a4, lane);
+        LAT2_BIAS(s5, 4, 4) seq_mm<SQ, 4>(a4, s5, ring, ws, wave); lrelu(s5);
+    }
+    lat2_publish<50, true, W>(xchA, irs, LT::x_off(5), s5, lane, wave);
+    __syncthreads();
+    LAT_T(6);
+    {
+        v4 a5[4]; lat_collect(xchA, a5, lane);
+        LAT2_BIAS(s6, 5, 7) seq_mm<SQ, 5>(a5, s6, ring, ws, wave); lrelu(s6);
+    }
+    lat2_publish<100, true, W>(xchB, irs, LT::x_off(6), s6, lane, wave);
+    __syncthreads();
+    LAT_T(7);
+    {
+        v4 a6[7]; lat_collect(xchB, a6, lane);
+        LAT2_BIAS(s7, 6, 13) seq_mm<SQ, 6>(a6, s7, ring, ws, wave); lrelu(s7);
+    }
+    lat2_publish<200, true, W>(xchA, irs, LT::x_off(7), s7, lane, wave);
+    __syncthreads();
+    LAT_T(8);
+    {
+        v4 a7[13]; lat_collect(xchA, a7, lane);
+        LAT2_BIAS(o8, 7, TF) seq_mm<SQ, 7>(a7, o8, ring, ws, wave);                       // de4: no activation
+    }
+    // ---------------- loss, dL/drecon ----------------
+    double lacc = 0.0;
+    {
+        const int t = wave;                       // LF == 1: at most one recon tile per wave
+        static_assert(LF == 1, "recon tiles per wave");
+        const v4 x0 = a0[t < TF ? t : TF - 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float d = o8[0][r] - x0[r];
+            const bool live = valid && t < TF && slot_feature(F, t < TF ? t : TF - 1, g, r) >= 0;
+            if (live) lacc += (double)d * (double)d;
+            o8[0][r] = live ? d * (2.0f / (float)F) : 0.f;
+        }
+    }
+    // ---------------- backward chain (input gradients), publishing dZ images ----------------
+    lat2_publish<F, false, W>(xchB, irs, LT::z_off(7), o8, lane, wave);
+    __syncthreads();
+    LAT_T(9);
+    {
+        v4 d8[TF]; lat_collect(xchB, d8, lane);
+        v4 dx[L13]; zero_tiles(dx);
+        seq_mm<SQ, 8>(d8, dx, ring, ws, wave); lrelu_bwd(dx, s7);
+#pragma unroll
+        for (int i = 0; i < L13; ++i) s7[i] = dx[i];          // s7 now holds dZ_6 (own tiles)
+    }
+    lat2_publish<200, false, W>(xchA, irs, LT::z_off(6), s7, lane, wave);
+    __syncthreads();
+    LAT_T(10);
+    {
+        v4 d7[13]; lat_collect(xchA, d7, lane);
+        v4 dx[L7]; zero_tiles(dx);
+        seq_mm<SQ, 9>(d7, dx, ring, ws, wave); lrelu_bwd(dx, s6);
+#pragma unroll
+        for (int i = 0; i < L7; ++i) s6[i] = dx[i];
+    }
+    lat2_publish<100, false, W>(xchB, irs, LT::z_off(5), s6, lane, wave);
+    __syncthreads();
+    LAT_T(11);
+    {
+        v4 d6[7]; lat_collect(xchB, d6, lane);
+        v4 dx[L4]; zero_tiles(dx);
+        seq_mm<SQ, 10>(d6, dx, ring, ws, wave); lrelu_bwd(dx, s5);
+#pragma unroll
+        for (int i = 0; i < L4; ++i) s5[i] = dx[i];
+    }
+    lat2_publish<50, false, W>(xchA, irs, LT::z_off(4), s5, lane, wave);
+    __syncthreads();
+    LAT_T(12);
+    {
+        v4 d5[4]; lat_collect(xchA, d5, lane);
+        v4 dx[1]; zero_tiles(dx);
+        seq_mm<SQ, 11>(d5, dx, ring, ws, wave);                                            // dL/dz: en4 has no activation
+        s4[0] = dx[0];
+    }
+    lat2_publish<Z, false, W>(xchB, irs, LT::z_off(3), s4, lane, wave);
+    __syncthreads();
+    LAT_T(13);
+    {
+        v4 d4[TZ]; lat_collect(xchB, d4, lane);
+        v4 dx[L4]; zero_tiles(dx);
+        seq_mm<SQ, 12>(d4, dx, ring, ws, wave); lrelu_bwd(dx, s3);
+#pragma unroll
+        for (int i = 0; i < L4; ++i) s3[i] = dx[i];
+    }
+    lat2_publish<50, false, W>(xchA, irs, LT::z_off(2), s3, lane, wave);
+    __syncthreads();
+    LAT_T(14);
+    {
+        v4 d3[4]; lat_collect(xchA, d3, lane);
+        v4 dx[L7]; zero_tiles(dx);
+        seq_mm<SQ, 13>(d3, dx, ring, ws, wave); lrelu_bwd(dx, s2);
+#pragma unroll
+        for (int i = 0; i < L7; ++i) s2[i] = dx[i];
+    }
+    lat2_publish<100, false, W>(xchB, irs, LT::z_off(1), s2, lane, wave);
+    __syncthreads();
+    LAT_T(15);
+    {
+        v4 d2[7]; lat_collect(xchB, d2, lane);
+        v4 dx[L13]; zero_tiles(dx);
+        seq_mm<SQ, 14>(d2, dx, ring, ws, wave); lrelu_bwd(dx, s1);
+#pragma unroll
+        for (int i = 0; i < L13; ++i) s1[i] = dx[i];
+    }
+    lat2_publish<200, false, W>(nullptr, irs, LT::z_off(0), s1, lane, wave);
+#undef LAT2_BIAS
+    // loss partial of this 16-row block: lanes of a wave, then waves 0..W-1 (fixed order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lacc += __shfl_down(lacc, off);
+    if (lane == 0) loss_lds[wave] = lacc;
+    __syncthreads();
+    LAT_T(16);
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) sum += loss_lds[w];
+        loss_part[blockIdx.x] = sum;
+    }
+}
+
+struct AdamArgs {   // scalars of one Adam step (launch_adam's), and where the state lives
+    float *params, *pcopy, *m, *v, *packed;
+    const int *sc_off, *sc_idx;
+    double *loss_accum;
+    double b1, b2, eps, step_size, bc2_sqrt;
+};
+
+// grid = 8 x ceil((dW tiles + 1) / 8).  A block contracts dZ^T (tile nt of layer l) with X (tile kt) over all 16-row
+// blocks.  Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2, so XCD c takes the CONTIGUOUS
+// tile range [c * per, (c + 1) * per): neighbouring tiles share their X / dZ image slices, each slice then crosses the
+// fabric into (about) one L2 instead of eight.  The map entry and the optimiser state of the thread's parameter are
+// requested BEFORE the image loop, so the dependent global round trips overlap instead of queueing up.
+template <class N, bool ADAM>
+__global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ imgs, int nblk, const double *__restrict__ loss_part,
+                                                      const int *__restrict__ inv_map, float *__restrict__ grads, AdamArgs ad) {
+    using LT = Lat<N>;
+    constexpr int kImgFloats = LT::z_off(N::L) * kImgStride, T = N::slab_off(N::L), np = N::nparams();
+    constexpr int kPerXcd = (T + 1 + 7) / 8;
+    __shared__ __attribute__((aligned(16))) v4 red[4 * 64];
+    const int tile = (blockIdx.x & 7) * kPerXcd + (blockIdx.x >> 3);
+    if (tile > T) return;
+    if (tile == T) {   // loss: fixed-order sum of the per-block partials, / C
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int k = 0; k < nblk; ++k) s += loss_part[k];
+            const float gl = (float)(s * (1.0 / N::dim(0)));
+            if (grads) grads[np] = gl;
+            if (ADAM && ad.loss_accum) *ad.loss_accum += (double)gl;
+        }
+        return;
+    }
+    const int p = inv_map[tile * 256 + threadIdx.x];
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < N::L; ++j) if (tile >= N::slab_off(j)) l = j;
+    int nt_count = tiles(N::dim(1)), soff = 0, xo = LT::x_off(0), zo = LT::z_off(0);
+#pragma unroll
+    for (int j = 1; j < N::L; ++j)
+        if (l == j) { nt_count = tiles(N::dim(j + 1)); soff = N::slab_off(j); xo = LT::x_off(j); zo = LT::z_off(j); }
+    const int idx = tile - soff, kt = idx / nt_count, nt = idx - kt * nt_count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    const float *pz = imgs + ((zo + 16 * nt + i) * kImgStride + 4 * g);
+    const float *px = imgs + ((xo + 16 * kt + i) * kImgStride + 4 * g);
+    float pm = 0.f, pv = 0.f, pp = 0.f;
+    int s0 = 0, s1 = 0;
+    if (ADAM && p >= 0) { pm = ad.m[p]; pv = ad.v[p]; pp = ad.params[p]; s0 = ad.sc_off[p]; s1 = ad.sc_off[p + 1]; }
+    v4 acc = (v4){0.f, 0.f, 0.f, 0.f};
+    for (int b0 = wave; b0 < nblk; b0 += 32) {   // 8 blocks per wave in flight
+        v4 a[8], x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + 4 * u;
+            const bool ok = b < nblk;
+            a[u] = ok ? *(const v4 *)(pz + (int64_t)b * kImgFloats) : (v4){0.f, 0.f, 0.f, 0.f};
+            x[u] = ok ? *(const v4 *)(px + (int64_t)b * kImgFloats) : (v4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = mfma(a[u][r], x[u][r], acc);
+    }
+    red[wave * 64 + lane] = acc;
+    int sidx[4] = {-1, -1, -1, -1};                                  // packed copies of this parameter (forward, transposed, region E)
+    if (ADAM && p >= 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (s0 + k < s1) sidx[k] = ad.sc_idx[s0 + k];
+    }
+    __syncthreads();
+    const float *rf = (const float *)red;
+    const int e = threadIdx.x;
+    const float gsum = ((rf[e] + rf[256 + e]) + rf[512 + e]) + rf[768 + e];
+    if (p < 0) return;
+    if (grads) grads[p] = gsum;
+    if (ADAM) {   // elementwise.hip adam_k, on the 256 parameters this tile owns
+        const double gi = (double)gsum;
+        double mi = (double)pm, vi = (double)pv;
+        mi = mi + (gi - mi) * (1.0 - ad.b1);
+        vi = vi * ad.b2 + (1.0 - ad.b2) * gi * gi;
+        const double denom = sqrt(vi) / ad.bc2_sqrt + ad.eps;
+        const float pn = (float)((double)pp - ad.step_size * (mi / denom));
+        ad.m[p] = (float)mi;
+        ad.v[p] = (float)vi;
+        ad.params[p] = pn;
+        if (ad.pcopy) ad.pcopy[p] = pn;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (sidx[k] >= 0) ad.packed[sidx[k]] = pn;
+        for (int k = s0 + 4; k < s1; ++k) ad.packed[ad.sc_idx[k]] = pn;
+    }
 }
 
 // Slab reduction in SLAB order: thread i sums float4 i of every workgroup slab (fully coalesced 16-byte
@@ -1165,7 +1570,10 @@ struct FusedState {
     DevBuf sc_off, sc_idx;   // CSR parameter -> packed float positions (fused Adam + pack)
     int packed_floats = 0;
     int nwg_max = 256;
-    int64_t latency_max_rows = 4096;   // <= this many rows: lat_train_kernel (BALER_AMD_LATENCY_ROWS overrides)
+    int64_t latency_max_rows = 4096;   // <= this many rows: small-batch kernels (BALER_AMD_LATENCY_ROWS overrides)
+    int lat_version = 2;               // 2 = lat2_chain_kernel + lat2_dw_kernel, 1 = lat_train_kernel + reduce (BALER_AMD_LAT)
+    int lat_waves = 4;                 // waves per workgroup of lat2_chain_kernel: 4 or 8 (BALER_AMD_LAT_WAVES)
+    DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
 };
 
 template <int F, int Z, bool TRAIN>
@@ -1269,6 +1677,8 @@ struct FusedOps {
     int (*decode)(bamd_handle *, const void *, int, int64_t, const double *, const uint8_t *, void *, int, hipStream_t);
     int (*forward_loss)(bamd_handle *, const void *, int, int64_t, const double *, void *, int, double *, hipStream_t);
     int (*fwd_bwd)(bamd_handle *, const void *, int, int64_t, const double *, void *, hipStream_t);
+    // fwd + bwd + Adam + pack in two launches (small batches only; returns BAMD_ERR_UNSUPPORTED when n is too large)
+    int (*train_step)(bamd_handle *, const void *, int, int64_t, const double *, void *, const AdamArgs &, hipStream_t);
 };
 
 static FusedState *state_of(bamd_handle *h) { return (FusedState *)h->fused_state; }
@@ -1328,6 +1738,7 @@ template <int F, int Z> struct Impl {
                        hipStream_t s) {
         FusedState *st = state_of(h);
         const int np = N::nparams();
+        if (n <= st->latency_max_rows && st->lat_version == 2) return small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
         if (n <= st->latency_max_rows) {
             // small batch: one workgroup per 16-row tile, layer outputs split over the 4 waves
             int grid = (int)((n + 15) / 16);
@@ -1357,8 +1768,41 @@ template <int F, int Z> struct Impl {
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
+    // small batch: chain kernel (one workgroup per 16-row block) + one workgroup per weight-gradient tile; with
+    // `ad` the second kernel also applies Adam and refreshes the packed weights (grads may then be null)
+    static int small_batch(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
+                           const AdamArgs *ad, hipStream_t s) {
+        FusedState *st = state_of(h);
+        const int nblk = (int)((n + 15) / 16);
+        constexpr size_t img_bytes = (size_t)Lat<N>::z_off(N::L) * kImgStride * sizeof(float);
+        int rc = st->imgs.ensure(img_bytes * (size_t)nblk);
+        if (rc) return rc;
+        rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk > 1024 ? nblk : 1024));
+        if (rc) return rc;
+        if (st->lat_waves == 8)
+            hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 8>), dim3(nblk), dim3(512), 0, s, (const v4 *)h->packed.p, x,
+                               x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
+        else
+            hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 4>), dim3(nblk), dim3(256), 0, s, (const v4 *)h->packed.p, x,
+                               x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
+        const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
+        if (ad)
+            hipLaunchKernelGGL((lat2_dw_kernel<N, true>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
+                               (const double *)h->lossp.p, (const int *)st->slab_map.p, (float *)grads, *ad);
+        else
+            hipLaunchKernelGGL((lat2_dw_kernel<N, false>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
+                               (const double *)h->lossp.p, (const int *)st->slab_map.p, (float *)grads, AdamArgs{});
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
+                          const AdamArgs &ad, hipStream_t s) {
+        FusedState *st = state_of(h);
+        if (n > st->latency_max_rows || st->lat_version != 2) return BAMD_ERR_UNSUPPORTED;
+        return small_batch(h, x, x_dtype, n, features, grads, &ad, s);
+    }
     static const FusedOps *ops() {
-        static const FusedOps o = {setup, encode, decode, forward_loss, fwd_bwd};
+        static const FusedOps o = {setup, encode, decode, forward_loss, fwd_bwd, train_step};
         return &o;
     }
 };
@@ -1376,7 +1820,7 @@ template <int F, int Z> struct ImplInfer {
     }
     static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, false>(h, st); }
     static const FusedOps *ops() {
-        static const FusedOps o = {setup, Impl<F, Z>::encode, nullptr, nullptr, nullptr};
+        static const FusedOps o = {setup, Impl<F, Z>::encode, nullptr, nullptr, nullptr, nullptr};
         return &o;
     }
 };
@@ -1404,6 +1848,8 @@ int fused_setup(bamd_handle *h) {
     FusedState *st = new FusedState();
     st->ops = ops;
     if (const char *lr = getenv("BALER_AMD_LATENCY_ROWS")) st->latency_max_rows = atoll(lr);
+    if (const char *lv = getenv("BALER_AMD_LAT")) st->lat_version = atoi(lv) == 1 ? 1 : 2;
+    if (const char *lw = getenv("BALER_AMD_LAT_WAVES")) st->lat_waves = atoi(lw) == 8 ? 8 : 4;
     h->fused_state = st;
     int rc = ops->setup(h, st);
     if (rc) return rc;
@@ -1417,6 +1863,7 @@ void fused_teardown(bamd_handle *h) {
     st->pack_src.release();
     st->slab_map.release();
     st->dz.release();
+    st->imgs.release();
     st->sc_off.release();
     st->sc_idx.release();
     delete st;
@@ -1461,5 +1908,25 @@ int fused_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const d
     if (!state_of(h)->ops->fwd_bwd) return generic_fwd_bwd(h, x, x_dtype, n, features, grads, s);
     return state_of(h)->ops->fwd_bwd(h, x, x_dtype, n, features, grads, s);
 }
+int fused_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
+                     void *params, void *m, void *v, const bamd_adam &hp, double *loss_accum, hipStream_t s) {
+    if (!h->fused_ok || !state_of(h)->ops->train_step) return BAMD_ERR_UNSUPPORTED;
+    FusedState *st = state_of(h);
+    AdamArgs ad;
+    ad.params = (float *)params; ad.pcopy = (float *)h->params.p; ad.m = (float *)m; ad.v = (float *)v;
+    ad.packed = (float *)h->packed.p;
+    ad.sc_off = (const int *)st->sc_off.p; ad.sc_idx = (const int *)st->sc_idx.p;
+    ad.loss_accum = loss_accum;
+    ad.b1 = hp.beta1; ad.b2 = hp.beta2; ad.eps = hp.eps;      // same scalars as launch_adam (elementwise.hip)
+    ad.step_size = hp.lr / (1.0 - pow(hp.beta1, (double)hp.step));
+    ad.bc2_sqrt = sqrt(1.0 - pow(hp.beta2, (double)hp.step));
+    return st->ops->train_step(h, x, x_dtype, n, features, grads, ad, s);
+}
+
+#ifdef BAMD_LAT_TRACE
+extern "C" int bamd_debug_lat_trace(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lat_trace), sizeof(unsigned long long) * (n < 64 ? n : 64));
+}
+#endif
 
 }  // namespace bamd

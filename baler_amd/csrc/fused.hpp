@@ -16,4 +16,8 @@ int fused_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, co
                        void *recon, int recon_dtype, double *loss_sum, hipStream_t s);
 int fused_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
                   hipStream_t s);
+// fwd + loss + bwd + Adam (+ re-pack) of one small batch in two launches; BAMD_ERR_UNSUPPORTED when this handle /
+// batch size has no such path (the caller then runs fused_fwd_bwd / generic_fwd_bwd followed by launch_adam)
+int fused_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
+                     void *params, void *m, void *v, const bamd_adam &hp, double *loss_accum, hipStream_t s);
 }  // namespace bamd

@@ -5,9 +5,9 @@ Same epoch semantics as the reference: the whole normalised dataset resident on 
 kept and weighted equally in the epoch mean (training.py:97-99), Adam with torch defaults
 (training.py:266), ReduceLROnPlateau / EarlyStopping between epochs (training.py:269-323).
 
-What differs is how a step executes: ONE native ``bamd_fwd_bwd`` (forward + loss + backward, fused
-HIP/MFMA kernels) and ONE native ``bamd_adam_step`` per batch, the running loss accumulated ON THE
-DEVICE and read once per epoch (the reference syncs with ``loss.item()`` every step,
+What differs is how a step executes: ONE native ``bamd_train_step`` per batch (forward + loss +
+backward + Adam, fused HIP/MFMA kernels; data-parallel: ``bamd_fwd_bwd``, the gradient all-reduce,
+then ``bamd_adam_step``), the running loss accumulated ON THE DEVICE and read once per epoch (the reference syncs with ``loss.item()`` every step,
 training.py:97).  Under ``torch.distributed`` (one process per GPU, RCCL) every global batch is split
 into contiguous row slices, one per rank, and the flat ``[grads | loss]`` buffer is SUM-all-reduced
 between the two native calls; every rank then applies the identical Adam step.
@@ -41,12 +41,18 @@ class Adam:
         """No work: bamd_fwd_bwd overwrites the gradient buffer (reference training.py:68)."""
 
     def train_step(self, handle, batch, world=1):
-        """forward+loss+backward -> [all-reduce] -> Adam, all asynchronous on the current stream."""
-        handle.fwd_bwd(batch, self.grads)
-        if world > 1:
-            bdist.allreduce_sum(self.grads)
-        self.step_count += 1
+        """forward+loss+backward -> [all-reduce] -> Adam, all asynchronous on the current stream.  A single process
+        issues ONE native call per batch (bamd_train_step: for small batches the Adam update is fused into the
+        weight-gradient kernel); data-parallel ranks need the all-reduce between the two halves."""
         g = self.param_groups[0]
+        if world == 1:
+            self.step_count += 1
+            handle.train_step(batch, self.model.flat, self.m, self.v, self.step_count, g["lr"], g["betas"][0],
+                              g["betas"][1], g["eps"], loss_accum=self.loss_accum, grads=self.grads)
+            return
+        handle.fwd_bwd(batch, self.grads)
+        bdist.allreduce_sum(self.grads)
+        self.step_count += 1
         handle.adam_step(self.model.flat, self.grads, self.m, self.v, self.step_count, g["lr"],
                          g["betas"][0], g["betas"][1], g["eps"], loss_accum=self.loss_accum)
 

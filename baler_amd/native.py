@@ -23,7 +23,7 @@ SYMBOLS = (
     "bamd_abi_version", "bamd_last_error", "bamd_device_count", "bamd_create", "bamd_destroy",
     "bamd_param_count", "bamd_mode_of", "bamd_load_params", "bamd_minmax", "bamd_normalize",
     "bamd_renormalize", "bamd_encode", "bamd_decode", "bamd_forward_loss", "bamd_fwd_bwd",
-    "bamd_adam_step", "bamd_emd_rows", "bamd_activation_means",
+    "bamd_adam_step", "bamd_train_step", "bamd_emd_rows", "bamd_activation_means",
 )
 
 
@@ -70,6 +70,7 @@ def lib():
     L.bamd_forward_loss.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp, vp]
     L.bamd_fwd_bwd.argtypes = [vp, vp, ci, i64, vp, vp, vp]
     L.bamd_adam_step.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, vp]
+    L.bamd_train_step.argtypes = [vp, vp, ci, i64, vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, vp]
     L.bamd_emd_rows.argtypes = [vp, vp, ci, i64, ci, vp, vp]
     L.bamd_activation_means.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp]
     for name in SYMBOLS:
@@ -232,6 +233,20 @@ class Handle:
         hp = AdamHP(int(step), float(lr), float(beta1), float(beta2), float(eps))
         _check(lib().bamd_adam_step(self._h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), ctypes.byref(hp),
                                     _ptr(loss_accum), _stream()), "bamd_adam_step")
+
+    def train_step(self, x, params, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, loss_accum=None, grads=None,
+                   features=None):
+        """fwd + loss + bwd + Adam of one batch in one call (= fwd_bwd then adam_step; no all-reduce in between)."""
+        x = _dev_tensor(x)
+        for t in (params, m, v):
+            _dev_tensor(t)
+            if t.dtype != self.param_dtype:
+                raise NativeError("optimizer tensors must have the handle's parameter type")
+        if grads is not None and (grads.dtype != self.param_dtype or grads.numel() < self.nparams + 1):
+            raise NativeError("grads must hold param_count+1 elements of the handle's parameter type")
+        hp = AdamHP(int(step), float(lr), float(beta1), float(beta2), float(eps))
+        _check(lib().bamd_train_step(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(params), _ptr(grads),
+                                     _ptr(m), _ptr(v), ctypes.byref(hp), _ptr(loss_accum), _stream()), "bamd_train_step")
 
     def activation_means(self, x, features=None, max_nodes=200):
         x = _dev_tensor(x)

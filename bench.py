@@ -220,10 +220,12 @@ def main():
         nb = 400
         def bs512_pass():
             for i in range(nb):
-                h.fwd_bwd(x[i * 512:(i + 1) * 512], grads)
-                if world > 1:
-                    bdist.allreduce_sum(grads)
                 state["t"] += 1
+                if world == 1:      # what training.fit issues: one bamd_train_step per batch
+                    h.train_step(x[i * 512:(i + 1) * 512], flat, m, v, state["t"], 1e-3, loss_accum=loss_acc)
+                    continue
+                h.fwd_bwd(x[i * 512:(i + 1) * 512], grads)
+                bdist.allreduce_sum(grads)
                 h.adam_step(flat, grads, m, v, state["t"], 1e-3, loss_accum=loss_acc)
         bs512_pass()
         t512 = timed(bs512_pass, 1, world, dev)

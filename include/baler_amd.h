@@ -137,6 +137,15 @@ int bamd_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, con
  * training.py:97 without the per-step host sync). */
 int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, void *v,
                    const bamd_adam *hp, double *loss_accum, void *stream);
+/* Replaces: the whole body of the training.fit batch loop (training.py:64-97: zero_grad, forward,
+ * loss, backward, optimizer.step, running_loss += loss) in ONE call; exactly bamd_fwd_bwd() followed
+ * by bamd_adam_step() on the same arguments, for single-process training (no all-reduce between the
+ * two).  Small batches (the reference's batch_size = 512 regime) run as two launches: the layer chain,
+ * then one workgroup per weight-gradient tile that also applies Adam to the parameters it owns.
+ * grads may be NULL (the gradient is then not materialised); otherwise as in bamd_fwd_bwd(). */
+int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features,
+                    void *params, void *grads, void *m, void *v, const bamd_adam *hp,
+                    double *loss_accum, void *stream);
 
 /* ---- diagnostics -------------------------------------------------------------------------------
  * Replaces: the EMD term of utils.mse_loss_emd_l1 (utils.py:112-119): sum over rows of the 1-D

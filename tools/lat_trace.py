@@ -1,0 +1,37 @@
+"""Per-layer shader-clock timeline of lat2_chain_kernel's workgroup 0 (needs a -DBAMD_LAT_TRACE build):
+
+    BALER_AMD_LIB=.abl/trace.so python tools/lat_trace.py
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from baler_amd import native, synth                               # noqa: E402
+from baler_amd.modules import models                              # noqa: E402
+
+dev = torch.device("cuda", 0)
+x = torch.from_numpy(synth.cms_rows(512 * 50)).to(dev)
+x = native.normalize(x, native.minmax(x))
+model = models.AE(24, 15).to(dev)
+h = model.handle()
+n = h.nparams
+grads = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+m = torch.zeros(n, dtype=torch.float32, device=dev)
+v = torch.zeros(n, dtype=torch.float32, device=dev)
+for i in range(50):
+    h.train_step(x[i * 512:(i + 1) * 512], model.flat, m, v, i + 1, 1e-3)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 64)()
+L = native.lib()
+L.bamd_debug_lat_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
+rc = L.bamd_debug_lat_trace(buf, 64)
+t = np.array(buf[:17], dtype=np.int64)
+names = ["issue wf0/wf1", "x rows + bias", "L0", "L1", "L2", "L3", "L4", "L5", "L6", "L7+loss",
+         "B7", "B6", "B5", "B4", "B3", "B2", "B1+loss sum"]
+print("rc", rc, "total cycles", t[16] - t[0])
+for i in range(1, 17):
+    print(f"{names[i]:16s} {t[i] - t[i - 1]:7d} cycles")
