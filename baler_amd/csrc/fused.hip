@@ -1570,7 +1570,9 @@ struct FusedState {
     DevBuf sc_off, sc_idx;   // CSR parameter -> packed float positions (fused Adam + pack)
     int packed_floats = 0;
     int nwg_max = 256;
-    int64_t latency_max_rows = 4096;   // <= this many rows: small-batch kernels (BALER_AMD_LATENCY_ROWS overrides)
+    // <= this many rows: small-batch kernels (BALER_AMD_LATENCY_ROWS overrides).  Measured us/step small-batch vs
+    // throughput pair: 1024 rows 27 / 74, 4096 44 / 88, 8192 76 / 101, 16384 133 / 131
+    int64_t latency_max_rows = 12288;
     int lat_version = 2;               // 2 = lat2_chain_kernel + lat2_dw_kernel, 1 = lat_train_kernel + reduce (BALER_AMD_LAT)
     int lat_waves = 4;                 // waves per workgroup of lat2_chain_kernel: 4 or 8 (BALER_AMD_LAT_WAVES)
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block

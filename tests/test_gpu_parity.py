@@ -199,8 +199,13 @@ def test_gradients_golden(golden, data10k, mode, tol):
     assert torch.equal(grads, grads2)
 
 
-@pytest.mark.parametrize("n", [1, 7, 100, 272, 513, 4099])
-def test_gradients_ragged(n, data10k):
+@pytest.mark.parametrize("path", ["small-batch", "throughput"])
+@pytest.mark.parametrize("n", [1, 7, 100, 272, 513, 4099, 9999])
+def test_gradients_ragged(n, path, data10k, monkeypatch):
+    """Both fused training paths on ragged batch sizes: the small-batch kernels (chain + weight-gradient tiles, the
+    default up to 12288 rows) and the throughput pair (forced by BALER_AMD_LATENCY_ROWS=0, read at bamd_create)."""
+    if path == "throughput":
+        monkeypatch.setenv("BALER_AMD_LATENCY_ROWS", "0")
     dims = orc.ae_dims(24, 15)
     flat = orc.formula_params(dims, 31)
     h, p = make_handle(dims, flat, "fp32")
@@ -418,11 +423,11 @@ def test_abi_error_paths():
         make_handle(orc.ae_dims(24, 15), orc.formula_params(orc.ae_dims(24, 15), 1), "fp32")[0].encode(torch.zeros(4, 24))
 
 
-@pytest.mark.parametrize("n", [16, 37, 512, 4096, 5000])
+@pytest.mark.parametrize("n", [16, 37, 512, 4096, 5000, 20000])
 @pytest.mark.parametrize("mode", ["fp32", "fp64"])
 def test_train_step_equals_fwd_bwd_then_adam(n, mode):
     """bamd_train_step (training.py:64-97 in one call) == bamd_fwd_bwd + bamd_adam_step, bit for bit, on the
-    small-batch kernels (n <= 4096: Adam fused into the weight-gradient tiles), the throughput kernels and the
+    small-batch kernels (n <= 12288: Adam fused into the weight-gradient tiles), the throughput kernels and the
     generic fp64 path; and both follow the oracle's fit loop."""
     dims = orc.ae_dims(24, 15)
     p0 = orc.formula_params(dims, 11)
