@@ -102,7 +102,7 @@ def perform_compression(output_path, config, verbose: bool):
     normalization_features = []
     if config.apply_normalization:
         normalization_features = np.load(os.path.join(output_path, "training", "normalization_features.npy"))
-    compressed, _, _, _ = helper.compress(
+    compressed, error_bound_batch, error_bound_deltas, error_bound_index = helper.compress(
         model_path=os.path.join(output_path, "compressed_output", "model.pt"), config=config)
     end = time.time()
     print("Compression took:", f"{(end - start) / 60:.3} minutes")
@@ -113,6 +113,9 @@ def perform_compression(output_path, config, verbose: bool):
     saver = np.savez_compressed if config.extra_compression else np.savez
     saver(os.path.join(output_path, "compressed_output", "compressed.npz"), data=compressed, names=names,
           normalization_features=normalization_features)
+    if getattr(config, "save_error_bounded_deltas", False):    # baler.py:316-338
+        helper.save_deltas(os.path.join(output_path, "compressed_output"), error_bound_batch, error_bound_deltas,
+                           error_bound_index)
 
 
 def perform_decompression(output_path, config, verbose: bool):

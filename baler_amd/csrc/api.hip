@@ -223,6 +223,18 @@ int bamd_emd_rows(const void *x, const void *recon, int dtype, int64_t n_rows, i
     return launch_emd_rows(x, recon, dtype, n_rows, n_cols, out, (hipStream_t)stream);
 }
 
+int bamd_error_deltas(const void *x, const void *recon, int dtype, int64_t n_elems, double bound, uint8_t *flags,
+                      uint16_t *deltas, void *stream) {
+    BAMD_REQUIRE(dtype == BAMD_F32 || dtype == BAMD_F64, "bad dtype");
+    return launch_error_deltas(x, recon, dtype, n_elems, bound, flags, deltas, (hipStream_t)stream);
+}
+
+int bamd_apply_deltas(void *out, int dtype, int n_cols, const int64_t *rows, const int32_t *cols, const uint16_t *deltas,
+                      int64_t count, void *stream) {
+    BAMD_REQUIRE(dtype == BAMD_F32 || dtype == BAMD_F64, "bad dtype");
+    return launch_apply_deltas(out, dtype, n_cols, rows, cols, deltas, count, (hipStream_t)stream);
+}
+
 int bamd_activation_means(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features,
                           double *out, int max_nodes, void *stream) {
     BAMD_CHECK_MODEL(h);

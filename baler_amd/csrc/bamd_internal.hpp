@@ -78,6 +78,10 @@ int launch_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int
                    hipStream_t s);
 int launch_emd_rows(const void *x, const void *recon, int dtype, int64_t n, int c, double *out,
                     hipStream_t s);
+int launch_error_deltas(const void *x, const void *recon, int dtype, int64_t n, double bound, uint8_t *flags, void *deltas,
+                        hipStream_t s);
+int launch_apply_deltas(void *out, int dtype, int n_cols, const int64_t *rows, const int32_t *cols, const void *deltas,
+                        int64_t count, hipStream_t s);
 int launch_adam(void *params, void *params_copy, const void *grads, void *m, void *v, int64_t np,
                 size_t esize, const bamd_adam &hp, double *loss_accum, const int *sc_off, const int *sc_idx,
                 void *packed, hipStream_t s);

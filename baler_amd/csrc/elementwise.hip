@@ -234,6 +234,67 @@ int launch_emd_rows(const void *x, const void *r, int dtype, int64_t n, int c, d
     return BAMD_OK;
 }
 
+// ---- error-bounded deltas (helper.py:442-470, 708-718) -----------------------------------------------
+// numpy semantics, element by element, in the arrays' own dtype T: err = (recon - x) / x * 100, +-inf -> 0, a NaN
+// never exceeds the bound; delta = float16(recon) - float16(x) rounded to float16 (np.subtract(..., dtype=float16)
+// casts BOTH operands first).  double -> float16 must round ONCE: go through float with round-to-odd (truncate and
+// set the sticky bit), then the hardware's float -> half round-to-nearest-even.
+__device__ __forceinline__ _Float16 to_f16(float f) { return (_Float16)f; }
+__device__ __forceinline__ _Float16 to_f16(double d) {
+    float f = __double2float_rz(d);
+    if ((double)f != d && isfinite(f)) f = __uint_as_float(__float_as_uint(f) | 1u);
+    return (_Float16)f;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) error_deltas_k(const T *__restrict__ x, const T *__restrict__ recon, int64_t n, T bound,
+                                                      uint8_t *__restrict__ flags, _Float16 *__restrict__ deltas) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T v = x[i], d = recon[i];
+        T err = (d - v) / v * (T)100;
+        if (isinf(err)) err = (T)0;
+        flags[i] = fabs(err) > bound ? 1 : 0;
+        deltas[i] = to_f16(d) - to_f16(v);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) apply_deltas_k(T *__restrict__ out, int n_cols, const int64_t *__restrict__ rows,
+                                                      const int32_t *__restrict__ cols, const _Float16 *__restrict__ deltas,
+                                                      int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[rows[i] * n_cols + cols[i]] -= (T)deltas[i];
+}
+
+int launch_error_deltas(const void *x, const void *recon, int dtype, int64_t n, double bound, uint8_t *flags, void *deltas,
+                        hipStream_t s) {
+    BAMD_REQUIRE(n >= 0 && (n == 0 || (x && recon && flags && deltas)), "bad arguments");
+    if (n == 0) return BAMD_OK;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    if (dtype == BAMD_F64)
+        hipLaunchKernelGGL(error_deltas_k<double>, dim3(grid), dim3(256), 0, s, (const double *)x, (const double *)recon, n,
+                           bound, flags, (_Float16 *)deltas);
+    else
+        hipLaunchKernelGGL(error_deltas_k<float>, dim3(grid), dim3(256), 0, s, (const float *)x, (const float *)recon, n,
+                           (float)bound, flags, (_Float16 *)deltas);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+int launch_apply_deltas(void *out, int dtype, int n_cols, const int64_t *rows, const int32_t *cols, const void *deltas,
+                        int64_t count, hipStream_t s) {
+    BAMD_REQUIRE(count >= 0 && n_cols > 0 && (count == 0 || (out && rows && cols && deltas)), "bad arguments");
+    if (count == 0) return BAMD_OK;
+    const dim3 grid((unsigned)((count + 255) / 256));
+    if (dtype == BAMD_F64)
+        hipLaunchKernelGGL(apply_deltas_k<double>, grid, dim3(256), 0, s, (double *)out, n_cols, rows, cols,
+                           (const _Float16 *)deltas, count);
+    else
+        hipLaunchKernelGGL(apply_deltas_k<float>, grid, dim3(256), 0, s, (float *)out, n_cols, rows, cols,
+                           (const _Float16 *)deltas, count);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
 // ---- fused Adam ---------------------------------------------------------------------------------
 // torch.optim.Adam single-tensor step (training.py:266; torch/optim/adam.py _single_tensor_adam) over
 // ONE flat buffer: p, g, m, v are read once and p, m, v written once (28 B/param in fp32).  The

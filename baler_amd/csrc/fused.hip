@@ -827,308 +827,38 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
 
 #endif
 
-// ---- latency kernel for small batches (the reference's batch_size = 512 regime) ----------------------------
+// ---- small-batch kernels (the reference's batch_size = 512 regime; used up to FusedState::latency_max_rows) -------
 // The throughput kernels give a whole 16-row chain to ONE wave: a 512-row batch occupies 32 waves for ~55 us
-// whatever the chip size.  Here a workgroup owns ONE 16-row tile and its 4 waves split every layer's OUTPUT
-// tiles (tile t -> wave t mod 4); after each layer the waves swap their tiles through a double-buffered LDS
-// exchange (one barrier per layer) so that each wave again holds the full input of the next layer.  The
-// X^T / dZ^T images of ALL layers stay in LDS (130 KB for 16 rows) and the weight-gradient tiles are formed in
-// one phase at the end, each written straight into the workgroup's slab (no accumulation: one tile per
-// workgroup).  Per-layer critical path = ceil(NT/4) tiles instead of NT.  Waves with fewer tiles recompute
-// their last tile (identical instruction streams, no divergence); the weight-fragment ring is primed for the
-// NEXT layer before the exchange barrier so its L2 latency hides behind the barrier.
-constexpr int kLS = 20;   // LDS row stride (floats) of the 16-row images: 16 columns + 4 pad
-
+// whatever the chip size.  Here the step is two launches:
+//   lat2_chain_kernel: a workgroup owns ONE 16-row block and its W waves split every layer's OUTPUT tiles (tile t ->
+//     wave t mod W); after each layer the waves swap their tiles through a double-buffered LDS exchange (one barrier
+//     per layer) so that each wave again holds the full input of the next layer.  Per-layer critical path =
+//     ceil(NT/W) tiles instead of NT.  Waves with fewer tiles recompute their last tile (identical instruction
+//     streams, no divergence).  The X^T / dZ^T images of all layers go to global memory ([16-row block][slot][16
+//     rows], 104 KiB per block).
+//   lat2_dw_kernel: one workgroup per weight-gradient TILE (298 of them: the whole chip, not 32 CUs), contracting
+//     over ALL rows of the batch (fixed order: wave w takes blocks w, w+4, ..; then waves 0..3), optionally fused
+//     with the Adam update of exactly those 256 parameters and the refresh of their packed copies.
+// History (profiles/README.md): the first version kept the images in LDS, formed every [dW | db] tile per workgroup
+// with 4-step MFMAs, wrote a 247-KiB slab per workgroup and reduced the slabs in a second kernel, with an 8-deep
+// fragment ring: 28 + 6 + 5 us per 512-row step against 17 + 6 us now.
 template <class N> struct Lat {
     __host__ __device__ static constexpr int x_rows(int l) { return 16 * tiles(N::dim(l) + 1); }
     __host__ __device__ static constexpr int z_rows(int l) { return 16 * tiles(N::dim(l + 1)); }
     __host__ __device__ static constexpr int x_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += x_rows(j); return s; }
     __host__ __device__ static constexpr int z_off(int l) { int s = x_off(N::L); for (int j = 0; j < l; ++j) s += z_rows(j); return s; }
-    static constexpr int img_floats = (x_off(N::L) + (z_off(N::L) - x_off(N::L))) * kLS;
     static constexpr int xch_f4 = 13 * 64;                       // one exchange buffer: up to 13 tiles
-    static constexpr int lds_bytes = img_floats * 4 + 2 * xch_f4 * 16 + (N::bf_off(N::L) - N::bf_off(0)) * 16;
 };
 
 __device__ __forceinline__ v4 frag_rt(const WStream &ws, int idx) {   // runtime (wave-uniform) fragment index
     return __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
 }
 
-// fragment f of this wave's walk over a layer: k-tile q = f / NL, local tile i = f % NL, global tile min(w+4i, NT-1)
-template <int KD, int NT>
-__device__ __forceinline__ int lat_frag_index(int base, int f, int wave) {
-    constexpr int NL = (NT + 3) / 4;
-    const int q = f / NL, i = f % NL;
-    int t = wave + 4 * i;
-    t = t < NT ? t : NT - 1;
-    return base + q * NT + t;
-}
-template <int KD, int NT>
-__device__ __forceinline__ void lat_prime(Ring &ring, const WStream &ws, int base, int wave) {
-    constexpr int NF = tiles(KD) * ((NT + 3) / 4);
-#pragma unroll
-    for (int f = 0; f < kRing && f < NF; ++f) ring.slot[f] = frag_rt(ws, lat_frag_index<KD, NT>(base, f, wave));
-}
-// out[i] += frags(q, tile w+4i) . in[q]
-template <int KD, int NT>
-__device__ __forceinline__ void lat_gemm(const v4 (&in)[tiles(KD)], v4 (&out)[(NT + 3) / 4], Ring &ring, const WStream &ws,
-                                         int base, int wave) {
-    constexpr int NL = (NT + 3) / 4, NF = tiles(KD) * NL;
-#pragma unroll
-    for (int f = 0; f < NF; f += 2) {
-        const bool two = f + 1 < NF;
-        const int q0 = f / NL, i0 = f % NL, q1 = two ? (f + 1) / NL : q0, i1 = two ? (f + 1) % NL : i0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (r < tile_steps(KD, q0)) out[i0] = mfma(ring.slot[f % kRing][r], in[q0][r], out[i0]);
-            if (two && r < tile_steps(KD, q1)) out[i1] = mfma(ring.slot[(f + 1) % kRing][r], in[q1][r], out[i1]);
-        }
-        if (f + kRing < NF) ring.slot[f % kRing] = frag_rt(ws, lat_frag_index<KD, NT>(base, f + kRing, wave));
-        if (two && f + 1 + kRing < NF) ring.slot[(f + 1) % kRing] = frag_rt(ws, lat_frag_index<KD, NT>(base, f + 1 + kRing, wave));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// own tiles -> exchange buffer (C layout, 1 KiB per tile) and -> the [slot][16 rows] image (ONES: X image with
-// the ones slot that carries db)
-template <int D, bool ONES>
-__device__ __forceinline__ void lat_publish(v4 *xch, float *img, const v4 (&loc)[(tiles(D) + 3) / 4], int lane, int wave) {
-    constexpr int NT = tiles(D), NL = (NT + 3) / 4;
-    constexpr int T1 = tiles(D) - 1, V = D - 16 * T1, R1 = V / 4, G1 = V % 4;
-    const int g = lane >> 4, col = lane & 15;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int t = wave + 4 * i;
-        if (t < NT) {
-            if (xch) xch[t * 64 + lane] = loc[i];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = loc[i][r];
-                if (ONES && t == T1 && r == R1 && g == G1) v = 1.0f;
-                img[(16 * t + 4 * g + r) * kLS + col] = v;
-            }
-        }
-    }
-}
 template <int NT> __device__ __forceinline__ void lat_collect(const v4 *xch, v4 (&all)[NT], int lane) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) all[t] = xch[t * 64 + lane];
 }
 
-template <int F, int Z>
-__global__ void __launch_bounds__(256) lat_train_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
-                                                        const double *__restrict__ feats, v4 *__restrict__ slabs) {
-    using N = Net<F, Z>;
-    using LT = Lat<N>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *img = lds;
-    v4 *xchA = (v4 *)(lds + LT::img_floats), *xchB = xchA + LT::xch_f4;
-    v4 *bias_lds = xchB + LT::xch_f4;
-    stage_bias<N>(bias_lds, packed);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
-    v4 *slab = slabs + (int64_t)blockIdx.x * N::slab_f4();
-    WStream ws = make_stream(packed, N::packed_f4() * 16, lane);
-    const int64_t row = (int64_t)blockIdx.x * 16 + (lane & 15);
-    const bool valid = row < n;
-    Ring ring;
-    constexpr int TF = tiles(F), TZ = tiles(Z);
-    static_assert(TF <= 4 && TZ == 1, "input / latent tiles");
-
-#define LAT_BIAS(loc, l, NTl)                                                                            \
-    _Pragma("unroll") for (int i = 0; i < (NTl + 3) / 4; ++i) {                                          \
-        int t_ = wave + 4 * i; t_ = t_ < NTl ? t_ : NTl - 1;                                             \
-        loc[i] = bias_lds[(N::bf_off(l) - N::bf_off(0)) + t_ * 4 + g];                                   \
-    }
-    // ---------------- forward ----------------
-    v4 a0[TF];
-    load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
-    lat_prime<F, 13>(ring, ws, N::wf_off(0) / 64, wave);
-    {   // X image of layer 0 (= the input): every wave holds all of a0, wave t publishes tile t
-        v4 own[(TF + 3) / 4];
-#pragma unroll
-        for (int i = 0; i < (TF + 3) / 4; ++i) own[i] = a0[(wave + 4 * i) < TF ? (wave + 4 * i) : TF - 1];
-        lat_publish<F, true>(nullptr, img + LT::x_off(0) * kLS, own, lane, wave);
-    }
-    v4 s1[4], s2[2], s3[1], s4[1], s5[1], s6[2], s7[4], o8[1];
-    LAT_BIAS(s1, 0, 13) lat_gemm<F, 13>(a0, s1, ring, ws, N::wf_off(0) / 64, wave); lrelu(s1);
-    lat_prime<200, 7>(ring, ws, N::wf_off(1) / 64, wave);
-    lat_publish<200, true>(xchA, img + LT::x_off(1) * kLS, s1, lane, wave);
-    __syncthreads();
-    {
-        v4 a1[13]; lat_collect(xchA, a1, lane);
-        LAT_BIAS(s2, 1, 7) lat_gemm<200, 7>(a1, s2, ring, ws, N::wf_off(1) / 64, wave); lrelu(s2);
-    }
-    lat_prime<100, 4>(ring, ws, N::wf_off(2) / 64, wave);
-    lat_publish<100, true>(xchB, img + LT::x_off(2) * kLS, s2, lane, wave);
-    __syncthreads();
-    {
-        v4 a2[7]; lat_collect(xchB, a2, lane);
-        LAT_BIAS(s3, 2, 4) lat_gemm<100, 4>(a2, s3, ring, ws, N::wf_off(2) / 64, wave); lrelu(s3);
-    }
-    lat_prime<50, TZ>(ring, ws, N::wf_off(3) / 64, wave);
-    lat_publish<50, true>(xchA, img + LT::x_off(3) * kLS, s3, lane, wave);
-    __syncthreads();
-    {
-        v4 a3[4]; lat_collect(xchA, a3, lane);
-        LAT_BIAS(s4, 3, TZ) lat_gemm<50, TZ>(a3, s4, ring, ws, N::wf_off(3) / 64, wave);   // en4: no activation
-    }
-    lat_prime<Z, 4>(ring, ws, N::wf_off(4) / 64, wave);
-    lat_publish<Z, true>(xchB, img + LT::x_off(4) * kLS, s4, lane, wave);
-    __syncthreads();
-    {
-        v4 a4[TZ]; lat_collect(xchB, a4, lane);
-        LAT_BIAS(s5, 4, 4) lat_gemm<Z, 4>(a4, s5, ring, ws, N::wf_off(4) / 64, wave); lrelu(s5);
-    }
-    lat_prime<50, 7>(ring, ws, N::wf_off(5) / 64, wave);
-    lat_publish<50, true>(xchA, img + LT::x_off(5) * kLS, s5, lane, wave);
-    __syncthreads();
-    {
-        v4 a5[4]; lat_collect(xchA, a5, lane);
-        LAT_BIAS(s6, 5, 7) lat_gemm<50, 7>(a5, s6, ring, ws, N::wf_off(5) / 64, wave); lrelu(s6);
-    }
-    lat_prime<100, 13>(ring, ws, N::wf_off(6) / 64, wave);
-    lat_publish<100, true>(xchB, img + LT::x_off(6) * kLS, s6, lane, wave);
-    __syncthreads();
-    {
-        v4 a6[7]; lat_collect(xchB, a6, lane);
-        LAT_BIAS(s7, 6, 13) lat_gemm<100, 13>(a6, s7, ring, ws, N::wf_off(6) / 64, wave); lrelu(s7);
-    }
-    lat_prime<200, TF>(ring, ws, N::wf_off(7) / 64, wave);
-    lat_publish<200, true>(xchA, img + LT::x_off(7) * kLS, s7, lane, wave);
-    __syncthreads();
-    {
-        v4 a7[13]; lat_collect(xchA, a7, lane);
-        LAT_BIAS(o8, 7, TF) lat_gemm<200, TF>(a7, o8, ring, ws, N::wf_off(7) / 64, wave);   // de4: no activation
-    }
-    // ---------------- loss, dL/drecon ----------------
-    double lacc = 0.0;
-    {
-        const int t = wave;                       // TF <= 4: at most one recon tile per wave
-        const v4 x0 = a0[t < TF ? t : TF - 1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float d = o8[0][r] - x0[r];
-            const bool live = valid && t < TF && slot_feature(F, t < TF ? t : TF - 1, g, r) >= 0;
-            if (live) lacc += (double)d * (double)d;
-            o8[0][r] = live ? d * (2.0f / (float)F) : 0.f;
-        }
-    }
-    // ---------------- backward chain (input gradients), publishing dZ images ----------------
-    lat_prime<F, 13>(ring, ws, N::wb_off(7) / 64, wave);
-    lat_publish<F, false>(xchB, img + LT::z_off(7) * kLS, o8, lane, wave);
-    __syncthreads();
-    {
-        v4 d8[TF]; lat_collect(xchB, d8, lane);
-        v4 dx[4]; zero_tiles(dx);
-        lat_gemm<F, 13>(d8, dx, ring, ws, N::wb_off(7) / 64, wave); lrelu_bwd(dx, s7);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s7[i] = dx[i];          // s7 now holds dZ_6 (own tiles)
-    }
-    lat_prime<200, 7>(ring, ws, N::wb_off(6) / 64, wave);
-    lat_publish<200, false>(xchA, img + LT::z_off(6) * kLS, s7, lane, wave);
-    __syncthreads();
-    {
-        v4 d7[13]; lat_collect(xchA, d7, lane);
-        v4 dx[2]; zero_tiles(dx);
-        lat_gemm<200, 7>(d7, dx, ring, ws, N::wb_off(6) / 64, wave); lrelu_bwd(dx, s6);
-        s6[0] = dx[0]; s6[1] = dx[1];
-    }
-    lat_prime<100, 4>(ring, ws, N::wb_off(5) / 64, wave);
-    lat_publish<100, false>(xchB, img + LT::z_off(5) * kLS, s6, lane, wave);
-    __syncthreads();
-    {
-        v4 d6[7]; lat_collect(xchB, d6, lane);
-        v4 dx[1]; zero_tiles(dx);
-        lat_gemm<100, 4>(d6, dx, ring, ws, N::wb_off(5) / 64, wave); lrelu_bwd(dx, s5);
-        s5[0] = dx[0];
-    }
-    lat_prime<50, TZ>(ring, ws, N::wb_off(4) / 64, wave);
-    lat_publish<50, false>(xchA, img + LT::z_off(4) * kLS, s5, lane, wave);
-    __syncthreads();
-    {
-        v4 d5[4]; lat_collect(xchA, d5, lane);
-        v4 dx[1]; zero_tiles(dx);
-        lat_gemm<50, TZ>(d5, dx, ring, ws, N::wb_off(4) / 64, wave);      // dL/dz: en4 has no activation
-        s4[0] = dx[0];
-    }
-    lat_prime<Z, 4>(ring, ws, N::wb_off(3) / 64, wave);
-    lat_publish<Z, false>(xchB, img + LT::z_off(3) * kLS, s4, lane, wave);
-    __syncthreads();
-    {
-        v4 d4[TZ]; lat_collect(xchB, d4, lane);
-        v4 dx[1]; zero_tiles(dx);
-        lat_gemm<Z, 4>(d4, dx, ring, ws, N::wb_off(3) / 64, wave); lrelu_bwd(dx, s3);
-        s3[0] = dx[0];
-    }
-    lat_prime<50, 7>(ring, ws, N::wb_off(2) / 64, wave);
-    lat_publish<50, false>(xchA, img + LT::z_off(2) * kLS, s3, lane, wave);
-    __syncthreads();
-    {
-        v4 d3[4]; lat_collect(xchA, d3, lane);
-        v4 dx[2]; zero_tiles(dx);
-        lat_gemm<50, 7>(d3, dx, ring, ws, N::wb_off(2) / 64, wave); lrelu_bwd(dx, s2);
-        s2[0] = dx[0]; s2[1] = dx[1];
-    }
-    lat_prime<100, 13>(ring, ws, N::wb_off(1) / 64, wave);
-    lat_publish<100, false>(xchB, img + LT::z_off(1) * kLS, s2, lane, wave);
-    __syncthreads();
-    {
-        v4 d2[7]; lat_collect(xchB, d2, lane);
-        v4 dx[4]; zero_tiles(dx);
-        lat_gemm<100, 13>(d2, dx, ring, ws, N::wb_off(1) / 64, wave); lrelu_bwd(dx, s1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s1[i] = dx[i];
-    }
-    lat_publish<200, false>(nullptr, img + LT::z_off(0) * kLS, s1, lane, wave);
-    __syncthreads();
-#undef LAT_BIAS
-    // ---------------- weight gradients: [dW | db] tiles over this tile's 16 rows, straight to the slab ----------------
-    auto dw_layer = [&](int slab_off, int nt_count, int tot, const float *imz, const float *imx) {
-        // fragment reads of tile idx+4 are issued before the MFMAs of tile idx (LDS latency hidden)
-        auto fetch = [&](int idx, v4 &a, v4 &b) {
-            idx = idx < tot ? idx : tot - 1;
-            const int kt = idx / nt_count, nt = idx - kt * nt_count;
-            a = *(const v4 *)(imz + (16 * nt + (lane & 15)) * kLS + 4 * g);
-            b = *(const v4 *)(imx + (16 * kt + (lane & 15)) * kLS + 4 * g);
-        };
-        v4 a, b, an, bn;
-        fetch(wave, a, b);
-        for (int idx = wave; idx < tot; idx += 4) {
-            fetch(idx + 4, an, bn);
-            v4 acc = (v4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = mfma(a[r], b[r], acc);
-            slab[(slab_off + idx) * 64 + lane] = acc;
-            a = an; b = bn;
-        }
-    };
-#ifndef BAMD_ABLATE_LATDW
-#pragma unroll
-    for (int l = 0; l < N::L; ++l)
-        dw_layer(N::slab_off(l), tiles(N::dim(l + 1)), N::dw_tiles(l), img + LT::z_off(l) * kLS, img + LT::x_off(l) * kLS);
-#endif
-    // loss partial of this tile
-    __syncthreads();
-    double *sh = (double *)lds;
-    sh[threadIdx.x] = lacc;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *(double *)(slab + N::slab_off(N::L) * 64) = sh[0];
-}
-
-// ---- small-batch path, second generation: chain kernel + weight-gradient tile kernel ----------------------
-// lat_train_kernel is bound by two things a profile shows: (1) its 8-deep fragment ring keeps 8 KiB per wave in
-// flight while every step's first touch of the (just re-packed) weights comes from HBM/Infinity Cache (~1 us):
-// 145 KiB per wave / 8 KiB x 1 us = 18 us of the 28; (2) every workgroup forms the full [dW | db] of its 16 rows
-// with 4-step MFMAs and writes a 247-KiB slab that a second kernel reads back (10 us + 6 us).
-//   lat2_chain_kernel: same register/LDS-exchange chain, W waves per workgroup, but the fragments of WHOLE layers
-//     are requested two layers ahead (up to 49 fragments = 196 registers in flight per wave), and the X^T / dZ^T
-//     images go to global memory ([16-row block][slot][16 rows], 104 KiB per block) instead of LDS.
-//   lat2_dw_kernel: one workgroup per weight-gradient TILE (298 of them: the whole chip, not 32 CUs), contracting
-//     over ALL rows of the batch (fixed order: wave w takes blocks w, w+4, ..; then waves 0..3), optionally fused
-//     with the Adam update of exactly those 256 parameters and the refresh of their packed copies.
 constexpr int kImgStride = 16;   // floats per slot in the global images (= rows per block)
 
 #ifdef BAMD_LAT_TRACE   // debug build: shader-clock stamps of workgroup 0 at every layer boundary (tools/lat_trace.py)
@@ -1460,6 +1190,12 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
         }
         return;
     }
+#ifdef BAMD_LAT_TRACE
+#define DW_T(i) do { if ((blockIdx.x == 0 || blockIdx.x == 150) && threadIdx.x == 0) g_lat_trace[32 + (blockIdx.x ? 8 : 0) + i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DW_T(i) do {} while (0)
+#endif
+    DW_T(0);
     const int p = inv_map[tile * 256 + threadIdx.x];
     int l = 0;
 #pragma unroll
@@ -1475,6 +1211,7 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
     float pm = 0.f, pv = 0.f, pp = 0.f;
     int s0 = 0, s1 = 0;
     if (ADAM && p >= 0) { pm = ad.m[p]; pv = ad.v[p]; pp = ad.params[p]; s0 = ad.sc_off[p]; s1 = ad.sc_off[p + 1]; }
+    DW_T(1);
     v4 acc = (v4){0.f, 0.f, 0.f, 0.f};
     for (int b0 = wave; b0 < nblk; b0 += 32) {   // 8 blocks per wave in flight
         v4 a[8], x[8];
@@ -1490,6 +1227,7 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = mfma(a[u][r], x[u][r], acc);
     }
+    DW_T(2);
     red[wave * 64 + lane] = acc;
     int sidx[4] = {-1, -1, -1, -1};                                  // packed copies of this parameter (forward, transposed, region E)
     if (ADAM && p >= 0) {
@@ -1497,6 +1235,7 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
         for (int k = 0; k < 4; ++k) if (s0 + k < s1) sidx[k] = ad.sc_idx[s0 + k];
     }
     __syncthreads();
+    DW_T(3);
     const float *rf = (const float *)red;
     const int e = threadIdx.x;
     const float gsum = ((rf[e] + rf[256 + e]) + rf[512 + e]) + rf[768 + e];
@@ -1517,6 +1256,7 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
         for (int k = 0; k < 4; ++k) if (sidx[k] >= 0) ad.packed[sidx[k]] = pn;
         for (int k = s0 + 4; k < s1; ++k) ad.packed[ad.sc_idx[k]] = pn;
     }
+    DW_T(4);
 }
 
 // Slab reduction in SLAB order: thread i sums float4 i of every workgroup slab (fully coalesced 16-byte
@@ -1573,7 +1313,6 @@ struct FusedState {
     // <= this many rows: small-batch kernels (BALER_AMD_LATENCY_ROWS overrides).  Measured us/step small-batch vs
     // throughput pair: 1024 rows 27 / 74, 4096 44 / 88, 8192 76 / 101, 16384 133 / 131
     int64_t latency_max_rows = 12288;
-    int lat_version = 2;               // 2 = lat2_chain_kernel + lat2_dw_kernel, 1 = lat_train_kernel + reduce (BALER_AMD_LAT)
     int lat_waves = 4;                 // waves per workgroup of lat2_chain_kernel: 4 or 8 (BALER_AMD_LAT_WAVES)
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
 };
@@ -1704,8 +1443,6 @@ template <int F, int Z> struct Impl {
         if (rc) return rc;
         BAMD_HIP(hipFuncSetAttribute((const void *)train_dec_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
         BAMD_HIP(hipFuncSetAttribute((const void *)train_enc_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
-        BAMD_HIP(hipFuncSetAttribute((const void *)lat_train_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     Lat<N>::lds_bytes));
         return BAMD_OK;
     }
     static int encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
@@ -1740,20 +1477,7 @@ template <int F, int Z> struct Impl {
                        hipStream_t s) {
         FusedState *st = state_of(h);
         const int np = N::nparams();
-        if (n <= st->latency_max_rows && st->lat_version == 2) return small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
-        if (n <= st->latency_max_rows) {
-            // small batch: one workgroup per 16-row tile, layer outputs split over the 4 waves
-            int grid = (int)((n + 15) / 16);
-            int rc = h->slabs.ensure((size_t)N::slab_f4() * 16 * (size_t)grid);
-            if (rc) return rc;
-            hipLaunchKernelGGL((lat_train_kernel<F, Z>), dim3(grid), dim3(256), Lat<N>::lds_bytes, s, (const v4 *)h->packed.p,
-                               x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p);
-            hipLaunchKernelGGL(reduce_slabs_k<float>, dim3((N::slab_off(N::L) * 64 + 1 + 255) / 256), dim3(256), 0, s,
-                               (const v4 *)h->slabs.p, grid, N::slab_f4(), N::slab_off(N::L) * 64, (const int *)st->slab_map.p,
-                               np, 1.0 / F, (float *)grads);
-            BAMD_HIP(hipGetLastError());
-            return BAMD_OK;
-        }
+        if (n <= st->latency_max_rows) return small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
         int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
         int grid = (int)(ngroups < st->nwg_max ? ngroups : st->nwg_max);
         int rc = h->slabs.ensure((size_t)N::slab_f4() * 16 * (size_t)grid);
@@ -1800,7 +1524,7 @@ template <int F, int Z> struct Impl {
     static int train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
                           const AdamArgs &ad, hipStream_t s) {
         FusedState *st = state_of(h);
-        if (n > st->latency_max_rows || st->lat_version != 2) return BAMD_ERR_UNSUPPORTED;
+        if (n > st->latency_max_rows) return BAMD_ERR_UNSUPPORTED;
         return small_batch(h, x, x_dtype, n, features, grads, &ad, s);
     }
     static const FusedOps *ops() {
@@ -1850,7 +1574,6 @@ int fused_setup(bamd_handle *h) {
     FusedState *st = new FusedState();
     st->ops = ops;
     if (const char *lr = getenv("BALER_AMD_LATENCY_ROWS")) st->latency_max_rows = atoll(lr);
-    if (const char *lv = getenv("BALER_AMD_LAT")) st->lat_version = atoi(lv) == 1 ? 1 : 2;
     if (const char *lw = getenv("BALER_AMD_LAT_WAVES")) st->lat_waves = atoi(lw) == 8 ? 8 : 4;
     h->fused_state = st;
     int rc = ops->setup(h, st);

@@ -205,11 +205,12 @@ def _derive_sizes(config, data_shape, names_len):
 
 
 def compress(model_path, config):
-    """reference helper.py:473-616.  Returns (compressed ndarray, [], [], []) (error-bounded deltas are
-    a later row).  The input is re-normalised with ITS OWN min/max (helper.py:500-504); with
-    ``torch.distributed`` the rows are sharded over ranks with no collective and gathered in rank order."""
-    if getattr(config, "save_error_bounded_deltas", False):
-        raise NotImplementedError("save_error_bounded_deltas is not implemented yet (SURVEY.md 8(f) row 3)")
+    """reference helper.py:473-616.  Returns (compressed ndarray, batches, deltas, indices); the last three are
+    empty lists unless ``config.save_error_bounded_deltas`` (then: batch numbers, one float16 array per batch and
+    one ``(rows, cols)`` tuple per batch, helper.py:589-606).  The input is re-normalised with ITS OWN min/max
+    (helper.py:500-504); with ``torch.distributed`` the rows are sharded over ranks with no collective and
+    gathered in rank order."""
+    want_deltas = bool(getattr(config, "save_error_bounded_deltas", False))
     data, original_shape = _load_to_device(config.input_path)
     if hasattr(config, "convert_to_blocks") and config.convert_to_blocks:
         data = data_processing.convert_to_blocks_util(config.convert_to_blocks, data)
@@ -230,11 +231,74 @@ def compress(model_path, config):
     rank, world = bdist.rank_world()
     lo, hi = bdist.shard_rows(flat.shape[0], rank, world)
     out = torch.empty((hi - lo, config.latent_space_size), dtype=flat.dtype, device=flat.device)
+    if want_deltas:
+        flags = torch.empty((hi - lo, n_features), dtype=torch.uint8, device=flat.device)
+        deltas = torch.empty((hi - lo, n_features), dtype=torch.float16, device=flat.device)
     for s in range(lo, hi, ROW_BLOCK):
         e = min(s + ROW_BLOCK, hi)
-        out[s - lo:e - lo] = h.encode(flat[s:e], features=feats)
+        if not want_deltas:
+            out[s - lo:e - lo] = h.encode(flat[s:e], features=feats)
+            continue
+        # the side channel compares decode(encode(x)) with the NORMALISED input (helper.py:589-606)
+        xn = native.normalize(flat[s:e], feats, out_dtype=flat.dtype) if feats is not None else flat[s:e]
+        z = h.encode(xn)
+        out[s - lo:e - lo] = z
+        flags[s - lo:e - lo], deltas[s - lo:e - lo] = native.error_deltas(xn, h.decode(z),
+                                                                          config.error_bounded_requirement)
     compressed = _gather_rows(out, flat.shape[0], world)
-    return compressed, [], [], []
+    if not want_deltas:
+        return compressed, [], [], []
+    flags = _gather_rows(flags, flat.shape[0], world)
+    deltas = _gather_rows(deltas, flat.shape[0], world)
+    return (compressed,) + split_deltas(flags, deltas, config.batch_size)
+
+
+def split_deltas(flags, deltas, batch_size):
+    """Dense (flags, float16 deltas) of the whole table -> the reference's per-batch side channel
+    (helper.py:589-606): batch numbers, flagged deltas (row-major, as ``np.where`` orders them) and
+    ``(rows, cols)`` with rows counted inside the batch.  Every batch is listed, flagged or not."""
+    batches, out_deltas, out_index = [], [], []
+    for idx, s in enumerate(range(0, flags.shape[0], batch_size)):
+        rows, cols = np.nonzero(flags[s:s + batch_size])
+        batches.append(idx)
+        out_deltas.append(np.ascontiguousarray(deltas[s:s + batch_size][rows, cols]))
+        out_index.append((rows, cols))
+    print("Total Deltas Found - ", int(sum(len(d) for d in out_deltas)))
+    return batches, out_deltas, out_index
+
+
+def save_deltas(comp_dir, batches, deltas, index):
+    """baler.py:316-338: the two gzip'd ``np.save`` object arrays the reference's decompress reads back
+    (``compressed_deltas.npz.gz``: one entry per batch; ``compressed_batch_index_metadata.npz.gz``:
+    ``[batch numbers, (rows, cols) per batch]``).  Entries are float16 ARRAYS where the reference stored Python
+    lists of float16 scalars -- the consumer indexes them the same way (helper.py:708-718)."""
+    import gzip
+    d_arr = np.empty(len(batches), dtype=object)
+    i_arr = np.empty((2, len(batches)), dtype=object)
+    for k, b in enumerate(batches):
+        d_arr[k] = deltas[k]
+        i_arr[0, k] = b
+        i_arr[1, k] = index[k]
+    with gzip.GzipFile(os.path.join(comp_dir, "compressed_deltas.npz.gz"), "w") as f:
+        np.save(file=f, arr=d_arr)
+    with gzip.GzipFile(os.path.join(comp_dir, "compressed_batch_index_metadata.npz.gz"), "w") as f:
+        np.save(file=f, arr=i_arr)
+
+
+def load_deltas(input_path_deltas, input_batch_index, batch_size):
+    """Side channel files -> flat (global rows int64, cols int32, deltas float16) host arrays (helper.py:655-665)."""
+    import gzip
+    loaded_deltas = np.load(gzip.GzipFile(input_path_deltas, "r"), allow_pickle=True)
+    loaded_index = np.load(gzip.GzipFile(input_batch_index, "r"), allow_pickle=True)
+    rows, cols, vals = [], [], []
+    for k, b in enumerate(loaded_index[0]):
+        r, c = loaded_index[1][k]
+        rows.append(np.asarray(r, dtype=np.int64) + int(b) * batch_size)
+        cols.append(np.asarray(c, dtype=np.int32))
+        vals.append(np.asarray(loaded_deltas[k], dtype=np.float16).reshape(-1))
+    if not rows:
+        return np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float16)
+    return np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
 
 
 def _gather_rows(local, n_total, world):
@@ -251,9 +315,9 @@ def _gather_rows(local, n_total, world):
 
 def decompress(model_path, input_path, input_path_deltas, input_batch_index, model_name, config,
                output_path, original_shape):
-    """reference helper.py:619-733.  Returns (decompressed ndarray, names, normalization_features)."""
-    if getattr(config, "save_error_bounded_deltas", False):
-        raise NotImplementedError("save_error_bounded_deltas is not implemented yet (SURVEY.md 8(f) row 3)")
+    """reference helper.py:619-733.  Returns (decompressed ndarray, names, normalization_features).  With
+    ``config.save_error_bounded_deltas`` the stored float16 deltas are subtracted from the decoder output of
+    their batch (helper.py:708-718), on the device, before the caller un-normalises."""
     loaded = np.load(input_path)
     data = loaded["data"]
     names = loaded["names"]
@@ -276,6 +340,13 @@ def decompress(model_path, input_path, input_path_deltas, input_batch_index, mod
     for s in range(lo, hi, ROW_BLOCK):
         e = min(s + ROW_BLOCK, hi)
         out[s - lo:e - lo] = h.decode(z[s:e])
+    if getattr(config, "save_error_bounded_deltas", False):
+        rows, cols, vals = load_deltas(input_path_deltas, input_batch_index, config.batch_size)
+        mine = (rows >= lo) & (rows < hi)                     # this rank's row shard
+        dev = out.device
+        native.apply_deltas(out, torch.from_numpy(rows[mine] - lo).to(dev), torch.from_numpy(cols[mine]).to(dev),
+                            torch.from_numpy(vals[mine]).to(dev))
+        print("Total Deltas Added - ", int(len(rows)))
     decompressed = _gather_rows(out, z.shape[0], world)
     if config.data_dimension == 2 and getattr(config, "model_type", None) == "dense":
         decompressed = decompressed.reshape((len(decompressed), original_shape[1], original_shape[2]))

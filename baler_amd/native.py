@@ -24,6 +24,7 @@ SYMBOLS = (
     "bamd_param_count", "bamd_mode_of", "bamd_load_params", "bamd_minmax", "bamd_normalize",
     "bamd_renormalize", "bamd_encode", "bamd_decode", "bamd_forward_loss", "bamd_fwd_bwd",
     "bamd_adam_step", "bamd_train_step", "bamd_emd_rows", "bamd_activation_means",
+    "bamd_error_deltas", "bamd_apply_deltas",
 )
 
 
@@ -73,6 +74,8 @@ def lib():
     L.bamd_train_step.argtypes = [vp, vp, ci, i64, vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, vp]
     L.bamd_emd_rows.argtypes = [vp, vp, ci, i64, ci, vp, vp]
     L.bamd_activation_means.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp]
+    L.bamd_error_deltas.argtypes = [vp, vp, ci, i64, dbl, vp, vp, vp]
+    L.bamd_apply_deltas.argtypes = [vp, ci, ci, vp, vp, vp, i64, vp]
     for name in SYMBOLS:
         getattr(L, name)
     _lib = L
@@ -153,6 +156,32 @@ def emd_rows(x, recon):
     out = torch.empty(1, dtype=torch.float64, device=x.device)
     _check(lib().bamd_emd_rows(_ptr(x), _ptr(recon), _dt(x), x.shape[0], x.shape[1], _ptr(out), _stream()),
            "bamd_emd_rows")
+    return out
+
+
+def error_deltas(x, recon, bound):
+    """helper.save_error_bounded_requirement for a whole table: -> (flags uint8 (n, c), deltas float16 (n, c))."""
+    x = _dev_tensor(x)
+    recon = _dev_tensor(recon)
+    if x.dtype != recon.dtype or x.shape != recon.shape:
+        raise NativeError("error_deltas: x and recon must have the same dtype and shape")
+    flags = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    deltas = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _check(lib().bamd_error_deltas(_ptr(x), _ptr(recon), _dt(x), x.numel(), float(bound), _ptr(flags), _ptr(deltas),
+                                   _stream()), "bamd_error_deltas")
+    return flags, deltas
+
+
+def apply_deltas(out, rows, cols, deltas):
+    """out[rows[i], cols[i]] -= deltas[i] in place (rows int64, cols int32, deltas float16; device tensors)."""
+    out = _dev_tensor(out)
+    rows, cols, deltas = _dev_tensor(rows), _dev_tensor(cols), _dev_tensor(deltas)
+    if rows.dtype != torch.int64 or cols.dtype != torch.int32 or deltas.dtype != torch.float16:
+        raise NativeError("apply_deltas: rows int64, cols int32, deltas float16 expected")
+    if not (rows.numel() == cols.numel() == deltas.numel()):
+        raise NativeError("apply_deltas: rows, cols and deltas must have the same length")
+    _check(lib().bamd_apply_deltas(_ptr(out), _dt(out), out.shape[1], _ptr(rows), _ptr(cols), _ptr(deltas), rows.numel(),
+                                   _stream()), "bamd_apply_deltas")
     return out
 
 

@@ -153,6 +153,19 @@ int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, 
  * is overwritten.  Forward-only metric; n_cols <= 64. */
 int bamd_emd_rows(const void *x, const void *recon, int dtype, int64_t n_rows, int n_cols,
                   double *out, void *stream);
+/* ---- error-bounded deltas side channel (config.save_error_bounded_deltas) -------------------------
+ * Replaces: helper.save_error_bounded_requirement (helper.py:442-470) for a whole table at once.
+ * x, recon: n_elems values of `dtype` (the normalised input and decode(encode(x)), row-major).
+ * flags[i] = |(recon[i]-x[i])/x[i]*100| > bound with numpy's rules (+-inf -> 0, NaN never exceeds);
+ * deltas[i] = IEEE binary16 bits of float16(recon[i]) - float16(x[i]) (np.subtract(dtype=float16)).
+ * The caller compacts flags/deltas into the per-batch (row, col) lists of helper.py:589-606. */
+int bamd_error_deltas(const void *x, const void *recon, int dtype, int64_t n_elems, double bound,
+                      uint8_t *flags, uint16_t *deltas, void *stream);
+/* Replaces: the delta loop of helper.decompress (helper.py:708-718): for i < count,
+ * out[rows[i]][cols[i]] -= float16 deltas[i]; out is (n_rows, n_cols) of `dtype`, row-major, decoder
+ * output BEFORE un-normalisation.  rows/cols/deltas are device arrays; (row, col) pairs are unique. */
+int bamd_apply_deltas(void *out, int dtype, int n_cols, const int64_t *rows, const int32_t *cols,
+                      const uint16_t *deltas, int64_t count, void *stream);
 /* Replaces: activation extraction (models.py:160-183, diagnostics.py:10-47): mean over the batch of
  * leaky_relu(pre-activation) for every activated layer; out is (n_layers-2, max_nodes) float64
  * device memory, padded with NaN. */

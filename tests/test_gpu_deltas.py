@@ -1,0 +1,144 @@
+"""Error-bounded deltas side channel on the GPU against oracle/deltas.py and the
+reference-generated fixture g14_deltas.npz."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from baler_amd import native, synth
+from oracle import c_oracle as orc
+from oracle import deltas as odeltas
+
+from test_gpu_cli import _write_project
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(dtype, rng):
+    x = rng.uniform(0.0, 1.0, size=(513, 24)).astype(dtype)
+    r = (x * (1.0 + rng.normal(scale=0.08, size=x.shape))).astype(dtype)
+    x[::7, 3] = 0.0                       # inf -> 0
+    x[5::11, 4] = 0.0
+    r[5::11, 4] = 0.0                     # 0/0 = NaN never exceeds
+    # operands that sit on float16 rounding boundaries (ties and just off ties): the double -> half path must
+    # round once, not through float
+    h = rng.integers(0x2000, 0x3c00, size=200).astype(np.uint16).view(np.float16).astype(np.float64)
+    ulp = np.abs(np.nextafter(h.astype(np.float16), np.float16(np.inf)).astype(np.float64) - h)
+    ties = h + 0.5 * ulp
+    r.ravel()[:200] = ties.astype(dtype)
+    r.ravel()[200:400] = (ties * (1 + 1e-9)).astype(dtype)
+    r.ravel()[400:600] = (ties * (1 - 1e-9)).astype(dtype)
+    return x, r
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_error_deltas_kernel_bit_exact(dtype):
+    rng = np.random.default_rng(3)
+    x, r = _cases(dtype, rng)
+    flags, deltas = native.error_deltas(torch.from_numpy(x).cuda(), torch.from_numpy(r).cuda(), 10)
+    flags = flags.cpu().numpy()
+    deltas = deltas.cpu().numpy()
+    want_d, (rows, cols) = odeltas.error_bounded_requirement(10, r, x)
+    got_r, got_c = np.nonzero(flags)
+    assert np.array_equal(got_r, rows) and np.array_equal(got_c, cols)
+    assert deltas[rows, cols].tobytes() == np.array(want_d, dtype=np.float16).tobytes()
+    # the dense delta plane equals numpy's float16 subtraction everywhere, flagged or not
+    with np.errstate(invalid="ignore"):
+        full = np.subtract(r, x, dtype=np.float16)
+    assert deltas.tobytes() == full.tobytes()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_apply_deltas_kernel(dtype):
+    rng = np.random.default_rng(4)
+    out = rng.normal(size=(300, 24))
+    flags = rng.uniform(size=out.shape) < 0.2
+    rows, cols = np.nonzero(flags)
+    vals = rng.normal(size=len(rows)).astype(np.float16)
+    o = torch.from_numpy(out).to(dtype).cuda()
+    want = o.cpu().numpy().copy()
+    odeltas.apply_deltas(want, list(vals), (rows, cols))
+    native.apply_deltas(o, torch.from_numpy(rows).cuda(), torch.from_numpy(cols.astype(np.int32)).cuda(),
+                        torch.from_numpy(vals).cuda())
+    assert np.array_equal(o.cpu().numpy(), want)
+    native.apply_deltas(o, torch.zeros(0, dtype=torch.int64).cuda(), torch.zeros(0, dtype=torch.int32).cuda(),
+                        torch.zeros(0, dtype=torch.float16).cuda())          # empty side channel: no-op
+
+
+_DELTA_CONFIG = '''
+def set_config(c):
+    c.input_path = "workspaces/W/data/P.npz"
+    c.data_dimension = 1
+    c.compression_ratio = 1.6
+    c.apply_normalization = True
+    c.custom_norm = False
+    c.model_name = "AE"
+    c.epochs = 1
+    c.lr = 0.001
+    c.batch_size = 128
+    c.test_size = 0
+    c.early_stopping = False
+    c.lr_scheduler = False
+    c.deterministic_algorithm = True
+    c.reg_param = 0.001
+    c.RHO = 0.05
+    c.l1 = True
+    c.activation_extraction = False
+    c.intermittent_model_saving = False
+    c.separate_model_saving = False
+    c.extra_compression = False
+    c.save_error_bounded_deltas = True
+    c.error_bounded_requirement = 10
+    c.convert_to_blocks = False
+'''
+
+
+@pytest.mark.parametrize("mode", ["fp64", "fp32"])
+def test_cli_compress_decompress_with_deltas(tmp_path, monkeypatch, golden, mode):
+    """--mode compress / decompress with save_error_bounded_deltas=True on the fixture's model and rows: the side
+    channel files hold the reference's flagged sets and float16 deltas, and decompress applies them."""
+    from baler_amd import baler
+    from baler_amd.modules import helper, models
+    g = golden("g14_deltas.npz")
+    n, bs = int(g["n_rows"]), int(g["batch_size"])
+    raw = synth.cms_rows(n, row0=int(g["row0"]))
+    out = _write_project(tmp_path, monkeypatch, "W", "P", _DELTA_CONFIG, raw, synth.CMS_NAMES)
+    flat = golden("g7_c1_model_f32.npz")["final_params_f32"].astype(np.float64)
+    models.set_default_mode(mode)
+    try:
+        m = models.AE(24, 15).load_flat(flat)
+        helper.model_saver(m, str(out / "compressed_output" / "model.pt"))
+        np.save(out / "training" / "normalization_features.npy", orc.find_minmax(raw))
+        baler.main(["--project", "W", "P", "--mode", "compress"])
+        rows, cols, vals = helper.load_deltas(str(out / "compressed_output" / "compressed_deltas.npz.gz"),
+                                              str(out / "compressed_output" / "compressed_batch_index_metadata.npz.gz"), bs)
+        want = set(zip(g["rows"].tolist(), g["cols"].tolist()))
+        got = set(zip(rows.tolist(), cols.tolist()))
+        if mode == "fp64":
+            assert got == want and vals.tobytes() == g["deltas"].tobytes()
+        else:
+            # fp32 arithmetic moves |err%| by ~1e-5 relative: only elements sitting on the bound may flip, and a
+            # delta may differ by one float16 ulp
+            assert len(got ^ want) <= max(2, len(want) // 500)
+            ref = dict(zip(zip(g["rows"].tolist(), g["cols"].tolist()), g["deltas"].astype(np.float64)))
+            dv = np.array([abs(float(v) - ref[k]) for k, v in zip(zip(rows.tolist(), cols.tolist()), vals) if k in ref])
+            assert dv.max() <= 1e-3 and (dv > 0).mean() < 0.02
+        baler.main(["--project", "W", "P", "--mode", "decompress"])
+        dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
+        # expected: corrected normalised output (fixture) un-normalised and int-cast like baler.py:426-435
+        nf = orc.find_minmax(raw)
+        data_n = orc.normalize(raw)
+        gr, gc = g["rows"].astype(np.int64), g["cols"].astype(np.int64)
+        int_mask = np.array([t == "int" for t in synth.CMS_TYPE_LIST])
+        # at flagged positions the restored value is x up to float16 rounding of the delta (normalised units)
+        restored_n = (dec[gr, gc] - nf[0][gc]) / nf[1][gc]
+        fl = ~int_mask[gc]
+        diff = np.abs(restored_n[fl] - g["corrected_at_flagged"][fl])
+        if mode == "fp64":
+            assert diff.max() < 1e-9
+        else:   # fp32 decoder output: 1e-7-level differences, plus one float16 ulp (<= 4.9e-4) where a delta rounds the other way
+            assert diff.max() < 5e-4 and (diff > 2e-5).mean() < 0.02
+        assert np.abs(restored_n[fl] - data_n[gr, gc][fl]).max() < 1e-3
+    finally:
+        models.set_default_mode("fp32")

@@ -224,3 +224,31 @@ def test_data_parallel_world2_gloo(tmp_path):
         env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DP-OK" in out.stdout
+
+
+def test_delta_side_channel_files_roundtrip(tmp_path):
+    """split_deltas -> save_deltas -> load_deltas (host logic of helper.py:589-606, baler.py:316-338,
+    helper.py:655-665), and the list-of-float16 form the reference's own writer produced loads the same way."""
+    import gzip
+    from baler_amd.modules import helper
+    rng = np.random.default_rng(5)
+    flags = (rng.uniform(size=(300, 24)) < 0.1).astype(np.uint8)
+    flags[128:256] = 0                                      # a batch with nothing flagged
+    deltas = rng.normal(size=(300, 24)).astype(np.float16)
+    batches, dl, index = helper.split_deltas(flags, deltas, 128)
+    assert batches == [0, 1, 2] and len(dl[1]) == 0 and len(index[1][0]) == 0
+    helper.save_deltas(str(tmp_path), batches, dl, index)
+    rows, cols, vals = helper.load_deltas(str(tmp_path / "compressed_deltas.npz.gz"),
+                                          str(tmp_path / "compressed_batch_index_metadata.npz.gz"), 128)
+    want_r, want_c = np.nonzero(flags)
+    assert np.array_equal(rows, want_r) and np.array_equal(cols, want_c)
+    assert vals.tobytes() == deltas[want_r, want_c].tobytes()
+    # reference-style writer: Python lists of float16 scalars inside the object array
+    d_arr = np.empty(3, dtype=object)
+    for k in range(3):
+        d_arr[k] = [np.float16(v) for v in dl[k]]
+    with gzip.GzipFile(tmp_path / "compressed_deltas.npz.gz", "w") as f:
+        np.save(file=f, arr=d_arr)
+    rows2, cols2, vals2 = helper.load_deltas(str(tmp_path / "compressed_deltas.npz.gz"),
+                                             str(tmp_path / "compressed_batch_index_metadata.npz.gz"), 128)
+    assert np.array_equal(rows2, rows) and vals2.tobytes() == vals.tobytes()

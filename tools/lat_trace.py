@@ -35,3 +35,9 @@ names = ["issue wf0/wf1", "x rows + bias", "L0", "L1", "L2", "L3", "L4", "L5", "
 print("rc", rc, "total cycles", t[16] - t[0])
 for i in range(1, 17):
     print(f"{names[i]:16s} {t[i] - t[i - 1]:7d} cycles")
+
+t = np.array(buf[:64], dtype=np.int64)
+for blk, o in ((0, 32), (150, 40)):
+    d = t[o:o + 5]
+    print(f"dw block {blk}: start +{d[0] - t[16]} after the chain's last stamp; map/state issued {d[1] - d[0]}, images+mfma {d[2] - d[1]}, "
+          f"scatter idx + barrier {d[3] - d[2]}, adam + stores {d[4] - d[3]}")
