@@ -349,5 +349,12 @@ def decompress(model_path, input_path, input_path_deltas, input_batch_index, mod
         print("Total Deltas Added - ", int(len(rows)))
     decompressed = _gather_rows(out, z.shape[0], world)
     if config.data_dimension == 2 and getattr(config, "model_type", None) == "dense":
-        decompressed = decompressed.reshape((len(decompressed), original_shape[1], original_shape[2]))
+        blocks = getattr(config, "convert_to_blocks", None)
+        if blocks:
+            # rows are blocks here, not frames.  The reference reshapes with the FRAME shape (helper.py:728-731) and so
+            # raises ValueError for its own exafel1/exafel2 configs (dense model + convert_to_blocks); the caller
+            # (perform_decompression, baler.py:394-408) folds the blocks back into frames.
+            decompressed = decompressed.reshape((len(decompressed), blocks[1], blocks[2]))
+        else:
+            decompressed = decompressed.reshape((len(decompressed), original_shape[1], original_shape[2]))
     return decompressed, names, normalization_features

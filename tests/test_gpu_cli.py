@@ -259,3 +259,45 @@ def test_cli_cfd_dense_2d(tmp_path, monkeypatch):
     dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
     assert dec.shape == (60, 50, 50) and dec.dtype == np.float32
     assert rel(dec.reshape(60, 2500), orc.decode(dims, final, comp["data"].astype(np.float64))) < 1e-5
+
+
+def test_cli_blocks_2d_with_validation_split(tmp_path, monkeypatch):
+    """The reference's exafel1/exafel2 shape of run (public_datasets/exafel1 config): 2-D frames cut into 25x25
+    blocks (convert_to_blocks = [1, 25, 25], data_processing.py:26-34), CFD_dense_AE(625, 7) in float32,
+    batch_size 32, test_size 0.2, no normalisation -- end to end against the CPU oracle replaying the same run
+    (SURVEY section 8(f) row 4)."""
+    from baler_amd import baler
+    from baler_amd.modules import helper, models
+    from oracle import host_logic
+    field = synth.cfd_field(40)                                   # (40, 50, 50)
+    cfg = (_CFD_CONFIG.replace("c.convert_to_blocks = False", "c.convert_to_blocks = [1, 25, 25]")
+           .replace("c.batch_size = 6000", "c.batch_size = 32").replace("c.test_size = 0", "c.test_size = 0.2")
+           .replace("c.epochs = 3", "c.epochs = 2"))
+    out = _write_project(tmp_path, monkeypatch, "CFD", "anim", cfg, field, np.array([]))
+    models.set_default_mode("fp32")
+    dims = orc.ae_dims(625, 7)
+    init = orc.formula_params(dims, 79)
+    monkeypatch.setattr(helper, "model_init",
+                        lambda name: (lambda n_features, z_dim: getattr(models, name)(n_features, z_dim).load_flat(init)))
+    for mode in ("train", "compress", "decompress"):
+        baler.main(["--project", "CFD", "anim", "--mode", mode])
+    blocks = field.reshape(160, 25, 25)                           # total_size // (25*25) blocks, row-major
+    x = blocks.astype(np.float32).astype(np.float64).reshape(160, 625)
+    tr, te = host_logic.split_indices(160, 0.2)
+    st = orc.FitState(dims, init.astype(np.float32).astype(np.float64))
+    want = []
+    for _ in range(2):
+        el, _ = orc.fit_epoch(st, x[tr], 32, 1e-3)
+        want.append((el, orc.validate_epoch(st.dims, st.params, x[te], 32)))
+    loss = np.load(out / "training" / "loss_data.npy")
+    assert loss.shape == (2, 2)
+    assert rel(loss[0], [w[0] for w in want]) < 1e-4 and rel(loss[1], [w[1] for w in want]) < 1e-4
+    sd = torch.load(out / "compressed_output" / "model.pt")
+    assert tuple(sd["en1.weight"].shape) == (200, 625) and tuple(sd["en4.weight"].shape) == (7, 50)
+    final = np.concatenate([v.numpy().ravel().astype(np.float64) for v in sd.values()])
+    comp = np.load(out / "compressed_output" / "compressed.npz")
+    assert comp["data"].shape == (160, 7)
+    assert rel(comp["data"], orc.encode(dims, final, x)) < 1e-5
+    dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
+    assert dec.shape == (40, 50, 50)                              # blocks folded back into the original frames
+    assert rel(dec.reshape(160, 625), orc.decode(dims, final, comp["data"].astype(np.float64))) < 1e-5
