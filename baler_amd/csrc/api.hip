@@ -186,6 +186,21 @@ int bamd_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, con
     return generic_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
 }
 
+int bamd_fwd_bwd_latent(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features,
+                        const void *latent_grad, void *grads, void *stream) {
+    BAMD_CHECK_MODEL(h);
+    BAMD_REQUIRE(grads && x && n_rows > 0, "bad arguments");
+    if (!latent_grad) return bamd_fwd_bwd(h, x, x_dtype, n_rows, features, grads, stream);
+    // the regulariser's gradient enters between the decoder's and the encoder's backward products: layer-wise path
+    return generic_fwd_bwd(h, x, x_dtype, n_rows, features, grads, (hipStream_t)stream, latent_grad);
+}
+
+int bamd_swd(const void *z, const void *prior, const void *proj, int dtype, int64_t n_rows, int z_dim, int n_proj,
+             double reg_weight, double *loss_out, void *dz_out, void *stream) {
+    BAMD_REQUIRE(dtype == BAMD_F32 || dtype == BAMD_F64, "bad dtype");
+    return launch_swd(z, prior, proj, dtype, n_rows, z_dim, n_proj, reg_weight, loss_out, dz_out, (hipStream_t)stream);
+}
+
 int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, void *v, const bamd_adam *hp,
                    double *loss_accum, void *stream) {
     BAMD_CHECK_MODEL(h);

@@ -78,6 +78,8 @@ int launch_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int
                    hipStream_t s);
 int launch_emd_rows(const void *x, const void *recon, int dtype, int64_t n, int c, double *out,
                     hipStream_t s);
+int launch_swd(const void *z, const void *prior, const void *proj, int dtype, int64_t n, int d, int ns, double reg_weight,
+               double *loss_out, void *dz_out, hipStream_t s);
 int launch_error_deltas(const void *x, const void *recon, int dtype, int64_t n, double bound, uint8_t *flags, void *deltas,
                         hipStream_t s);
 int launch_apply_deltas(void *out, int dtype, int n_cols, const int64_t *rows, const int32_t *cols, const void *deltas,
@@ -94,7 +96,8 @@ int generic_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n,
                          const double *features, void *recon, int recon_dtype, double *loss_sum,
                          hipStream_t s);
 int generic_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
-                    void *grads, hipStream_t s);
+                    void *grads, hipStream_t s,
+                    const void *latent_grad = nullptr);   // latent_grad: (n, z_dim) of the compute type, added to dL/dz
 int generic_activation_means(bamd_handle *h, const void *x, int x_dtype, int64_t n,
                              const double *features, double *out, int max_nodes, hipStream_t s);
 

@@ -54,6 +54,8 @@ template <typename T> struct Epi {
     int act;           // FWD: apply leaky relu
     const T *ymask;    // DX: post-activation output of the previous layer (sign = pre-activation sign)
     int64_t ld_mask;
+    const T *add;      // DX: extra gradient added to the result (latent regulariser injected at the bottleneck)
+    int64_t ld_add;
     T *gw, *gb;        // DW: slab bases of this layer's dW and db
     int64_t kin;       // DW: in-features (column kin of the product is db)
     int64_t slab_stride;
@@ -71,6 +73,7 @@ __device__ __forceinline__ void epilogue(const Epi<T> &e, int64_t row, int64_t c
     } else if (EPI == EPI_DX) {
         if (row < e.n_rows && col < e.n_cols) {
             if (e.ymask) val = e.ymask[row * e.ld_mask + col] > (T)0 ? val : val * (T)kSlope;
+            if (e.add) val += e.add[row * e.ld_add + col];
             e.out[row * e.ld + col] = val;
         }
     } else {
@@ -483,7 +486,7 @@ int generic_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, 
 
 template <typename T>
 static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
-                     void *grads_v, hipStream_t s) {
+                     void *grads_v, const void *latent_grad, hipStream_t s) {
     Work<T> wk;
     int rc = carve<T>(h, n, true, wk);
     if (rc) return rc;
@@ -534,6 +537,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 Epi<T> e{};
                 e.out = dz_next; e.ld = K; e.n_rows = rows; e.n_cols = K;
                 e.ymask = h->has_act(l - 1) ? wk.y[l] : nullptr; e.ld_mask = K;
+                if (latent_grad && l == h->L / 2) { e.add = (const T *)latent_grad + r0 * K; e.ld_add = K; }   // dL/dz of the caller's regulariser
                 launch_gemm<T, EPI_DX, true, false>(A, B, (int64_t)N, e, rows, K, 1, s);
                 T *t = dz; dz = dz_next; dz_next = t;
             }
@@ -546,9 +550,9 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
 }
 
 int generic_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
-                    void *grads, hipStream_t s) {
-    if (h->esize == 8) return fwd_bwd_T<double>(h, x, x_dtype, n, features, grads, s);
-    return fwd_bwd_T<float>(h, x, x_dtype, n, features, grads, s);
+                    void *grads, hipStream_t s, const void *latent_grad) {
+    if (h->esize == 8) return fwd_bwd_T<double>(h, x, x_dtype, n, features, grads, latent_grad, s);
+    return fwd_bwd_T<float>(h, x, x_dtype, n, features, grads, latent_grad, s);
 }
 
 template <typename T>

@@ -40,11 +40,26 @@ class Adam:
     def zero_grad(self):
         """No work: bamd_fwd_bwd overwrites the gradient buffer (reference training.py:68)."""
 
-    def train_step(self, handle, batch, world=1):
+    def train_step(self, handle, batch, world=1, swae_latent_dim=None):
         """forward+loss+backward -> [all-reduce] -> Adam, all asynchronous on the current stream.  A single process
         issues ONE native call per batch (bamd_train_step: for small batches the Adam update is fused into the
         weight-gradient kernel); data-parallel ranks need the all-reduce between the two halves."""
         g = self.param_groups[0]
+        if swae_latent_dim is not None:
+            # loss = mse + sliced-Wasserstein(z) (training.py:73-80, utils.py:27-77): encode, regulariser forward +
+            # backward on the latent batch, then the usual backward with dL/dz injected at the bottleneck
+            if world > 1:
+                raise NotImplementedError("loss_function_swae sorts the latent codes across ONE batch; it is not "
+                                          "defined for a batch split over ranks")
+            z = handle.encode(batch, out_dtype=self.model.flat.dtype)
+            reg_weight = 100 / (batch.shape[0] * (batch.shape[0] - 1))
+            swd, dz = utils.compute_swd(z, 2.0, reg_weight, swae_latent_dim, 2000, "normal")
+            handle.fwd_bwd_latent(batch, dz, self.grads)
+            self.grads[-1:] += swd.to(self.grads.dtype)          # running loss = mse + swd, like loss.item()
+            self.step_count += 1
+            handle.adam_step(self.model.flat, self.grads, self.m, self.v, self.step_count, g["lr"], g["betas"][0],
+                             g["betas"][1], g["eps"], loss_accum=self.loss_accum)
+            return
         if world == 1:
             self.step_count += 1
             handle.train_step(batch, self.model.flat, self.m, self.v, self.step_count, g["lr"], g["betas"][0],
@@ -55,6 +70,13 @@ class Adam:
         self.step_count += 1
         handle.adam_step(self.model.flat, self.grads, self.m, self.v, self.step_count, g["lr"],
                          g["betas"][0], g["betas"][1], g["eps"], loss_accum=self.loss_accum)
+
+
+def _swae_dim(config, model):
+    """Latent size when config.custom_loss_function selects the sliced-Wasserstein loss (training.py:73-76), else None."""
+    if getattr(config, "custom_loss_function", None) == "loss_function_swae":
+        return model.z_dim
+    return None
 
 
 def _batches(n_rows, bs):
@@ -83,7 +105,7 @@ def fit(config, model, train_dl, model_children, regular_param, optimizer, laten
     spans = _batches(data.shape[0], bs)
     for lo, hi in spans:
         a, b = _rank_slice(lo, hi, rank, world) if world > 1 else (lo, hi)
-        optimizer.train_step(h, data[a:b], world)
+        optimizer.train_step(h, data[a:b], world, swae_latent_dim=_swae_dim(config, model))
     # one device->host read per epoch (the reference does one per step)
     last = float(optimizer.grads[model.nparams].item())
     epoch_loss = float(optimizer.loss_accum.item()) / len(spans)
@@ -219,7 +241,7 @@ def _fit_with_capture(config, model, train_dl, model_children, optimizer, want_a
             model._dirty = False
             model.capture_activations(data[lo:hi])
         a, b = _rank_slice(lo, hi, rank, world) if world > 1 else (lo, hi)
-        optimizer.train_step(h, data[a:b], world)
+        optimizer.train_step(h, data[a:b], world, swae_latent_dim=_swae_dim(config, model))
     last = float(optimizer.grads[model.nparams].item())
     epoch_loss = float(optimizer.loss_accum.item()) / len(spans)
     model._dirty = False

@@ -29,6 +29,46 @@ def mse_sum_loss_l1(model_children, true_data, reconstructed_data, reg_param, va
     return (d * d).sum() / x.shape[1], 0, 0
 
 
+def get_random_projections(proj_dist, latent_dim, num_samples):
+    """reference utils.py:79-91: num_samples random unit vectors of the latent space, drawn from torch's global
+    CPU generator like the reference does.  [S x D]"""
+    if proj_dist == "normal":
+        rand_samples = torch.randn(num_samples, latent_dim)
+    elif proj_dist == "cauchy":
+        rand_samples = (torch.distributions.Cauchy(torch.tensor([0.0]), torch.tensor([1.0]))
+                        .sample((num_samples, latent_dim)).squeeze())
+    else:
+        raise ValueError("Unknown projection distribution.")
+    return rand_samples / rand_samples.norm(dim=1).view(-1, 1)
+
+
+def swae_draws(z, latent_dim, num_projections=2000, projection_dist="normal"):
+    """The two random tensors of one loss_function_swae call, in the reference's order (utils.py:59-66):
+    prior_z = randn_like(z), then the projection matrix.  -> (prior (n, d), proj (S, d)), on z's device and dtype."""
+    prior_z = torch.randn_like(z)
+    proj = get_random_projections(projection_dist, latent_dim, num_projections).to(device=z.device, dtype=z.dtype)
+    return prior_z, proj.contiguous()
+
+
+def compute_swd(z, p, reg_weight, latent_dim, num_projections, proj_dist, draws=None):
+    """reference utils.py:58-77 on the native kernel (bamd_swd): -> (swd loss tensor (1,), dL/dz)."""
+    if float(p) != 2.0:
+        raise NotImplementedError("the sliced-Wasserstein kernel implements wasserstein_deg = 2 (the reference default)")
+    prior_z, proj = draws if draws is not None else swae_draws(z, latent_dim, num_projections, proj_dist)
+    return native.swd(z.contiguous(), prior_z.contiguous(), proj, reg_weight)
+
+
+def loss_function_swae(inputs, z, reconstructions, latent_dim, reg_weight=100, wasserstein_deg=2.0,
+                       num_projections=2000, projection_dist="normal", draws=None):
+    """reference utils.py:27-55: (loss, mse_sum_loss, SWD) as device tensors (forward values; the training loop takes
+    the gradient from bamd_swd + bamd_fwd_bwd_latent)."""
+    batch_size = inputs.shape[0]
+    reg_weight = reg_weight / (batch_size * (batch_size - 1))
+    mse_sum_loss, _, _ = mse_sum_loss_l1(None, inputs, reconstructions, 0, True)
+    swd, _ = compute_swd(z, wasserstein_deg, reg_weight, latent_dim, num_projections, projection_dist, draws)
+    return mse_sum_loss + swd[0], mse_sum_loss, swd[0]
+
+
 def emd_rows(true_data, reconstructed_data):
     """Sum over rows of the 1-D Wasserstein distance between a row's columns (device kernel)."""
     return native.emd_rows(true_data.contiguous(), reconstructed_data.contiguous())

@@ -24,7 +24,7 @@ SYMBOLS = (
     "bamd_param_count", "bamd_mode_of", "bamd_load_params", "bamd_minmax", "bamd_normalize",
     "bamd_renormalize", "bamd_encode", "bamd_decode", "bamd_forward_loss", "bamd_fwd_bwd",
     "bamd_adam_step", "bamd_train_step", "bamd_emd_rows", "bamd_activation_means",
-    "bamd_error_deltas", "bamd_apply_deltas",
+    "bamd_error_deltas", "bamd_apply_deltas", "bamd_fwd_bwd_latent", "bamd_swd",
 )
 
 
@@ -75,6 +75,8 @@ def lib():
     L.bamd_emd_rows.argtypes = [vp, vp, ci, i64, ci, vp, vp]
     L.bamd_activation_means.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp]
     L.bamd_error_deltas.argtypes = [vp, vp, ci, i64, dbl, vp, vp, vp]
+    L.bamd_fwd_bwd_latent.argtypes = [vp, vp, ci, i64, vp, vp, vp, vp]
+    L.bamd_swd.argtypes = [vp, vp, vp, ci, i64, ci, ci, dbl, vp, vp, vp]
     L.bamd_apply_deltas.argtypes = [vp, ci, ci, vp, vp, vp, i64, vp]
     for name in SYMBOLS:
         getattr(L, name)
@@ -157,6 +159,18 @@ def emd_rows(x, recon):
     _check(lib().bamd_emd_rows(_ptr(x), _ptr(recon), _dt(x), x.shape[0], x.shape[1], _ptr(out), _stream()),
            "bamd_emd_rows")
     return out
+
+
+def swd(z, prior, proj, reg_weight):
+    """utils.compute_swd forward + backward: -> (loss float64[1], dz like z).  z, prior (n, d); proj (s, d) unit rows."""
+    z, prior, proj = _dev_tensor(z), _dev_tensor(prior), _dev_tensor(proj)
+    if not (z.dtype == prior.dtype == proj.dtype) or z.shape != prior.shape or proj.shape[1] != z.shape[1]:
+        raise NativeError("swd: z/prior (n, d) and proj (s, d) must share dtype and latent size")
+    loss = torch.empty(1, dtype=torch.float64, device=z.device)
+    dz = torch.empty_like(z)
+    _check(lib().bamd_swd(_ptr(z), _ptr(prior), _ptr(proj), _dt(z), z.shape[0], z.shape[1], proj.shape[0],
+                          float(reg_weight), _ptr(loss), _ptr(dz), _stream()), "bamd_swd")
+    return loss, dz
 
 
 def error_deltas(x, recon, bound):
@@ -253,6 +267,18 @@ class Handle:
             raise NativeError("grads must hold param_count+1 elements of the handle's parameter type")
         _check(lib().bamd_fwd_bwd(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(grads), _stream()),
                "bamd_fwd_bwd")
+
+    def fwd_bwd_latent(self, x, latent_grad, grads, features=None):
+        """fwd_bwd with dL/dz of a latent regulariser (n, z_dim; handle parameter type) injected at the bottleneck."""
+        x = _dev_tensor(x)
+        grads = _dev_tensor(grads)
+        latent_grad = _dev_tensor(latent_grad)
+        if grads.dtype != self.param_dtype or grads.numel() < self.nparams + 1:
+            raise NativeError("grads must hold param_count+1 elements of the handle's parameter type")
+        if latent_grad.dtype != self.param_dtype or tuple(latent_grad.shape) != (x.shape[0], self.z_dim):
+            raise NativeError("latent_grad must be (n_rows, z_dim) of the handle's parameter type")
+        _check(lib().bamd_fwd_bwd_latent(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(latent_grad),
+                                         _ptr(grads), _stream()), "bamd_fwd_bwd_latent")
 
     def adam_step(self, params, grads, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, loss_accum=None):
         for t in (params, grads, m, v):

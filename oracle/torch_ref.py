@@ -120,3 +120,23 @@ def decompress_loop(model, z, bs):
             out = model.decode(batch).cpu().detach().numpy()
             out_all = out if idx == 0 else np.concatenate((out_all, out))
     return out_all
+
+
+def swae_loss_and_grads(model, x, prior_z, proj, reg_weight=100.0):
+    """utils.loss_function_swae + loss.backward() (utils.py:27-77, training.py:73-92) with the two random draws
+    (prior_z = randn_like(z); proj = unit rows [S x D]) passed in instead of taken from torch's global generator.
+    Returns (loss, mse_sum_loss, swd, flat gradient in state-dict order).  Pinned against the reference by
+    tools/gen_golden_swae.py (tests/golden/g15_swae.npz)."""
+    model.zero_grad()
+    recon = model(x)
+    z = model.encode(x)
+    bsz = x.shape[0]
+    rw = reg_weight / (bsz * (bsz - 1))
+    mse = F.mse_loss(recon, x, reduction="sum") / x.shape[1]
+    pm = proj.transpose(0, 1)
+    w = torch.sort(z.matmul(pm).t(), dim=1)[0] - torch.sort(prior_z.matmul(pm).t(), dim=1)[0]
+    swd = rw * w.pow(2.0).mean()
+    loss = mse + swd
+    loss.backward()
+    g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    return float(loss.detach()), float(mse.detach()), float(swd.detach()), g.detach().numpy().astype(np.float64)
