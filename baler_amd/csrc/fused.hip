@@ -180,11 +180,20 @@ template <int NT> __device__ __forceinline__ void lrelu(v4 (&a)[NT]) {
 #ifdef BAMD_ABLATE_LRELU
     return;
 #endif
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f k2 = (v2f){0.01f, 0.01f};
+    asm volatile("" : "+v"(k2));   // a register pair, not a literal: with the literal hipcc scalarises back to v_mul_f32
+    const v4 kk = (v4){k2[0], k2[1], k2[0], k2[1]};
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+        // x > 0 ? x : 0.01 x == max(x, 0.01 x) == med3(x, 0.01 x, +inf).  The products of a tile are one vector
+        // multiply (two v_pk_mul_f32 instead of four v_mul_f32: every VALU instruction costs MFMA issue slots), then
+        // v_med3 per register (FLT_MAX, not inf: hipcc folds med3(x,y,inf) back into canonicalise + v_max)
+        v4 m = a[t] * kk;
+        asm("" : "+v"(m));            // keep the product a vector: extract-of-fmul would be scalarised again
 #pragma unroll
-        for (int r = 0; r < 4; ++r)   // x > 0 ? x : 0.01 x == max(x, 0.01 x) == med3(x, 0.01 x, +inf): v_mul + v_med3, and
-            a[t][r] = __builtin_amdgcn_fmed3f(a[t][r], a[t][r] * 0.01f, 3.402823466e38f);   // (FLT_MAX, not inf: hipcc folds med3(x,y,inf) back into canonicalise + v_max)
+        for (int r = 0; r < 4; ++r) a[t][r] = __builtin_amdgcn_fmed3f(a[t][r], m[r], 3.402823466e38f);
+    }
 }
 // dZ = dY * lrelu'(pre) ; sign(pre) == sign(post-activation y)
 template <int NT> __device__ __forceinline__ void lrelu_bwd(v4 (&d)[NT], const v4 (&y)[NT]) {
@@ -192,9 +201,12 @@ template <int NT> __device__ __forceinline__ void lrelu_bwd(v4 (&d)[NT], const v
     return;
 #endif
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+        v4 sl;                                    // slope per register (v_cmp + v_cndmask), then one vector multiply
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[t][r] = y[t][r] > 0.f ? d[t][r] : d[t][r] * 0.01f;
+        for (int r = 0; r < 4; ++r) sl[r] = y[t][r] > 0.f ? 1.0f : 0.01f;
+        d[t] = d[t] * sl;
+    }
 }
 
 // one Linear layer of the forward chain.  S = stream description (frag base of every layer, total)
