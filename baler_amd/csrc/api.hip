@@ -3,6 +3,7 @@
 
 #include "bamd_internal.hpp"
 #include "fused.hpp"
+#include "bf16.hpp"
 
 namespace bamd {
 
@@ -56,10 +57,6 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
     BAMD_REQUIRE(dims && out, "null argument");
     BAMD_REQUIRE(n_layers >= 2 && n_layers % 2 == 0, "n_layers must be even and >= 2");
     BAMD_REQUIRE(mode == BAMD_MODE_F32 || mode == BAMD_MODE_F64 || mode == BAMD_MODE_BF16, "unknown mode");
-    if (mode == BAMD_MODE_BF16) {
-        set_error("BAMD_MODE_BF16 (throughput mode, ~3e-3 relative error) is not implemented yet; use BAMD_MODE_F32");
-        return BAMD_ERR_UNSUPPORTED;
-    }
     for (int l = 0; l <= n_layers; ++l) BAMD_REQUIRE(dims[l] > 0, "layer widths must be positive");
     int ndev = bamd_device_count();
     if (ndev <= 0) {
@@ -94,6 +91,10 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
     if (rc) { delete h; return rc; }
     rc = fused_setup(h);
     if (rc) { bamd_destroy(h); return rc; }
+    if (mode == BAMD_MODE_BF16) {   // inference on bf16 MFMA; training calls of such a handle run on the fp32 layer-wise kernels
+        rc = bf16_setup(h);
+        if (rc) { bamd_destroy(h); return rc; }
+    }
     *out = h;
     return BAMD_OK;
 }
@@ -102,6 +103,7 @@ void bamd_destroy(bamd_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     fused_teardown(h);
+    bf16_teardown(h);
     h->params.release();
     h->packed.release();
     h->work.release();
@@ -122,6 +124,7 @@ int bamd_load_params(bamd_handle *h, const void *params, int dtype, void *stream
     int rc = launch_convert(params, dtype, h->params.p, h->esize == 8 ? BAMD_F64 : BAMD_F32, h->nparams, s);
     if (rc) return rc;
     h->params_loaded = true;
+    if (h->mode == BAMD_MODE_BF16) return bf16_pack(h, s);
     return fused_pack(h, s);
 }
 
@@ -150,6 +153,7 @@ int bamd_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, cons
     BAMD_REQUIRE(n_rows >= 0 && ((x && z) || n_rows == 0), "bad arguments");
     if (n_rows == 0) return BAMD_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (h->mode == BAMD_MODE_BF16) return bf16_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
     if (h->fused_ok) return fused_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
     return generic_forward(h, x, x_dtype, n_rows, features, 0, h->L / 2, z, z_dtype, nullptr, nullptr, s);
 }
@@ -160,6 +164,7 @@ int bamd_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n_rows, cons
     BAMD_REQUIRE(n_rows >= 0 && ((z && out) || n_rows == 0), "bad arguments");
     if (n_rows == 0) return BAMD_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (h->mode == BAMD_MODE_BF16) return bf16_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);
     if (h->fused_ok) return fused_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);
     return generic_forward(h, z, z_dtype, n_rows, nullptr, h->L / 2, h->L, out, out_dtype, features, int_mask, s);
 }
@@ -169,6 +174,7 @@ int bamd_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows
     BAMD_CHECK_MODEL(h);
     BAMD_REQUIRE(x && loss_sum && n_rows > 0, "bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (h->mode == BAMD_MODE_BF16) return bf16_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
     if (h->fused_ok) return fused_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
     return generic_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
 }
@@ -210,7 +216,9 @@ int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, voi
     const int *sc_off = nullptr, *sc_idx = nullptr;
     void *packed = nullptr;
     fused_scatter(h, &sc_off, &sc_idx, &packed);   // Adam also refreshes the packed weight copy (one launch)
-    return launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, sc_off, sc_idx, packed, s);
+    int rc = launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, sc_off, sc_idx, packed, s);
+    if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16) rc = bf16_pack(h, s);
+    return rc;
 }
 
 int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features, void *params,

@@ -62,6 +62,7 @@ struct bamd_handle {
     bool params_loaded = false;
     bool fused_ok = false;          // shape is served by the fused register-chained kernels
     void *fused_state = nullptr;    // index maps of the fused path (fused.hip)
+    void *bf16_state = nullptr;     // packed bf16 weights + maps of the bf16 inference mode (bf16.hip)
 
     bool has_act(int l) const { return !(l == L / 2 - 1 || l == L - 1); }
 };

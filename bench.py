@@ -216,6 +216,18 @@ def main():
         t_dec = timed(lambda: h.decode(z), n_enc, world, dev)
         out["decode_rows_per_s"] = world * a.rows * n_enc / t_dec
         out["encode_tflops"] = FLOP_ENCODE_ROW * a.rows * n_enc / t_enc / 1e12
+        if a.mode == "fp32":
+            # the bf16 inference mode on the same rows and weights (a throughput mode: ~2e-3 / 6e-3 rel. error on
+            # encode / decode, not the 1e-5 parity mode that `value` is measured in)
+            hb = native.Handle(model.dims, "bf16")
+            hb.load_params(flat)
+            zb = hb.encode(x)
+            out["bf16_encode_rel_err_vs_fp32"] = float((zb.double() - z.double()).norm() / z.double().norm())
+            t_b = timed(lambda: hb.encode(x), n_enc, world, dev)
+            out["bf16_encode_rows_per_s"] = world * a.rows * n_enc / t_b
+            t_b = timed(lambda: hb.decode(z), n_enc, world, dev)
+            out["bf16_decode_rows_per_s"] = world * a.rows * n_enc / t_b
+            hb.close()
         # strict reference batching: global batch 512 x n_gpus... kept at 512 rows per GPU, sequential steps
         nb = 400
         def bs512_pass():

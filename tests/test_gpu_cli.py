@@ -301,3 +301,33 @@ def test_cli_blocks_2d_with_validation_split(tmp_path, monkeypatch):
     dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
     assert dec.shape == (40, 50, 50)                              # blocks folded back into the original frames
     assert rel(dec.reshape(160, 625), orc.decode(dims, final, comp["data"].astype(np.float64))) < 1e-5
+
+
+def test_cli_compress_decompress_bf16_mode(workspace, golden, monkeypatch):
+    """BALER_AMD_MODE=bf16 (the throughput mode of compress / decompress): same CLI, same artefacts and dtypes,
+    outputs at the bf16 bar against the oracle's fp64 encode / decode of the same model."""
+    from baler_amd import baler
+    from baler_amd.modules import helper, models
+    out = workspace
+    _reset_config()
+    flat = golden("g7_c1_model_f32.npz")["final_params_f32"].astype(np.float64)
+    dims = orc.ae_dims(24, 15)
+    raw = synth.cms_rows(10000)
+    models.set_default_mode("bf16")
+    try:
+        helper.model_saver(models.AE(24, 15).load_flat(flat), str(out / "compressed_output" / "model.pt"))
+        np.save(out / "training" / "normalization_features.npy", orc.find_minmax(raw))
+        baler.main(["--project", "CMS_workspace", "CMS_project_v1", "--mode", "compress"])
+        baler.main(["--project", "CMS_workspace", "CMS_project_v1", "--mode", "decompress"])
+    finally:
+        models.set_default_mode("fp32")
+    comp = np.load(out / "compressed_output" / "compressed.npz")["data"]
+    assert comp.dtype == np.float64 and comp.shape == (10000, 15)
+    zo = orc.encode(dims, flat, orc.normalize(raw))
+    assert rel(comp, zo) < 2e-2
+    dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
+    nf = orc.find_minmax(raw)
+    want = orc.renormalize(orc.decode(dims, flat, comp), nf[0], nf[1])
+    fl = np.array([t != "int" for t in synth.CMS_TYPE_LIST])
+    assert dec.dtype == np.float64 and rel(dec[:, fl], want[:, fl]) < 2e-2
+    assert np.array_equal(dec[:, ~fl], np.trunc(dec[:, ~fl]))
