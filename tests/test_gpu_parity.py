@@ -524,6 +524,44 @@ def test_bf16_mode_training_calls_run_in_fp32(data10k):
     assert rel(z1.cpu().numpy(), orc.encode(dims, p.cpu().numpy().astype(np.float64)[:-1], x)) < BF16_TOL
 
 
+@pytest.mark.parametrize("n", [12288, 12289])
+def test_small_batch_threshold_boundary(n):
+    """12288 rows is the last batch size on the small-batch kernels, 12289 the first on the throughput pair: same
+    gradient (1e-5 of the oracle, and of each other at fp32 rounding level)."""
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 13)
+    x = orc.normalize(synth.cms_rows(n, row0=3))
+    h, p = make_handle(dims, flat, "fp32")
+    grads = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), grads)
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    gh = grads.cpu().numpy().astype(np.float64)
+    assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
+
+
+def test_train_step_empty_batch_and_generic_fallback():
+    """bamd_train_step with n_rows = 0 (an empty shard) is fwd_bwd's zero gradient + an Adam step; shapes without
+    a fused path (CFD_dense_AE) take the fwd_bwd + adam_step route behind the same entry point."""
+    dims = orc.ae_dims(24, 15)
+    h, p = make_handle(dims, orc.formula_params(dims, 2), "fp32")
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    before = p.clone()
+    h.train_step(torch.zeros((0, 24), dtype=torch.float64, device="cuda"), p, m, v, 1, 1e-3)
+    assert torch.equal(p, before) and float(m.abs().max()) == 0.0       # zero gradient: Adam moves nothing
+    dims2 = orc.ae_dims(625, 7)
+    f2 = orc.formula_params(dims2, 3)
+    x = synth.cfd_field(4).reshape(16, 625)
+    ha, pa = make_handle(dims2, f2, "fp32")
+    hb, pb = make_handle(dims2, f2, "fp32")
+    ma, va, mb_, vb = (torch.zeros_like(pa) for _ in range(4))
+    g = torch.zeros_like(pa)
+    for t in (1, 2):
+        ha.train_step(dev(x, torch.float32), pa, ma, va, t, 1e-3)
+        hb.fwd_bwd(dev(x, torch.float32), g)
+        hb.adam_step(pb, g, mb_, vb, t, 1e-3)
+    assert torch.equal(pa, pb)
+
+
 def test_bf16_mode_unsupported_shape():
     with pytest.raises(native.NativeError):
         native.Handle(orc.ae_dims(2500, 25), "bf16")
