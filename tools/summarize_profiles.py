@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 CSVs of a gpurun call (gpurun_out/prof_f, pmcf_f, pmcf_w, pmcf_m, bench_final.json) into the
+"""Turn the rocprofv3 CSVs of tools/profile_r1.sh (gpurun_out/prof_f, pmcf_f, pmcf_w, pmcf_m, bench_final.json) into the
 committed summaries profiles/r1_kernel_stats.csv, profiles/r1_pmc_summary.json, profiles/r1_bench.json and print the
 numbers that profiles/README.md quotes."""
 import collections
@@ -11,11 +11,11 @@ import shutil
 
 def load(pattern):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(pattern):
+    for f in glob.glob(pattern, recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r['Kernel_Name']
             k = ('train_dec_kernel' if 'train_dec' in kn else 'train_enc_kernel' if 'train_enc' in kn else
-                 'lat_train_kernel' if 'lat_train' in kn else 'reduce_slabs_k' if 'reduce_slabs' in kn else
+                 'lat2_chain_kernel' if 'lat2_chain' in kn else 'lat2_dw_kernel' if 'lat2_dw' in kn else 'reduce_slabs_k' if 'reduce_slabs' in kn else
                  'infer_kernel<encode>' if 'infer_kernel<24, 15, 0>' in kn else
                  'infer_kernel<decode>' if 'infer_kernel<24, 15, 1>' in kn else 'adam_k' if 'adam_k' in kn else None)
             if k:
@@ -24,8 +24,8 @@ def load(pattern):
             for k, cs in d.items()}
 
 
-f, w, m = (load(f'gpurun_out/pmcf_{x}/runc/*_counter_collection.csv') for x in 'fwm')
-out = {"note": "per launch, 1,000,000 rows (lat_train_kernel: 512 rows), fp32 mode; FETCH_SIZE/WRITE_SIZE in KB as reported by "
+f, w, m = (load(f'gpurun_out/pmcf_{x}/**/*counter_collection.csv') for x in 'fwm')
+out = {"note": "per launch, 1,000,000 rows (lat2_* kernels: 512 rows), fp32 mode; FETCH_SIZE/WRITE_SIZE in KB as reported by "
                "rocprofv3 (separate --pmc passes, --kernel-trace only); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 "
                "correction: FETCH_SIZE reports half of a wide coalesced read; checked on minmax_partial: 96 MB reported for a "
                "192 MB read)", "kernels": {}}
@@ -36,7 +36,7 @@ for k in sorted(set(f) | set(w)):
 out["fwd_bwd_hbm_bytes_per_launch"] = sum(out["kernels"][k]["hbm_bytes"] for k in ('train_dec_kernel', 'train_enc_kernel', 'reduce_slabs_k'))
 out["rows"] = 1000000
 json.dump(out, open('profiles/r1_pmc_summary.json', 'w'), indent=1)
-shutil.copy(glob.glob('gpurun_out/prof_f/runc/*_kernel_stats.csv')[0], 'profiles/r1_kernel_stats.csv')
+shutil.copy(glob.glob('gpurun_out/prof_f/**/*kernel_stats.csv', recursive=True)[0], 'profiles/r1_kernel_stats.csv')
 d = json.load(open('gpurun_out/bench_final.json'))
 d["roofline"]["traffic"] = out["fwd_bwd_hbm_bytes_per_launch"]
 json.dump(d, open('profiles/r1_bench.json', 'w'), indent=1)
