@@ -122,31 +122,31 @@ def perform_decompression(output_path, config, verbose: bool):
     """reference baler.py:341-456: decode, un-normalise with the TRAINING features, cast "int" columns."""
     print("Decompressing...")
     start = time.time()
-    data_before_shape = np.load(config.input_path)["data"].shape
+    data_before_shape = helper.npz_array_shape(config.input_path, "data")   # header only: the table is not re-read
     comp_dir = os.path.join(output_path, "compressed_output")
+    int_mask = None
+    type_list = getattr(config, "type_list", None)
+    if type_list is not None:
+        # astype(int) written back into the float64 array == truncation toward zero (baler.py:426-435)
+        int_mask = np.array([np.issubdtype(np.dtype(t), np.integer) for t in type_list], dtype=np.uint8)
+    renorm = None
+    if config.apply_normalization:   # un-normalise with the TRAINING features (baler.py:410-418), on the device
+        normalization_features = np.load(os.path.join(output_path, "training", "normalization_features.npy"))
+        renorm = (normalization_features, int_mask)
     decompressed, names, normalization_features = helper.decompress(
         model_path=os.path.join(comp_dir, "model.pt"),
         input_path=os.path.join(comp_dir, "compressed.npz"),
         input_path_deltas=os.path.join(comp_dir, "compressed_deltas.npz.gz"),
         input_batch_index=os.path.join(comp_dir, "compressed_batch_index_metadata.npz.gz"),
         model_name=config.model_name, config=config, output_path=output_path,
-        original_shape=data_before_shape)
+        original_shape=data_before_shape, renorm=renorm)
     rank, _ = bdist.rank_world()
     if rank != 0:
         return
     if hasattr(config, "convert_to_blocks") and config.convert_to_blocks:
         decompressed = decompressed.reshape(data_before_shape[0], data_before_shape[1], data_before_shape[2])
-
-    int_mask = None
-    type_list = getattr(config, "type_list", None)
-    if type_list is not None:
-        # astype(int) written back into the float64 array == truncation toward zero (baler.py:426-435)
-        int_mask = np.array([np.issubdtype(np.dtype(t), np.integer) for t in type_list], dtype=np.uint8)
     if config.apply_normalization:
         print("Un-normalizing...")
-        normalization_features = np.load(os.path.join(output_path, "training", "normalization_features.npy"))
-        decompressed = helper.renormalize(decompressed, normalization_features[0], normalization_features[1],
-                                          int_mask)
     elif int_mask is not None and int_mask.any():
         decompressed = np.array(decompressed, copy=True)
         cols = np.nonzero(int_mask)[0]

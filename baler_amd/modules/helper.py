@@ -144,6 +144,15 @@ def renormalize(data, true_min_list, feature_range_list, int_mask=None):
     return data_processing.renormalize_func(data, true_min_list, feature_range_list, int_mask)
 
 
+def npz_array_shape(path, key):
+    """Shape of one array of an .npz archive from its .npy header (np.load(path)[key].shape reads the whole array)."""
+    import zipfile
+    with zipfile.ZipFile(path) as zf, zf.open(key + ".npy") as f:
+        version = np.lib.format.read_magic(f)
+        header = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
+        return tuple(header[0])
+
+
 def _load_to_device(path):
     loaded = np.load(path)
     data = loaded["data"]
@@ -314,10 +323,15 @@ def _gather_rows(local, n_total, world):
 
 
 def decompress(model_path, input_path, input_path_deltas, input_batch_index, model_name, config,
-               output_path, original_shape):
+               output_path, original_shape, renorm=None):
     """reference helper.py:619-733.  Returns (decompressed ndarray, names, normalization_features).  With
     ``config.save_error_bounded_deltas`` the stored float16 deltas are subtracted from the decoder output of
-    their batch (helper.py:708-718), on the device, before the caller un-normalises."""
+    their batch (helper.py:708-718), on the device, before un-normalisation.
+
+    ``renorm`` (not in the reference signature; optional): ``(features (2, C) float64, int_mask or None)``.  When
+    given, the un-normalisation ``x*range + min`` and the truncation of the "int" columns that the reference applies
+    afterwards on the host (baler.py:410-435) run on the device -- fused into the decode kernel's store when there are
+    no deltas -- so the decompressed table crosses PCIe once (float64) instead of three times."""
     loaded = np.load(input_path)
     data = loaded["data"]
     names = loaded["names"]
@@ -336,17 +350,27 @@ def decompress(model_path, input_path, input_path_deltas, input_batch_index, mod
     z = z.to(get_device())
     rank, world = bdist.rank_world()
     lo, hi = bdist.shard_rows(z.shape[0], rank, world)
-    out = torch.empty((hi - lo, number_of_columns), dtype=z.dtype, device=z.device)
+    want_deltas = bool(getattr(config, "save_error_bounded_deltas", False))
+    r_feats = r_mask = None
+    if renorm is not None:
+        r_feats = torch.as_tensor(np.asarray(renorm[0], dtype=np.float64).reshape(2, -1), device=z.device).contiguous()
+        if renorm[1] is not None:
+            r_mask = torch.as_tensor(np.asarray(renorm[1], dtype=np.uint8), device=z.device).contiguous()
+    fuse = renorm is not None and not want_deltas
+    out = torch.empty((hi - lo, number_of_columns), dtype=torch.float64 if fuse else z.dtype, device=z.device)
     for s in range(lo, hi, ROW_BLOCK):
         e = min(s + ROW_BLOCK, hi)
-        out[s - lo:e - lo] = h.decode(z[s:e])
-    if getattr(config, "save_error_bounded_deltas", False):
+        out[s - lo:e - lo] = (h.decode(z[s:e], features=r_feats, int_mask=r_mask, out_dtype=torch.float64) if fuse
+                              else h.decode(z[s:e]))
+    if want_deltas:
         rows, cols, vals = load_deltas(input_path_deltas, input_batch_index, config.batch_size)
         mine = (rows >= lo) & (rows < hi)                     # this rank's row shard
         dev = out.device
         native.apply_deltas(out, torch.from_numpy(rows[mine] - lo).to(dev), torch.from_numpy(cols[mine]).to(dev),
                             torch.from_numpy(vals[mine]).to(dev))
         print("Total Deltas Added - ", int(len(rows)))
+        if renorm is not None:
+            out = native.renormalize(out, r_feats, r_mask)
     decompressed = _gather_rows(out, z.shape[0], world)
     if config.data_dimension == 2 and getattr(config, "model_type", None) == "dense":
         blocks = getattr(config, "convert_to_blocks", None)

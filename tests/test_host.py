@@ -252,3 +252,12 @@ def test_delta_side_channel_files_roundtrip(tmp_path):
     rows2, cols2, vals2 = helper.load_deltas(str(tmp_path / "compressed_deltas.npz.gz"),
                                              str(tmp_path / "compressed_batch_index_metadata.npz.gz"), 128)
     assert np.array_equal(rows2, rows) and vals2.tobytes() == vals.tobytes()
+
+
+def test_npz_array_shape_reads_header_only(tmp_path):
+    from baler_amd.modules import helper
+    a = np.arange(24.0).reshape(2, 3, 4)
+    np.savez(tmp_path / "a.npz", data=a, names=np.array(["x"]))
+    np.savez_compressed(tmp_path / "b.npz", data=a[0], names=np.array(["x"]))
+    assert helper.npz_array_shape(str(tmp_path / "a.npz"), "data") == (2, 3, 4)
+    assert helper.npz_array_shape(str(tmp_path / "b.npz"), "data") == (3, 4)
