@@ -152,8 +152,15 @@ template <typename T, int EPI, bool A_KFAST, bool B_KFAST>
 __global__ void __launch_bounds__(256) gemm_big_k(Opnd<T> A, Opnd<T> B, int64_t kred, Epi<T> e) {
     using v4 = typename MF<T>::v4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T(*As)[128][20] = (T(*)[128][20])smem_raw;                       // [2][128][20]
-    T(*Bs)[128][20] = (T(*)[128][20])(smem_raw + 2 * 128 * 20 * sizeof(T));
+    // per operand two staging buffers of 2560 elements.  K-fast operands: [128 outer][16 k] with the four 16-byte k groups
+    // of row o XOR-swizzled by (o >> 1) & 3: conflict-free 16-byte stores (8 lanes = 2 rows = 32 banks) AND fragment reads
+    // (8 lanes = 8 rows, k group g: 8 distinct 4-bank groups); a padded [128][20] layout had 2-way store conflicts.
+    // K-slow operands (outer index contiguous in memory): [16 k][132] (128 outer + 4 pad), so the
+    // 4 consecutive outer elements a thread loads are ONE 16-byte LDS store -- transposing them into the [outer][k] layout
+    // took four 4-byte stores that land 16-deep on two banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.89 on the
+    // weight-gradient product) -- and the MFMA fragments are read as four 4-byte loads (lane groups on disjoint bank halves).
+    T *As = (T *)smem_raw;
+    T *Bs = As + 2 * 2560;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int64_t i0 = (int64_t)blockIdx.y * 128, j0 = (int64_t)blockIdx.x * 128;
@@ -207,23 +214,19 @@ __global__ void __launch_bounds__(256) gemm_big_k(Opnd<T> A, Opnd<T> B, int64_t 
         gload_one(A, A_KFAST, vecA, i0, k0, ra);
         gload_one(B, B_KFAST, vecB, j0, k0, rb);
     };
-    auto lstore_one = [&](T (*S)[20], bool KF, const T (&reg)[8]) {
+    auto lstore_one = [&](T *S, bool KF, const T (&reg)[8]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (KF) {
-                v4 v;
+            v4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = reg[4 * h + j];
-                *(v4 *)&S[(tid >> 2) + 64 * h][4 * (tid & 3)] = v;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) S[4 * (tid & 31) + j][(tid >> 5) + 8 * h] = reg[4 * h + j];
-            }
+            for (int j = 0; j < 4; ++j) v[j] = reg[4 * h + j];
+            if (KF) { const int o = (tid >> 2) + 64 * h; *(v4 *)&S[o * 16 + 4 * ((tid & 3) ^ ((o >> 1) & 3))] = v; }
+            else *(v4 *)&S[((tid >> 5) + 8 * h) * 132 + 4 * (tid & 31)] = v;
         }
     };
     auto lstore = [&](int buf) {
-        lstore_one(As[buf], A_KFAST, ra);
-        lstore_one(Bs[buf], B_KFAST, rb);
+        lstore_one(As + buf * 2560, A_KFAST, ra);
+        lstore_one(Bs + buf * 2560, B_KFAST, rb);
     };
     if (k_lo < k_hi) {
         gload(k_lo);
@@ -235,13 +238,22 @@ __global__ void __launch_bounds__(256) gemm_big_k(Opnd<T> A, Opnd<T> B, int64_t 
         const bool more = k0 + 16 < k_hi;
         if (more) gload(k0 + 16);
         T a4[4][4], b4[4][4];
+        auto frag = [&](const T *S, bool KF, int o0, T (&f)[4]) {      // 16 outer x 16 k fragment of one 16-wide sub-tile
+            if (KF) {
+                const int o = o0 + (lane & 15);
+                const v4 v = *(const v4 *)&S[o * 16 + 4 * ((lane >> 4) ^ ((o >> 1) & 3))];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+                for (int r = 0; r < 4; ++r) f[r] = v[r];
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                a4[t][r] = As[buf][wr * 64 + t * 16 + (lane & 15)][4 * (lane >> 4) + r];
-                b4[t][r] = Bs[buf][wc * 64 + t * 16 + (lane & 15)][4 * (lane >> 4) + r];
+                for (int r = 0; r < 4; ++r) f[r] = S[(4 * (lane >> 4) + r) * 132 + o0 + (lane & 15)];
             }
+        };
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            frag(As + buf * 2560, A_KFAST, wr * 64 + t * 16, a4[t]);
+            frag(Bs + buf * 2560, B_KFAST, wc * 64 + t * 16, b4[t]);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
