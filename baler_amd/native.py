@@ -8,7 +8,6 @@ calls raise ``NativeError``.
 import ctypes
 import os
 
-import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

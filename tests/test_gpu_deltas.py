@@ -1,6 +1,5 @@
 """Error-bounded deltas side channel on the GPU against oracle/deltas.py and the
 reference-generated fixture g14_deltas.npz."""
-import os
 
 import numpy as np
 import pytest

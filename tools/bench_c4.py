@@ -4,7 +4,7 @@ on the generic layer-wise MFMA path (N frames of 50x50)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from baler_amd import native, synth
+from baler_amd import synth
 from baler_amd.modules import models
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 x = torch.as_tensor(synth.cfd_field(n).reshape(n, 2500).astype(np.float32)).cuda()

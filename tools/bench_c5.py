@@ -3,7 +3,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from baler_amd import native, synth
+from baler_amd import synth
 from baler_amd.modules import models
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 x = torch.as_tensor(synth.wide_rows(n, 512).astype(np.float32)).cuda()
