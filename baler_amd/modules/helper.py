@@ -262,6 +262,17 @@ def compress(model_path, config):
     return (compressed,) + split_deltas(flags, deltas, config.batch_size)
 
 
+def save_error_bounded_requirement(config, decoded_output, data_batch):
+    """reference helper.py:442-470 for ONE batch of host arrays (kept for callers of the reference function; the
+    compress path evaluates the whole table at once): -> (list of float16 deltas, (rows, cols))."""
+    dev = get_device()
+    x = torch.as_tensor(np.ascontiguousarray(data_batch), device=dev)
+    r = torch.as_tensor(np.ascontiguousarray(decoded_output), device=dev).to(x.dtype)
+    flags, deltas = native.error_deltas(x, r, config.error_bounded_requirement)
+    rows, cols = np.nonzero(flags.cpu().numpy())
+    return list(deltas.cpu().numpy()[rows, cols]), (rows, cols)
+
+
 def split_deltas(flags, deltas, batch_size):
     """Dense (flags, float16 deltas) of the whole table -> the reference's per-batch side channel
     (helper.py:589-606): batch numbers, flagged deltas (row-major, as ``np.where`` orders them) and

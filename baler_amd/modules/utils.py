@@ -69,6 +69,14 @@ def loss_function_swae(inputs, z, reconstructions, latent_dim, reg_weight=100, w
     return mse_sum_loss + swd[0], mse_sum_loss, swd[0]
 
 
+def mse_loss_emd_l1(model_children, true_data, reconstructed_data, reg_param, validate):
+    """reference utils.py:94-132 with ``validate=True``: the summed per-row 1-D Wasserstein distance (a float).  The
+    training variant is unreachable in the reference (and adds to an empty tensor, utils.py:122-128)."""
+    if not validate:
+        raise NotImplementedError("mse_loss_emd_l1(validate=False) is dead code in the reference (utils.py:122-130)")
+    return float(emd_rows(true_data, reconstructed_data))
+
+
 def emd_rows(true_data, reconstructed_data):
     """Sum over rows of the 1-D Wasserstein distance between a row's columns (device kernel)."""
     return native.emd_rows(true_data.contiguous(), reconstructed_data.contiguous())
