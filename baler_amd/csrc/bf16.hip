@@ -323,29 +323,46 @@ __global__ void __launch_bounds__(64 * kWaves) bf16_infer_kernel(const uint4 *__
 #pragma unroll
             for (int mb = 0; mb < kMB; ++mb)
 #pragma unroll
-                for (int t = 0; t < N::nt(7); ++t)
+                for (int t = 0; t < N::nt(7); ++t) {
+                    const int f0 = 16 * t + 4 * g;                   // this lane's 4 consecutive output features of tile t
+                    if (!valid[mb] || f0 >= F) continue;
+                    const int64_t i0 = row[mb] * F + f0;
+                    double d[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int f = 16 * t + 4 * g + r;
-                        if (valid[mb] && f < F) {
-                            const int64_t i = row[mb] * F + f;
-                            if (out) {
-                                if (feats) {   // norm*range + min with two roundings (numpy), trunc for "int" columns (baler.py:420-435)
-                                    double d = __dadd_rn(__dmul_rn((double)y[t][mb][r], fl[96 + f]), fl[64 + f]);
-                                    if (imask && imask[f]) d = trunc(d);
-                                    if (out_f64) ((double *)out)[i] = d; else ((float *)out)[i] = (float)d;
-                                } else {
-                                    if (out_f64) ((double *)out)[i] = (double)y[t][mb][r]; else ((float *)out)[i] = y[t][mb][r];
-                                }
-                            }
-                            if (xref) {
-                                double xv = xref_f64 ? ((const double *)xref)[i] : (double)((const float *)xref)[i];
-                                if (xref_feats) xv = (xv - fl[f]) / fl[32 + f];
-                                const double d = (double)y[t][mb][r] - (double)(float)xv;
-                                lacc += d * d;
-                            }
+                        d[r] = (double)y[t][mb][r];
+                        if (feats && f0 + r < F) {   // norm*range + min with two roundings (numpy), trunc for "int" columns (baler.py:420-435)
+                            d[r] = __dadd_rn(__dmul_rn(d[r], fl[96 + f0 + r]), fl[64 + f0 + r]);
+                            if (imask && imask[f0 + r]) d[r] = trunc(d[r]);
                         }
                     }
+                    if (out) {
+                        if (F % 4 == 0) {                            // 32 / 16 contiguous, aligned bytes per lane: vector stores
+                            if (out_f64) {
+                                *(double2 *)((double *)out + i0) = make_double2(d[0], d[1]);
+                                *(double2 *)((double *)out + i0 + 2) = make_double2(d[2], d[3]);
+                            } else {
+                                *(float4 *)((float *)out + i0) = make_float4((float)d[0], (float)d[1], (float)d[2], (float)d[3]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (f0 + r < F) {
+                                    if (out_f64) ((double *)out)[i0 + r] = d[r]; else ((float *)out)[i0 + r] = (float)d[r];
+                                }
+                        }
+                    }
+                    if (xref) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (f0 + r < F) {
+                                double xv = xref_f64 ? ((const double *)xref)[i0 + r] : (double)((const float *)xref)[i0 + r];
+                                if (xref_feats) xv = (xv - fl[f0 + r]) / fl[32 + f0 + r];
+                                const double e = (double)y[t][mb][r] - (double)(float)xv;
+                                lacc += e * e;
+                            }
+                    }
+                }
         }
     }
     if (DEC && loss_part) {
