@@ -565,3 +565,31 @@ def test_train_step_empty_batch_and_generic_fallback():
 def test_bf16_mode_unsupported_shape():
     with pytest.raises(native.NativeError):
         native.Handle(orc.ae_dims(2500, 25), "bf16")
+
+
+def test_two_handles_two_streams(data10k):
+    """Handles are independent and every call is asynchronous on the caller's stream: two models driven from two
+    torch streams interleave without cross-talk (scratch, packed weights and slabs are per handle)."""
+    dims = orc.ae_dims(24, 15)
+    fa, fb = orc.formula_params(dims, 51), orc.formula_params(dims, 52)
+    ha, pa = make_handle(dims, fa, "fp32")
+    hb, pb = make_handle(dims, fb, "fp32")
+    x = dev(data10k[:4096])
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ga, gb = torch.zeros_like(pa), torch.zeros_like(pb)
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            za = ha.encode(x)
+            ha.fwd_bwd(x, ga)
+        with torch.cuda.stream(sb):
+            zb = hb.encode(x)
+            hb.fwd_bwd(x, gb)
+        outs.append((za, zb))
+    torch.cuda.synchronize()
+    assert rel(outs[-1][0].cpu().numpy(), orc.encode(dims, fa, data10k[:4096])) < TOL32
+    assert rel(outs[-1][1].cpu().numpy(), orc.encode(dims, fb, data10k[:4096])) < TOL32
+    la, gra = orc.fwd_bwd(dims, fa, data10k[:4096])
+    lb, grb = orc.fwd_bwd(dims, fb, data10k[:4096])
+    assert rel(ga.cpu().numpy()[:-1], gra) < TOL32 and rel(gb.cpu().numpy()[:-1], grb) < TOL32
