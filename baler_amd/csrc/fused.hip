@@ -168,6 +168,26 @@ __device__ __forceinline__ void chain_gemm(const v4 (&in)[tiles(KD)], v4 (&out)[
     }
 }
 
+// Two batch tiles per wave: every fragment feeds both tiles' accumulators (the two independent MFMA chains that
+// chain_gemm gets from pairing fragments), so a 32-row pass issues HALF the fragment loads per MFMA of a 16-row one.
+// Every non-MFMA instruction costs ~8 cycles of MFMA issue; used by the inference kernels, which have the registers.
+template <int KD, int NT, int BASE, int TOTAL>
+__device__ __forceinline__ void chain_gemm2(const v4 (&in0)[tiles(KD)], const v4 (&in1)[tiles(KD)], v4 (&out0)[NT], v4 (&out1)[NT],
+                                            Ring &ring, const WStream &ws) {
+    constexpr int NF = tiles(KD) * NT;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < tile_steps(KD, f / NT)) {
+                out0[f % NT] = mfma(ring.slot[(BASE + f) % kRing][r], in0[f / NT][r], out0[f % NT]);
+                out1[f % NT] = mfma(ring.slot[(BASE + f) % kRing][r], in1[f / NT][r], out1[f % NT]);
+            }
+        ring.slot[(BASE + f) % kRing] = frag(ws, (BASE + f + kRing) % pad_total(TOTAL));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int NT> __device__ __forceinline__ void init_bias(v4 (&out)[NT], const v4 *bias_lds, int lane) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) out[t] = bias_lds[t * 4 + (lane >> 4)];
@@ -216,6 +236,16 @@ __device__ __forceinline__ void fwd_layer(const v4 (&in)[tiles(N::dim(l))], v4 (
     init_bias(out, bias_lds + (N::bf_off(l) - N::bf_off(0)), lane);
     chain_gemm<N::dim(l), tiles(N::dim(l + 1)), S::fwd_base(l), S::total>(in, out, ring, ws);
     if (N::act(l)) lrelu(out);
+}
+template <class N, class S, int l>
+__device__ __forceinline__ void fwd_layer2(const v4 (&in0)[tiles(N::dim(l))], const v4 (&in1)[tiles(N::dim(l))],
+                                           v4 (&out0)[tiles(N::dim(l + 1))], v4 (&out1)[tiles(N::dim(l + 1))], Ring &ring,
+                                           const WStream &ws, const v4 *bias_lds, int lane) {
+    init_bias(out0, bias_lds + (N::bf_off(l) - N::bf_off(0)), lane);
+#pragma unroll
+    for (int t = 0; t < tiles(N::dim(l + 1)); ++t) out1[t] = out0[t];
+    chain_gemm2<N::dim(l), tiles(N::dim(l + 1)), S::fwd_base(l), S::total>(in0, in1, out0, out1, ring, ws);
+    if (N::act(l)) { lrelu(out0); lrelu(out1); }
 }
 // dY_{l-1}^T = W_l^T dZ_l^T
 template <class N, class S, int l>
@@ -471,6 +501,50 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
             __syncthreads();
         }
         if (threadIdx.x == 0) loss_part[blockIdx.x] = sh[0];
+    }
+}
+
+// Encode / decode with TWO 16-row tiles per wave (see chain_gemm2): same results, half the fragment loads per MFMA.
+template <int F, int Z, int KIND>
+__global__ void __launch_bounds__(256) infer2_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
+                                                     const double *__restrict__ feats, void *__restrict__ out, int out_f64,
+                                                     const uint8_t *__restrict__ imask) {
+    using N = Net<F, Z>;
+    using S = typename std::conditional<KIND == K_ENCODE, StreamEncode<N>, StreamDecode<N>>::type;
+    static_assert(KIND == K_ENCODE || KIND == K_DECODE, "pair kernel: encode or decode");
+    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
+    stage_bias<N>(bias_lds, packed);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t npair = (n + 31) / 32;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, threadIdx.x & 63);
+    Ring ring;
+    ring_prime<S::total>(ring, ws);
+    for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < npair; pr += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = pr * 32 + (lane & 15), r1 = r0 + 16;
+        const bool v0 = r0 < n, v1 = r1 < n;
+        asm volatile("" : "+v"(ws.voff));   // keep the weight loads inside the loop (see infer_kernel)
+        if (KIND == K_ENCODE) {
+            v4 a0[tiles(F)], b0[tiles(F)], a1[13], b1[13], a2[7], b2[7], a3[4], b3[4], a4[tiles(Z)], b4[tiles(Z)];
+            load_rows<F>(a0, xin, in_f64, r0, v0, lane, feats);
+            load_rows<F>(b0, xin, in_f64, r1, v1, lane, feats);
+            fwd_layer2<N, S, 0>(a0, b0, a1, b1, ring, ws, bias_lds, lane);
+            fwd_layer2<N, S, 1>(a1, b1, a2, b2, ring, ws, bias_lds, lane);
+            fwd_layer2<N, S, 2>(a2, b2, a3, b3, ring, ws, bias_lds, lane);
+            fwd_layer2<N, S, 3>(a3, b3, a4, b4, ring, ws, bias_lds, lane);
+            store_rows<Z>(a4, out, out_f64, r0, v0, lane, nullptr, nullptr);
+            store_rows<Z>(b4, out, out_f64, r1, v1, lane, nullptr, nullptr);
+        } else {
+            v4 a4[tiles(Z)], b4[tiles(Z)], a5[4], b5[4], a6[7], b6[7], a7[13], b7[13], a8[tiles(F)], b8[tiles(F)];
+            load_rows<Z>(a4, xin, in_f64, r0, v0, lane, nullptr);
+            load_rows<Z>(b4, xin, in_f64, r1, v1, lane, nullptr);
+            fwd_layer2<N, S, 4>(a4, b4, a5, b5, ring, ws, bias_lds, lane);
+            fwd_layer2<N, S, 5>(a5, b5, a6, b6, ring, ws, bias_lds, lane);
+            fwd_layer2<N, S, 6>(a6, b6, a7, b7, ring, ws, bias_lds, lane);
+            fwd_layer2<N, S, 7>(a7, b7, a8, b8, ring, ws, bias_lds, lane);
+            store_rows<F>(a8, out, out_f64, r0, v0, lane, feats, imask);
+            store_rows<F>(b8, out, out_f64, r1, v1, lane, feats, imask);
+        }
+        ring_tail<S::total>(ring, ws);
     }
 }
 
@@ -1436,6 +1510,10 @@ struct FusedOps {
 
 static FusedState *state_of(bamd_handle *h) { return (FusedState *)h->fused_state; }
 
+static bool infer_pair() {   // two 16-row tiles per wave in encode / decode (BALER_AMD_INFER_PAIR=0: one tile, for A/B runs)
+    static const bool on = !(getenv("BALER_AMD_INFER_PAIR") && getenv("BALER_AMD_INFER_PAIR")[0] == '0');
+    return on;
+}
 static int infer_grid(int64_t n) {
     int64_t wg = ((n + 15) / 16 + 3) / 4;
     return (int)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg));
@@ -1461,6 +1539,13 @@ template <int F, int Z> struct Impl {
                       hipStream_t s) {
         static const int extra_lds = getenv("BALER_AMD_INFER_LDS") ? atoi(getenv("BALER_AMD_INFER_LDS")) : 0;   // occupancy experiments
         if (extra_lds) (void)hipFuncSetAttribute((const void *)infer_kernel<F, Z, K_ENCODE>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+        if (F <= 64 && infer_pair()) {
+            hipLaunchKernelGGL((infer2_kernel<F <= 64 ? F : 24, Z, K_ENCODE>), dim3(infer_grid((n + 1) / 2)), dim3(256), 0, s,
+                               (const v4 *)h->packed.p, x, x_dtype == BAMD_F64, n, features, z, z_dtype == BAMD_F64,
+                               (const uint8_t *)nullptr);
+            BAMD_HIP(hipGetLastError());
+            return BAMD_OK;
+        }
         hipLaunchKernelGGL((infer_kernel<F, Z, K_ENCODE>), dim3(infer_grid(n)), dim3(256), extra_lds, s, (const v4 *)h->packed.p, x,
                            x_dtype == BAMD_F64, n, features, z, z_dtype == BAMD_F64, (const uint8_t *)nullptr, (double *)nullptr);
         BAMD_HIP(hipGetLastError());
@@ -1468,6 +1553,12 @@ template <int F, int Z> struct Impl {
     }
     static int decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features, const uint8_t *int_mask,
                       void *out, int out_dtype, hipStream_t s) {
+        if (infer_pair()) {
+            hipLaunchKernelGGL((infer2_kernel<F, Z, K_DECODE>), dim3(infer_grid((n + 1) / 2)), dim3(256), 0, s,
+                               (const v4 *)h->packed.p, z, z_dtype == BAMD_F64, n, features, out, out_dtype == BAMD_F64, int_mask);
+            BAMD_HIP(hipGetLastError());
+            return BAMD_OK;
+        }
         hipLaunchKernelGGL((infer_kernel<F, Z, K_DECODE>), dim3(infer_grid(n)), dim3(256), 0, s, (const v4 *)h->packed.p, z,
                            z_dtype == BAMD_F64, n, features, out, out_dtype == BAMD_F64, int_mask, (double *)nullptr);
         BAMD_HIP(hipGetLastError());
