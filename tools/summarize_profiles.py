@@ -16,8 +16,8 @@ def load(pattern):
             kn = r['Kernel_Name']
             k = ('train_dec_kernel' if 'train_dec' in kn else 'train_enc_kernel' if 'train_enc' in kn else
                  'lat2_chain_kernel' if 'lat2_chain' in kn else 'lat2_dw_kernel' if 'lat2_dw' in kn else 'reduce_slabs_k' if 'reduce_slabs' in kn else
-                 'infer_kernel<encode>' if 'infer_kernel<24, 15, 0>' in kn else
-                 'infer_kernel<decode>' if 'infer_kernel<24, 15, 1>' in kn else 'adam_k' if 'adam_k' in kn else None)
+                 'infer_kernel<encode>' if ('infer_kernel<24, 15, 0>' in kn or 'infer2_kernel<24, 15, 0>' in kn) else
+                 'infer_kernel<decode>' if ('infer_kernel<24, 15, 1>' in kn or 'infer2_kernel<24, 15, 1>' in kn) else 'adam_k' if 'adam_k' in kn else None)
             if k:
                 d[k][r['Counter_Name']].append(float(r['Counter_Value']))
     return {k: {c: (max(v) if k in ('reduce_slabs_k', 'adam_k') else sum(v) / len(v)) for c, v in cs.items()}
