@@ -1,6 +1,10 @@
-"""Per-layer shader-clock timeline of lat2_chain_kernel's workgroup 0 (needs a -DBAMD_LAT_TRACE build):
+"""Per-layer shader-clock timeline of the small-batch kernels' workgroup 0 (needs a -DBAMD_LAT_TRACE build):
 
-    BALER_AMD_LIB=.abl/trace.so python tools/lat_trace.py
+    cd baler_amd/csrc && mkdir -p ../../.abl && \
+      hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 \
+            -DBAMD_LAT_TRACE -c fused.hip -o /tmp/fused_trace.o && \
+      hipcc --offload-arch=gfx950 -shared -fPIC -o ../../.abl/trace.so api.o elementwise.o generic.o swd.o bf16.o /tmp/fused_trace.o
+    BALER_AMD_LIB=$PWD/.abl/trace.so python tools/lat_trace.py          (on the GPU box)
 """
 import ctypes
 import os
