@@ -37,6 +37,19 @@ void DevBuf::release() {
 
 using namespace bamd;
 
+namespace {
+// The handle's buffers live on its device: make it current for the duration of a call and give the caller's current
+// device back afterwards (a single process that drives several GPUs must not find its device changed under it).
+struct DeviceGuard {
+    int prev = -1, rc = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) rc = (int)hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
 extern "C" {
 
 int bamd_abi_version(void) { return BAMD_ABI_VERSION; }
@@ -64,7 +77,8 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
         return BAMD_ERR_NO_DEVICE;
     }
     BAMD_REQUIRE(device >= 0 && device < ndev, "device ordinal out of range");
-    BAMD_HIP(hipSetDevice(device));
+    DeviceGuard guard(device);
+    BAMD_REQUIRE(guard.rc == hipSuccess, "cannot select the device");
     hipDeviceProp_t prop;
     BAMD_HIP(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -101,7 +115,7 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
 
 void bamd_destroy(bamd_handle *h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     fused_teardown(h);
     bf16_teardown(h);
     h->params.release();
@@ -119,7 +133,8 @@ int bamd_mode_of(const bamd_handle *h) { return h ? h->mode : BAMD_ERR_INVALID; 
 int bamd_load_params(bamd_handle *h, const void *params, int dtype, void *stream) {
     BAMD_REQUIRE(h && params, "null argument");
     BAMD_REQUIRE(dtype == BAMD_F32 || dtype == BAMD_F64, "bad dtype");
-    BAMD_HIP(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    BAMD_REQUIRE(guard.rc == hipSuccess, "cannot select the handle's device");
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_convert(params, dtype, h->params.p, h->esize == 8 ? BAMD_F64 : BAMD_F32, h->nparams, s);
     if (rc) return rc;
@@ -145,7 +160,8 @@ int bamd_renormalize(const void *x, int dtype, int64_t n_rows, int n_cols, const
 #define BAMD_CHECK_MODEL(h)                                                        \
     BAMD_REQUIRE(h, "null handle");                                                \
     BAMD_REQUIRE((h)->params_loaded, "bamd_load_params() has not been called");    \
-    BAMD_HIP(hipSetDevice((h)->device)); /* the handle's buffers live on its device */
+    DeviceGuard guard_((h)->device);                                               \
+    BAMD_REQUIRE(guard_.rc == hipSuccess, "cannot select the handle's device");
 
 int bamd_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features, void *z,
                 int z_dtype, void *stream) {
