@@ -42,18 +42,30 @@ __global__ void __launch_bounds__(256) minmax_partial(const T *__restrict__ x, i
     }
 }
 
-__global__ void minmax_final(const double *__restrict__ part, int nblk, int c,
-                             double *__restrict__ features) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c) return;
+// one workgroup per column: 256 threads stride over the block partials, LDS tree (min / max are exact in any order)
+__global__ void __launch_bounds__(256) minmax_final(const double *__restrict__ part, int nblk, int c,
+                                                    double *__restrict__ features) {
+    __shared__ double smn[256], smx[256];
+    const int col = blockIdx.x;
     double mn = INFINITY, mx = -INFINITY;
-    for (int b = 0; b < nblk; ++b) {
-        double a = part[((int64_t)b * 2 + 0) * c + col], d = part[((int64_t)b * 2 + 1) * c + col];
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const double a = part[((int64_t)b * 2 + 0) * c + col], d = part[((int64_t)b * 2 + 1) * c + col];
         mn = a < mn ? a : mn;
         mx = d > mx ? d : mx;
     }
-    features[col] = mn;
-    features[c + col] = mx - mn;
+    smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            smn[threadIdx.x] = smn[threadIdx.x + st] < smn[threadIdx.x] ? smn[threadIdx.x + st] : smn[threadIdx.x];
+            smx[threadIdx.x] = smx[threadIdx.x + st] > smx[threadIdx.x] ? smx[threadIdx.x + st] : smx[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        features[col] = smn[0];
+        features[c + col] = smx[0] - smn[0];
+    }
 }
 
 // handle-free kernels keep one grow-only scratch buffer per (device, purpose); calls on one device are expected from
@@ -83,7 +95,7 @@ int launch_minmax(const void *x, int dtype, int64_t n, int c, double *features, 
     else
         hipLaunchKernelGGL(minmax_partial<float>, grid, dim3(256), 0, s, (const float *)x, n, c,
                            tcols, part);
-    hipLaunchKernelGGL(minmax_final, dim3((c + 255) / 256), dim3(256), 0, s, part, nblk, c, features);
+    hipLaunchKernelGGL(minmax_final, dim3(c), dim3(256), 0, s, part, nblk, c, features);
     BAMD_HIP(hipGetLastError());
     return BAMD_OK;
 }
