@@ -21,7 +21,16 @@ __global__ void __launch_bounds__(256) minmax_partial(const T *__restrict__ x, i
     const int col = blockIdx.y * tcols + lc;
     double mn = INFINITY, mx = -INFINITY;
     if (lr < R && col < c) {
-        for (int64_t r = (int64_t)blockIdx.x * R + lr; r < n; r += (int64_t)gridDim.x * R) {
+        const int64_t step = (int64_t)gridDim.x * R;
+        int64_t r = (int64_t)blockIdx.x * R + lr;
+        for (; r + 7 * step < n; r += 8 * step) {      // 8 independent loads in flight per thread (HBM latency ~2 us)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (double)x[(r + u * step) * c + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+        }
+        for (; r < n; r += step) {
             double v = (double)x[r * c + col];
             mn = v < mn ? v : mn;
             mx = v > mx ? v : mx;
