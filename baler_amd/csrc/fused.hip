@@ -611,6 +611,10 @@ __device__ __forceinline__ void dw_phase(const float *__restrict__ qdz, const fl
     // MFMAs alternate (see chain_gemm); LDS fragment reads run one step ahead of the MFMAs.
     constexpr int NP = (D::T + 1) / 2, U = 4 * NP;
     const int g = lane >> 4, i = lane & 15;
+    // LDS addresses as 32-bit: per-lane part once per phase, wave-uniform tile part from the scalar unit, the 16-row group
+    // as the instruction's immediate offset: one v_add per fragment pointer (generic pointers cost a 64-bit mad + shift each)
+    typedef const float __attribute__((address_space(3))) *lds_cf;
+    const lds_cf la = (lds_cf)qdz + (i * kQS + 4 * g), lb = (lds_cf)qx + (i * kQS + 4 * g);
     v4 fa[2][2], fb[2][2];   // [buffer][tile of the pair]
     auto lds_frags = [&](int u, v4 (&a)[2], v4 (&b)[2]) {
 #pragma unroll
@@ -620,8 +624,8 @@ __device__ __forceinline__ void dw_phase(const float *__restrict__ qdz, const fl
                 int idx = wave + 4 * it;
                 idx = idx < D::TOT ? idx : D::TOT - 1;
                 const int kt = idx / D::NT, nt = idx - kt * D::NT;
-                a[h] = *(const v4 *)(qdz + (16 * nt + i) * kQS + 4 * g + 16 * (u & 3));
-                b[h] = *(const v4 *)(qx + (16 * kt + i) * kQS + 4 * g + 16 * (u & 3));
+                a[h] = *(const v4 __attribute__((address_space(3))) *)(la + nt * (16 * kQS) + 16 * (u & 3));
+                b[h] = *(const v4 __attribute__((address_space(3))) *)(lb + kt * (16 * kQS) + 16 * (u & 3));
             }
         }
     };
