@@ -112,7 +112,10 @@ __device__ __forceinline__ WStream make_stream(const v4 *base, int bytes, int la
 __device__ __forceinline__ v4 frag(const WStream &ws, int idx) {
     return __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
 }
-constexpr int kRing = 8;
+#ifndef BAMD_RING
+#define BAMD_RING 8
+#endif
+constexpr int kRing = BAMD_RING;
 #ifndef BAMD_CHAIN_WAYS
 #define BAMD_CHAIN_WAYS 2
 #endif
