@@ -22,6 +22,8 @@ __global__ void __launch_bounds__(256) probe(const v4 *w, float *out, int iters)
     v4 bt[13];
     for (int i = 0; i < 13; ++i) bt[i] = (v4){1.f + lane, 2.f, 3.f, 4.f + i};
     float a0 = 1.0f + lane, b0 = 2.0f, x = 0.5f * lane;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f pk = (v2f){1.0f, 1.0f};
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 1 << 20, 0x00020000);
     int voff = lane * 16;
     v4 ring[8];
@@ -38,7 +40,7 @@ __global__ void __launch_bounds__(256) probe(const v4 *w, float *out, int iters)
         } else if (VAR == 5) {
 #pragma unroll
             for (int k = 0; k < 64; ++k) acc[0] = mfma(a0, b0, acc[0]);
-        } else if (VAR >= 6 && VAR <= 9) {
+        } else if (VAR >= 6 && VAR <= 13) {
             // cost of one extra instruction of a given kind per MFMA (2 accumulators, register operands)
 #pragma unroll
             for (int k = 0; k < 64; ++k) {
@@ -47,6 +49,15 @@ __global__ void __launch_bounds__(256) probe(const v4 *w, float *out, int iters)
                 if (VAR == 7) asm volatile("s_waitcnt vmcnt(7)");
                 if (VAR == 8) asm volatile("v_mov_b32 %0, %0" : "+v"(x));
                 if (VAR == 9) asm volatile("s_nop 0");
+                if (VAR == 10) {   // one independent 16-byte LDS read per MFMA (result never waited for inside the loop body)
+                    v4 t; asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"(voff)); asm volatile("" :: "v"(t));
+                }
+                if (VAR == 11) {   // one independent 16-byte buffer load per MFMA (L1-resident address)
+                    v4 t = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (k & 7) * 1024, 0));
+                    asm volatile("" :: "v"(t));
+                }
+                if (VAR == 12) asm volatile("ds_write_b32 %0, %1" :: "v"(voff), "v"(x));
+                if (VAR == 13) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(pk));
             }
         } else if (VAR == 4) {
 #pragma unroll
@@ -70,7 +81,8 @@ __global__ void __launch_bounds__(256) probe(const v4 *w, float *out, int iters)
         }
     }
     v4 s = acc[0] + acc[1] + acc[2] + acc[3];
-    out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3] + x;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+    out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3] + x + pk[0];
 }
 
 template <int VAR> void run(const v4 *w, float *out, const char *name, int lds) {
@@ -102,5 +114,9 @@ int main() {
     run<7>(w, out, "2 acc + 1 s_waitcnt per MFMA", lds);
     run<8>(w, out, "2 acc + 1 v_mov_b32 per MFMA", lds);
     run<9>(w, out, "2 acc + 1 s_nop 0 per MFMA", lds);
+    run<10>(w, out, "2 acc + 1 ds_read_b128 per MFMA", lds);
+    run<11>(w, out, "2 acc + 1 buffer_load_dwordx4 per MFMA", lds);
+    run<12>(w, out, "2 acc + 1 ds_write_b32 per MFMA", lds);
+    run<13>(w, out, "2 acc + 1 v_pk_mul_f32 per MFMA", lds);
     return 0;
 }
