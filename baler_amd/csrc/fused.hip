@@ -1406,7 +1406,6 @@ struct FusedState {
     // <= this many rows: small-batch kernels (BALER_AMD_LATENCY_ROWS overrides).  Measured us/step small-batch vs
     // throughput pair: 1024 rows 27 / 74, 4096 44 / 88, 8192 76 / 101, 16384 133 / 131
     int64_t latency_max_rows = 12288;
-    int lat_waves = 4;                 // waves per workgroup of lat2_chain_kernel: 4 or 8 (BALER_AMD_LAT_WAVES)
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
 };
 
@@ -1615,12 +1614,9 @@ template <int F, int Z> struct Impl {
         if (rc) return rc;
         rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk > 1024 ? nblk : 1024));
         if (rc) return rc;
-        if (st->lat_waves == 8)
-            hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 8>), dim3(nblk), dim3(512), 0, s, (const v4 *)h->packed.p, x,
-                               x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
-        else
-            hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 4>), dim3(nblk), dim3(256), 0, s, (const v4 *)h->packed.p, x,
-                               x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
+        // 4 waves per workgroup: a CU has four MFMA units, 8 waves (2 per SIMD) measured no faster (23.4 vs 23.3 us per step)
+        hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 4>), dim3(nblk), dim3(256), 0, s, (const v4 *)h->packed.p, x,
+                           x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
         const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
         if (ad)
             hipLaunchKernelGGL((lat2_dw_kernel<N, true>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
@@ -1684,7 +1680,6 @@ int fused_setup(bamd_handle *h) {
     FusedState *st = new FusedState();
     st->ops = ops;
     if (const char *lr = getenv("BALER_AMD_LATENCY_ROWS")) st->latency_max_rows = atoll(lr);
-    if (const char *lw = getenv("BALER_AMD_LAT_WAVES")) st->lat_waves = atoi(lw) == 8 ? 8 : 4;
     h->fused_state = st;
     int rc = ops->setup(h, st);
     if (rc) return rc;
