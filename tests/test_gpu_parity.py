@@ -611,3 +611,22 @@ def test_row_offsets_beyond_4gib(mode):
     assert bool(torch.isfinite(z).all()) and bool(torch.isfinite(d).all())
     del x, z, d
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n", [700, 20000])
+def test_fused_normalisation_on_load_in_training(n):
+    """features != NULL: the kernels normalise on load ((x - min)/range in float64, one rounding to float32), so
+    training on raw rows + features equals training on pre-normalised rows bit for bit (small-batch and throughput
+    kernels; the CLI pre-normalises like the reference, an FFI caller need not)."""
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 19)
+    raw = synth.cms_rows(n, row0=11)
+    feats = orc.find_minmax(raw)
+    h, p = make_handle(dims, flat, "fp32")
+    ga, gb = torch.zeros_like(p), torch.zeros_like(p)
+    h.fwd_bwd(dev(raw), ga, features=dev(feats))
+    h.fwd_bwd(dev(orc.normalize(raw)), gb)
+    assert torch.equal(ga, gb)
+    _, la = h.forward_loss(dev(raw), features=dev(feats), want_recon=False)
+    _, lb = h.forward_loss(dev(orc.normalize(raw)), want_recon=False)
+    assert la.item() == lb.item()
