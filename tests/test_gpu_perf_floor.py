@@ -1,0 +1,58 @@
+"""Throughput floors on MI355X (generous: ~80 % of the rates in profiles/README.md), so a later change that silently
+drops a kernel off its fast path -- spills, a lost fragment ring, a fallback to the layer-wise kernels -- fails a test
+instead of only showing up in the next bench line.  Synthetic uniform rows; timing by HIP events on the launch stream."""
+import numpy as np
+import pytest
+import torch
+
+from baler_amd import native
+from oracle import c_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _handle(mode="fp32"):
+    dims = orc.ae_dims(24, 15)
+    h = native.Handle(dims, mode)
+    p = torch.from_numpy(np.concatenate([orc.formula_params(dims, 1), [0.0]]).astype(np.float32)).cuda()
+    h.load_params(p)
+    return h, p
+
+
+def _ms(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def test_throughput_floors():
+    n = 1_000_000
+    x = torch.rand((n, 24), dtype=torch.float64, device="cuda")
+    h, p = _handle()
+    grads = torch.zeros_like(p)
+    t_train = _ms(lambda: h.fwd_bwd(x, grads), 5)
+    z = h.encode(x)
+    t_enc = _ms(lambda: h.encode(x), 5)
+    t_dec = _ms(lambda: h.decode(z), 5)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    state = {"t": 0}
+
+    def steps512():
+        for i in range(200):
+            state["t"] += 1
+            h.train_step(x[i * 512:(i + 1) * 512], p, m, v, state["t"], 1e-3)
+    t_512 = _ms(steps512, 2) / 200
+    hb, _ = _handle("bf16")
+    t_benc = _ms(lambda: hb.encode(x), 5)
+    print(f"fwd_bwd {t_train:.3f} ms, encode {t_enc:.3f} ms, decode {t_dec:.3f} ms, bs512 step {1e3 * t_512:.1f} us, "
+          f"bf16 encode {t_benc:.3f} ms per 1M rows")
+    assert t_train < 4.5, "training pair fell off its fast path (profiles: 3.55 ms per 1M rows)"
+    assert t_enc < 0.70 and t_dec < 0.70, "fp32 encode / decode (profiles: 0.53 / 0.53 ms per 1M rows)"
+    assert 1e3 * t_512 < 32.0, "small-batch step (profiles: 23.4 us)"
+    assert t_benc < 0.20, "bf16 encode (profiles: 0.09-0.13 ms per 1M rows)"
