@@ -39,8 +39,8 @@ DTYPE_NAME = {"fp32": "f32", "fp64": "f64", "bf16": "bf16"}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=1_000_000, help="rows per GPU")
     ap.add_argument("--mode", default=os.environ.get("BALER_AMD_MODE", "fp32"), choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
