@@ -55,7 +55,7 @@ typedef enum bamd_dtype { BAMD_F32 = 0, BAMD_F64 = 1 } bamd_dtype;
  * training parity).  BF16 = inference (bamd_encode / bamd_decode / bamd_forward_loss) on
  * v_mfma_f32_16x16x32_bf16 with fp32 accumulation, weights rounded from the fp32 master copy and kept in
  * LDS: a THROUGHPUT mode for compress / decompress (outputs within ~1e-2 rel.; measured 2e-3 encode,
- * 6e-3 decode), 4.5-5x the F32 rate.  Available for the 24-column AE (latent 15/12/8/6); training
+ * 6e-3 decode), 4-5x the F32 rate.  Available for the 24-column AE (latent 15/12/8/6); training
  * entry points of a BF16 handle run on the fp32 layer-wise kernels and re-pack the bf16 weights. */
 typedef enum bamd_mode { BAMD_MODE_F32 = 0, BAMD_MODE_F64 = 1, BAMD_MODE_BF16 = 2 } bamd_mode;
 
