@@ -648,10 +648,12 @@ __device__ __forceinline__ void dw_phase(const float *__restrict__ qdz, const fl
 
 template <class N, int l>
 __device__ __forceinline__ void dw_flush(v4 *__restrict__ slab, const v4 (&acc)[DW<N, l>::T], int lane, int wave) {
+    // partial-gradient buffer is TILE-major: [tile][workgroup][64 lanes] (`slab` already points at this workgroup's column):
+    // the reduction then streams gridDim.x KiB contiguously per tile instead of striding 298 KiB between workgroups
 #pragma unroll
     for (int it = 0; it < DW<N, l>::T; ++it) {
         const int idx = wave + 4 * it;
-        if (idx < DW<N, l>::TOT) slab[(N::slab_off(l) + idx) * 64 + lane] = acc[it];
+        if (idx < DW<N, l>::TOT) slab[(int64_t)(N::slab_off(l) + idx) * gridDim.x * 64 + lane] = acc[it];
     }
 }
 
@@ -672,7 +674,7 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
     v4 *bias_lds = (v4 *)(lds + (kImgA + kImgB) * kQS);
     stage_bias<N>(bias_lds, packed);
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    v4 *slab = slabs + (int64_t)blockIdx.x * N::slab_f4();
+    v4 *slab = slabs + (int64_t)blockIdx.x * 64;   // column of this workgroup in the [tile][workgroup][lane] buffer
     const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
     WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, threadIdx.x & 63);
     double lacc = 0.0;
@@ -787,7 +789,7 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
         if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *(double *)(slab + N::slab_off(N::L) * 64) = sh[0];
+    if (threadIdx.x == 0) ((double *)(slabs + (int64_t)N::slab_off(N::L) * gridDim.x * 64))[blockIdx.x] = sh[0];   // loss partials after the tiles
 }
 
 #if BAMD_SPLIT == 2
@@ -804,7 +806,7 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
     v4 *bias_lds = (v4 *)(lds + (kImgA + kImgB) * kQS);
     stage_bias<N>(bias_lds, packed);
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    v4 *slab = slabs + (int64_t)blockIdx.x * N::slab_f4();
+    v4 *slab = slabs + (int64_t)blockIdx.x * 64;   // column of this workgroup in the [tile][workgroup][lane] buffer
     const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
     WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, threadIdx.x & 63);
     v4 g1[DW<N, 1>::T], g0[DW<N, 0>::T];
@@ -862,7 +864,7 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
     v4 *bias_lds = (v4 *)(lds + (kImgA + kImgB) * kQS);
     stage_bias<N>(bias_lds, packed);
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    v4 *slab = slabs + (int64_t)blockIdx.x * N::slab_f4();
+    v4 *slab = slabs + (int64_t)blockIdx.x * 64;   // column of this workgroup in the [tile][workgroup][lane] buffer
     const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
     WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, threadIdx.x & 63);
     v4 g3[DW<N, 3>::T], g2[DW<N, 2>::T], g1[DW<N, 1>::T], g0[DW<N, 0>::T];
@@ -1352,27 +1354,38 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
     DW_T(4);
 }
 
-// Slab reduction in SLAB order: thread i sums float4 i of every workgroup slab (fully coalesced 16-byte
-// loads, fixed order => bitwise reproducible) and scatters the four sums to their canonical (state-dict)
-// positions through the inverse map (-1 = padding).  grads[np] = sum of the loss partials / C.
+// Reduction of the per-workgroup partial gradients ([tile][workgroup][64 lanes] float4, see dw_flush).
 template <typename T>
-__global__ void __launch_bounds__(256) reduce_slabs_k(const v4 *__restrict__ slabs, int nslab, int slab_f4, int tile_f4,
-                                                      const int *__restrict__ inv_map, int np, double inv_c,
-                                                      T *__restrict__ grads) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < tile_f4) {
-        v4 s = (v4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int k = 0; k < nslab; ++k) s += slabs[(int64_t)k * slab_f4 + i];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int p = inv_map[4 * i + c];
-            if (p >= 0) grads[p] = (T)s[c];
+__global__ void __launch_bounds__(64) reduce_slabs_k(const v4 *__restrict__ slabs, int nslab, int ntiles, const int *__restrict__ inv_map,
+                                                     int np, double inv_c, T *__restrict__ grads) {
+    // one wave per tile: lane l sums float4 l of the tile over the workgroups in workgroup order (fixed => bitwise
+    // reproducible), streaming nslab KiB of contiguous memory, and scatters the four sums to their canonical
+    // (state-dict) positions through the inverse map (-1 = padding).  Block ntiles: grads[np] = sum of loss partials / C.
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    if (tile == ntiles) {
+        if (lane == 0) {
+            const double *lp = (const double *)(slabs + (int64_t)ntiles * nslab * 64);
+            double l = 0.0;
+            for (int k = 0; k < nslab; ++k) l += lp[k];
+            grads[np] = (T)(l * inv_c);
         }
-    } else if (i == tile_f4) {
-        double s = 0.0;
-        for (int k = 0; k < nslab; ++k) s += *(const double *)(slabs + (int64_t)k * slab_f4 + tile_f4);
-        grads[np] = (T)(s * inv_c);
+        return;
+    }
+    const v4 *src = slabs + (int64_t)tile * nslab * 64 + lane;
+    v4 s = (v4){0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {
+        v4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(k + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; k < nslab; ++k) s += src[k * 64];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int p = inv_map[(tile * 64 + lane) * 4 + c];
+        if (p >= 0) grads[p] = (T)s[c];
     }
 }
 
@@ -1597,9 +1610,8 @@ template <int F, int Z> struct Impl {
                            x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (v4 *)st->dz.p);
         hipLaunchKernelGGL((train_enc_kernel<F, Z>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
                            x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (const v4 *)st->dz.p);
-        hipLaunchKernelGGL(reduce_slabs_k<float>, dim3((N::slab_off(N::L) * 64 + 1 + 255) / 256), dim3(256), 0, s,
-                           (const v4 *)h->slabs.p, grid, N::slab_f4(), N::slab_off(N::L) * 64, (const int *)st->slab_map.p, np,
-                           1.0 / F, (float *)grads);
+        hipLaunchKernelGGL(reduce_slabs_k<float>, dim3(N::slab_off(N::L) + 1), dim3(64), 0, s, (const v4 *)h->slabs.p, grid,
+                           N::slab_off(N::L), (const int *)st->slab_map.p, np, 1.0 / F, (float *)grads);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
