@@ -1266,7 +1266,8 @@ struct AdamArgs {   // scalars of one Adam step (launch_adam's), and where the s
 // tile range [c * per, (c + 1) * per): neighbouring tiles share their X / dZ image slices, each slice then crosses the
 // fabric into (about) one L2 instead of eight.  The map entry and the optimiser state of the thread's parameter are
 // requested BEFORE the image loop, so the dependent global round trips overlap instead of queueing up.
-template <class N, bool ADAM>
+enum { DW_WRITE = 0, DW_ADAM = 1, DW_ACCUM = 2 };   // grads = g | Adam on g (+ grads = g) | grads += g
+template <class N, int MODE>
 __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ imgs, int nblk, const double *__restrict__ loss_part,
                                                       const int *__restrict__ inv_map, float *__restrict__ grads, AdamArgs ad) {
     using LT = Lat<N>;
@@ -1280,8 +1281,8 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
             double s = 0.0;
             for (int k = 0; k < nblk; ++k) s += loss_part[k];
             const float gl = (float)(s * (1.0 / N::dim(0)));
-            if (grads) grads[np] = gl;
-            if (ADAM && ad.loss_accum) *ad.loss_accum += (double)gl;
+            if (grads) grads[np] = MODE == DW_ACCUM ? grads[np] + gl : gl;
+            if (MODE == DW_ADAM && ad.loss_accum) *ad.loss_accum += (double)gl;
         }
         return;
     }
@@ -1305,7 +1306,7 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
     const float *px = imgs + ((xo + 16 * kt + i) * kImgStride + 4 * g);
     float pm = 0.f, pv = 0.f, pp = 0.f;
     int s0 = 0, s1 = 0;
-    if (ADAM && p >= 0) { pm = ad.m[p]; pv = ad.v[p]; pp = ad.params[p]; s0 = ad.sc_off[p]; s1 = ad.sc_off[p + 1]; }
+    if (MODE == DW_ADAM && p >= 0) { pm = ad.m[p]; pv = ad.v[p]; pp = ad.params[p]; s0 = ad.sc_off[p]; s1 = ad.sc_off[p + 1]; }
     DW_T(1);
     v4 acc = (v4){0.f, 0.f, 0.f, 0.f};
     for (int b0 = wave; b0 < nblk; b0 += 32) {   // 8 blocks per wave in flight
@@ -1325,7 +1326,7 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
     DW_T(2);
     red[wave * 64 + lane] = acc;
     int sidx[4] = {-1, -1, -1, -1};                                  // packed copies of this parameter (forward, transposed, region E)
-    if (ADAM && p >= 0) {
+    if (MODE == DW_ADAM && p >= 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (s0 + k < s1) sidx[k] = ad.sc_idx[s0 + k];
     }
@@ -1335,8 +1336,8 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
     const int e = threadIdx.x;
     const float gsum = ((rf[e] + rf[256 + e]) + rf[512 + e]) + rf[768 + e];
     if (p < 0) return;
-    if (grads) grads[p] = gsum;
-    if (ADAM) {   // elementwise.hip adam_k, on the 256 parameters this tile owns
+    if (grads) grads[p] = MODE == DW_ACCUM ? grads[p] + gsum : gsum;
+    if (MODE == DW_ADAM) {   // elementwise.hip adam_k, on the 256 parameters this tile owns
         const double gi = (double)gsum;
         double mi = (double)pm, vi = (double)pv;
         mi = mi + (gi - mi) * (1.0 - ad.b1);
@@ -1420,6 +1421,7 @@ struct FusedState {
     // throughput pair: 1024 rows 27 / 74, 4096 44 / 88, 8192 76 / 101, 16384 133 / 131
     int64_t latency_max_rows = 12288;
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
+    bool tail_split = true;            // short remainder of the persistent loop on the small-batch kernels (BALER_AMD_TAIL_SPLIT=0: off)
 };
 
 template <int F, int Z, bool TRAIN>
@@ -1602,6 +1604,16 @@ template <int F, int Z> struct Impl {
         if (n <= st->latency_max_rows) return small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
         int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
         int grid = (int)(ngroups < st->nwg_max ? ngroups : st->nwg_max);
+        // Persistent-loop quantisation: with 15,625 row groups on 256 workgroups the 62nd iteration runs on 9 of them.
+        // A short remainder (<= 32 groups) goes to the small-batch kernels instead, accumulated into the same gradient:
+        // ~23 us against one ~56-us iteration of the pair.
+        int64_t tail_rows = 0;
+        if (ngroups > grid && ngroups % grid != 0 && ngroups % grid <= 32 && st->tail_split) {
+            const int64_t main_rows = (ngroups - ngroups % grid) * kRowsPerWG;
+            tail_rows = n - main_rows;
+            n = main_rows;
+            ngroups -= ngroups % grid;
+        }
         int rc = h->slabs.ensure((size_t)N::slab_f4() * 16 * (size_t)grid);
         if (rc) return rc;
         rc = st->dz.ensure((size_t)((n + 15) / 16 * 16) * (kSplit == 2 ? 7 * 64 : 64));   // whole 16-row tiles
@@ -1613,12 +1625,16 @@ template <int F, int Z> struct Impl {
         hipLaunchKernelGGL(reduce_slabs_k<float>, dim3(N::slab_off(N::L) + 1), dim3(64), 0, s, (const v4 *)h->slabs.p, grid,
                            N::slab_off(N::L), (const int *)st->slab_map.p, np, 1.0 / F, (float *)grads);
         BAMD_HIP(hipGetLastError());
+        if (tail_rows > 0) {
+            const char *xt = (const char *)x + (size_t)n * F * (x_dtype == BAMD_F64 ? 8 : 4);
+            return small_batch(h, xt, x_dtype, tail_rows, features, grads, nullptr, s, true);
+        }
         return BAMD_OK;
     }
     // small batch: chain kernel (one workgroup per 16-row block) + one workgroup per weight-gradient tile; with
     // `ad` the second kernel also applies Adam and refreshes the packed weights (grads may then be null)
     static int small_batch(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
-                           const AdamArgs *ad, hipStream_t s) {
+                           const AdamArgs *ad, hipStream_t s, bool accumulate = false) {
         FusedState *st = state_of(h);
         const int nblk = (int)((n + 15) / 16);
         constexpr size_t img_bytes = (size_t)Lat<N>::z_off(N::L) * kImgStride * sizeof(float);
@@ -1631,10 +1647,13 @@ template <int F, int Z> struct Impl {
                            x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
         const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
         if (ad)
-            hipLaunchKernelGGL((lat2_dw_kernel<N, true>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
+            hipLaunchKernelGGL((lat2_dw_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
                                (const double *)h->lossp.p, (const int *)st->slab_map.p, (float *)grads, *ad);
+        else if (accumulate)
+            hipLaunchKernelGGL((lat2_dw_kernel<N, DW_ACCUM>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
+                               (const double *)h->lossp.p, (const int *)st->slab_map.p, (float *)grads, AdamArgs{});
         else
-            hipLaunchKernelGGL((lat2_dw_kernel<N, false>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
+            hipLaunchKernelGGL((lat2_dw_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
                                (const double *)h->lossp.p, (const int *)st->slab_map.p, (float *)grads, AdamArgs{});
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
@@ -1692,6 +1711,7 @@ int fused_setup(bamd_handle *h) {
     FusedState *st = new FusedState();
     st->ops = ops;
     if (const char *lr = getenv("BALER_AMD_LATENCY_ROWS")) st->latency_max_rows = atoll(lr);
+    if (const char *ts = getenv("BALER_AMD_TAIL_SPLIT")) st->tail_split = ts[0] != '0';
     h->fused_state = st;
     int rc = ops->setup(h, st);
     if (rc) return rc;

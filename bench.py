@@ -201,7 +201,7 @@ def main():
         pass
     out["roofline"] = {
         "bound": "mfma",
-        "kernel": "bamd_fwd_bwd = train_dec_kernel + train_enc_kernel (+ 0.02 ms partial-gradient reduction)",
+        "kernel": "bamd_fwd_bwd = train_dec_kernel + train_enc_kernel (+ 0.02 ms partial-gradient reduction; the last 576 rows on the small-batch kernels)",
         "achieved": achieved, "peak": PEAK_TFLOPS[a.mode], "unit": "TFLOP/s",
         "frac": achieved / PEAK_TFLOPS[a.mode], "traffic": traffic,
         "launch_ms": k_ms, "algorithmic_flop_per_row": FLOP_TRAIN_ROW, "rows_per_launch": a.rows,
