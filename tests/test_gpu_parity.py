@@ -630,3 +630,23 @@ def test_fused_normalisation_on_load_in_training(n):
     _, la = h.forward_loss(dev(raw), features=dev(feats), want_recon=False)
     _, lb = h.forward_loss(dev(orc.normalize(raw)), want_recon=False)
     assert la.item() == lb.item()
+
+
+def test_persistent_loop_remainder_on_small_batch_kernels(monkeypatch):
+    """33,095 rows = 2 full rounds of 256 workgroups + 6 groups + 7 rows: the remainder is accumulated by the small-batch
+    kernels (default) or run as a third, mostly idle round (BALER_AMD_TAIL_SPLIT=0): same gradient, both at the oracle bar."""
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 23)
+    n = 2 * 256 * 64 + 6 * 64 - 57
+    x = orc.normalize(synth.cms_rows(n, row0=5))
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    res = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("BALER_AMD_TAIL_SPLIT", split)
+        h, p = make_handle(dims, flat, "fp32")
+        g = torch.zeros_like(p)
+        h.fwd_bwd(dev(x), g)
+        gh = g.cpu().numpy().astype(np.float64)
+        assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
+        res.append(gh)
+    assert rel(res[0], res[1]) < 1e-6 and not np.array_equal(res[0], res[1])     # two different summation orders
