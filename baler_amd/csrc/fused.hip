@@ -766,10 +766,10 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
 
         q_write_x<100>(imgB, a2, lane, wave); q_write(imgB + DW<N, 2>::rows_x * kQS, d3, lane, wave);
         bwd_layer<N, S, 2>(d3, d2, ring, ws); lrelu_bwd(d2, a2);
-        if (valid) {                                                   // dZ_1 hand-off: 7 tiles per row, slot order
+        // dZ_1 hand-off, [16-row tile][t][lane]: 1 KiB contiguous per store.  Rows beyond n store exact zeros (their dL/drecon
+        // was zeroed above), so the second kernel loads the record without a validity select.
 #pragma unroll
-            for (int t = 0; t < 7; ++t) dz_out[((row >> 4) * 7 + t) * 64 + lane] = d2[t];   // [16-row tile][t][lane]: 1 KiB contiguous per store
-        }
+        for (int t = 0; t < 7; ++t) dz_out[((row >> 4) * 7 + t) * 64 + lane] = d2[t];
         __syncthreads();
         dw_phase<N, 2>(imgB + DW<N, 2>::rows_x * kQS, imgB, g2, lane, wave);
 #endif
@@ -818,7 +818,7 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
         const int64_t row0 = (int64_t)blockIdx.x * kRowsPerWG + 16 * wave + (lane & 15);
         load_rows<F>(a0n, xin, in_f64, row0, row0 < n, lane, feats);
 #pragma unroll
-        for (int t = 0; t < 7; ++t) d2n[t] = row0 < n ? dz_in[((row0 >> 4) * 7 + t) * 64 + lane] : (v4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 7; ++t) d2n[t] = dz_in[((row0 >> 4) * 7 + t) * 64 + lane];
     }
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         asm volatile("" : "+v"(ws.voff), "+s"(wave), "+v"(lane));   // see train_dec_kernel
@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
         __syncthreads();
         load_rows_issue<F>(xraw, xin, in_f64, row_next, valid_next, lane);   // lands during the long dW phase
 #pragma unroll
-        for (int t = 0; t < 7; ++t) d2n[t] = valid_next ? dz_in[((row_next >> 4) * 7 + t) * 64 + lane] : (v4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 7; ++t) d2n[t] = dz_in[((row_next >> 4) * 7 + t) * 64 + lane];   // one round past the end stays inside the buffer
         dw_phase<N, 1>(imgB + DW<N, 1>::rows_x * kQS, imgB, g1, lane, wave);
         load_rows_finish<F>(a0n, xraw, valid_next, lane, feats);
 
@@ -1616,7 +1616,8 @@ template <int F, int Z> struct Impl {
         }
         int rc = h->slabs.ensure((size_t)N::slab_f4() * 16 * (size_t)grid);
         if (rc) return rc;
-        rc = st->dz.ensure((size_t)((n + 15) / 16 * 16) * (kSplit == 2 ? 7 * 64 : 64));   // whole 16-row tiles
+        // whole row groups + one round of prefetch overrun (the second kernel loads the next group's record unconditionally)
+        rc = st->dz.ensure((size_t)(ngroups + grid) * kRowsPerWG * (kSplit == 2 ? 7 * 64 : 64));
         if (rc) return rc;
         hipLaunchKernelGGL((train_dec_kernel<F, Z>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
                            x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (v4 *)st->dz.p);
