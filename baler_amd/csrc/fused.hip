@@ -294,30 +294,34 @@ template <int D> struct RawRows { double v[tiles(D) * 4]; };
 
 template <int D>
 __device__ __forceinline__ void load_rows_issue(RawRows<D> &raw, const void *x, int is_f64, int64_t row, bool valid, int lane) {
+    // Branch-free: lanes beyond the last row read row 0 and padding slots read feature 0 (always inside the table), so no
+    // lane needs an exec-masked branch or a zero fill.  Their values are never used: padding slots meet zero weights and
+    // unmapped gradient slots, rows beyond n get a zero loss gradient / are not stored.
     constexpr int NS = tiles(D) * 4;
     const int g = lane >> 4;
+#ifdef BAMD_ABLATE_XLOAD
 #pragma unroll
     for (int s = 0; s < NS; ++s) raw.v[s] = 0.0;
-#ifdef BAMD_ABLATE_XLOAD
-    valid = false;
+    return;
 #endif
-    if (valid) {
-        if (is_f64) {
+    const int64_t base = (valid ? row : 0) * D;
+    // slot (t, r) holds a feature on SOME lane group iff the tile is full or 4r < its valid count (r-major partial tiles)
+    auto used = [](int s) { return D - 16 * (s >> 2) >= 16 || 4 * (s & 3) < D - 16 * (s >> 2); };
+    if (is_f64) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int f = slot_feature(D, s >> 2, g, s & 3);
-                if (f >= 0) raw.v[s] = ((const double *)x)[row * D + f];
-            }
-        } else {
-            float w[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int f = slot_feature(D, s >> 2, g, s & 3);
-                w[s] = f >= 0 ? ((const float *)x)[row * D + f] : 0.f;
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) raw.v[s] = (double)w[s];
+        for (int s = 0; s < NS; ++s) {
+            const int f = slot_feature(D, s >> 2, g, s & 3);
+            raw.v[s] = used(s) ? ((const double *)x)[base + (f >= 0 ? f : 0)] : 0.0;
         }
+    } else {
+        float w[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int f = slot_feature(D, s >> 2, g, s & 3);
+            w[s] = used(s) ? ((const float *)x)[base + (f >= 0 ? f : 0)] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) raw.v[s] = (double)w[s];
     }
 }
 
@@ -326,13 +330,13 @@ __device__ __forceinline__ void load_rows_finish(v4 (&a)[tiles(D)], RawRows<D> &
                                                  const double *__restrict__ feats) {
     constexpr int NS = tiles(D) * 4;
     const int g = lane >> 4;
-    if (feats && valid) {
+    if (feats) {
         double mn[NS], rg[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int f = slot_feature(D, s >> 2, g, s & 3);
-            mn[s] = f >= 0 ? feats[f] : 0.0;
-            rg[s] = f >= 0 ? feats[D + f] : 1.0;
+            mn[s] = feats[f >= 0 ? f : 0];
+            rg[s] = feats[D + (f >= 0 ? f : 0)];
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) raw.v[s] = (raw.v[s] - mn[s]) / rg[s];   // (x - min)/(max - min) in float64
