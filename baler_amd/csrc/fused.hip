@@ -395,34 +395,44 @@ __device__ __forceinline__ void load_rows_wide(v4 (&a)[tiles(D)], const void *x,
 template <int D>
 __device__ __forceinline__ void store_rows(const v4 (&a)[tiles(D)], void *out, int is_f64, int64_t row, bool valid,
                                            int lane, const double *__restrict__ renorm, const uint8_t *__restrict__ imask) {
+    // ONE lane mask (valid row) around everything and the uniform dtype / renorm tests outside the element loops; a slot
+    // needs its own lane test only if it is padding on SOME lane group (the last register of a partial r-major tile).
     const int g = lane >> 4;
+    if (!valid) return;
+    double v[tiles(D)][4];
+#pragma unroll
+    for (int t = 0; t < tiles(D); ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[t][r] = (double)a[t][r];
+            const int f = slot_feature(D, t, g, r);
+            if (renorm && f >= 0) {
+                // norm*range + min with two roundings (numpy), then trunc for "int" columns (baler.py:420-435)
+                v[t][r] = __dadd_rn(__dmul_rn(v[t][r], renorm[D + f]), renorm[f]);
+                if (imask && imask[f]) v[t][r] = trunc(v[t][r]);
+            }
+        }
 #pragma unroll
     for (int t = 0; t < tiles(D); ++t) {
-        if (D > 64 && D - 16 * t >= 16 && !renorm) {   // wide rows: one 16/32-byte store per full tile
-            if (valid) {
-                const int64_t i = row * D + 16 * t + 4 * g;
-                if (is_f64) {
-                    *(double2 *)((double *)out + i) = make_double2((double)a[t][0], (double)a[t][1]);
-                    *(double2 *)((double *)out + i + 2) = make_double2((double)a[t][2], (double)a[t][3]);
-                } else {
-                    *(float4 *)((float *)out + i) = make_float4(a[t][0], a[t][1], a[t][2], a[t][3]);
-                }
+        const int left = D - 16 * t;                       // features from this tile on
+        if (left >= 16 && D % 4 == 0) {                    // full tile, aligned rows: the lane's 4 consecutive features as vectors
+            const int64_t i = row * D + 16 * t + 4 * g;
+            if (is_f64) {
+                *(double2 *)((double *)out + i) = make_double2(v[t][0], v[t][1]);
+                *(double2 *)((double *)out + i + 2) = make_double2(v[t][2], v[t][3]);
+            } else {
+                *(float4 *)((float *)out + i) = make_float4((float)v[t][0], (float)v[t][1], (float)v[t][2], (float)v[t][3]);
             }
             continue;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            const bool some = left >= 16 || 4 * r < left, all = left >= 16 || 4 * r + 3 < left;   // compile-time per (t, r)
+            if (!some) continue;
             const int f = slot_feature(D, t, g, r);
-            if (valid && f >= 0) {
+            if (all || f >= 0) {
                 const int64_t i = row * D + f;
-                if (renorm) {
-                    // norm*range + min with two roundings (numpy), then trunc for "int" columns (baler.py:420-435)
-                    double d = __dadd_rn(__dmul_rn((double)a[t][r], renorm[D + f]), renorm[f]);
-                    if (imask && imask[f]) d = trunc(d);
-                    if (is_f64) ((double *)out)[i] = d; else ((float *)out)[i] = (float)d;
-                } else {
-                    if (is_f64) ((double *)out)[i] = (double)a[t][r]; else ((float *)out)[i] = a[t][r];
-                }
+                if (is_f64) ((double *)out)[i] = v[t][r]; else ((float *)out)[i] = (float)v[t][r];
             }
         }
     }
