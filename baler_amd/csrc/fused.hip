@@ -631,18 +631,29 @@ __device__ __forceinline__ void dw_phase(const float *__restrict__ qdz, const fl
     // LDS addresses as 32-bit: per-lane part once per phase, wave-uniform tile part from the scalar unit, the 16-row group
     // as the instruction's immediate offset: one v_add per fragment pointer (generic pointers cost a 64-bit mad + shift each)
     typedef const float __attribute__((address_space(3))) *lds_cf;
+    typedef const v4 __attribute__((address_space(3))) *lds_cv4;
     const lds_cf la = (lds_cf)qdz + (i * kQS + 4 * g), lb = (lds_cf)qx + (i * kQS + 4 * g);
+    const lds_cf la_w = la + wave * (16 * kQS);          // tile "wave" of the dZ image
     v4 fa[2][2], fb[2][2];   // [buffer][tile of the pair]
     auto lds_frags = [&](int u, v4 (&a)[2], v4 (&b)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int it = 2 * (u >> 2) + h;
             if (it < D::T) {
-                int idx = wave + 4 * it;
-                idx = idx < D::TOT ? idx : D::TOT - 1;
-                const int kt = idx / D::NT, nt = idx - kt * D::NT;
-                a[h] = *(const v4 __attribute__((address_space(3))) *)(la + nt * (16 * kQS) + 16 * (u & 3));
-                b[h] = *(const v4 __attribute__((address_space(3))) *)(lb + kt * (16 * kQS) + 16 * (u & 3));
+                // tile index = wave + 4 it -> (kt, nt) = divmod(.., NT).  When 4 it .. 4 it + 3 stay inside one row of the
+                // tile grid, kt does not depend on the wave and nt = (4 it) % NT + wave: both addresses are a per-phase
+                // register plus an IMMEDIATE offset (no per-tile address arithmetic at all); otherwise compute them.
+                const int c = (4 * it) % D::NT, k0 = (4 * it) / D::NT;
+                if (c + 3 < D::NT && 4 * it + 3 < D::TOT) {
+                    a[h] = *(lds_cv4)(la_w + c * (16 * kQS) + 16 * (u & 3));
+                    b[h] = *(lds_cv4)(lb + k0 * (16 * kQS) + 16 * (u & 3));
+                } else {
+                    int idx = wave + 4 * it;
+                    idx = idx < D::TOT ? idx : D::TOT - 1;
+                    const int kt = idx / D::NT, nt = idx - kt * D::NT;
+                    a[h] = *(lds_cv4)(la + nt * (16 * kQS) + 16 * (u & 3));
+                    b[h] = *(lds_cv4)(lb + kt * (16 * kQS) + 16 * (u & 3));
+                }
             }
         }
     };
