@@ -582,11 +582,18 @@ __device__ __forceinline__ void q_write(float *__restrict__ q, const v4 (&a)[NT]
 #ifdef BAMD_ABLATE_QWRITE
     return;
 #endif
+    // One base address per register r (slot 4g + r of tile 0); tiles are 16 * kQS floats = 17 x 256 bytes apart, so
+    // the stores of tiles t, t+1 pair into ds_write2st64_b32 with IMMEDIATE offsets: 4 address adds per image instead
+    // of one per tile (ds_write2_b32 reaches only 1 KiB, which pairs registers r, r+1 and needs a new base every tile).
+    typedef float __attribute__((address_space(3))) *lds_f;
     const int col = 16 * wave + (lane & 15), g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int r = 0; r < 4; ++r) {
+        lds_f p = (lds_f)q + ((4 * g + r) * kQS + col);
+        asm volatile("" : "+v"(p));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) q[(16 * t + 4 * g + r) * kQS + col] = a[t][r];
+        for (int t = 0; t < NT; ++t) p[t * 16 * kQS] = a[t][r];
+    }
 }
 // X^T image with the ones row in the first padding slot of dimension D (carries db through the GEMM)
 template <int D>
@@ -597,15 +604,19 @@ __device__ __forceinline__ void q_write_x(float *__restrict__ q, const v4 (&a)[t
 #endif
     constexpr int T = tiles(D) - 1, V = D - 16 * T;      // partial tile, V valid slots; ones slot idx = V
     constexpr int R1 = V / 4, G1 = V % 4;
+    typedef float __attribute__((address_space(3))) *lds_f;
     const int col = 16 * wave + (lane & 15), g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < tiles(D); ++t)
+    for (int r = 0; r < 4; ++r) {                        // see q_write: tiles t, t+1 pair with immediate offsets
+        lds_f p = (lds_f)q + ((4 * g + r) * kQS + col);
+        asm volatile("" : "+v"(p));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int t = 0; t < tiles(D); ++t) {
             float v = a[t][r];
             if (t == T && r == R1 && g == G1) v = 1.0f;
-            q[(16 * t + 4 * g + r) * kQS + col] = v;
+            p[t * 16 * kQS] = v;
         }
+    }
 }
 
 template <class N, int l> struct DW {
