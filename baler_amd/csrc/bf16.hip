@@ -299,18 +299,25 @@ __global__ void __launch_bounds__(64 * kWaves) bf16_infer_kernel(const uint4 *__
             v4 z[N::nt(3)][kMB];
             blayer_then_last<N::kb(2), N::nt(2), N::nt(3)>(a2, z, w + N::f_off(2) * 64, bias + N::b_off(2), w + N::f_off(3) * 64,
                                                            bias + N::b_off(3), g);
+            // one lane mask per batch tile, the output dtype test outside the element loops, a per-element feature test
+            // only for registers that are padding on some lane group
 #pragma unroll
-            for (int mb = 0; mb < kMB; ++mb)
+            for (int mb = 0; mb < kMB; ++mb) {
+                if (!valid[mb]) continue;
 #pragma unroll
-                for (int t = 0; t < N::nt(3); ++t)
+                for (int t = 0; t < N::nt(3); ++t) {
+                    const int64_t i0 = row[mb] * Z + 16 * t + 4 * g;
+                    if (out_f64) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int f = 16 * t + 4 * g + r;
-                        if (valid[mb] && f < Z) {
-                            if (out_f64) ((double *)out)[row[mb] * Z + f] = (double)z[t][mb][r];
-                            else ((float *)out)[row[mb] * Z + f] = z[t][mb][r];
-                        }
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * t + 12 + r < Z || 16 * t + 4 * g + r < Z) ((double *)out)[i0 + r] = (double)z[t][mb][r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * t + 12 + r < Z || 16 * t + 4 * g + r < Z) ((float *)out)[i0 + r] = z[t][mb][r];
                     }
+                }
+            }
         } else {
             bf8 a4[1][kMB], a5[N::kb(5)][kMB], a6[N::kb(6)][kMB];
 #pragma unroll
