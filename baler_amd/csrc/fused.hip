@@ -307,19 +307,21 @@ __device__ __forceinline__ void load_rows_issue(RawRows<D> &raw, const void *x, 
     const int64_t base = (valid ? row : 0) * D;
     // slot (t, r) holds a feature on SOME lane group iff the tile is full or 4r < its valid count (r-major partial tiles)
     auto used = [](int s) { return D - 16 * (s >> 2) >= 16 || 4 * (s & 3) < D - 16 * (s >> 2); };
+    // ... and on EVERY lane group iff the tile is full or 4r + 3 < count: then its index needs no select
+    auto every = [](int s) { return D - 16 * (s >> 2) >= 16 || 4 * (s & 3) + 3 < D - 16 * (s >> 2); };
+    auto feat = [&](int s) {
+        const int t = s >> 2, r = s & 3;
+        if (D - 16 * t >= 16) return 16 * t + 4 * g + r;
+        const int f = 16 * t + 4 * r + g;                 // r-major partial tile (slot_feature)
+        return every(s) ? f : (4 * r + g < D - 16 * t ? f : 0);
+    };
     if (is_f64) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int f = slot_feature(D, s >> 2, g, s & 3);
-            raw.v[s] = used(s) ? ((const double *)x)[base + (f >= 0 ? f : 0)] : 0.0;
-        }
+        for (int s = 0; s < NS; ++s) raw.v[s] = used(s) ? ((const double *)x)[base + feat(s)] : 0.0;
     } else {
         float w[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int f = slot_feature(D, s >> 2, g, s & 3);
-            w[s] = used(s) ? ((const float *)x)[base + (f >= 0 ? f : 0)] : 0.f;
-        }
+        for (int s = 0; s < NS; ++s) w[s] = used(s) ? ((const float *)x)[base + feat(s)] : 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) raw.v[s] = (double)w[s];
     }
@@ -334,9 +336,12 @@ __device__ __forceinline__ void load_rows_finish(v4 (&a)[tiles(D)], RawRows<D> &
         double mn[NS], rg[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int f = slot_feature(D, s >> 2, g, s & 3);
-            mn[s] = feats[f >= 0 ? f : 0];
-            rg[s] = feats[D + (f >= 0 ? f : 0)];
+            const int t = s >> 2, r = s & 3, left = D - 16 * t;
+            int f = left >= 16 ? 16 * t + 4 * g + r : 16 * t + 4 * r + g;
+            if (!(left >= 16 || 4 * r + 3 < left)) f = (4 * r + g < left) ? f : 0;     // padding on some lane group: clamp
+            if (!(left >= 16 || 4 * r < left)) f = 0;                                  // padding everywhere
+            mn[s] = feats[f];
+            rg[s] = feats[D + f];
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) raw.v[s] = (raw.v[s] - mn[s]) / rg[s];   // (x - min)/(max - min) in float64
