@@ -45,7 +45,8 @@ def perform_training(output_path, config, verbose: bool):
     """reference baler.py:84-207."""
     train_set_norm, test_set_norm, normalization_features, original_shape = helper.process(
         config.input_path, config.custom_norm, config.test_size, config.apply_normalization,
-        config.convert_to_blocks if hasattr(config, "convert_to_blocks") else None, verbose)
+        config.convert_to_blocks if hasattr(config, "convert_to_blocks") else None, verbose,
+        batch_size=bdist.global_batch(config))      # data parallel: each rank keeps only its slice of every global batch
     if verbose:
         print("Training and testing sets normalized")
 

@@ -147,6 +147,10 @@ int bamd_minmax(const void *x, int dtype, int64_t n_rows, int n_cols, double *fe
     return launch_minmax(x, dtype, n_rows, n_cols, features, (hipStream_t)stream);
 }
 
+int bamd_col_minmax(const void *x, int dtype, int64_t n_rows, int n_cols, double *minmax, void *stream) {
+    return launch_minmax(x, dtype, n_rows, n_cols, minmax, (hipStream_t)stream, true);
+}
+
 int bamd_normalize(const void *x, int dtype, int64_t n_rows, int n_cols, const double *features, void *out,
                    int out_dtype, void *stream) {
     return launch_normalize(x, dtype, n_rows, n_cols, features, out, out_dtype, (hipStream_t)stream);

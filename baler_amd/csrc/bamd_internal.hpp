@@ -70,7 +70,8 @@ struct bamd_handle {
 namespace bamd {
 
 // ---- elementwise.hip ----------------------------------------------------------------------------
-int launch_minmax(const void *x, int dtype, int64_t n, int c, double *features, hipStream_t s);
+DevBuf &scratch_for(int purpose, hipStream_t s);   // grow-only scratch of the handle-free kernels, per (purpose, device, stream)
+int launch_minmax(const void *x, int dtype, int64_t n, int c, double *features, hipStream_t s, bool raw = false);
 int launch_normalize(const void *x, int dtype, int64_t n, int c, const double *features, void *out,
                      int out_dtype, hipStream_t s);
 int launch_renormalize(const void *x, int dtype, int64_t n, int c, const double *features,

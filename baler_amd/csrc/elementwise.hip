@@ -2,6 +2,10 @@
 // dtype conversion, the per-row EMD metric and the fused Adam step.  gfx950 only.
 #include "bamd_internal.hpp"
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 namespace bamd {
 
 template <typename T>
@@ -53,7 +57,7 @@ __global__ void __launch_bounds__(256) minmax_partial(const T *__restrict__ x, i
 
 // one workgroup per column: 256 threads stride over the block partials, LDS tree (min / max are exact in any order)
 __global__ void __launch_bounds__(256) minmax_final(const double *__restrict__ part, int nblk, int c,
-                                                    double *__restrict__ features) {
+                                                    double *__restrict__ features, int raw) {
     __shared__ double smn[256], smx[256];
     const int col = blockIdx.x;
     double mn = INFINITY, mx = -INFINITY;
@@ -73,27 +77,30 @@ __global__ void __launch_bounds__(256) minmax_final(const double *__restrict__ p
     }
     if (threadIdx.x == 0) {
         features[col] = smn[0];
-        features[c + col] = smx[0] - smn[0];
+        features[c + col] = raw ? smx[0] : smx[0] - smn[0];   // raw: [min ; max] for a cross-rank min / max reduction
     }
 }
 
-// handle-free kernels keep one grow-only scratch buffer per (device, purpose); calls on one device are expected from
-// one host thread at a time (the scratch is reused, not per-stream)
-static DevBuf &scratch_for(int purpose) {
-    static DevBuf bufs[2][64];
+// Handle-free kernels keep grow-only scratch buffers keyed by (purpose, device, STREAM): two streams never share a
+// partials buffer (stream B's partial kernel would overwrite what stream A's final kernel is still reading), and a
+// buffer is only ever re-used -- or, on growth, freed -- behind work of its own stream (hipFree waits for the device).
+DevBuf &scratch_for(int purpose, hipStream_t s) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, hipStream_t>, DevBuf> bufs;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    return bufs[purpose][dev & 63];
+    std::lock_guard<std::mutex> lock(mu);
+    return bufs[std::make_tuple(purpose, dev, s)];
 }
 
-int launch_minmax(const void *x, int dtype, int64_t n, int c, double *features, hipStream_t s) {
+int launch_minmax(const void *x, int dtype, int64_t n, int c, double *features, hipStream_t s, bool raw) {
     BAMD_REQUIRE(x && features && n > 0 && c > 0, "bad arguments");
     const int tcols = c < 256 ? c : 256;
     const int R = 256 / tcols;
     int64_t want = (n + R - 1) / R;
     int nblk = (int)(want < 1024 ? want : 1024);
     int ncb = (c + tcols - 1) / tcols;
-    DevBuf &scratch = scratch_for(0);
+    DevBuf &scratch = scratch_for(0, s);
     int rc = scratch.ensure((size_t)nblk * 2 * c * sizeof(double));
     if (rc) return rc;
     double *part = (double *)scratch.p;
@@ -104,7 +111,7 @@ int launch_minmax(const void *x, int dtype, int64_t n, int c, double *features, 
     else
         hipLaunchKernelGGL(minmax_partial<float>, grid, dim3(256), 0, s, (const float *)x, n, c,
                            tcols, part);
-    hipLaunchKernelGGL(minmax_final, dim3(c), dim3(256), 0, s, part, nblk, c, features);
+    hipLaunchKernelGGL(minmax_final, dim3(c), dim3(256), 0, s, part, nblk, c, features, raw ? 1 : 0);
     BAMD_HIP(hipGetLastError());
     return BAMD_OK;
 }
@@ -242,7 +249,7 @@ int launch_emd_rows(const void *x, const void *r, int dtype, int64_t n, int c, d
                     hipStream_t s) {
     BAMD_REQUIRE(x && r && out && n > 0 && c > 0 && c <= 64, "bad arguments (n_cols must be <= 64)");
     int nblk = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
-    DevBuf &scratch = scratch_for(1);
+    DevBuf &scratch = scratch_for(1, s);
     int rc = scratch.ensure(sizeof(double) * nblk);
     if (rc) return rc;
     double *part = (double *)scratch.p;

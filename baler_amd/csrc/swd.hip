@@ -122,11 +122,9 @@ int launch_swd(const void *z, const void *prior, const void *proj, int dtype, in
                double *loss_out, void *dz_out, hipStream_t s) {
     BAMD_REQUIRE(z && prior && proj && loss_out && dz_out && d > 0 && ns > 0, "bad arguments");
     BAMD_REQUIRE(n >= 2 && n <= 4096, "the sliced-Wasserstein kernel sorts one batch in LDS: 2 <= n_rows <= 4096");
-    static DevBuf scratch[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dtype == BAMD_F64) return swd_T<double>(z, prior, proj, (int)n, d, ns, reg_weight, loss_out, dz_out, scratch[dev & 63], s);
-    return swd_T<float>(z, prior, proj, (int)n, d, ns, reg_weight, loss_out, dz_out, scratch[dev & 63], s);
+    DevBuf &scratch = scratch_for(2, s);   // keyed by (device, stream): see elementwise.hip
+    if (dtype == BAMD_F64) return swd_T<double>(z, prior, proj, (int)n, d, ns, reg_weight, loss_out, dz_out, scratch, s);
+    return swd_T<float>(z, prior, proj, (int)n, d, ns, reg_weight, loss_out, dz_out, scratch, s);
 }
 
 }  // namespace bamd

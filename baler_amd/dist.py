@@ -2,7 +2,16 @@
 on the GPU box, "gloo" in CPU tests).  The hot path has exactly one exchange: a SUM all-reduce of the
 flat ``[grads | loss]`` buffer per optimiser step (the loss is a row SUM, so the global-batch gradient
 is the sum -- not the mean -- of shard gradients).  compress / decompress shard
-rows with no collective.
+rows with no data-path collective; off the hot path there are two more exchanges, once per file: a
+MIN and a MAX all-reduce of the per-column extrema (2 x C doubles) when the table is row-sharded, and
+the rank-ordered gather of the encoded / decoded shards onto rank 0, which writes the artefact.
+
+Global-batch policy (``batch_policy``): ``config.batch_size`` is the GLOBAL batch by default -- a DP run
+takes exactly the optimiser steps of the single-process run with the same config, each rank computing
+1/N of every batch (strict; what the reference's config means).  With ``config.dp_batch = "per_gpu"`` (or
+``BALER_AMD_DP_BATCH=per_gpu``) every GPU takes ``batch_size`` rows per step and the global batch is
+N x batch_size: the run equals the single-process reference run with ``batch_size = N x 512`` (fixture g12
+for N = 8), and a step keeps one GPU as busy as it is in the single-GPU run.
 """
 import os
 
@@ -64,6 +73,61 @@ def broadcast(t, src=0):
 def barrier():
     if is_dist():
         td.barrier()
+
+
+def batch_policy(config=None):
+    """-> "global" (config.batch_size is the global batch; default) or "per_gpu" (global = world x batch_size)."""
+    v = os.environ.get("BALER_AMD_DP_BATCH") or getattr(config, "dp_batch", None) or "global"
+    if v not in ("global", "per_gpu"):
+        raise ValueError(f"dp_batch must be 'global' or 'per_gpu', got {v!r}")
+    return v
+
+
+def global_batch(config, world=None):
+    """Rows per optimiser step over all ranks."""
+    if world is None:
+        world = rank_world()[1]
+    bs = int(config.batch_size)
+    return bs * world if (world > 1 and batch_policy(config) == "per_gpu") else bs
+
+
+def allreduce_minmax(mm):
+    """mm = [min ; max] (2, C) float64 of this rank's rows -> the extrema over all ranks, in place: one MIN and one
+    MAX all-reduce of C doubles (exact in any order)."""
+    if is_dist() and td.get_world_size() > 1:
+        td.all_reduce(mm[0], op=td.ReduceOp.MIN)
+        td.all_reduce(mm[1], op=td.ReduceOp.MAX)
+    return mm
+
+
+def gather_rows(local, n_total, dst=0):
+    """Rank-ordered concatenation of contiguous row shards (shard_rows) onto rank `dst`: ONE gather of device tensors
+    padded to the largest shard (RCCL: N-1 point-to-point transfers GPU to GPU over xGMI, straight into `dst`'s
+    buffer; no pickling, no host round trip per rank).  Returns the (n_total, ...) tensor on `dst`, None elsewhere."""
+    if not (is_dist() and td.get_world_size() > 1):
+        return local
+    rank, world = td.get_rank(), td.get_world_size()
+    pad = (n_total + world - 1) // world                     # shard_rows gives base or base + 1 rows: <= ceil(n / world)
+    tail = tuple(local.shape[1:])
+    send = local.contiguous()
+    if local.shape[0] != pad:
+        send = torch.zeros((pad,) + tail, dtype=local.dtype, device=local.device)
+        send[:local.shape[0]] = local
+    recv = parts = None
+    if rank == dst:
+        recv = torch.empty((world, pad) + tail, dtype=local.dtype, device=local.device)
+        parts = list(recv.unbind(0))
+    td.gather(send, parts, dst=dst)
+    if rank != dst:
+        return None
+    recv = recv.reshape((world * pad,) + tail)
+    if n_total == world * pad:
+        return recv
+    keep = []
+    for r in range(world):
+        lo, hi = shard_rows(n_total, r, world)
+        keep.append(recv[r * pad:r * pad + (hi - lo)])
+    return torch.cat(keep)
 
 
 def shard_rows(n_rows, rank=None, world=None):

@@ -86,14 +86,18 @@ def normalize(data, custom_norm: bool):
     return out.cpu().numpy() if was_np else out
 
 
-def split(data, test_size: float, random_state: int):
-    """sklearn train_test_split(data, test_size, random_state) (helper.py:315-317) restated:
-    permutation of RandomState(random_state); test = first ceil(test_size*n), train = the rest."""
-    n = data.shape[0]
+def split_indices(n: int, test_size: float, random_state: int):
+    """Row indices (train, test) of sklearn's train_test_split(test_size, random_state) (helper.py:315-317) restated:
+    permutation of RandomState(random_state); test = first ceil(test_size*n), train = the next floor((1-test_size)*n)."""
     n_test = int(np.ceil(test_size * n))
     n_train = int(np.floor((1.0 - test_size) * n))
     perm = np.random.RandomState(random_state).permutation(n)
-    tr, te = perm[n_test:n_test + n_train], perm[:n_test]
+    return perm[n_test:n_test + n_train], perm[:n_test]
+
+
+def split(data, test_size: float, random_state: int):
+    """train_test_split(data, test_size, random_state) on a host array or a device tensor (see split_indices)."""
+    tr, te = split_indices(data.shape[0], test_size, random_state)
     if isinstance(data, torch.Tensor):
         tri = torch.as_tensor(tr, device=data.device)
         tei = torch.as_tensor(te, device=data.device)

@@ -18,6 +18,7 @@ import torch
 sys.path.append(os.getcwd())
 
 from .. import dist as bdist
+from .. import hostio
 from .. import native
 from . import data_processing, training
 
@@ -153,37 +154,96 @@ def npz_array_shape(path, key):
         return tuple(header[0])
 
 
-def _load_to_device(path):
-    loaded = np.load(path)
-    data = loaded["data"]
-    t = torch.from_numpy(np.ascontiguousarray(data))
-    if t.dtype not in (torch.float32, torch.float64):
-        t = t.to(torch.float64)
-    return t.to(get_device()), data.shape
+def _open_table(path, convert_to_blocks=None):
+    """-> (host view of the table -- a memory map when the archive stores it uncompressed --, original shape)."""
+    src = hostio.open_npz_array(path, "data")
+    original_shape = tuple(src.shape)
+    if convert_to_blocks:
+        print("Converted Dataset to Blocks of Size - ", convert_to_blocks, " from original ", original_shape)
+        src = src.reshape(-1, convert_to_blocks[1], convert_to_blocks[2])   # data_processing.py:26-34 (a view)
+    return src, original_shape
 
 
-def process(input_path, custom_norm, test_size, apply_normalization, convert_to_blocks, verbose):
-    """reference helper.py:277-319.  Returns (train_set, test_set, normalization_features,
-    original_shape); the two sets are DEVICE tensors (the dataset crosses PCIe once), the features a
-    numpy array as in the reference."""
-    data, original_shape = _load_to_device(input_path)
+def _load_to_device(path, plan=None, convert_to_blocks=None):
+    """Rows `plan` (default: all) of the archive's table -> device tensor, streamed through pinned staging."""
+    src, original_shape = _open_table(path, convert_to_blocks)
+    return hostio.upload_rows(src, plan, get_device()), original_shape
+
+
+def _minmax_features(local, world):
+    """find_minmax (data_processing.py:113-130) of a row-sharded table: per-rank column extrema, MIN / MAX all-reduce,
+    range = max - min -- bit-identical to the single-process reduction.  -> (2, prod(shape[1:])) float64, device."""
+    flat = local.reshape(local.shape[0], -1)
+    if world == 1:
+        return native.minmax(flat)
+    if flat.shape[0] > 0:
+        mm = native.col_minmax(flat)
+    else:      # a rank without rows: neutral elements
+        mm = torch.stack([torch.full((flat.shape[1],), float("inf"), dtype=torch.float64, device=flat.device),
+                          torch.full((flat.shape[1],), float("-inf"), dtype=torch.float64, device=flat.device)])
+    bdist.allreduce_minmax(mm)
+    return torch.stack([mm[0], mm[1] - mm[0]])
+
+
+def process(input_path, custom_norm, test_size, apply_normalization, convert_to_blocks, verbose, batch_size=None):
+    """reference helper.py:277-319.  Returns (train_set, test_set, normalization_features, original_shape); the
+    features are a numpy array as in the reference, the two sets live on the DEVICE (the dataset crosses PCIe once,
+    through pinned double-buffered staging).
+
+    Under ``torch.distributed`` with ``batch_size`` given (the GLOBAL batch, dist.global_batch) every rank reads from
+    the file, uploads and normalises ONLY the rows it trains on -- its slice of every global batch (SURVEY.md section
+    8(e)) -- and the sets are ``training.ShardedRows``; the column min/max comes from one MIN/MAX all-reduce."""
+    rank, world = bdist.rank_world()
+    src, original_shape = _open_table(input_path, convert_to_blocks)
     if verbose:
         print("Original Dataset Shape - ", tuple(original_shape))
-    if convert_to_blocks:
-        data = data_processing.convert_to_blocks_util(convert_to_blocks, data)
-    feats = data_processing.find_minmax(data)
+    n = src.shape[0]
+    sharded = world > 1 and batch_size is not None
+    if not sharded:
+        data = hostio.upload_rows(src, None, get_device())
+        feats = _minmax_features(data, 1).reshape((2,) + tuple(data.shape[1:]))
+        train_plan = test_plan = None
+    else:
+        if not test_size:
+            train_plan = test_plan = hostio.RowPlan.cyclic(n, batch_size, rank, world)
+            data = hostio.upload_rows(src, train_plan, get_device())
+            feats = _minmax_features(data, world)               # the ranks' shards tile the table
+        else:
+            tr_idx, te_idx = data_processing.split_indices(n, test_size, random_state=1)
+            train_plan = hostio.RowPlan.cyclic(n, batch_size, rank, world, index=tr_idx)
+            test_plan = hostio.RowPlan.cyclic(n, batch_size, rank, world, index=te_idx)
+            # min/max is over the WHOLE table (helper.py:300-303 runs before the split): a contiguous 1/N slice per
+            # rank, streamed through the device once and dropped
+            probe = hostio.upload_rows(src, hostio.RowPlan.contiguous(n, rank, world), get_device())
+            feats = _minmax_features(probe, world)
+            del probe
+            data = None
+        feats = feats.reshape((2,) + tuple(src.shape[1:]))
     normalization_features = feats.cpu().numpy()
+
+    def norm(t):
+        if not (apply_normalization and not custom_norm) or t.shape[0] == 0:
+            return t
+        flat = t.reshape(t.shape[0], -1)
+        return native.normalize(flat.contiguous(), feats.reshape(2, -1).contiguous(), torch.float64).reshape(t.shape)
+
     if apply_normalization:
         print("Normalizing the data...")
-        if not custom_norm:
-            flat = data.reshape(data.shape[0], -1)
-            data = native.normalize(flat.contiguous(), feats.reshape(2, -1).contiguous(),
-                                    torch.float64).reshape(data.shape)
-    if not test_size:
-        train_set = data
-        test_set = train_set
-    else:
+    if not sharded:
+        data = norm(data)
+        if not test_size:
+            return data, data, normalization_features, original_shape
         train_set, test_set = data_processing.split(data, test_size=test_size, random_state=1)
+        return train_set, test_set, normalization_features, original_shape
+
+    def shard(plan, local):
+        return training.ShardedRows(norm(local), plan.n_global, plan.local_spans, batch_size, rank, world)
+
+    if not test_size:
+        train_set = shard(train_plan, data)
+        return train_set, train_set, normalization_features, original_shape
+    train_set = shard(train_plan, hostio.upload_rows(src, train_plan, get_device()))
+    test_set = shard(test_plan, hostio.upload_rows(src, test_plan, get_device()))
     return train_set, test_set, normalization_features, original_shape
 
 
@@ -217,48 +277,61 @@ def compress(model_path, config):
     """reference helper.py:473-616.  Returns (compressed ndarray, batches, deltas, indices); the last three are
     empty lists unless ``config.save_error_bounded_deltas`` (then: batch numbers, one float16 array per batch and
     one ``(rows, cols)`` tuple per batch, helper.py:589-606).  The input is re-normalised with ITS OWN min/max
-    (helper.py:500-504); with ``torch.distributed`` the rows are sharded over ranks with no collective and
-    gathered in rank order."""
+    (helper.py:500-504).  With ``torch.distributed`` every rank reads, uploads and encodes only its contiguous row
+    range (no data-path collective; the min/max of the sharded table is one MIN/MAX all-reduce of 2 x C doubles) and
+    the latent codes are gathered GPU to GPU onto rank 0, which alone returns them (other ranks: 0 rows).
+
+    Pipeline per rank: file -> pinned staging -> HBM (double buffered), column min/max, then per ROW_BLOCK one
+    ``bamd_encode`` with the normalisation fused into the load (evaluated in float64 on the UNCAST source values, as
+    the reference normalises before it casts, helper.py:500-504,560-563), the download of block k overlapping the
+    encode of block k+1."""
     want_deltas = bool(getattr(config, "save_error_bounded_deltas", False))
-    data, original_shape = _load_to_device(config.input_path)
-    if hasattr(config, "convert_to_blocks") and config.convert_to_blocks:
-        data = data_processing.convert_to_blocks_util(config.convert_to_blocks, data)
+    rank, world = bdist.rank_world()
+    src, original_shape = _open_table(config.input_path, getattr(config, "convert_to_blocks", None) or None)
     names = np.load(config.input_path)["names"]
-    n_features = _derive_sizes(config, data.shape, len(names))
-    flat = data.reshape(data.shape[0], -1).contiguous()
+    n_features = _derive_sizes(config, src.shape, len(names))
+    n_total = src.shape[0]
+    plan = hostio.RowPlan.contiguous(n_total, rank, world)
+    flat = hostio.upload_rows(src, plan, get_device())
+    flat = flat.reshape(flat.shape[0], -1)
     feats = None
     if config.apply_normalization and not config.custom_norm:
         print("Normalizing...")
-        feats = native.minmax(flat)
-    if config.data_dimension == 2:
-        flat = flat.to(torch.float32)  # reference: torch.tensor(data, dtype=float32) (helper.py:560-563)
+        feats = _minmax_features(flat, world)
+    # reference: 1-D tables stay float64, 2-D ones become float32 AFTER normalisation (helper.py:560-563)
+    work_dtype = torch.float32 if config.data_dimension == 2 else flat.dtype
+    if feats is None and flat.dtype != work_dtype:
+        flat = flat.to(work_dtype)
 
     model = data_processing.load_model(data_processing.initialise_model(config.model_name), model_path,
                                        n_features=n_features, z_dim=config.latent_space_size)
     model.eval()
     h = model.handle()
-    rank, world = bdist.rank_world()
-    lo, hi = bdist.shard_rows(flat.shape[0], rank, world)
-    out = torch.empty((hi - lo, config.latent_space_size), dtype=flat.dtype, device=flat.device)
+    n_local = flat.shape[0]
+    out = torch.empty((n_local, config.latent_space_size), dtype=work_dtype, device=flat.device)
     if want_deltas:
-        flags = torch.empty((hi - lo, n_features), dtype=torch.uint8, device=flat.device)
-        deltas = torch.empty((hi - lo, n_features), dtype=torch.float16, device=flat.device)
-    for s in range(lo, hi, ROW_BLOCK):
-        e = min(s + ROW_BLOCK, hi)
+        flags = torch.empty((n_local, n_features), dtype=torch.uint8, device=flat.device)
+        deltas = torch.empty((n_local, n_features), dtype=torch.float16, device=flat.device)
+    ready = []
+    for s in range(0, n_local, ROW_BLOCK):
+        e = min(s + ROW_BLOCK, n_local)
         if not want_deltas:
-            out[s - lo:e - lo] = h.encode(flat[s:e], features=feats)
-            continue
-        # the side channel compares decode(encode(x)) with the NORMALISED input (helper.py:589-606)
-        xn = native.normalize(flat[s:e], feats, out_dtype=flat.dtype) if feats is not None else flat[s:e]
-        z = h.encode(xn)
-        out[s - lo:e - lo] = z
-        flags[s - lo:e - lo], deltas[s - lo:e - lo] = native.error_deltas(xn, h.decode(z),
-                                                                          config.error_bounded_requirement)
-    compressed = _gather_rows(out, flat.shape[0], world)
+            h.encode(flat[s:e], features=feats, out=out[s:e])
+        else:
+            # the side channel compares decode(encode(x)) with the NORMALISED input (helper.py:589-606)
+            xn = native.normalize(flat[s:e], feats, out_dtype=work_dtype) if feats is not None else flat[s:e]
+            h.encode(xn, out=out[s:e])
+            flags[s:e], deltas[s:e] = native.error_deltas(xn, h.decode(out[s:e]), config.error_bounded_requirement)
+        ev = torch.cuda.Event()
+        ev.record()
+        ready.append((e, ev))
+    compressed = _gather_rows(out, n_total, world, ready)
     if not want_deltas:
         return compressed, [], [], []
-    flags = _gather_rows(flags, flat.shape[0], world)
-    deltas = _gather_rows(deltas, flat.shape[0], world)
+    flags = _gather_rows(flags, n_total, world)
+    deltas = _gather_rows(deltas, n_total, world)
+    if rank != 0:
+        return compressed, [], [], []
     return (compressed,) + split_deltas(flags, deltas, config.batch_size)
 
 
@@ -321,16 +394,17 @@ def load_deltas(input_path_deltas, input_batch_index, batch_size):
     return np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
 
 
-def _gather_rows(local, n_total, world):
-    """Concatenate per-rank row shards in rank order on the host (no data-path collective needed for a
-    single rank; multi-rank uses all_gather_object of host arrays, off the hot path)."""
-    host = local.cpu().numpy()
+def _gather_rows(local, n_total, world, ready=None):
+    """Per-rank row shards (contiguous ranges in rank order) -> ONE host array on rank 0; other ranks get a 0-row
+    array (only rank 0 writes artefacts).  Multi-rank: one device-to-device gather onto rank 0 (dist.gather_rows, RCCL
+    over xGMI), then a single pinned, double-buffered download -- nothing is pickled and no rank but 0 touches PCIe.
+    ``ready``: per-block completion events of the producer (single rank: the download of block k overlaps block k+1)."""
     if world == 1:
-        return host
-    import torch.distributed as td
-    parts = [None] * world
-    td.all_gather_object(parts, host)
-    return np.concatenate(parts)
+        return hostio.download_rows(local, ready=ready)
+    full = bdist.gather_rows(local, n_total, dst=0)
+    if full is None:
+        return np.empty((0,) + tuple(local.shape[1:]), dtype=hostio.download_rows(local[:0]).dtype)
+    return hostio.download_rows(full)
 
 
 def decompress(model_path, input_path, input_path_deltas, input_batch_index, model_name, config,
@@ -344,10 +418,10 @@ def decompress(model_path, input_path, input_path_deltas, input_batch_index, mod
     afterwards on the host (baler.py:410-435) run on the device -- fused into the decode kernel's store when there are
     no deltas -- so the decompressed table crosses PCIe once (float64) instead of three times."""
     loaded = np.load(input_path)
-    data = loaded["data"]
+    data = hostio.open_npz_array(input_path, "data")     # memory-mapped when stored: a rank reads only its rows
     names = loaded["names"]
     normalization_features = loaded["normalization_features"]
-    latent_space_size = len(data[0])
+    latent_space_size = data.shape[1]
     model_dict = torch.load(str(model_path), map_location="cpu")
     number_of_columns = len(model_dict[list(model_dict.keys())[-1]])  # len(de4.bias), helper.py:668-674
 
@@ -355,12 +429,11 @@ def decompress(model_path, input_path, input_path_deltas, input_batch_index, mod
                                        n_features=number_of_columns, z_dim=latent_space_size)
     model.eval()
     h = model.handle()
-    z = torch.from_numpy(np.ascontiguousarray(data))
-    if z.dtype not in (torch.float32, torch.float64):
-        z = z.to(torch.float64)
-    z = z.to(get_device())
     rank, world = bdist.rank_world()
-    lo, hi = bdist.shard_rows(z.shape[0], rank, world)
+    n_total = data.shape[0]
+    lo, hi = bdist.shard_rows(n_total, rank, world)
+    # this rank's latent rows only, through pinned double-buffered staging
+    z = hostio.upload_rows(data, hostio.RowPlan.contiguous(n_total, rank, world), get_device())
     want_deltas = bool(getattr(config, "save_error_bounded_deltas", False))
     r_feats = r_mask = None
     if renorm is not None:
@@ -369,11 +442,18 @@ def decompress(model_path, input_path, input_path_deltas, input_batch_index, mod
             r_mask = torch.as_tensor(np.asarray(renorm[1], dtype=np.uint8), device=z.device).contiguous()
     fuse = renorm is not None and not want_deltas
     out = torch.empty((hi - lo, number_of_columns), dtype=torch.float64 if fuse else z.dtype, device=z.device)
-    for s in range(lo, hi, ROW_BLOCK):
-        e = min(s + ROW_BLOCK, hi)
-        out[s - lo:e - lo] = (h.decode(z[s:e], features=r_feats, int_mask=r_mask, out_dtype=torch.float64) if fuse
-                              else h.decode(z[s:e]))
+    ready = []
+    for s in range(0, hi - lo, ROW_BLOCK):
+        e = min(s + ROW_BLOCK, hi - lo)
+        if fuse:
+            h.decode(z[s:e], features=r_feats, int_mask=r_mask, out=out[s:e])
+        else:
+            h.decode(z[s:e], out=out[s:e])
+        ev = torch.cuda.Event()
+        ev.record()
+        ready.append((e, ev))
     if want_deltas:
+        ready = None
         rows, cols, vals = load_deltas(input_path_deltas, input_batch_index, config.batch_size)
         mine = (rows >= lo) & (rows < hi)                     # this rank's row shard
         dev = out.device
@@ -382,7 +462,9 @@ def decompress(model_path, input_path, input_path_deltas, input_batch_index, mod
         print("Total Deltas Added - ", int(len(rows)))
         if renorm is not None:
             out = native.renormalize(out, r_feats, r_mask)
-    decompressed = _gather_rows(out, z.shape[0], world)
+    decompressed = _gather_rows(out, n_total, world, ready)
+    if rank != 0:
+        return decompressed, names, normalization_features
     if config.data_dimension == 2 and getattr(config, "model_type", None) == "dense":
         blocks = getattr(config, "convert_to_blocks", None)
         if blocks:

@@ -10,7 +10,9 @@ backward + Adam, fused HIP/MFMA kernels; data-parallel: ``bamd_fwd_bwd``, the gr
 then ``bamd_adam_step``), the running loss accumulated ON THE DEVICE and read once per epoch (the reference syncs with ``loss.item()`` every step,
 training.py:97).  Under ``torch.distributed`` (one process per GPU, RCCL) every global batch is split
 into contiguous row slices, one per rank, and the flat ``[grads | loss]`` buffer is SUM-all-reduced
-between the two native calls; every rank then applies the identical Adam step.
+between the two native calls; every rank then applies the identical Adam step.  A rank keeps ONLY its
+slices resident (``ShardedRows``: the block-cyclic row shard of SURVEY.md section 8(e), built by
+``helper.process``); a plain tensor / array is still accepted and sliced per batch.
 """
 import os
 import random
@@ -20,6 +22,7 @@ import numpy as np
 import torch
 
 from .. import dist as bdist
+from .. import hostio
 from . import helper, utils
 
 
@@ -85,10 +88,38 @@ def _batches(n_rows, bs):
 
 def _rank_slice(lo, hi, rank, world):
     """Contiguous slice of global batch [lo,hi) owned by `rank` (sizes differ by at most one row)."""
-    n = hi - lo
-    base, rem = divmod(n, world)
-    a = lo + rank * base + min(rank, rem)
-    return a, a + base + (1 if rank < rem else 0)
+    return hostio.RowPlan.slice_of(lo, hi, rank, world)
+
+
+class ShardedRows:
+    """The rows of a data-parallel dataset that THIS rank keeps resident: its slice of every global batch, stored
+    back to back (``local``), with ``spans[i]`` = the local row range of global batch i.  ``shape`` is the GLOBAL
+    shape, so callers that size the model from ``data.shape[1]`` (baler.py:107-125) see what they saw before."""
+
+    def __init__(self, local, n_global, spans, global_batch, rank, world):
+        self.local, self.n_global, self.spans = local, int(n_global), list(spans)
+        self.global_batch, self.rank, self.world = int(global_batch), rank, world
+
+    @property
+    def shape(self):
+        return (self.n_global,) + tuple(self.local.shape[1:])
+
+    def map_local(self, fn):
+        return ShardedRows(fn(self.local), self.n_global, self.spans, self.global_batch, self.rank, self.world)
+
+
+def _local_batches(data, bs, rank, world):
+    """-> (tensor to slice, [(lo, hi) of this rank's rows of every global batch]) for a ShardedRows or a replicated
+    tensor (then the rank slices each global batch itself)."""
+    if isinstance(data, ShardedRows):
+        if data.global_batch != bs or data.world != world:
+            raise ValueError(f"dataset was sharded for global batch {data.global_batch} on {data.world} ranks; "
+                             f"the loop runs global batch {bs} on {world}")
+        return data.local, data.spans
+    spans = _batches(data.shape[0], bs)
+    if world > 1:
+        spans = [_rank_slice(lo, hi, rank, world) for lo, hi in spans]
+    return data, spans
 
 
 def fit(config, model, train_dl, model_children, regular_param, optimizer, latent_dim, RHO, l1,
@@ -102,10 +133,9 @@ def fit(config, model, train_dl, model_children, regular_param, optimizer, laten
     rank, world = bdist.rank_world()
     h = model.handle()
     optimizer.loss_accum.zero_()
-    spans = _batches(data.shape[0], bs)
-    for lo, hi in spans:
-        a, b = _rank_slice(lo, hi, rank, world) if world > 1 else (lo, hi)
-        optimizer.train_step(h, data[a:b], world, swae_latent_dim=_swae_dim(config, model))
+    rows, spans = _local_batches(data, bs, rank, world)
+    for a, b in spans:
+        optimizer.train_step(h, rows[a:b], world, swae_latent_dim=_swae_dim(config, model))
     # one device->host read per epoch (the reference does one per step)
     last = float(optimizer.grads[model.nparams].item())
     epoch_loss = float(optimizer.loss_accum.item()) / len(spans)
@@ -121,12 +151,11 @@ def validate(model, test_dl, model_children, reg_param):
     data, bs = test_dl
     rank, world = bdist.rank_world()
     h = model.handle()
-    spans = _batches(data.shape[0], bs)
-    losses = torch.zeros(len(spans), dtype=torch.float64, device=data.device)
-    for i, (lo, hi) in enumerate(spans):
-        a, b = _rank_slice(lo, hi, rank, world) if world > 1 else (lo, hi)
+    rows, spans = _local_batches(data, bs, rank, world)
+    losses = torch.zeros(len(spans), dtype=torch.float64, device=rows.device)
+    for i, (a, b) in enumerate(spans):
         if b > a:
-            h.forward_loss(data[a:b], want_recon=False, loss_out=losses[i:i + 1])
+            h.forward_loss(rows[a:b], want_recon=False, loss_out=losses[i:i + 1])
     if world > 1:
         bdist.allreduce_sum(losses)
     host = losses.cpu().numpy()
@@ -137,6 +166,8 @@ def validate(model, test_dl, model_children, reg_param):
 
 def _to_device_dataset(arr, config, device):
     """reference training.py:194-231: 1-D data float64 (n, c); 2-D dense data float32 (n, h*w)."""
+    if isinstance(arr, ShardedRows):
+        return arr.map_local(lambda t: _to_device_dataset(t, config, device))
     t = arr if isinstance(arr, torch.Tensor) else torch.as_tensor(np.asarray(arr))
     if config.data_dimension == 2:
         if getattr(config, "model_type", None) != "dense":
@@ -148,7 +179,9 @@ def _to_device_dataset(arr, config, device):
 
 
 def train(model, variables, train_data, test_data, project_path, config):
-    """reference training.py:150-348 (same artefacts: loss_data.npy, activations.npy, model_{epoch}.pt)."""
+    """reference training.py:150-348 (same artefacts: loss_data.npy, activations.npy, model_{epoch}.pt).
+    ``train_data`` / ``test_data``: arrays / device tensors (every rank holds them whole and slices its share of a
+    batch) or ``ShardedRows`` from ``helper.process`` (every rank holds only its share)."""
     if config.deterministic_algorithm:
         random.seed(0)
         torch.manual_seed(0)
@@ -156,7 +189,8 @@ def train(model, variables, train_data, test_data, project_path, config):
         # the native kernels are bitwise deterministic by construction (fixed-order reductions)
 
     test_size = config.test_size
-    bs = config.batch_size
+    rank, world = bdist.rank_world()
+    bs = bdist.global_batch(config, world)      # rows per optimiser step over all ranks (dist.batch_policy)
     epochs = config.epochs
     device = helper.get_device()
     model = model.to(device)
@@ -179,14 +213,19 @@ def train(model, variables, train_data, test_data, project_path, config):
 
     train_loss, val_loss = [], []
     start = time.time()
-    rank, world = bdist.rank_world()
     want_acts = bool(getattr(config, "activation_extraction", False))
     trained_model = model
 
     for epoch in range(epochs):
         print(f"Epoch {epoch + 1} of {epochs}")
+        # The reference's forward hooks fire on EVERY forward (models.py:160-183) and only the last one survives.
+        # Without a validation split that is the epoch's last TRAINING batch with the weights it sees, i.e. before its
+        # optimiser step: captured inside fit, in every epoch that can be the last (the final one; any, with early
+        # stopping).  With a split it is the last VALIDATION batch of the last epoch with the post-step weights, which
+        # are still the model's weights when the loop ends: captured once, after the loop.
+        capture = want_acts and not test_size and (epoch == epochs - 1 or bool(config.early_stopping))
         train_epoch_loss, _, _, trained_model = _fit_with_capture(
-            config, model, train_dl, model_children, optimizer, want_acts)
+            config, model, train_dl, model_children, optimizer, capture)
         train_loss.append(train_epoch_loss)
 
         if test_size:
@@ -207,6 +246,10 @@ def train(model, variables, train_data, test_data, project_path, config):
                 helper.model_saver(model, os.path.join(project_path, f"model_{epoch}.pt"))
 
     end = time.time()
+    if want_acts and test_size:
+        rows, spans = _local_batches(valid_ds, bs, rank, world)
+        model._dirty = False
+        _capture(model, rows, spans[-1], world)
     if rank == 0:
         if want_acts:
             acts = model.get_activations().get("means")
@@ -217,31 +260,53 @@ def train(model, variables, train_data, test_data, project_path, config):
     return trained_model
 
 
+def _capture(model, rows, span, world):
+    """Activation means of one GLOBAL batch from this rank's rows of it: mean = sum over ranks of (local mean x
+    local rows) / global rows -- one SUM all-reduce of the (6, 200) table plus the row count."""
+    a, b = span
+    if world == 1:
+        model.capture_activations(rows[a:b])
+        return
+    if b > a:
+        part = model.capture_activations(rows[a:b]) * float(b - a)
+    else:
+        part = model_nan_pattern(model, rows.device)      # no rows of this batch here: contributes 0 (NaN on the padding)
+    cnt = torch.tensor([float(b - a)], dtype=torch.float64, device=rows.device)
+    bdist.allreduce_sum(part)
+    bdist.allreduce_sum(cnt)
+    model.activations = {"means": part / cnt}
+
+
+def model_nan_pattern(model, device):
+    """(layers, 200) table that is NaN where activations.npy is padding (nodes beyond a layer's width), 0 elsewhere."""
+    L = len(model.dims) - 1
+    widths = [model.dims[l + 1] for l in range(L) if not (l == L // 2 - 1 or l == L - 1)]
+    t = torch.zeros((len(widths), 200), dtype=torch.float64, device=device)
+    for i, w in enumerate(widths):
+        t[i, w:] = float("nan")
+    return t
+
+
 def _fit_with_capture(config, model, train_dl, model_children, optimizer, want_acts):
-    """fit(), plus the activation snapshot of the epoch's last batch taken with the weights that batch
-    sees (i.e. before its optimiser step), as the reference's forward hooks do."""
+    """fit(), plus -- when asked -- the activation snapshot of the epoch's last batch taken with the weights that
+    batch sees (i.e. before its optimiser step), as the reference's forward hooks do."""
     if not want_acts:
         return fit(config, model, train_dl, model_children, getattr(config, "reg_param", 0.0), optimizer,
                    getattr(config, "latent_space_size", None), getattr(config, "RHO", None),
                    getattr(config, "l1", None), config.data_dimension)
     data, bs = train_dl
-    spans = _batches(data.shape[0], bs)
-    if len(spans) == 1:
-        model.capture_activations(data[spans[0][0]:spans[0][1]])
-        return fit(config, model, train_dl, model_children, config.reg_param, optimizer,
-                   getattr(config, "latent_space_size", None), config.RHO, config.l1, config.data_dimension)
+    rank, world = bdist.rank_world()
+    rows, spans = _local_batches(data, bs, rank, world)
     # all batches but the last, then capture, then the last batch
     print("### Beginning Training")
     model.train()
-    rank, world = bdist.rank_world()
     h = model.handle()
     optimizer.loss_accum.zero_()
-    for i, (lo, hi) in enumerate(spans):
+    for i, (a, b) in enumerate(spans):
         if i == len(spans) - 1:
-            model._dirty = False
-            model.capture_activations(data[lo:hi])
-        a, b = _rank_slice(lo, hi, rank, world) if world > 1 else (lo, hi)
-        optimizer.train_step(h, data[a:b], world, swae_latent_dim=_swae_dim(config, model))
+            model._dirty = False      # the native Adam kept the handle's packed weights in step with model.flat
+            _capture(model, rows, (a, b), world)
+        optimizer.train_step(h, rows[a:b], world, swae_latent_dim=_swae_dim(config, model))
     last = float(optimizer.grads[model.nparams].item())
     epoch_loss = float(optimizer.loss_accum.item()) / len(spans)
     model._dirty = False

@@ -23,7 +23,7 @@ SYMBOLS = (
     "bamd_param_count", "bamd_mode_of", "bamd_load_params", "bamd_minmax", "bamd_normalize",
     "bamd_renormalize", "bamd_encode", "bamd_decode", "bamd_forward_loss", "bamd_fwd_bwd",
     "bamd_adam_step", "bamd_train_step", "bamd_emd_rows", "bamd_activation_means",
-    "bamd_error_deltas", "bamd_apply_deltas", "bamd_fwd_bwd_latent", "bamd_swd",
+    "bamd_error_deltas", "bamd_apply_deltas", "bamd_fwd_bwd_latent", "bamd_swd", "bamd_col_minmax",
 )
 
 
@@ -63,6 +63,7 @@ def lib():
     L.bamd_mode_of.argtypes = [vp]
     L.bamd_load_params.argtypes = [vp, vp, ci, vp]
     L.bamd_minmax.argtypes = [vp, ci, i64, ci, vp, vp]
+    L.bamd_col_minmax.argtypes = [vp, ci, i64, ci, vp, vp]
     L.bamd_normalize.argtypes = [vp, ci, i64, ci, vp, vp, ci, vp]
     L.bamd_renormalize.argtypes = [vp, ci, i64, ci, vp, vp, vp, vp]
     L.bamd_encode.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp]
@@ -105,8 +106,17 @@ def _dev_tensor(t):
     return t
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(t=None):
+    """The current stream OF THE TENSOR'S DEVICE (not of whichever device happens to be current: a stream handle of
+    cuda:0 is not valid for buffers and a handle that live on cuda:1)."""
+    dev = t.device if t is not None else None
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _same_device(what, first, *others):
+    for t in others:
+        if t is not None and t.device != first.device:
+            raise NativeError(f"{what}: tensors live on different devices ({first.device} vs {t.device})")
 
 
 def _ptr(t):
@@ -126,7 +136,19 @@ def minmax(x):
     x = _dev_tensor(x)
     n, c = x.shape
     out = torch.empty((2, c), dtype=torch.float64, device=x.device)
-    _check(lib().bamd_minmax(_ptr(x), _dt(x), n, c, _ptr(out), _stream()), "bamd_minmax")
+    with torch.cuda.device(x.device):
+        _check(lib().bamd_minmax(_ptr(x), _dt(x), n, c, _ptr(out), _stream(x)), "bamd_minmax")
+    return out
+
+
+def col_minmax(x):
+    """Raw column extrema of this rank's rows: x (n, c) f32/f64 -> (2, c) f64 [min ; max] (bamd_col_minmax); the
+    data-parallel form of find_minmax all-reduces row 0 with MIN and row 1 with MAX and takes range = max - min."""
+    x = _dev_tensor(x)
+    n, c = x.shape
+    out = torch.empty((2, c), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().bamd_col_minmax(_ptr(x), _dt(x), n, c, _ptr(out), _stream(x)), "bamd_col_minmax")
     return out
 
 
@@ -134,18 +156,22 @@ def normalize(x, features, out_dtype=torch.float64):
     x = _dev_tensor(x)
     features = _dev_tensor(features)
     n, c = x.shape
+    _same_device("normalize", x, features)
     out = torch.empty((n, c), dtype=out_dtype, device=x.device)
-    _check(lib().bamd_normalize(_ptr(x), _dt(x), n, c, _ptr(features), _ptr(out), _dt(out), _stream()),
-           "bamd_normalize")
+    with torch.cuda.device(x.device):
+        _check(lib().bamd_normalize(_ptr(x), _dt(x), n, c, _ptr(features), _ptr(out), _dt(out), _stream(x)),
+               "bamd_normalize")
     return out
 
 
 def renormalize(x, features, int_mask=None):
     x = _dev_tensor(x)
     n, c = x.shape
+    _same_device("renormalize", x, features, int_mask)
     out = torch.empty((n, c), dtype=torch.float64, device=x.device)
-    _check(lib().bamd_renormalize(_ptr(x), _dt(x), n, c, _ptr(features), _ptr(int_mask), _ptr(out),
-                                  _stream()), "bamd_renormalize")
+    with torch.cuda.device(x.device):
+        _check(lib().bamd_renormalize(_ptr(x), _dt(x), n, c, _ptr(features), _ptr(int_mask), _ptr(out),
+                                      _stream(x)), "bamd_renormalize")
     return out
 
 
@@ -154,9 +180,11 @@ def emd_rows(x, recon):
     recon = _dev_tensor(recon)
     if x.dtype != recon.dtype or x.shape != recon.shape:
         raise NativeError("emd_rows: x and recon must have the same dtype and shape")
+    _same_device("emd_rows", x, recon)
     out = torch.empty(1, dtype=torch.float64, device=x.device)
-    _check(lib().bamd_emd_rows(_ptr(x), _ptr(recon), _dt(x), x.shape[0], x.shape[1], _ptr(out), _stream()),
-           "bamd_emd_rows")
+    with torch.cuda.device(x.device):
+        _check(lib().bamd_emd_rows(_ptr(x), _ptr(recon), _dt(x), x.shape[0], x.shape[1], _ptr(out), _stream(x)),
+               "bamd_emd_rows")
     return out
 
 
@@ -165,10 +193,12 @@ def swd(z, prior, proj, reg_weight):
     z, prior, proj = _dev_tensor(z), _dev_tensor(prior), _dev_tensor(proj)
     if not (z.dtype == prior.dtype == proj.dtype) or z.shape != prior.shape or proj.shape[1] != z.shape[1]:
         raise NativeError("swd: z/prior (n, d) and proj (s, d) must share dtype and latent size")
+    _same_device("swd", z, prior, proj)
     loss = torch.empty(1, dtype=torch.float64, device=z.device)
     dz = torch.empty_like(z)
-    _check(lib().bamd_swd(_ptr(z), _ptr(prior), _ptr(proj), _dt(z), z.shape[0], z.shape[1], proj.shape[0],
-                          float(reg_weight), _ptr(loss), _ptr(dz), _stream()), "bamd_swd")
+    with torch.cuda.device(z.device):
+        _check(lib().bamd_swd(_ptr(z), _ptr(prior), _ptr(proj), _dt(z), z.shape[0], z.shape[1], proj.shape[0],
+                              float(reg_weight), _ptr(loss), _ptr(dz), _stream(z)), "bamd_swd")
     return loss, dz
 
 
@@ -178,10 +208,12 @@ def error_deltas(x, recon, bound):
     recon = _dev_tensor(recon)
     if x.dtype != recon.dtype or x.shape != recon.shape:
         raise NativeError("error_deltas: x and recon must have the same dtype and shape")
+    _same_device("error_deltas", x, recon)
     flags = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     deltas = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-    _check(lib().bamd_error_deltas(_ptr(x), _ptr(recon), _dt(x), x.numel(), float(bound), _ptr(flags), _ptr(deltas),
-                                   _stream()), "bamd_error_deltas")
+    with torch.cuda.device(x.device):
+        _check(lib().bamd_error_deltas(_ptr(x), _ptr(recon), _dt(x), x.numel(), float(bound), _ptr(flags), _ptr(deltas),
+                                       _stream(x)), "bamd_error_deltas")
     return flags, deltas
 
 
@@ -193,8 +225,10 @@ def apply_deltas(out, rows, cols, deltas):
         raise NativeError("apply_deltas: rows int64, cols int32, deltas float16 expected")
     if not (rows.numel() == cols.numel() == deltas.numel()):
         raise NativeError("apply_deltas: rows, cols and deltas must have the same length")
-    _check(lib().bamd_apply_deltas(_ptr(out), _dt(out), out.shape[1], _ptr(rows), _ptr(cols), _ptr(deltas), rows.numel(),
-                                   _stream()), "bamd_apply_deltas")
+    _same_device("apply_deltas", out, rows, cols, deltas)
+    with torch.cuda.device(out.device):
+        _check(lib().bamd_apply_deltas(_ptr(out), _dt(out), out.shape[1], _ptr(rows), _ptr(cols), _ptr(deltas),
+                                       rows.numel(), _stream(out)), "bamd_apply_deltas")
     return out
 
 
@@ -226,45 +260,69 @@ class Handle:
         except Exception:
             pass
 
+    def _s(self):
+        """Current torch stream of THE HANDLE'S device (the library makes that device current for the call)."""
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _mine(self, *tensors):
+        for t in tensors:
+            if t is not None and t.device != self.device:
+                raise NativeError(f"tensor on {t.device} passed to a handle that lives on {self.device}")
+
     @property
     def z_dim(self):
         return self.dims[(len(self.dims) - 1) // 2]
 
     def load_params(self, flat):
         flat = _dev_tensor(flat)
+        self._mine(flat)
         if flat.numel() < self.nparams:
             raise NativeError("parameter vector too short")
-        _check(lib().bamd_load_params(self._h, _ptr(flat), _dt(flat), _stream()), "bamd_load_params")
+        _check(lib().bamd_load_params(self._h, _ptr(flat), _dt(flat), self._s()), "bamd_load_params")
 
-    def encode(self, x, features=None, out_dtype=None):
-        x = _dev_tensor(x)
-        out = torch.empty((x.shape[0], self.z_dim), dtype=out_dtype or x.dtype, device=x.device)
-        _check(lib().bamd_encode(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(out), _dt(out),
-                                 _stream()), "bamd_encode")
+    def _out(self, out, rows, cols, dtype, device):
+        """Caller-provided output (a contiguous row block of a preallocated result) or a fresh tensor."""
+        if out is None:
+            return torch.empty((rows, cols), dtype=dtype, device=device)
+        _dev_tensor(out)
+        self._mine(out)
+        if tuple(out.shape) != (rows, cols):
+            raise NativeError(f"out has shape {tuple(out.shape)}, expected {(rows, cols)}")
         return out
 
-    def decode(self, z, features=None, int_mask=None, out_dtype=None):
+    def encode(self, x, features=None, out_dtype=None, out=None):
+        x = _dev_tensor(x)
+        self._mine(x, features)
+        out = self._out(out, x.shape[0], self.z_dim, out_dtype or x.dtype, x.device)
+        _check(lib().bamd_encode(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(out), _dt(out),
+                                 self._s()), "bamd_encode")
+        return out
+
+    def decode(self, z, features=None, int_mask=None, out_dtype=None, out=None):
         z = _dev_tensor(z)
-        out = torch.empty((z.shape[0], self.dims[-1]), dtype=out_dtype or z.dtype, device=z.device)
+        self._mine(z, features, int_mask)
+        out = self._out(out, z.shape[0], self.dims[-1], out_dtype or z.dtype, z.device)
         _check(lib().bamd_decode(self._h, _ptr(z), _dt(z), z.shape[0], _ptr(features), _ptr(int_mask),
-                                 _ptr(out), _dt(out), _stream()), "bamd_decode")
+                                 _ptr(out), _dt(out), self._s()), "bamd_decode")
         return out
 
     def forward_loss(self, x, features=None, want_recon=True, loss_out=None):
         x = _dev_tensor(x)
+        self._mine(x, features, loss_out)
         recon = torch.empty_like(x) if want_recon else None
         loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float64, device=x.device)
         _check(lib().bamd_forward_loss(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(recon),
-                                       _dt(recon) if recon is not None else F32, _ptr(loss), _stream()),
+                                       _dt(recon) if recon is not None else F32, _ptr(loss), self._s()),
                "bamd_forward_loss")
         return recon, loss
 
     def fwd_bwd(self, x, grads, features=None):
         x = _dev_tensor(x)
         grads = _dev_tensor(grads)
+        self._mine(x, grads, features)
         if grads.dtype != self.param_dtype or grads.numel() < self.nparams + 1:
             raise NativeError("grads must hold param_count+1 elements of the handle's parameter type")
-        _check(lib().bamd_fwd_bwd(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(grads), _stream()),
+        _check(lib().bamd_fwd_bwd(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(grads), self._s()),
                "bamd_fwd_bwd")
 
     def fwd_bwd_latent(self, x, latent_grad, grads, features=None):
@@ -272,26 +330,29 @@ class Handle:
         x = _dev_tensor(x)
         grads = _dev_tensor(grads)
         latent_grad = _dev_tensor(latent_grad)
+        self._mine(x, grads, latent_grad, features)
         if grads.dtype != self.param_dtype or grads.numel() < self.nparams + 1:
             raise NativeError("grads must hold param_count+1 elements of the handle's parameter type")
         if latent_grad.dtype != self.param_dtype or tuple(latent_grad.shape) != (x.shape[0], self.z_dim):
             raise NativeError("latent_grad must be (n_rows, z_dim) of the handle's parameter type")
         _check(lib().bamd_fwd_bwd_latent(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(latent_grad),
-                                         _ptr(grads), _stream()), "bamd_fwd_bwd_latent")
+                                         _ptr(grads), self._s()), "bamd_fwd_bwd_latent")
 
     def adam_step(self, params, grads, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, loss_accum=None):
+        self._mine(params, grads, m, v, loss_accum)
         for t in (params, grads, m, v):
             _dev_tensor(t)
             if t.dtype != self.param_dtype:
                 raise NativeError("optimizer tensors must have the handle's parameter type")
         hp = AdamHP(int(step), float(lr), float(beta1), float(beta2), float(eps))
         _check(lib().bamd_adam_step(self._h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), ctypes.byref(hp),
-                                    _ptr(loss_accum), _stream()), "bamd_adam_step")
+                                    _ptr(loss_accum), self._s()), "bamd_adam_step")
 
     def train_step(self, x, params, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, loss_accum=None, grads=None,
                    features=None):
         """fwd + loss + bwd + Adam of one batch in one call (= fwd_bwd then adam_step; no all-reduce in between)."""
         x = _dev_tensor(x)
+        self._mine(x, params, m, v, grads, loss_accum, features)
         for t in (params, m, v):
             _dev_tensor(t)
             if t.dtype != self.param_dtype:
@@ -300,11 +361,12 @@ class Handle:
             raise NativeError("grads must hold param_count+1 elements of the handle's parameter type")
         hp = AdamHP(int(step), float(lr), float(beta1), float(beta2), float(eps))
         _check(lib().bamd_train_step(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(params), _ptr(grads),
-                                     _ptr(m), _ptr(v), ctypes.byref(hp), _ptr(loss_accum), _stream()), "bamd_train_step")
+                                     _ptr(m), _ptr(v), ctypes.byref(hp), _ptr(loss_accum), self._s()), "bamd_train_step")
 
     def activation_means(self, x, features=None, max_nodes=200):
         x = _dev_tensor(x)
+        self._mine(x, features)
         out = torch.empty((len(self.dims) - 3, max_nodes), dtype=torch.float64, device=x.device)
         _check(lib().bamd_activation_means(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(out),
-                                           max_nodes, _stream()), "bamd_activation_means")
+                                           max_nodes, self._s()), "bamd_activation_means")
         return out

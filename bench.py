@@ -26,6 +26,41 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+
+
+def _spawn_ranks_if_needed():
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks OURSELVES.  The parent never touches
+    the GPU (no torch import, no HIP call): it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    bench.py <same args>` as a CHILD process, relays its output (rank 0 prints the one JSON line) and exits with the
+    child's return code.  Under torchrun (WORLD_SIZE set) this is a no-op."""
+    if "WORLD_SIZE" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:      # a free port: two benches on one host must not collide
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    _spawn_ranks_if_needed()
+
 import numpy as np
 import torch
 
@@ -127,8 +162,8 @@ def main():
 
     rank, world, local = bdist.init_from_env()
     if world != a.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE is {world} (launch with --nproc-per-node {a.gpus}, "
+                         f"or run `python bench.py --gpus {a.gpus}` and let it start the ranks)")
     native.require_gpu()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -186,6 +221,8 @@ def main():
             "compute_mode": a.mode,
         },
         "train_rows_per_s": value, "last_batch_loss": final_loss,
+        "rccl_ranks": bdist.rank_world()[1],
+        "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
     }
 
     achieved = FLOP_TRAIN_ROW * a.rows / (k_ms * 1e-3) / 1e12

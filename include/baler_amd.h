@@ -92,6 +92,11 @@ int bamd_load_params(bamd_handle *h, const void *params, int dtype, void *stream
  * (2, n_cols) float64, device memory. */
 int bamd_minmax(const void *x, int dtype, int64_t n_rows, int n_cols, double *features,
                 void *stream);
+/* The same reduction as bamd_minmax() with the raw extrema as output: minmax = [min ; max], (2, n_cols) float64.
+ * For row-sharded tables (one process per GPU): every rank reduces its own rows, the caller combines the ranks
+ * with one MIN and one MAX all-reduce of n_cols doubles each and forms range = max - min once -- bit-identical to
+ * data_processing.find_minmax (data_processing.py:113-130) over the whole table. */
+int bamd_col_minmax(const void *x, int dtype, int64_t n_rows, int n_cols, double *minmax, void *stream);
 /* Replaces: helper.normalize -> data_processing.normalize (helper.py:261-274,
  * data_processing.py:133-153): out = (x - min)/(max - min) per column, evaluated in float64 and
  * rounded to out_dtype. */

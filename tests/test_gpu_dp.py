@@ -11,6 +11,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import free_port
+
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -58,7 +60,7 @@ def test_dp_training_two_ranks_one_gpu(tmp_path):
     script.write_text(_WORKER)
     env = dict(os.environ, REPO=REPO, OUT=str(tmp_path), BALER_AMD_FORCE_DEVICE="0", BALER_AMD_DIST_BACKEND="gloo",
                MODE="fp64")
-    r = _torchrun(2, [str(script)], env, 29541)
+    r = _torchrun(2, [str(script)], env, free_port())
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     p0, p1 = np.load(tmp_path / "params_rank0.npy"), np.load(tmp_path / "params_rank1.npy")
     assert np.array_equal(p0, p1)                       # replicated Adam: identical on every rank
@@ -76,10 +78,119 @@ def test_dp_training_two_ranks_one_gpu(tmp_path):
 def test_bench_two_ranks_one_gpu(tmp_path):
     env = dict(os.environ, BALER_AMD_FORCE_DEVICE="0", BALER_AMD_DIST_BACKEND="gloo")
     r = _torchrun(2, [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "65536",
-                      "--no-extras"], env, 29542)
+                      "--no-extras"], env, free_port())
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                # rank 0 prints ONE JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+
+
+_CLI_WORKER = r'''
+import os, sys, shutil
+sys.path.insert(0, os.environ["REPO"])
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from baler_amd import baler, dist as bdist, synth
+from baler_amd.modules import helper, models, training
+from oracle import c_oracle as orc
+rank, world, local = bdist.init_from_env()
+torch.cuda.set_device(local)
+models.set_default_mode(os.environ.get("MODE", "fp64"))
+init = orc.formula_params(orc.ae_dims(24, 15), 5)
+
+def factory(name):
+    cls = getattr(models, name)
+    def make(n_features, z_dim):
+        m = cls(n_features, z_dim)
+        return m.load_flat(init) if rank == 0 else m       # rank 0's weights are broadcast by training.train
+    return make
+helper.model_init = factory
+
+# what a rank keeps resident: ONLY its slice of every global batch, normalised with the whole table's min/max
+cfg, *_ = helper.get_arguments(["--project", "CMS_workspace", "CMS_project_v1", "--mode", "train"])
+G = bdist.global_batch(cfg, world)
+tr, te, feats, shape = helper.process(cfg.input_path, cfg.custom_norm, cfg.test_size, cfg.apply_normalization, None, False,
+                                      batch_size=G)
+raw = synth.cms_rows(3000)
+full = orc.normalize(raw)
+assert isinstance(tr, training.ShardedRows) and tr is te and tr.shape == (3000, 24) and tuple(shape) == (3000, 24)
+mine = np.concatenate([full[slice(*training._rank_slice(lo, min(lo + G, 3000), rank, world))] for lo in range(0, 3000, G)])
+assert tr.local.shape[0] == len(mine) and abs(len(mine) - 3000 / world) <= 6
+assert np.array_equal(tr.local.cpu().numpy(), mine)                      # bit-identical to the single-process table
+assert np.array_equal(feats, np.stack([raw.min(0), raw.max(0) - raw.min(0)]))
+np.save(os.environ["OUT"] + f"/resident_rows_rank{rank}.npy", np.array([tr.local.shape[0]]))
+
+for mode in ("train", "compress", "decompress"):
+    baler.main(["--project", "CMS_workspace", "CMS_project_v1", "--mode", mode])
+bdist.barrier()
+'''
+
+
+def _dp_workspace(tmp_path, epochs=3, extra=""):
+    from baler_amd import synth
+    ws = tmp_path / "workspaces"
+    proj = ws / "CMS_workspace" / "CMS_project_v1"
+    for d in ("config", "output/compressed_output", "output/decompressed_output", "output/plotting", "output/training"):
+        os.makedirs(proj / d, exist_ok=True)
+    os.makedirs(ws / "CMS_workspace" / "data", exist_ok=True)
+    (ws / "__init__.py").write_text("")
+    src = open(os.path.join(REPO, "workspaces", "CMS_workspace", "CMS_project_v1", "config", "CMS_project_v1_config.py")).read()
+    assert "c.epochs = 25" in src
+    src = src.replace("c.epochs = 25", f"c.epochs = {epochs}")
+    (proj / "config" / "CMS_project_v1_config.py").write_text(src + extra)
+    np.savez(ws / "CMS_workspace" / "data" / "example_CMS_data.npz", data=synth.cms_rows(3000), names=synth.CMS_NAMES)
+    return proj / "output"
+
+
+@pytest.mark.parametrize("policy", ["global", "per_gpu"])
+def test_cli_dp_sharded_residency(tmp_path, policy):
+    """train -> compress -> decompress through the real CLI on 2 ranks (one GPU, gloo): every rank reads, uploads and
+    keeps only its rows; the artefacts equal the single-process oracle run with the same GLOBAL batch."""
+    from baler_amd import synth
+    from oracle import c_oracle as orc
+    out = _dp_workspace(tmp_path)
+    script = tmp_path / "cli_worker.py"
+    script.write_text(_CLI_WORKER)
+    env = dict(os.environ, REPO=REPO, OUT=str(tmp_path), BALER_AMD_FORCE_DEVICE="0", BALER_AMD_DIST_BACKEND="gloo",
+               MODE="fp64", BALER_AMD_DP_BATCH=policy)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rows = [int(np.load(tmp_path / f"resident_rows_rank{k}.npy")[0]) for k in range(2)]
+    assert sum(rows) == 3000 and max(rows) <= 1506                        # half the table per rank, not all of it
+    G = 512 if policy == "global" else 1024
+    dims = orc.ae_dims(24, 15)
+    st = orc.FitState(dims, orc.formula_params(dims, 5))
+    raw = synth.cms_rows(3000)
+    data = orc.normalize(raw)
+    want = [orc.fit_epoch(st, data, G, 1e-3)[0] for _ in range(3)]
+    loss = np.load(out / "training" / "loss_data.npy")
+    assert np.linalg.norm(loss[0] - want) / np.linalg.norm(want) < 1e-9
+    comp = np.load(out / "compressed_output" / "compressed.npz")["data"]
+    z = orc.encode(dims, st.params, data)
+    assert comp.shape == (3000, 15) and np.linalg.norm(comp - z) / np.linalg.norm(z) < 1e-8
+    dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
+    rec = orc.decode(dims, st.params, z) * (raw.max(0) - raw.min(0)) + raw.min(0)
+    int_cols = [i for i, t in enumerate(synth.CMS_TYPE_LIST) if t == "int"]
+    rec[:, int_cols] = np.trunc(rec[:, int_cols])
+    assert dec.shape == (3000, 24)
+    close = np.isclose(dec, rec, rtol=1e-7, atol=1e-9)
+    assert close.mean() > 0.9999                                          # a truncation may flip where rec sits on an integer
+
+
+def test_bench_spawns_two_ranks_one_gpu():
+    """`python bench.py --gpus 2` as the driver runs it (no torchrun, no WORLD_SIZE): the parent starts the two ranks
+    itself and relays the single JSON line."""
+    env = dict(os.environ, BALER_AMD_FORCE_DEVICE="0", BALER_AMD_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--rows", "65536", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "gloo" and d["value"] > 0

@@ -15,6 +15,8 @@ from baler_amd import dist as bdist
 from baler_amd import native, synth
 from baler_amd.modules import helper, models, training, utils
 
+from conftest import free_port
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -220,7 +222,7 @@ def test_data_parallel_world2_gloo(tmp_path):
     env = dict(os.environ, REPO=REPO, OMP_NUM_THREADS="1")
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-         "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
         env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DP-OK" in out.stdout
