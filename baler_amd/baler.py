@@ -39,6 +39,7 @@ def main(argv=None):
                         "outputs written by baler_amd (the artefact formats are identical).")
     else:
         raise NameError("Baler mode " + mode + " not recognised. Use baler_amd --help to see available modes.")
+    bdist.barrier()      # rank 0 writes the artefacts: no rank leaves a mode before they are complete
 
 
 def perform_training(output_path, config, verbose: bool):

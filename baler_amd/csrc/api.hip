@@ -108,6 +108,8 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
     if (mode == BAMD_MODE_BF16) {   // inference on bf16 MFMA; training calls of such a handle run on the fp32 layer-wise kernels
         rc = bf16_setup(h);
         if (rc) { bamd_destroy(h); return rc; }
+        rc = bf16_train_setup(h);
+        if (rc) { bamd_destroy(h); return rc; }
     }
     *out = h;
     return BAMD_OK;
@@ -118,6 +120,7 @@ void bamd_destroy(bamd_handle *h) {
     DeviceGuard guard(h->device);
     fused_teardown(h);
     bf16_teardown(h);
+    bf16_train_teardown(h);
     h->params.release();
     h->packed.release();
     h->work.release();
@@ -139,7 +142,11 @@ int bamd_load_params(bamd_handle *h, const void *params, int dtype, void *stream
     int rc = launch_convert(params, dtype, h->params.p, h->esize == 8 ? BAMD_F64 : BAMD_F32, h->nparams, s);
     if (rc) return rc;
     h->params_loaded = true;
-    if (h->mode == BAMD_MODE_BF16) return bf16_pack(h, s);
+    if (h->mode == BAMD_MODE_BF16) {
+        rc = bf16_pack(h, s);
+        h->bf16_infer_stale = false;
+        return rc ? rc : bf16_train_pack(h, s);
+    }
     return fused_pack(h, s);
 }
 
@@ -161,6 +168,13 @@ int bamd_renormalize(const void *x, int dtype, int64_t n_rows, int n_cols, const
     return launch_renormalize(x, dtype, n_rows, n_cols, features, int_mask, out, (hipStream_t)stream);
 }
 
+// bf16 handles re-round the INFERENCE fragments lazily: a training step refreshes only what the next step reads
+static int bf16_sync(bamd_handle *h, hipStream_t s) {
+    if (h->mode != BAMD_MODE_BF16 || !h->bf16_infer_stale) return BAMD_OK;
+    h->bf16_infer_stale = false;
+    return bf16_pack(h, s);
+}
+
 #define BAMD_CHECK_MODEL(h)                                                        \
     BAMD_REQUIRE(h, "null handle");                                                \
     BAMD_REQUIRE((h)->params_loaded, "bamd_load_params() has not been called");    \
@@ -173,6 +187,7 @@ int bamd_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, cons
     BAMD_REQUIRE(n_rows >= 0 && ((x && z) || n_rows == 0), "bad arguments");
     if (n_rows == 0) return BAMD_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = bf16_sync(h, s)) return rc;
     if (h->mode == BAMD_MODE_BF16) return bf16_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
     if (h->fused_ok) return fused_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
     return generic_forward(h, x, x_dtype, n_rows, features, 0, h->L / 2, z, z_dtype, nullptr, nullptr, s);
@@ -184,6 +199,7 @@ int bamd_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n_rows, cons
     BAMD_REQUIRE(n_rows >= 0 && ((z && out) || n_rows == 0), "bad arguments");
     if (n_rows == 0) return BAMD_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = bf16_sync(h, s)) return rc;
     if (h->mode == BAMD_MODE_BF16) return bf16_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);
     if (h->fused_ok) return fused_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);
     return generic_forward(h, z, z_dtype, n_rows, nullptr, h->L / 2, h->L, out, out_dtype, features, int_mask, s);
@@ -194,6 +210,7 @@ int bamd_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows
     BAMD_CHECK_MODEL(h);
     BAMD_REQUIRE(x && loss_sum && n_rows > 0, "bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = bf16_sync(h, s)) return rc;
     if (h->mode == BAMD_MODE_BF16) return bf16_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
     if (h->fused_ok) return fused_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
     return generic_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
@@ -209,6 +226,7 @@ int bamd_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, con
         return BAMD_OK;
     }
     if (h->fused_ok) return fused_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
+    if (h->mode == BAMD_MODE_BF16 && bf16_train_ok(h)) return bf16_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
     return generic_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
 }
 
@@ -237,7 +255,10 @@ int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, voi
     void *packed = nullptr;
     fused_scatter(h, &sc_off, &sc_idx, &packed);   // Adam also refreshes the packed weight copy (one launch)
     int rc = launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, sc_off, sc_idx, packed, s);
-    if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16) rc = bf16_pack(h, s);
+    if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16) {
+        if (bf16_train_ok(h)) { h->bf16_infer_stale = true; rc = bf16_train_pack(h, s); }   // the next step's fragments now, the inference ones on demand
+        else rc = bf16_pack(h, s);
+    }
     return rc;
 }
 

@@ -63,6 +63,8 @@ struct bamd_handle {
     bool fused_ok = false;          // shape is served by the fused register-chained kernels
     void *fused_state = nullptr;    // index maps of the fused path (fused.hip)
     void *bf16_state = nullptr;     // packed bf16 weights + maps of the bf16 inference mode (bf16.hip)
+    void *bf16_train_state = nullptr;   // packed bf16 weights + maps of the bf16 training kernels (bf16_train.hip)
+    bool bf16_infer_stale = false;  // the inference fragments lag h->params (re-packed lazily by the next inference call)
 
     bool has_act(int l) const { return !(l == L / 2 - 1 || l == L - 1); }
 };

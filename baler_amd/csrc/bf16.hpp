@@ -12,4 +12,10 @@ int bf16_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const dou
                 void *out, int out_dtype, hipStream_t s);
 int bf16_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *recon,
                       int recon_dtype, double *loss_sum, hipStream_t s);
+// bf16 training (bf16_train.hip): fwd + loss + bwd on bf16 MFMA for the shapes it is instantiated for
+int bf16_train_setup(bamd_handle *h);            // leaves h->bf16_train_state null when the shape has no instantiation
+void bf16_train_teardown(bamd_handle *h);
+bool bf16_train_ok(const bamd_handle *h);
+int bf16_train_pack(bamd_handle *h, hipStream_t s);   // h->params (fp32) -> the training kernels' bf16 fragments
+int bf16_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, hipStream_t s);
 }  // namespace bamd

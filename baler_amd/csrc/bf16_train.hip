@@ -1,0 +1,787 @@
+// bf16 MFMA training of AE(F, Z) (BAMD_MODE_BF16): forward + sum-of-squares loss + backward on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation; the caller keeps fp32 master weights and fp32 Adam state
+// (bamd_adam_step), the library re-rounds its bf16 fragment copies after every step.
+//
+// Why this is not the fp32 kernels with another MFMA: a bf16 MFMA is 16 cycles and eats a 1-KiB weight fragment.
+// The fp32 path gives every wave its own 16 rows and lets it stream ALL weights (one fragment per 128 MFMA
+// cycles); at bf16 rates that is 64 B/clk per wave, 4x what a CU's L1 path delivers.  So here the WORKGROUP, not
+// the wave, owns a batch tile (64 rows) and the waves split every layer's OUTPUT tiles: a weight fragment is
+// loaded by one wave and feeds four MFMAs (the four 16-row tiles), i.e. the weights cross the L1 once per 64 rows.
+// Activations therefore live in LDS, not in registers:
+//   * image i = [64 batch rows][feature slots] in bf16, one per layer input X_i (2-bit XOR swizzle of the 16-byte
+//     chunks, row strides of 64 x odd bytes: every read shape below is bank-conflict free, tools/probe/lds_conflicts.py);
+//   * a layer's B operand (32 input features of one row per lane) is ONE ds_read_b128 of the row-major image;
+//   * the epilogue (bias was the accumulator's initial value; LeakyReLU; v_cvt_pk_bf16_f32) writes the C tile back
+//     with one ds_write_b64 per lane and tile;
+//   * the weight-gradient product [dW | db] = dZ^T [X | 1] contracts over the BATCH index, i.e. needs both images
+//     transposed: gfx950's ds_read_b64_tr_b16 delivers exactly that (4 rows x 16 columns per 16 lanes), so the same
+//     row-major images serve the chain (row reads) and the weight gradients (transposed reads) -- no second copy,
+//     no transposing stores.  The ones column that carries db is the first padding slot of every image: it is
+//     produced by the forward epilogue itself (packed bias 1.0 on zero weights).
+//   * dZ_{l-1} overwrites X_l in place once layer l's weight-gradient tiles have been read (same shape, same owner
+//     wave and lane): 116 KB of images for the whole network at 64 rows, no second set of buffers.
+// [dW | db] tiles stay in MFMA accumulators for the whole persistent loop (as in fused.hip) and are reduced over
+// workgroups in a fixed order: bitwise reproducible.  All 298 tiles x 256 floats do not fit one CU's registers
+// next to the chain, so training is two launches over the same rows (PART 0: forward, loss, decoder layers 7..4;
+// PART 1: encoder forward recomputed, layers 3..0, dL/dz handed over as 32 B per row).
+#include "bf16.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <utility>
+
+namespace bamd {
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+using v4 = float __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+constexpr int kRows = 64;      // batch rows per workgroup iteration (four 16-row MFMA tiles)
+
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <int F, int Z> struct TNet {
+    static constexpr int L = 8;
+    __host__ __device__ static constexpr int dim(int i) {
+        return i == 0 ? F : i == 1 ? 200 : i == 2 ? 100 : i == 3 ? 50 : i == 4 ? Z : i == 5 ? 50 : i == 6 ? 100 : i == 7 ? 200 : F;
+    }
+    __host__ __device__ static constexpr bool act(int l) { return !(l == 3 || l == 7); }
+    // forward product of layer l: k blocks of 32 input features x tiles of 16 output features
+    __host__ __device__ static constexpr int kb(int l) { return cdiv(dim(l), 32); }
+    __host__ __device__ static constexpr int nt(int l) { return cdiv(dim(l + 1), 16); }
+    // input-gradient product of layer l (dX_l = W_l^T dZ_l, l >= 1): k blocks over OUTPUT features, tiles over inputs
+    __host__ __device__ static constexpr int kbb(int l) { return cdiv(dim(l + 1), 32); }
+    __host__ __device__ static constexpr int ntb(int l) { return cdiv(dim(l), 16); }
+    // weight-gradient tiles of layer l: nt(l) x kt(l)  (the extra input slot carries db)
+    __host__ __device__ static constexpr int kt(int l) { return cdiv(dim(l) + 1, 16); }
+    // fragment stream (1-KiB units): forward layers 0..7 as [q][t], then backward layers 7..1 as [q][t]
+    __host__ __device__ static constexpr int ffo(int l) { int s = 0; for (int j = 0; j < l; ++j) s += kb(j) * nt(j); return s; }
+    __host__ __device__ static constexpr int bfo(int l) { int s = ffo(L); for (int j = L - 1; j > l; --j) s += kbb(j) * ntb(j); return s; }
+    __host__ __device__ static constexpr int nfrag() { return bfo(1) + kbb(1) * ntb(1); }
+    // bias fragments (float4 units): [t][g]
+    __host__ __device__ static constexpr int bo(int l) { int s = 0; for (int j = 0; j < l; ++j) s += nt(j) * 4; return s; }
+    __host__ __device__ static constexpr int nbias() { return bo(L); }
+    // LDS images: i = 0..7 holds X_i (the input of layer i) and later dZ_{i-1}; i = 8 holds dZ_7
+    __host__ __device__ static constexpr int iblocks(int i) { return i < L ? kb(i) : cdiv(F, 32); }
+    __host__ __device__ static constexpr int istride(int i) { int b = iblocks(i); return 64 * (b % 2 ? b : b + 1); }   // bytes, 64 x odd
+    __host__ __device__ static constexpr int ioff(int i) { int s = 0; for (int j = 0; j < i; ++j) s += kRows * istride(j); return s; }
+    __host__ __device__ static constexpr int img_bytes() { return ioff(L + 1); }
+    // weight-gradient tiles in the partial-gradient buffer
+    __host__ __device__ static constexpr int dwt(int l) { return nt(l) * kt(l); }
+    __host__ __device__ static constexpr int slab_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += dwt(j); return s; }
+    // ownership of layer l's tiles: by output tile (nt = wave + 4 i, every kt) or by input tile (kt = wave + 4 i)
+    __host__ __device__ static constexpr bool by_nt(int l) { return cdiv(nt(l), 4) * kt(l) <= cdiv(kt(l), 4) * nt(l); }
+    __host__ __device__ static constexpr int dwn(int l) { return by_nt(l) ? cdiv(nt(l), 4) * kt(l) : cdiv(kt(l), 4) * nt(l); }
+    // canonical (state-dict) offsets
+    __host__ __device__ static constexpr int w_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += dim(j + 1) * dim(j) + dim(j + 1); return s; }
+    __host__ __device__ static constexpr int b_off(int l) { return w_off(l) + dim(l + 1) * dim(l); }
+    __host__ __device__ static constexpr int nparams() { return w_off(L); }
+    static_assert(F % 8 == 0 && F < 32 && Z < 32, "input rows are read as 8-feature chunks of one 32-slot block");
+};
+
+// Which layers a launch covers.  PART 0: forward 0..7, loss, backward 7..4.  PART 1: forward 0..2, backward 3..0.
+// PART 2: everything in one launch (needs all 298 tiles in registers: kept for experiments).
+template <int PART> struct Part {
+    static constexpr int fwd_end = PART == 1 ? 3 : 8;        // forward layers [0, fwd_end)
+    static constexpr int bwd_hi = PART == 1 ? 3 : 7;         // backward layers bwd_hi .. bwd_lo
+    static constexpr int bwd_lo = PART == 0 ? 4 : 0;
+    __host__ __device__ static constexpr bool has(int l) { return l <= bwd_hi && l >= bwd_lo; }
+};
+
+// ---- the weight-fragment schedule of one iteration ------------------------------------------------------------
+// A STEP is one k block of one chain product; every wave loads at most 4 fragments per step, two steps ahead of the
+// MFMAs, into a ring of 3 step buffers.  The step count is padded to a multiple of 3 so that the ring wraps across
+// persistent iterations (padding steps load nothing).
+struct StepInfo { int bwd, l, q, valid; };
+template <class N, int PART> struct Sched {
+    using P = Part<PART>;
+    __host__ __device__ static constexpr int chain_lo() { return P::bwd_lo < 1 ? 1 : P::bwd_lo; }   // layer 0 has no input gradient
+    __host__ __device__ static constexpr int fstep(int l) { int s = 0; for (int j = 0; j < l; ++j) s += N::kb(j); return s; }
+    __host__ __device__ static constexpr int bstep(int l) { int s = fstep(P::fwd_end); for (int j = P::bwd_hi; j > l; --j) s += N::kbb(j); return s; }
+    static constexpr int real = bstep(chain_lo()) + N::kbb(chain_lo());
+    static constexpr int total = cdiv(real, 3) * 3;
+    __host__ __device__ static constexpr StepInfo info(int s) {
+        s %= total;
+        if (s >= real) return {0, 0, 0, 0};
+        for (int l = 0; l < P::fwd_end; ++l)
+            if (s < fstep(l) + N::kb(l)) return {0, l, s - fstep(l), 1};
+        for (int l = P::bwd_hi; l >= chain_lo(); --l)
+            if (s < bstep(l) + N::kbb(l)) return {1, l, s - bstep(l), 1};
+        return {0, 0, 0, 0};
+    }
+};
+
+// How the NT output tiles of a chain product are split over the 4 waves.  N-split slot i: tile wave + 4 i for ALL four
+// row tiles (the fragment is loaded by one wave only); M-split tile k: every wave computes it for ITS row tile (fragment
+// loaded by all four).  NT = 13 -> 3 N-split + tile 12 M-split; 7 -> 2 N-split slots (wave 3's second is empty);
+// 4 -> 1; 2 and 1 -> M-split.
+template <int NT> struct Split {
+    static constexpr int R = NT % 4;
+    static constexpr int NS = NT < 4 ? 0 : (R == 1 ? NT / 4 : cdiv(NT, 4));
+    static constexpr int MS = NT < 4 ? NT : (R == 1 ? 1 : 0);
+    static constexpr int NF = NS + MS;                        // fragments per step and wave
+    static constexpr int m0 = NT < 4 ? 0 : 4 * NS;           // first M-split tile
+    static constexpr bool ragged = NT >= 4 && R != 1 && R != 0;   // the last N-split slot does not exist on every wave
+    static_assert(NF <= 4, "ring step buffers hold 4 fragments");
+};
+
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;   // lane * 16
+};
+__device__ __forceinline__ bf8 frag_rt(const WStream &ws, int idx) {
+    return __builtin_bit_cast(bf8, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
+}
+struct Ring { bf8 buf[3][4]; };
+
+template <class N, int PART, int STEP>
+__device__ __forceinline__ void issue(Ring &ring, const WStream &ws, int wave) {
+    constexpr StepInfo si = Sched<N, PART>::info(STEP);
+    if constexpr (si.valid) {
+        constexpr int NT = si.bwd ? N::ntb(si.l) : N::nt(si.l);
+        using SP = Split<NT>;
+        constexpr int base = (si.bwd ? N::bfo(si.l) : N::ffo(si.l)) + si.q * NT;
+#pragma unroll
+        for (int k = 0; k < SP::NF; ++k) {
+            int t = k < SP::NS ? wave + 4 * k : SP::m0 + (k - SP::NS);
+            if (SP::ragged && k == SP::NS - 1) t = t < NT ? t : NT - 1;      // empty slot: load a valid fragment, unused
+            ring.buf[STEP % 3][k] = frag_rt(ws, base + t);
+        }
+    }
+}
+
+__device__ __forceinline__ v4 mfma(bf8 a, bf8 b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// ---- LDS addressing ---------------------------------------------------------------------------------------------
+// byte offset of 16-byte chunk c of row r in an image of row stride S: r S + ((c ^ sigma(r)) << 4), sigma(r) = (r >> 1) & 3.
+// Every access below is "lane part + compile-time part"; the lane parts for one stride are computed once:
+//   row    : B operand / input rows: lane (j, g) -> chunk g (+ 4 q) of row j (+ 16 m)
+//   wr[par]: C tile t of parity par: lane (j, g) -> its 8 bytes (features 16 t + 4 g ..) of row j (+ 16 m)
+//   tr[par]: transposed read of tile t of parity par: lane 4 q' + p of group g -> row 4 g + q' (+ 16 h + 32 kh), 8 bytes p
+typedef unsigned char __attribute__((address_space(3))) *lds_p;
+struct Lay {
+    int row, wr0, wr1, tr0, tr1;
+    // parity select as a conditional move (indexing a member array with a run-time value would put the struct in scratch)
+    __device__ __forceinline__ int wr(int par) const { return par ? wr1 : wr0; }
+    __device__ __forceinline__ int tr(int par) const { return par ? tr1 : tr0; }
+};
+template <int S> __device__ __forceinline__ Lay make_lay(int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const int sg = (j >> 1) & 3;
+    Lay a;
+    a.row = j * S + ((g ^ sg) << 4);
+    a.wr0 = j * S + ((((sg & 2)) | ((g >> 1) ^ (sg & 1))) << 4) + 8 * (g & 1);
+    a.wr1 = j * S + ((((2 ^ (sg & 2))) | ((g >> 1) ^ (sg & 1))) << 4) + 8 * (g & 1);
+    const int rr = 4 * g + ((lane & 15) >> 2), p = lane & 3, st = (rr >> 1) & 3;
+    a.tr0 = rr * S + ((((st & 2)) | ((p >> 1) ^ (st & 1))) << 4) + 8 * (p & 1);
+    a.tr1 = rr * S + ((((2 ^ (st & 2))) | ((p >> 1) ^ (st & 1))) << 4) + 8 * (p & 1);
+    return a;
+}
+// the four strides that occur (64 x {1, 3, 5, 7} bytes)
+struct Lays { Lay s1, s3, s5, s7; };
+template <int S> __device__ __forceinline__ const Lay &lay_of(const Lays &ls) {
+    static_assert(S == 64 || S == 192 || S == 320 || S == 448, "image stride");
+    if constexpr (S == 64) return ls.s1;
+    else if constexpr (S == 192) return ls.s3;
+    else if constexpr (S == 320) return ls.s5;
+    else return ls.s7;
+}
+
+__device__ __forceinline__ bf8 lds_b128(lds_p p) { return *(const bf8 __attribute__((address_space(3))) *)p; }
+__device__ __forceinline__ u2 lds_b64(lds_p p) { return *(const u2 __attribute__((address_space(3))) *)p; }
+__device__ __forceinline__ void lds_w64(lds_p p, u2 v) { *(u2 __attribute__((address_space(3))) *)p = v; }
+__device__ __forceinline__ s4 lds_tr(lds_p p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)p);
+}
+// operand of a weight-gradient MFMA: 8 batch rows per lane (k slot (g, 4 h + q) <-> row 16 h + 4 g + q of the 32-row half)
+template <int S> __device__ __forceinline__ bf8 tr_operand(lds_p base, int kh) {
+    const s4 lo = lds_tr(base + (32 * kh) * S), hi = lds_tr(base + (32 * kh + 16) * S);
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    const s8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf8, v);
+}
+
+__device__ __forceinline__ void lrelu4(v4 &a) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f k2 = (v2f){0.01f, 0.01f};
+    asm("" : "+v"(k2));                       // register pair, vector product: v_pk_mul_f32 (see fused.hip lrelu)
+    v4 m = a * (v4){k2[0], k2[1], k2[0], k2[1]};
+    asm("" : "+v"(m));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = __builtin_amdgcn_fmed3f(a[r], m[r], 3.402823466e38f);
+}
+__device__ __forceinline__ u2 pack4(const v4 &a) {
+    bf4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (__bf16)a[r];
+    return __builtin_bit_cast(u2, o);
+}
+// d *= lrelu'(pre): sign(pre) == sign(post); `y` = the 4 post-activation bf16 values of the same elements.
+// slope = sign bit set ? 0.01 : 1 through one sign-extending bit-field extract and one bit select per value.
+__device__ __forceinline__ void lrelu_bwd4(v4 &d, u2 y) {
+    const unsigned one = 0x3F800000u, small = 0x3C23D70Au;     // 1.0f, 0.01f
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int w = (int)y[r >> 1];
+        const int neg = (r & 1) ? (w >> 31) : __builtin_amdgcn_sbfe(w, 15, 1);      // all ones iff the bf16 is negative
+        const unsigned sl = (small & (unsigned)neg) | (one & ~(unsigned)neg);
+        d[r] *= __builtin_bit_cast(float, sl);
+    }
+}
+
+// ---- one chain product: NT output tiles over the 4 waves, KB k blocks, B operand from image IN ---------------------
+// acc tiles: an[i][m] = tile wave + 4 i, row tile m;  am[k] = tile m0 + k, row tile `wave`
+template <int NT> struct ChainAcc {
+    using SP = Split<NT>;
+    v4 an[SP::NS > 0 ? SP::NS : 1][4];
+    v4 am[SP::MS > 0 ? SP::MS : 1];
+};
+
+template <int NT, int SIN>
+__device__ __forceinline__ void chain_load_b(bf8 (&dst)[4], lds_p in_row, int wave, int q) {
+    if (Split<NT>::NS > 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dst[m] = lds_b128(in_row + 16 * m * SIN + 64 * q);
+    } else {
+        dst[0] = lds_b128(in_row + 16 * wave * SIN + 64 * q);              // M-split only: this wave's row tile
+    }
+}
+// k block Q of the product (every index a template constant: the ring and the B buffers stay in registers)
+template <class N, int PART, int STEP0, int KB, int NT, int SIN, int Q>
+__device__ __forceinline__ void chain_step(ChainAcc<NT> &acc, bf8 (&b)[2][4], lds_p in_row, Ring &ring, const WStream &ws, int wave,
+                                           bool last_ok) {
+    using SP = Split<NT>;
+    issue<N, PART, STEP0 + Q + 2>(ring, ws, wave);
+    if (Q + 1 < KB) chain_load_b<NT, SIN>(b[(Q + 1) & 1], in_row, wave, Q + 1);
+    const bf8 (&bq)[4] = b[Q & 1];
+#pragma unroll
+    for (int k = 0; k < SP::NS; ++k) {
+        if (SP::ragged && k == SP::NS - 1 && !last_ok) continue;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc.an[k][m] = mfma(ring.buf[(STEP0 + Q) % 3][k], bq[m], acc.an[k][m]);
+    }
+    if (SP::MS > 0) {
+        // M-split tiles use this wave's OWN row tile: with N-split tiles present it is read once more (a wave-uniform
+        // address) rather than selected from the four with 12 v_cndmask
+        const bf8 bw = SP::NS > 0 ? lds_b128(in_row + 16 * wave * SIN + 64 * Q) : bq[0];
+#pragma unroll
+        for (int k = 0; k < SP::MS; ++k) acc.am[k] = mfma(ring.buf[(STEP0 + Q) % 3][SP::NS + k], bw, acc.am[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class N, int PART, int STEP0, int KB, int NT, int SIN, int... Q>
+__device__ __forceinline__ void chain_mm_impl(ChainAcc<NT> &acc, lds_p in_row, Ring &ring, const WStream &ws, int wave,
+                                              std::integer_sequence<int, Q...>) {
+    using SP = Split<NT>;
+    const bool last_ok = !SP::ragged || wave + 4 * (SP::NS - 1) < NT;      // wave-uniform
+    bf8 b[2][4];
+    chain_load_b<NT, SIN>(b[0], in_row, wave, 0);
+    (chain_step<N, PART, STEP0, KB, NT, SIN, Q>(acc, b, in_row, ring, ws, wave, last_ok), ...);
+}
+template <class N, int PART, int STEP0, int KB, int NT, int SIN>
+__device__ __forceinline__ void chain_mm(ChainAcc<NT> &acc, lds_p in_row /* image base + lane row part */, Ring &ring,
+                                         const WStream &ws, int wave) {
+    chain_mm_impl<N, PART, STEP0, KB, NT, SIN>(acc, in_row, ring, ws, wave, std::make_integer_sequence<int, KB>{});
+}
+
+template <int NT> __device__ __forceinline__ void acc_bias(ChainAcc<NT> &acc, const v4 *bias /* layer's fragments */, int wave, int g) {
+    using SP = Split<NT>;
+#pragma unroll
+    for (int k = 0; k < SP::NS; ++k) {
+        int t = wave + 4 * k;
+        t = t < NT ? t : NT - 1;
+        const v4 b = bias[t * 4 + g];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc.an[k][m] = b;
+    }
+#pragma unroll
+    for (int k = 0; k < SP::MS; ++k) acc.am[k] = bias[(SP::m0 + k) * 4 + g];
+}
+template <int NT> __device__ __forceinline__ void acc_zero(ChainAcc<NT> &acc) {
+    using SP = Split<NT>;
+#pragma unroll
+    for (int k = 0; k < SP::NS; ++k)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc.an[k][m] = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < SP::MS; ++k) acc.am[k] = (v4){0.f, 0.f, 0.f, 0.f};
+}
+
+// epilogue of a chain product into image OUT (row stride SOUT): FWD: [LeakyReLU] -> bf16 -> store;  !FWD: [mask with the
+// sign of what the image holds at the same place] -> bf16 -> store in place.  `fn(tile, row tile, value)` visits every tile.
+template <int NT, int SOUT, class Fn>
+__device__ __forceinline__ void acc_visit(ChainAcc<NT> &acc, lds_p img, const Lay &lay, int wave, Fn fn) {
+    using SP = Split<NT>;
+    // N-split slot k: tile t = wave + 4 k: parity of t = parity of wave, chunk pair 2 t -> 32 (t & ~1) bytes
+    const lds_p wn = img + lay.wr(wave & 1) + 32 * (wave & ~1);
+#pragma unroll
+    for (int k = 0; k < SP::NS; ++k) {
+        if (SP::ragged && k == SP::NS - 1 && wave + 4 * k >= NT) continue;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fn(acc.an[k][m], wn + 128 * k + 16 * m * SOUT);
+    }
+    const lds_p wm0 = img + 16 * wave * SOUT;
+#pragma unroll
+    for (int k = 0; k < SP::MS; ++k) {
+        const int t = SP::m0 + k;                 // compile-time after unrolling
+        fn(acc.am[k], wm0 + lay.wr(t & 1) + 32 * (t & ~1));
+    }
+}
+
+// ---- weight-gradient tiles of layer l --------------------------------------------------------------------------------
+// A operand: dZ_l^T (image ZI, stride SZ), B operand: [X_l | 1] (image XI, stride SX), both by transposed reads;
+// contraction over the 64 rows = 2 MFMAs per tile.  Tiles owned by this wave: see TNet::by_nt.
+template <class N, int l, int SZ, int SX>
+__device__ __forceinline__ void dw_phase(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave) {
+    constexpr int NT = N::nt(l), KT = N::kt(l);
+    if constexpr (N::by_nt(l)) {
+        constexpr int NI = cdiv(NT, 4);
+        const lds_p za = zimg + lz.tr(wave & 1) + 32 * (wave & ~1);      // tile nt = wave + 4 i -> + 128 i
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (wave + 4 * i >= NT) continue;
+            const bf8 a0 = tr_operand<SZ>(za + 128 * i, 0), a1 = tr_operand<SZ>(za + 128 * i, 1);
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const lds_p xb = ximg + lx.tr(k & 1) + 32 * (k & ~1);
+                const bf8 b0 = tr_operand<SX>(xb, 0), b1 = tr_operand<SX>(xb, 1);
+                acc[i * KT + k] = mfma(a0, b0, acc[i * KT + k]);
+                acc[i * KT + k] = mfma(a1, b1, acc[i * KT + k]);
+            }
+        }
+    } else {
+        constexpr int KI = cdiv(KT, 4);
+        const lds_p xb = ximg + lx.tr(wave & 1) + 32 * (wave & ~1);      // tile kt = wave + 4 i
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            if (wave + 4 * i >= KT) continue;
+            const bf8 b0 = tr_operand<SX>(xb + 128 * i, 0), b1 = tr_operand<SX>(xb + 128 * i, 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const lds_p za = zimg + lz.tr(t & 1) + 32 * (t & ~1);
+                const bf8 a0 = tr_operand<SZ>(za, 0), a1 = tr_operand<SZ>(za, 1);
+                acc[i * NT + t] = mfma(a0, b0, acc[i * NT + t]);
+                acc[i * NT + t] = mfma(a1, b1, acc[i * NT + t]);
+            }
+        }
+    }
+}
+
+template <class N, int l>
+__device__ __forceinline__ void dw_flush(v4 *__restrict__ slab, const v4 (&acc)[N::dwn(l)], int lane, int wave) {
+    constexpr int NT = N::nt(l), KT = N::kt(l);
+    // partial-gradient buffer is TILE-major: [tile][workgroup][64 lanes]; `slab` points at this workgroup's column
+    if constexpr (N::by_nt(l)) {
+#pragma unroll
+        for (int i = 0; i < cdiv(NT, 4); ++i)
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int t = wave + 4 * i;
+                if (t < NT) slab[(int64_t)(N::slab_off(l) + k * NT + t) * gridDim.x * 64 + lane] = acc[i * KT + k];
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < cdiv(KT, 4); ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int k = wave + 4 * i;
+                if (k < KT) slab[(int64_t)(N::slab_off(l) + k * NT + t) * gridDim.x * 64 + lane] = acc[i * NT + t];
+            }
+    }
+}
+template <int NA> __device__ __forceinline__ void zero_acc(v4 (&a)[NA]) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a[i] = (v4){0.f, 0.f, 0.f, 0.f};
+}
+
+// ---- input rows ----------------------------------------------------------------------------------------------------
+// lane (j, g), g < F/8, reads features 8 g .. 8 g + 7 of row 16 wave + j (branch-free: rows beyond n read row 0)
+template <int F> struct RawX { double d[8]; };
+template <int F>
+__device__ __forceinline__ void x_issue(RawX<F> &raw, const void *x, int is_f64, int64_t row, int64_t n, int g) {
+    const int64_t base = (row < n ? row : 0) * F + (8 * g < F ? 8 * g : 0);
+    if (is_f64) {
+        const double2 *p = (const double2 *)((const double *)x + base);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const double2 t = p[e]; raw.d[2 * e] = t.x; raw.d[2 * e + 1] = t.y; }
+    } else {
+        const float4 *p = (const float4 *)((const float *)x + base);
+        const float4 t0 = p[0], t1 = p[1];
+        raw.d[0] = t0.x; raw.d[1] = t0.y; raw.d[2] = t0.z; raw.d[3] = t0.w; raw.d[4] = t1.x; raw.d[5] = t1.y; raw.d[6] = t1.z; raw.d[7] = t1.w;
+    }
+}
+
+template <int F, int Z, int PART>
+__global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict__ wfrags, const v4 *__restrict__ bias_g,
+                                                         const void *__restrict__ xin, int in_f64, int64_t n,
+                                                         const double *__restrict__ feats, v4 *__restrict__ slabs,
+                                                         u2 *__restrict__ dz, int loss_tile) {
+    using N = TNet<F, Z>;
+    using P = Part<PART>;
+    using SC = Sched<N, PART>;
+    extern __shared__ __attribute__((aligned(256))) unsigned char lds_raw[];
+    const lds_p img = (lds_p)lds_raw;
+    v4 *bias = (v4 *)(lds_raw + N::img_bytes());
+    float *xf = (float *)(bias + N::nbias());                 // fp32 copy of the normalised input rows: [64][32]
+    double *fl = (double *)(xf + kRows * 32);                 // [0..31] min, [32..63] range
+    for (int i = threadIdx.x; i < N::nbias(); i += 256) bias[i] = bias_g[i];
+    for (int i = threadIdx.x; i < N::img_bytes() / 16; i += 256) ((uint4 *)lds_raw)[i] = make_uint4(0, 0, 0, 0);   // finite padding slots
+    if (threadIdx.x < 64) {
+        const int f = threadIdx.x & 31, which = threadIdx.x >> 5;
+        fl[threadIdx.x] = (feats && f < F) ? feats[which * F + f] : (which ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ngroups = (n + kRows - 1) / kRows;
+    WStream ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wfrags, 0, N::nfrag() * 1024, 0x00020000);
+    ws.voff = lane * 16;
+    v4 *slab = slabs + (int64_t)blockIdx.x * 64;
+
+    v4 g7[P::has(7) ? N::dwn(7) : 1], g6[P::has(6) ? N::dwn(6) : 1], g5[P::has(5) ? N::dwn(5) : 1], g4[P::has(4) ? N::dwn(4) : 1];
+    v4 g3[P::has(3) ? N::dwn(3) : 1], g2[P::has(2) ? N::dwn(2) : 1], g1[P::has(1) ? N::dwn(1) : 1], g0[P::has(0) ? N::dwn(0) : 1];
+    zero_acc(g7); zero_acc(g6); zero_acc(g5); zero_acc(g4); zero_acc(g3); zero_acc(g2); zero_acc(g1); zero_acc(g0);
+    double lacc = 0.0;
+    Ring ring;
+    issue<N, PART, 0>(ring, ws, wave);
+    issue<N, PART, 1>(ring, ws, wave);
+    RawX<F> xraw;
+    x_issue<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15), n, lane >> 4);
+
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        // keep the weight loads and the LDS address arithmetic inside the loop (LICM would hoist hundreds of registers)
+        asm volatile("" : "+v"(ws.voff), "+s"(wave), "+v"(lane));
+        const int j = lane & 15, g = lane >> 4;
+        Lays ls;
+        ls.s1 = make_lay<64>(lane); ls.s3 = make_lay<192>(lane); ls.s5 = make_lay<320>(lane); ls.s7 = make_lay<448>(lane);
+        const int64_t row = grp * kRows + 16 * wave + j;
+        const bool valid = row < n;
+        // ---- input rows -> image 0 (bf16, with the ones slot) and the fp32 copy the loss uses -------------------------
+        {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int f = (8 * g < F ? 8 * g : 0) + e;
+                double d = xraw.d[e];
+                if (feats) d = (d - fl[f]) / fl[32 + f];
+                v[e] = 8 * g < F ? (float)d : (8 * g == F && e == 0 ? 1.0f : 0.f);     // slot F = the ones column
+            }
+            bf8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+            *(bf8 __attribute__((address_space(3))) *)(img + N::ioff(0) + lay_of<N::istride(0)>(ls).row + 16 * wave * N::istride(0)) = o;
+            float *xr = xf + (16 * wave + j) * 32 + 8 * g;
+            *(float4 *)xr = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4 *)(xr + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);       // next iteration's rows, a whole iteration ahead
+        __syncthreads();
+
+        // ---- forward ------------------------------------------------------------------------------------------------
+#define BAMD_FWD(l)                                                                                                          \
+        {                                                                                                                    \
+            ChainAcc<N::nt(l)> acc;                                                                                          \
+            acc_bias<N::nt(l)>(acc, bias + N::bo(l), wave, g);                                                               \
+            chain_mm<N, PART, SC::fstep(l), N::kb(l), N::nt(l), N::istride(l)>(                                              \
+                acc, img + N::ioff(l) + lay_of<N::istride(l)>(ls).row, ring, ws, wave);                                      \
+            acc_visit<N::nt(l), N::istride(l + 1)>(acc, img + N::ioff(l + 1), lay_of<N::istride(l + 1)>(ls), wave,           \
+                                                   [&](v4 &a, lds_p dst) { if (N::act(l)) lrelu4(a); lds_w64(dst, pack4(a)); }); \
+            __syncthreads();                                                                                                 \
+        }
+        BAMD_FWD(0) BAMD_FWD(1) BAMD_FWD(2)
+        if constexpr (P::fwd_end == 8) {
+            BAMD_FWD(3) BAMD_FWD(4) BAMD_FWD(5) BAMD_FWD(6)
+            // layer 7 + loss: NT = 2 -> this wave holds both output tiles of ITS 16 rows
+            ChainAcc<N::nt(7)> acc;
+            static_assert(N::nt(7) < 4, "loss epilogue expects the M-split form");
+            acc_bias<N::nt(7)>(acc, bias + N::bo(7), wave, g);
+            chain_mm<N, PART, SC::fstep(7), N::kb(7), N::nt(7), N::istride(7)>(acc, img + N::ioff(7) + lay_of<N::istride(7)>(ls).row,
+                                                                             ring, ws, wave);
+            const Lay &l8 = lay_of<N::istride(8)>(ls);
+#pragma unroll
+            for (int t = 0; t < N::nt(7); ++t) {
+                const float4 xv = *(const float4 *)(xf + (16 * wave + j) * 32 + 16 * t + 4 * g);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                v4 d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = acc.am[t][r] - xs[r];
+                    const bool live = valid && 16 * t + 4 * g + r < F;
+                    if (live) lacc += (double)e * (double)e;
+                    d[r] = live ? e * (2.0f / (float)F) : 0.f;              // dL/drecon = 2 (r - x) / C  (utils.py:195-199)
+                }
+                lds_w64(img + N::ioff(8) + 16 * wave * N::istride(8) + l8.wr(t & 1) + 32 * (t & ~1), pack4(d));
+            }
+            __syncthreads();
+        } else {
+            // PART 1: dL/dz of these rows from the first launch -> image 4 (tile 0 of row tile `wave`)
+            const u2 dzv = dz[row * 4 + g];                                 // rows beyond n: zeros (stored by PART 0)
+            lds_w64(img + N::ioff(4) + 16 * wave * N::istride(4) + lay_of<N::istride(4)>(ls).wr0, dzv);
+            __syncthreads();
+        }
+
+        // ---- backward: per layer  [input-gradient MFMAs | weight-gradient tiles]  barrier  [epilogue in place]  barrier -
+#define BAMD_BWD(l, G)                                                                                                       \
+        if constexpr (P::has(l)) {                                                                                           \
+            constexpr int ZI = (l) + 1;   /* dZ_l lives where X_{l+1} was; dZ_7 in image 8 */                               \
+            if constexpr ((l) >= 1) {                                                                                        \
+                ChainAcc<N::ntb(l)> acc;                                                                                     \
+                acc_zero<N::ntb(l)>(acc);                                                                                    \
+                chain_mm<N, PART, SC::bstep(l), N::kbb(l), N::ntb(l), N::istride(ZI)>(                                       \
+                    acc, img + N::ioff(ZI) + lay_of<N::istride(ZI)>(ls).row, ring, ws, wave);                                \
+                dw_phase<N, l, N::istride(ZI), N::istride(l)>(G, img + N::ioff(ZI), img + N::ioff(l),                        \
+                                                             lay_of<N::istride(ZI)>(ls), lay_of<N::istride(l)>(ls), wave);   \
+                __syncthreads();                                                                                             \
+                if constexpr (PART == 0 && (l) == P::bwd_lo) {                                                               \
+                    /* hand-off to the second launch: dL/dz, 4 bf16 per lane = 32 B per row (en4 has no activation) */       \
+                    static_assert(N::ntb(l) == 1, "dL/dz is one tile per row");                                              \
+                    dz[row * 4 + g] = pack4(acc.am[0]);                                                                      \
+                } else {                                                                                                     \
+                    acc_visit<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,              \
+                                                        [&](v4 &a, lds_p dst) {                                              \
+                                                            if (N::act((l) - 1)) lrelu_bwd4(a, lds_b64(dst));                \
+                                                            lds_w64(dst, pack4(a));                                          \
+                                                        });                                                                  \
+                }                                                                                                            \
+                __syncthreads();                                                                                             \
+            } else {                                                                                                         \
+                dw_phase<N, l, N::istride(ZI), N::istride(l)>(G, img + N::ioff(ZI), img + N::ioff(l),                        \
+                                                             lay_of<N::istride(ZI)>(ls), lay_of<N::istride(l)>(ls), wave);   \
+                __syncthreads();                                                                                             \
+            }                                                                                                                \
+        }
+        BAMD_BWD(7, g7) BAMD_BWD(6, g6) BAMD_BWD(5, g5) BAMD_BWD(4, g4) BAMD_BWD(3, g3) BAMD_BWD(2, g2) BAMD_BWD(1, g1) BAMD_BWD(0, g0)
+#undef BAMD_FWD
+#undef BAMD_BWD
+        // step over the padding steps and prime the ring for the next iteration (steps total, total + 1 = its steps 0, 1:
+        // already issued by the last two real steps when there is no padding)
+        if constexpr (SC::total - SC::real == 2) { issue<N, PART, SC::total>(ring, ws, wave); issue<N, PART, SC::total + 1>(ring, ws, wave); }
+        if constexpr (SC::total - SC::real == 1) { issue<N, PART, SC::total + 1>(ring, ws, wave); }
+    }
+    if constexpr (P::has(7)) dw_flush<N, 7>(slab, g7, lane, wave);
+    if constexpr (P::has(6)) dw_flush<N, 6>(slab, g6, lane, wave);
+    if constexpr (P::has(5)) dw_flush<N, 5>(slab, g5, lane, wave);
+    if constexpr (P::has(4)) dw_flush<N, 4>(slab, g4, lane, wave);
+    if constexpr (P::has(3)) dw_flush<N, 3>(slab, g3, lane, wave);
+    if constexpr (P::has(2)) dw_flush<N, 2>(slab, g2, lane, wave);
+    if constexpr (P::has(1)) dw_flush<N, 1>(slab, g1, lane, wave);
+    if constexpr (P::has(0)) dw_flush<N, 0>(slab, g0, lane, wave);
+    if constexpr (P::fwd_end == 8) {   // per-workgroup loss partial (fixed-order tree), stored after the tiles
+        __syncthreads();
+        double *sh = (double *)lds_raw;
+        sh[threadIdx.x] = lacc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) ((double *)(slabs + (int64_t)loss_tile * gridDim.x * 64))[blockIdx.x] = sh[0];
+    }
+}
+
+// Fixed-order reduction of the per-workgroup partial gradients ([tile][workgroup][64 lanes] float4) into the canonical
+// (state-dict) layout; block `ntiles`: grads[np] = sum of the loss partials / C.  One wave per tile (see fused.hip).
+__global__ void __launch_bounds__(64) reduce_tiles_k(const v4 *__restrict__ slabs, int nslab, int ntiles, const int *__restrict__ inv_map,
+                                                     int np, double inv_c, float *__restrict__ grads) {
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    if (tile == ntiles) {
+        if (lane == 0) {
+            const double *lp = (const double *)(slabs + (int64_t)ntiles * nslab * 64);
+            double l = 0.0;
+            for (int k = 0; k < nslab; ++k) l += lp[k];
+            grads[np] = (float)(l * inv_c);
+        }
+        return;
+    }
+    const v4 *src = slabs + (int64_t)tile * nslab * 64 + lane;
+    v4 s = (v4){0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {
+        v4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(k + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; k < nslab; ++k) s += src[k * 64];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int p = inv_map[(tile * 64 + lane) * 4 + c];
+        if (p >= 0) grads[p] = s[c];
+    }
+}
+
+// params (fp32, state-dict order) -> bf16 weight fragments [0, wcount) and fp32 bias fragments [wcount, wcount + bcount)
+// through one index map (-1: zero, -2: one -- the bias of an output padding slot that serves as the next layer's ones column)
+__global__ void __launch_bounds__(256) pack_train_k(const float *__restrict__ params, const int *__restrict__ src, int wcount,
+                                                    int bcount, __bf16 *__restrict__ wdst, float *__restrict__ bdst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= wcount + bcount) return;
+    const int s = src[i];
+    const float v = s >= 0 ? params[s] : (s == -2 ? 1.0f : 0.f);
+    if (i < wcount) wdst[i] = (__bf16)v; else bdst[i - wcount] = v;
+}
+
+struct TrainOps;
+struct TrainState {
+    const TrainOps *ops = nullptr;
+    DevBuf src, w, b, inv, dz;
+    int wcount = 0, bcount = 0, ntiles = 0, nparams = 0, n_features = 0;
+    int nwg_max = 256;
+};
+struct TrainOps {
+    int (*setup)(bamd_handle *, TrainState *);
+    int (*fwd_bwd)(bamd_handle *, TrainState *, const void *, int, int64_t, const double *, float *, hipStream_t);
+};
+TrainState *tstate(bamd_handle *h) { return (TrainState *)h->bf16_train_state; }
+
+template <int F, int Z> struct TImpl {
+    using N = TNet<F, Z>;
+    static constexpr size_t lds_bytes() { return (size_t)N::img_bytes() + (size_t)N::nbias() * 16 + kRows * 32 * 4 + 64 * 8; }
+    static_assert(lds_bytes() <= 160 * 1024, "LDS images exceed one CU");
+    static bool matches(const bamd_handle *h) {
+        if (h->L != 8) return false;
+        for (int i = 0; i <= 8; ++i)
+            if (h->dims[i] != N::dim(i)) return false;
+        return true;
+    }
+    static int setup(bamd_handle *h, TrainState *st) {
+        const size_t wcount = (size_t)N::nfrag() * 512, bcount = (size_t)N::nbias() * 4;
+        std::vector<int> src(wcount + bcount, -1);
+        for (int l = 0; l < N::L; ++l) {
+            const int K = N::dim(l), NN = N::dim(l + 1);
+            // forward fragment (q, t): lane (i, g) element e = W[16 t + i][32 q + 8 g + e]
+            for (int q = 0; q < N::kb(l); ++q)
+                for (int t = 0; t < N::nt(l); ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int n = 16 * t + (lane & 15), k = 32 * q + 8 * (lane >> 4) + e;
+                            if (n < NN && k < K) src[((size_t)(N::ffo(l) + q * N::nt(l) + t) * 64 + lane) * 8 + e] = N::w_off(l) + n * K + k;
+                        }
+            // backward fragment (q, t), l >= 1: lane (i, g) element e = W[32 q + 8 g + e][16 t + i]
+            for (int q = 0; q < N::kbb(l) && l >= 1; ++q)
+                for (int t = 0; t < N::ntb(l); ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int n = 32 * q + 8 * (lane >> 4) + e, k = 16 * t + (lane & 15);
+                            if (n < NN && k < K) src[((size_t)(N::bfo(l) + q * N::ntb(l) + t) * 64 + lane) * 8 + e] = N::w_off(l) + n * K + k;
+                        }
+            // bias fragment (t, g) component r = b[16 t + 4 g + r]; output slot NN (padding) = 1: the next layer's ones column
+            for (int t = 0; t < N::nt(l); ++t)
+                for (int g = 0; g < 4; ++g)
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = 16 * t + 4 * g + r;
+                        src[wcount + ((size_t)N::bo(l) + t * 4 + g) * 4 + r] = n < NN ? N::b_off(l) + n : (n == NN ? -2 : -1);
+                    }
+            static_assert(N::dim(1) % 16 && N::dim(2) % 16 && N::dim(3) % 16 && N::dim(4) % 16, "every layer output needs a padding slot for the ones column");
+        }
+        // accumulator tile (kt, nt) of layer l, lane (j, g), register r = dW[16 nt + 4 g + r][16 kt + j]; column K = db
+        const int ntiles = N::slab_off(N::L);
+        std::vector<int> inv((size_t)ntiles * 256, -1);
+        for (int l = 0; l < N::L; ++l) {
+            const int K = N::dim(l), NN = N::dim(l + 1);
+            for (int k = 0; k < N::kt(l); ++k)
+                for (int t = 0; t < N::nt(l); ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = 16 * t + 4 * (lane >> 4) + r, kc = 16 * k + (lane & 15);
+                            if (n >= NN) continue;
+                            const size_t o = ((size_t)(N::slab_off(l) + k * N::nt(l) + t) * 64 + lane) * 4 + r;
+                            if (kc < K) inv[o] = N::w_off(l) + n * K + kc;
+                            else if (kc == K) inv[o] = N::b_off(l) + n;
+                        }
+        }
+        {   // every parameter must be produced exactly once
+            std::vector<char> seen(N::nparams(), 0);
+            for (int v : inv) if (v >= 0) seen[v]++;
+            for (char c : seen) if (c != 1) { set_error("bf16 training: incomplete gradient map"); return BAMD_ERR_INVALID; }
+        }
+        st->wcount = (int)wcount; st->bcount = (int)bcount; st->ntiles = ntiles; st->nparams = N::nparams(); st->n_features = F;
+        int rc = st->src.ensure(src.size() * sizeof(int));
+        if (rc) return rc;
+        rc = st->inv.ensure(inv.size() * sizeof(int));
+        if (rc) return rc;
+        rc = st->w.ensure(wcount * sizeof(__bf16) + 4096);
+        if (rc) return rc;
+        rc = st->b.ensure(bcount * sizeof(float));
+        if (rc) return rc;
+        BAMD_HIP(hipMemcpy(st->src.p, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
+        BAMD_HIP(hipMemcpy(st->inv.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice));
+        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_train_kernel<F, Z, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes()));
+        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_train_kernel<F, Z, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes()));
+        return BAMD_OK;
+    }
+    static int fwd_bwd(bamd_handle *h, TrainState *st, const void *x, int x_dtype, int64_t n, const double *features, float *grads,
+                       hipStream_t s) {
+        const int64_t ngroups = (n + kRows - 1) / kRows;
+        const int grid = (int)(ngroups < st->nwg_max ? ngroups : st->nwg_max);
+        // tiles + one double per workgroup for the loss
+        int rc = h->slabs.ensure(((size_t)st->ntiles * 1024 + 16) * (size_t)grid);
+        if (rc) return rc;
+        rc = st->dz.ensure((size_t)ngroups * kRows * 32);          // dL/dz hand-off: 16 bf16 per row, whole row groups
+        if (rc) return rc;
+        hipLaunchKernelGGL((bf16_train_kernel<F, Z, 0>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, (const v4 *)st->b.p,
+                           x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
+        hipLaunchKernelGGL((bf16_train_kernel<F, Z, 1>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, (const v4 *)st->b.p,
+                           x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
+        hipLaunchKernelGGL(reduce_tiles_k, dim3(st->ntiles + 1), dim3(64), 0, s, (const v4 *)h->slabs.p, grid, st->ntiles,
+                           (const int *)st->inv.p, st->nparams, 1.0 / F, grads);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static const TrainOps *ops() {
+        static const TrainOps o = {setup, fwd_bwd};
+        return &o;
+    }
+};
+
+const TrainOps *find_train(const bamd_handle *h) {
+    if (TImpl<24, 15>::matches(h)) return TImpl<24, 15>::ops();
+    if (TImpl<24, 12>::matches(h)) return TImpl<24, 12>::ops();
+    if (TImpl<24, 8>::matches(h)) return TImpl<24, 8>::ops();
+    if (TImpl<24, 6>::matches(h)) return TImpl<24, 6>::ops();
+    return nullptr;
+}
+
+}  // namespace
+
+int bf16_train_setup(bamd_handle *h) {
+    const TrainOps *ops = find_train(h);
+    if (!ops) return BAMD_OK;                  // no bf16 training kernels for this shape: training calls use the fp32 layer-wise path
+    const char *env = getenv("BALER_AMD_BF16_TRAIN");
+    if (env && env[0] == '0') return BAMD_OK;
+    TrainState *st = new TrainState();
+    st->ops = ops;
+    h->bf16_train_state = st;
+    return ops->setup(h, st);
+}
+
+void bf16_train_teardown(bamd_handle *h) {
+    TrainState *st = tstate(h);
+    if (!st) return;
+    st->src.release(); st->w.release(); st->b.release(); st->inv.release(); st->dz.release();
+    delete st;
+    h->bf16_train_state = nullptr;
+}
+
+bool bf16_train_ok(const bamd_handle *h) { return h->bf16_train_state != nullptr; }
+
+int bf16_train_pack(bamd_handle *h, hipStream_t s) {
+    TrainState *st = tstate(h);
+    if (!st) return BAMD_OK;
+    const int count = st->wcount + st->bcount;
+    hipLaunchKernelGGL(pack_train_k, dim3((count + 255) / 256), dim3(256), 0, s, (const float *)h->params.p, (const int *)st->src.p,
+                       st->wcount, st->bcount, (__bf16 *)st->w.p, (float *)st->b.p);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+int bf16_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, hipStream_t s) {
+    TrainState *st = tstate(h);
+    return st->ops->fwd_bwd(h, st, x, x_dtype, n, features, (float *)grads, s);
+}
+
+}  // namespace bamd
