@@ -11,13 +11,13 @@
 //   * image i = [64 batch rows][feature slots] in bf16, one per layer input X_i (2-bit XOR swizzle of the 16-byte
 //     chunks, row strides of 64 x odd bytes: every read shape below is bank-conflict free, tools/probe/lds_conflicts.py);
 //   * a layer's B operand (32 input features of one row per lane) is ONE ds_read_b128 of the row-major image;
-//   * the epilogue (bias was the accumulator's initial value; LeakyReLU; v_cvt_pk_bf16_f32) writes the C tile back
-//     with one ds_write_b64 per lane and tile;
+//   * the epilogue (LeakyReLU; v_cvt_pk_bf16_f32) writes the C tile back with one ds_write_b64 per lane and tile;
 //   * the weight-gradient product [dW | db] = dZ^T [X | 1] contracts over the BATCH index, i.e. needs both images
 //     transposed: gfx950's ds_read_b64_tr_b16 delivers exactly that (4 rows x 16 columns per 16 lanes), so the same
 //     row-major images serve the chain (row reads) and the weight gradients (transposed reads) -- no second copy,
-//     no transposing stores.  The ones column that carries db is the first padding slot of every image: it is
-//     produced by the forward epilogue itself (packed bias 1.0 on zero weights).
+//     no transposing stores.  The first padding slot of every image is a ONES column: it carries db through the
+//     weight-gradient product, and the forward product reads the bias through it (the packed weights hold b in input
+//     column K, and a 1 at [padding output K'][column K] so that every layer regenerates the next layer's ones column);
 //   * dZ_{l-1} overwrites X_l in place once layer l's weight-gradient tiles have been read (same shape, same owner
 //     wave and lane): 116 KB of images for the whole network at 64 rows, no second set of buffers.
 // [dW | db] tiles stay in MFMA accumulators for the whole persistent loop (as in fused.hip) and are reduced over
@@ -61,9 +61,6 @@ template <int F, int Z> struct TNet {
     __host__ __device__ static constexpr int ffo(int l) { int s = 0; for (int j = 0; j < l; ++j) s += kb(j) * nt(j); return s; }
     __host__ __device__ static constexpr int bfo(int l) { int s = ffo(L); for (int j = L - 1; j > l; --j) s += kbb(j) * ntb(j); return s; }
     __host__ __device__ static constexpr int nfrag() { return bfo(1) + kbb(1) * ntb(1); }
-    // bias fragments (float4 units): [t][g]
-    __host__ __device__ static constexpr int bo(int l) { int s = 0; for (int j = 0; j < l; ++j) s += nt(j) * 4; return s; }
-    __host__ __device__ static constexpr int nbias() { return bo(L); }
     // LDS images: i = 0..7 holds X_i (the input of layer i) and later dZ_{i-1}; i = 8 holds dZ_7
     __host__ __device__ static constexpr int iblocks(int i) { return i < L ? kb(i) : cdiv(F, 32); }
     __host__ __device__ static constexpr int istride(int i) { int b = iblocks(i); return 64 * (b % 2 ? b : b + 1); }   // bytes, 64 x odd
@@ -213,23 +210,34 @@ __device__ __forceinline__ void lrelu4(v4 &a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] = __builtin_amdgcn_fmed3f(a[r], m[r], 3.402823466e38f);
 }
+// two v_cvt_pk_bf16_f32 (built pair by pair: a 4-element bf16 vector makes hipcc convert elements 2, 3 one by one + v_perm)
 __device__ __forceinline__ u2 pack4(const v4 &a) {
-    bf4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = (__bf16)a[r];
-    return __builtin_bit_cast(u2, o);
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 lo = {(__bf16)a[0], (__bf16)a[1]}, hi = {(__bf16)a[2], (__bf16)a[3]};
+    return (u2){__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
 }
-// d *= lrelu'(pre): sign(pre) == sign(post); `y` = the 4 post-activation bf16 values of the same elements.
-// slope = sign bit set ? 0.01 : 1 through one sign-extending bit-field extract and one bit select per value.
-__device__ __forceinline__ void lrelu_bwd4(v4 &d, u2 y) {
-    const unsigned one = 0x3F800000u, small = 0x3C23D70Au;     // 1.0f, 0.01f
+// dZ = bf16(d * lrelu'(pre)), sign(pre) == sign(post); `y` = the 4 post-activation bf16 values of the same elements.
+// Both candidates are rounded (d and 0.01 d, one v_pk_mul per pair) and the halves are picked by a sign mask of y
+// (v_pk_ashrrev_i16) with one v_bfi_b32 per pair: 2.5 VALU instructions per value including the conversion
+// (compare + select on the fp32 values: 3; mask arithmetic on the slope bits: 5.5).
+__device__ __forceinline__ u2 lrelu_bwd_pack4(const v4 &d, u2 y) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f k2 = (v2f){0.01f, 0.01f};
+    asm("" : "+v"(k2));
+    v4 m = d * (v4){k2[0], k2[1], k2[0], k2[1]};
+    asm("" : "+v"(m));
+    const u2 p1 = pack4(d), p2 = pack4(m);
+    unsigned sh = 0x000F000Fu;      // shift count per half (an inline constant would reach the low half only)
+    u2 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int w = (int)y[r >> 1];
-        const int neg = (r & 1) ? (w >> 31) : __builtin_amdgcn_sbfe(w, 15, 1);      // all ones iff the bf16 is negative
-        const unsigned sl = (small & (unsigned)neg) | (one & ~(unsigned)neg);
-        d[r] *= __builtin_bit_cast(float, sl);
+    for (int h = 0; h < 2; ++h) {
+        // 0xFFFF where the activation is negative.  Through asm: written as a shift of a 2 x i16 vector, hipcc (ROCm 7.2)
+        // uses the mask of y[0] for BOTH dwords (it drops the load of y[1]); the operands are plain VALU / LDS-load results
+        unsigned mask;
+        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(mask) : "v"(sh), "v"(y[h]));
+        o[h] = (p2[h] & mask) | (p1[h] & ~mask);                              // one v_bitop3_b32
     }
+    return o;
 }
 
 // ---- one chain product: NT output tiles over the 4 waves, KB k blocks, B operand from image IN ---------------------
@@ -257,18 +265,21 @@ __device__ __forceinline__ void chain_step(ChainAcc<NT> &acc, bf8 (&b)[2][4], ld
     issue<N, PART, STEP0 + Q + 2>(ring, ws, wave);
     if (Q + 1 < KB) chain_load_b<NT, SIN>(b[(Q + 1) & 1], in_row, wave, Q + 1);
     const bf8 (&bq)[4] = b[Q & 1];
+    // k block 0 starts from a literal zero C operand (no accumulator initialisation; the bias arrives through the
+    // ones slot of the input image, whose weight column holds it)
+    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < SP::NS; ++k) {
         if (SP::ragged && k == SP::NS - 1 && !last_ok) continue;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc.an[k][m] = mfma(ring.buf[(STEP0 + Q) % 3][k], bq[m], acc.an[k][m]);
+        for (int m = 0; m < 4; ++m) acc.an[k][m] = mfma(ring.buf[(STEP0 + Q) % 3][k], bq[m], Q == 0 ? zero : acc.an[k][m]);
     }
     if (SP::MS > 0) {
         // M-split tiles use this wave's OWN row tile: with N-split tiles present it is read once more (a wave-uniform
         // address) rather than selected from the four with 12 v_cndmask
         const bf8 bw = SP::NS > 0 ? lds_b128(in_row + 16 * wave * SIN + 64 * Q) : bq[0];
 #pragma unroll
-        for (int k = 0; k < SP::MS; ++k) acc.am[k] = mfma(ring.buf[(STEP0 + Q) % 3][SP::NS + k], bw, acc.am[k]);
+        for (int k = 0; k < SP::MS; ++k) acc.am[k] = mfma(ring.buf[(STEP0 + Q) % 3][SP::NS + k], bw, Q == 0 ? zero : acc.am[k]);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -285,29 +296,6 @@ template <class N, int PART, int STEP0, int KB, int NT, int SIN>
 __device__ __forceinline__ void chain_mm(ChainAcc<NT> &acc, lds_p in_row /* image base + lane row part */, Ring &ring,
                                          const WStream &ws, int wave) {
     chain_mm_impl<N, PART, STEP0, KB, NT, SIN>(acc, in_row, ring, ws, wave, std::make_integer_sequence<int, KB>{});
-}
-
-template <int NT> __device__ __forceinline__ void acc_bias(ChainAcc<NT> &acc, const v4 *bias /* layer's fragments */, int wave, int g) {
-    using SP = Split<NT>;
-#pragma unroll
-    for (int k = 0; k < SP::NS; ++k) {
-        int t = wave + 4 * k;
-        t = t < NT ? t : NT - 1;
-        const v4 b = bias[t * 4 + g];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc.an[k][m] = b;
-    }
-#pragma unroll
-    for (int k = 0; k < SP::MS; ++k) acc.am[k] = bias[(SP::m0 + k) * 4 + g];
-}
-template <int NT> __device__ __forceinline__ void acc_zero(ChainAcc<NT> &acc) {
-    using SP = Split<NT>;
-#pragma unroll
-    for (int k = 0; k < SP::NS; ++k)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc.an[k][m] = (v4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < SP::MS; ++k) acc.am[k] = (v4){0.f, 0.f, 0.f, 0.f};
 }
 
 // epilogue of a chain product into image OUT (row stride SOUT): FWD: [LeakyReLU] -> bf16 -> store;  !FWD: [mask with the
@@ -415,8 +403,7 @@ __device__ __forceinline__ void x_issue(RawX<F> &raw, const void *x, int is_f64,
 }
 
 template <int F, int Z, int PART>
-__global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict__ wfrags, const v4 *__restrict__ bias_g,
-                                                         const void *__restrict__ xin, int in_f64, int64_t n,
+__global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict__ wfrags, const void *__restrict__ xin, int in_f64, int64_t n,
                                                          const double *__restrict__ feats, v4 *__restrict__ slabs,
                                                          u2 *__restrict__ dz, int loss_tile) {
     using N = TNet<F, Z>;
@@ -424,10 +411,8 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     using SC = Sched<N, PART>;
     extern __shared__ __attribute__((aligned(256))) unsigned char lds_raw[];
     const lds_p img = (lds_p)lds_raw;
-    v4 *bias = (v4 *)(lds_raw + N::img_bytes());
-    float *xf = (float *)(bias + N::nbias());                 // fp32 copy of the normalised input rows: [64][32]
+    float *xf = (float *)(lds_raw + N::img_bytes());          // fp32 copy of the normalised input rows: [64][32]
     double *fl = (double *)(xf + kRows * 32);                 // [0..31] min, [32..63] range
-    for (int i = threadIdx.x; i < N::nbias(); i += 256) bias[i] = bias_g[i];
     for (int i = threadIdx.x; i < N::img_bytes() / 16; i += 256) ((uint4 *)lds_raw)[i] = make_uint4(0, 0, 0, 0);   // finite padding slots
     if (threadIdx.x < 64) {
         const int f = threadIdx.x & 31, which = threadIdx.x >> 5;
@@ -484,7 +469,6 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
 #define BAMD_FWD(l)                                                                                                          \
         {                                                                                                                    \
             ChainAcc<N::nt(l)> acc;                                                                                          \
-            acc_bias<N::nt(l)>(acc, bias + N::bo(l), wave, g);                                                               \
             chain_mm<N, PART, SC::fstep(l), N::kb(l), N::nt(l), N::istride(l)>(                                              \
                 acc, img + N::ioff(l) + lay_of<N::istride(l)>(ls).row, ring, ws, wave);                                      \
             acc_visit<N::nt(l), N::istride(l + 1)>(acc, img + N::ioff(l + 1), lay_of<N::istride(l + 1)>(ls), wave,           \
@@ -497,7 +481,6 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
             // layer 7 + loss: NT = 2 -> this wave holds both output tiles of ITS 16 rows
             ChainAcc<N::nt(7)> acc;
             static_assert(N::nt(7) < 4, "loss epilogue expects the M-split form");
-            acc_bias<N::nt(7)>(acc, bias + N::bo(7), wave, g);
             chain_mm<N, PART, SC::fstep(7), N::kb(7), N::nt(7), N::istride(7)>(acc, img + N::ioff(7) + lay_of<N::istride(7)>(ls).row,
                                                                              ring, ws, wave);
             const Lay &l8 = lay_of<N::istride(8)>(ls);
@@ -529,7 +512,6 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
             constexpr int ZI = (l) + 1;   /* dZ_l lives where X_{l+1} was; dZ_7 in image 8 */                               \
             if constexpr ((l) >= 1) {                                                                                        \
                 ChainAcc<N::ntb(l)> acc;                                                                                     \
-                acc_zero<N::ntb(l)>(acc);                                                                                    \
                 chain_mm<N, PART, SC::bstep(l), N::kbb(l), N::ntb(l), N::istride(ZI)>(                                       \
                     acc, img + N::ioff(ZI) + lay_of<N::istride(ZI)>(ls).row, ring, ws, wave);                                \
                 dw_phase<N, l, N::istride(ZI), N::istride(l)>(G, img + N::ioff(ZI), img + N::ioff(l),                        \
@@ -542,8 +524,7 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                 } else {                                                                                                     \
                     acc_visit<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,              \
                                                         [&](v4 &a, lds_p dst) {                                              \
-                                                            if (N::act((l) - 1)) lrelu_bwd4(a, lds_b64(dst));                \
-                                                            lds_w64(dst, pack4(a));                                          \
+                                                            lds_w64(dst, N::act((l) - 1) ? lrelu_bwd_pack4(a, lds_b64(dst)) : pack4(a)); \
                                                         });                                                                  \
                 }                                                                                                            \
                 __syncthreads();                                                                                             \
@@ -614,22 +595,20 @@ __global__ void __launch_bounds__(64) reduce_tiles_k(const v4 *__restrict__ slab
     }
 }
 
-// params (fp32, state-dict order) -> bf16 weight fragments [0, wcount) and fp32 bias fragments [wcount, wcount + bcount)
-// through one index map (-1: zero, -2: one -- the bias of an output padding slot that serves as the next layer's ones column)
-__global__ void __launch_bounds__(256) pack_train_k(const float *__restrict__ params, const int *__restrict__ src, int wcount,
-                                                    int bcount, __bf16 *__restrict__ wdst, float *__restrict__ bdst) {
+// params (fp32, state-dict order) -> bf16 weight fragments through an index map (-1: zero, -2: one)
+__global__ void __launch_bounds__(256) pack_train_k(const float *__restrict__ params, const int *__restrict__ src, int count,
+                                                    __bf16 *__restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= wcount + bcount) return;
+    if (i >= count) return;
     const int s = src[i];
-    const float v = s >= 0 ? params[s] : (s == -2 ? 1.0f : 0.f);
-    if (i < wcount) wdst[i] = (__bf16)v; else bdst[i - wcount] = v;
+    dst[i] = (__bf16)(s >= 0 ? params[s] : (s == -2 ? 1.0f : 0.f));
 }
 
 struct TrainOps;
 struct TrainState {
     const TrainOps *ops = nullptr;
-    DevBuf src, w, b, inv, dz;
-    int wcount = 0, bcount = 0, ntiles = 0, nparams = 0, n_features = 0;
+    DevBuf src, w, inv, dz;
+    int wcount = 0, ntiles = 0, nparams = 0, n_features = 0;
     int nwg_max = 256;
 };
 struct TrainOps {
@@ -640,7 +619,7 @@ TrainState *tstate(bamd_handle *h) { return (TrainState *)h->bf16_train_state; }
 
 template <int F, int Z> struct TImpl {
     using N = TNet<F, Z>;
-    static constexpr size_t lds_bytes() { return (size_t)N::img_bytes() + (size_t)N::nbias() * 16 + kRows * 32 * 4 + 64 * 8; }
+    static constexpr size_t lds_bytes() { return (size_t)N::img_bytes() + kRows * 32 * 4 + 64 * 8; }
     static_assert(lds_bytes() <= 160 * 1024, "LDS images exceed one CU");
     static bool matches(const bamd_handle *h) {
         if (h->L != 8) return false;
@@ -649,17 +628,22 @@ template <int F, int Z> struct TImpl {
         return true;
     }
     static int setup(bamd_handle *h, TrainState *st) {
-        const size_t wcount = (size_t)N::nfrag() * 512, bcount = (size_t)N::nbias() * 4;
-        std::vector<int> src(wcount + bcount, -1);
+        const size_t wcount = (size_t)N::nfrag() * 512;
+        std::vector<int> src(wcount, -1);
         for (int l = 0; l < N::L; ++l) {
             const int K = N::dim(l), NN = N::dim(l + 1);
-            // forward fragment (q, t): lane (i, g) element e = W[16 t + i][32 q + 8 g + e]
+            // forward fragment (q, t): lane (i, g) element e = [W | b | .][16 t + i][32 q + 8 g + e]: input column K (the ones
+            // slot of the image) holds the bias, and padding output K' = NN has a 1 there: it becomes the next image's ones slot
             for (int q = 0; q < N::kb(l); ++q)
                 for (int t = 0; t < N::nt(l); ++t)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
                             const int n = 16 * t + (lane & 15), k = 32 * q + 8 * (lane >> 4) + e;
-                            if (n < NN && k < K) src[((size_t)(N::ffo(l) + q * N::nt(l) + t) * 64 + lane) * 8 + e] = N::w_off(l) + n * K + k;
+                            int v = -1;
+                            if (n < NN && k < K) v = N::w_off(l) + n * K + k;
+                            else if (n < NN && k == K) v = N::b_off(l) + n;
+                            else if (n == NN && k == K) v = -2;
+                            src[((size_t)(N::ffo(l) + q * N::nt(l) + t) * 64 + lane) * 8 + e] = v;
                         }
             // backward fragment (q, t), l >= 1: lane (i, g) element e = W[32 q + 8 g + e][16 t + i]
             for (int q = 0; q < N::kbb(l) && l >= 1; ++q)
@@ -669,14 +653,10 @@ template <int F, int Z> struct TImpl {
                             const int n = 32 * q + 8 * (lane >> 4) + e, k = 16 * t + (lane & 15);
                             if (n < NN && k < K) src[((size_t)(N::bfo(l) + q * N::ntb(l) + t) * 64 + lane) * 8 + e] = N::w_off(l) + n * K + k;
                         }
-            // bias fragment (t, g) component r = b[16 t + 4 g + r]; output slot NN (padding) = 1: the next layer's ones column
-            for (int t = 0; t < N::nt(l); ++t)
-                for (int g = 0; g < 4; ++g)
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = 16 * t + 4 * g + r;
-                        src[wcount + ((size_t)N::bo(l) + t * 4 + g) * 4 + r] = n < NN ? N::b_off(l) + n : (n == NN ? -2 : -1);
-                    }
-            static_assert(N::dim(1) % 16 && N::dim(2) % 16 && N::dim(3) % 16 && N::dim(4) % 16, "every layer output needs a padding slot for the ones column");
+            static_assert(N::dim(0) % 32 && N::dim(1) % 32 && N::dim(2) % 32 && N::dim(3) % 32 && N::dim(4) % 32,
+                          "the ones slot must lie inside the last k block of every layer input");
+            static_assert(N::dim(1) % 16 && N::dim(2) % 16 && N::dim(3) % 16 && N::dim(4) % 16,
+                          "every layer output needs a padding slot for the ones column");
         }
         // accumulator tile (kt, nt) of layer l, lane (j, g), register r = dW[16 nt + 4 g + r][16 kt + j]; column K = db
         const int ntiles = N::slab_off(N::L);
@@ -699,14 +679,12 @@ template <int F, int Z> struct TImpl {
             for (int v : inv) if (v >= 0) seen[v]++;
             for (char c : seen) if (c != 1) { set_error("bf16 training: incomplete gradient map"); return BAMD_ERR_INVALID; }
         }
-        st->wcount = (int)wcount; st->bcount = (int)bcount; st->ntiles = ntiles; st->nparams = N::nparams(); st->n_features = F;
+        st->wcount = (int)wcount; st->ntiles = ntiles; st->nparams = N::nparams(); st->n_features = F;
         int rc = st->src.ensure(src.size() * sizeof(int));
         if (rc) return rc;
         rc = st->inv.ensure(inv.size() * sizeof(int));
         if (rc) return rc;
         rc = st->w.ensure(wcount * sizeof(__bf16) + 4096);
-        if (rc) return rc;
-        rc = st->b.ensure(bcount * sizeof(float));
         if (rc) return rc;
         BAMD_HIP(hipMemcpy(st->src.p, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
         BAMD_HIP(hipMemcpy(st->inv.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -723,10 +701,8 @@ template <int F, int Z> struct TImpl {
         if (rc) return rc;
         rc = st->dz.ensure((size_t)ngroups * kRows * 32);          // dL/dz hand-off: 16 bf16 per row, whole row groups
         if (rc) return rc;
-        hipLaunchKernelGGL((bf16_train_kernel<F, Z, 0>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, (const v4 *)st->b.p,
-                           x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
-        hipLaunchKernelGGL((bf16_train_kernel<F, Z, 1>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, (const v4 *)st->b.p,
-                           x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
+        hipLaunchKernelGGL((bf16_train_kernel<F, Z, 0>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
+        hipLaunchKernelGGL((bf16_train_kernel<F, Z, 1>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
         hipLaunchKernelGGL(reduce_tiles_k, dim3(st->ntiles + 1), dim3(64), 0, s, (const v4 *)h->slabs.p, grid, st->ntiles,
                            (const int *)st->inv.p, st->nparams, 1.0 / F, grads);
         BAMD_HIP(hipGetLastError());
@@ -762,7 +738,7 @@ int bf16_train_setup(bamd_handle *h) {
 void bf16_train_teardown(bamd_handle *h) {
     TrainState *st = tstate(h);
     if (!st) return;
-    st->src.release(); st->w.release(); st->b.release(); st->inv.release(); st->dz.release();
+    st->src.release(); st->w.release(); st->inv.release(); st->dz.release();
     delete st;
     h->bf16_train_state = nullptr;
 }
@@ -772,9 +748,8 @@ bool bf16_train_ok(const bamd_handle *h) { return h->bf16_train_state != nullptr
 int bf16_train_pack(bamd_handle *h, hipStream_t s) {
     TrainState *st = tstate(h);
     if (!st) return BAMD_OK;
-    const int count = st->wcount + st->bcount;
-    hipLaunchKernelGGL(pack_train_k, dim3((count + 255) / 256), dim3(256), 0, s, (const float *)h->params.p, (const int *)st->src.p,
-                       st->wcount, st->bcount, (__bf16 *)st->w.p, (float *)st->b.p);
+    hipLaunchKernelGGL(pack_train_k, dim3((st->wcount + 255) / 256), dim3(256), 0, s, (const float *)h->params.p,
+                       (const int *)st->src.p, st->wcount, (__bf16 *)st->w.p);
     BAMD_HIP(hipGetLastError());
     return BAMD_OK;
 }
