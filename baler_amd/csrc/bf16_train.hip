@@ -288,6 +288,9 @@ __device__ __forceinline__ void chain_mm_impl(ChainAcc<NT> &acc, lds_p in_row, R
                                               std::integer_sequence<int, Q...>) {
     using SP = Split<NT>;
     const bool last_ok = !SP::ragged || wave + 4 * (SP::NS - 1) < NT;      // wave-uniform
+#ifdef BAMD_ABLATE_CHAIN
+    return;
+#endif
     bf8 b[2][4];
     chain_load_b<NT, SIN>(b[0], in_row, wave, 0);
     (chain_step<N, PART, STEP0, KB, NT, SIN, Q>(acc, b, in_row, ring, ws, wave, last_ok), ...);
@@ -303,6 +306,9 @@ __device__ __forceinline__ void chain_mm(ChainAcc<NT> &acc, lds_p in_row /* imag
 template <int NT, int SOUT, class Fn>
 __device__ __forceinline__ void acc_visit(ChainAcc<NT> &acc, lds_p img, const Lay &lay, int wave, Fn fn) {
     using SP = Split<NT>;
+#ifdef BAMD_ABLATE_EPILOGUE
+    return;
+#endif
     // N-split slot k: tile t = wave + 4 k: parity of t = parity of wave, chunk pair 2 t -> 32 (t & ~1) bytes
     const lds_p wn = img + lay.wr(wave & 1) + 32 * (wave & ~1);
 #pragma unroll
@@ -325,6 +331,9 @@ __device__ __forceinline__ void acc_visit(ChainAcc<NT> &acc, lds_p img, const La
 template <class N, int l, int SZ, int SX>
 __device__ __forceinline__ void dw_phase(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave) {
     constexpr int NT = N::nt(l), KT = N::kt(l);
+#ifdef BAMD_ABLATE_DW
+    return;
+#endif
     if constexpr (N::by_nt(l)) {
         constexpr int NI = cdiv(NT, 4);
         const lds_p za = zimg + lz.tr(wave & 1) + 32 * (wave & ~1);      // tile nt = wave + 4 i -> + 128 i
@@ -507,6 +516,11 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
         }
 
         // ---- backward: per layer  [input-gradient MFMAs | weight-gradient tiles]  barrier  [epilogue in place]  barrier -
+#ifdef BAMD_EXP_NO_BARRIER
+#define BAMD_EXP_BARRIER
+#else
+#define BAMD_EXP_BARRIER __syncthreads();
+#endif
 #define BAMD_BWD(l, G)                                                                                                       \
         if constexpr (P::has(l)) {                                                                                           \
             constexpr int ZI = (l) + 1;   /* dZ_l lives where X_{l+1} was; dZ_7 in image 8 */                               \
@@ -516,7 +530,7 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                     acc, img + N::ioff(ZI) + lay_of<N::istride(ZI)>(ls).row, ring, ws, wave);                                \
                 dw_phase<N, l, N::istride(ZI), N::istride(l)>(G, img + N::ioff(ZI), img + N::ioff(l),                        \
                                                              lay_of<N::istride(ZI)>(ls), lay_of<N::istride(l)>(ls), wave);   \
-                __syncthreads();                                                                                             \
+                BAMD_EXP_BARRIER                                                                                             \
                 if constexpr (PART == 0 && (l) == P::bwd_lo) {                                                               \
                     /* hand-off to the second launch: dL/dz, 4 bf16 per lane = 32 B per row (en4 has no activation) */       \
                     static_assert(N::ntb(l) == 1, "dL/dz is one tile per row");                                              \

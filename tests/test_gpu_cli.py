@@ -105,6 +105,27 @@ def test_cli_train_compress_decompress(workspace, golden, monkeypatch, compute_m
         assert rel(comp["data"], z) < 1e-5
 
 
+def test_cli_bf16_training_mode(workspace, golden, monkeypatch):
+    """The whole C1 CLI run (25 epochs x 20 steps, then compress / decompress) with BALER_AMD_MODE=bf16: bf16 MFMA kernels
+    for training AND inference, fp32 master weights.  SURVEY.md section 0 acceptance for a reduced-precision mode: the loss
+    curve agrees with the reference's (g7) within 5 %; the checkpoint keeps the reference's format (float64 state dict)."""
+    g = golden("g7_c1_cli.npz")
+    out = workspace
+    for mode_name in ("train", "compress", "decompress"):
+        run_cli(mode_name, int(g["init_seed"]), "bf16", monkeypatch)
+    loss = np.load(out / "training" / "loss_data.npy")
+    assert loss.shape == (2, 25)
+    assert np.max(np.abs(loss[0] / g["loss_data"][0] - 1)) < 0.05
+    sd = torch.load(out / "compressed_output" / "model.pt")
+    assert all(v.dtype == torch.float64 for v in sd.values())
+    final = np.concatenate([v.numpy().ravel() for v in sd.values()])
+    comp = np.load(out / "compressed_output" / "compressed.npz")["data"]
+    z = orc.encode(orc.ae_dims(24, 15), final, orc.normalize(synth.cms_rows(10000)))
+    assert comp.shape == (10000, 15) and rel(comp, z) < 2e-2           # the bf16 inference bar
+    dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
+    assert dec.shape == (10000, 24) and np.isfinite(dec).all()
+
+
 def _reset_config():
     """helper.Config is a class mutated in place (like the reference's, helper.py:92-93): attributes of an
     earlier project (e.g. the CMS type_list) would leak into the next one within this test process."""
