@@ -506,8 +506,13 @@ def test_bf16_mode_encode_decode_forward(z_dim, data10k):
     assert np.array_equal(out[:, ~fl], np.trunc(out[:, ~fl]))
 
 
-def test_bf16_mode_training_calls_run_in_fp32(data10k):
-    """Training entry points of a bf16 handle run on the fp32 layer-wise kernels (1e-5 bar) and re-pack the bf16 weights."""
+@pytest.mark.parametrize("kernels", ["bf16", "fp32-layerwise"])
+def test_bf16_mode_training_calls(data10k, kernels, monkeypatch):
+    """Training entry points of a bf16 handle: the bf16 MFMA training kernels (their own 2e-2 bar, tests/test_gpu_bf16_train.py),
+    or -- with BALER_AMD_BF16_TRAIN=0 (read at bamd_create), and for shapes without an instantiation -- the fp32 layer-wise
+    kernels (1e-5 bar).  Either way the optimiser step reaches the packed bf16 weights that inference uses."""
+    if kernels == "fp32-layerwise":
+        monkeypatch.setenv("BALER_AMD_BF16_TRAIN", "0")
     dims = orc.ae_dims(24, 15)
     flat = orc.formula_params(dims, 9)
     h, p = make_handle(dims, flat, "bf16")
@@ -515,7 +520,7 @@ def test_bf16_mode_training_calls_run_in_fp32(data10k):
     grads = torch.zeros_like(p)
     h.fwd_bwd(dev(x, torch.float64), grads)
     lo, go = orc.fwd_bwd(dims, flat, x)
-    assert rel(grads.cpu().numpy()[:-1], go) < TOL32
+    assert rel(grads.cpu().numpy()[:-1], go) < (BF16_TOL if kernels == "bf16" else TOL32)
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     z0 = h.encode(dev(x))
     h.adam_step(p, grads, m, v, 1, 1e-2)
