@@ -64,10 +64,14 @@ if __name__ == "__main__":
 import numpy as np
 import torch
 
-# algorithmic (unpadded) work per row of AE(24,15): SURVEY.md section 8(d) / BASELINE.md section 4
+# algorithmic (unpadded) work per row: SURVEY.md section 8(d) / BASELINE.md section 4
 FLOP_TRAIN_ROW = 357_000
 FLOP_ENCODE_ROW = 61_100
-PEAK_TFLOPS = {"fp32": 157.3, "fp64": 78.6, "bf16": 2500.0}
+BYTES_TRAIN_ROW = 192            # the float64 input row, read once (algorithmic)
+BYTES_ENCODE_ROW = 192 + 120     # float64 row in, float64 latent row out
+FLOP_C4_ENCODE, FLOP_C4_TRAIN, FLOP_C5_ENCODE = 1_052_500, 5_315_000, 255_400
+PEAK_TFLOPS = {"fp32": 157.3, "fp64": 78.6, "bf16": 2500.0}        # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
 DTYPE_NAME = {"fp32": "f32", "fp64": "f64", "bf16": "bf16"}
 
 
@@ -79,8 +83,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=1_000_000, help="rows per GPU")
     ap.add_argument("--mode", default=os.environ.get("BALER_AMD_MODE", "fp32"), choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip encode/decode/bs512 side measurements")
-    ap.add_argument("--cpu-rows", type=int, default=400_000)
+    ap.add_argument("--no-extras", action="store_true", help="skip encode/decode/small-batch/bf16/C4/C5 side measurements")
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU baseline's epoch (bounded to ~20 s)")
     return ap.parse_args()
 
 
@@ -89,6 +93,17 @@ def log(msg):
 
 
 T0 = time.perf_counter()
+
+
+def source_hash():
+    """Hash of the kernel sources the running library was built from: a committed PMC summary is only quoted when it
+    was taken on the same sources."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "baler_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def timed(fn, steps, world, dev):
@@ -111,14 +126,38 @@ def timed(fn, steps, world, dev):
     return dt
 
 
+def event_ms(fn, reps):
+    """Average duration of fn on the launch stream by HIP events (fn must only enqueue work)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(rows):
-    """The reference's loops restated in plain PyTorch fp64 (oracle/torch_ref.py, bit-identical to the
-    imported reference in the authoring container): training.fit with DataLoader + loss.item() per step,
-    batch 512; helper.compress's encode loop.  Bounded sample of the same synthetic workload."""
+    """The reference's loops restated in plain PyTorch fp64 (oracle/torch_ref.py, bit-identical to the imported
+    reference in the authoring container): training.fit with DataLoader + loss.item() per step at batch 512, the
+    same epoch on pre-sliced batches (model time without the loader), and helper.compress's encode loop.  A BOUNDED
+    sample of the same synthetic workload (~20 s per leg); the rates are per row."""
     from baler_amd import synth
     from oracle import c_oracle as orc
     from oracle import torch_ref
-    data = orc.normalize(synth.cms_rows(rows))
+    full = orc.normalize(synth.cms_rows(min(rows, 1_000_000)))
     model = torch_ref.load_flat(torch_ref.DenseAE(24, 15), orc.formula_params(orc.ae_dims(24, 15), 7))
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     # 512-row fp64 GEMMs do not scale to every hardware thread of a big host: give the CPU its best
@@ -127,7 +166,7 @@ def cpu_baseline(rows):
     best, cores = None, 1
     for nt in sorted({min(hw, c) for c in (4, 8, 16, 32, 64)}):
         torch.set_num_threads(nt)
-        cal = torch_ref.make_loader(data[:10240], 512)
+        cal = torch_ref.make_loader(full[:10240], 512)
         torch_ref.fit_epoch(model, opt, cal)
         t0 = time.perf_counter()
         torch_ref.fit_epoch(model, opt, cal)
@@ -136,21 +175,36 @@ def cpu_baseline(rows):
         if best is None or dtc < best:
             best, cores = dtc, nt
     torch.set_num_threads(cores)
-    rows = int(min(rows, max(20480, 20.0 * 10240 / best)))  # bound the timed epoch to ~20 s
-    data = data[:rows]
+    n = int(min(len(full), max(20480, 20.0 * 10240 / best)))  # bound the timed epoch to ~20 s
+    data = full[:n]
     dl = torch_ref.make_loader(data, 512)
     t0 = time.perf_counter()
     torch_ref.fit_epoch(model, opt, dl)
     t_train = time.perf_counter() - t0
+    pre = list(torch.tensor(data, dtype=torch.float64).split(512))      # compute-only: batches sliced beforehand
     t0 = time.perf_counter()
-    torch_ref.compress_loop(model, data[:rows // 2], 512)
+    torch_ref.fit_epoch(model, opt, pre)
+    t_pre = time.perf_counter() - t0
+    n_enc = n // 2
+    t0 = time.perf_counter()
+    torch_ref.compress_loop(model, data[:n_enc], 512)
     t_enc = time.perf_counter() - t0
+    with torch.no_grad():
+        xe = torch.tensor(data[:n_enc], dtype=torch.float64)
+        t0 = time.perf_counter()
+        for b in xe.split(512):
+            model.encode(b)
+        t_enc_pre = time.perf_counter() - t0
     return {
-        "value": rows / t_train, "unit": "rows/s", "cores": cores, "kind": "port",
-        "encode_rows_per_s": (rows // 2) / t_enc,
-        "sample": f"{rows} rows x 24 cols, 1 epoch of training.fit at batch_size 512 through DataLoader "
-                  f"(fp64, torch {torch.__version__}, {cores} threads); encode loop of helper.compress on "
-                  f"{rows // 2} rows",
+        "value": n / t_train, "unit": "rows/s", "cores": cores, "kind": "port",
+        "train_compute_only_rows_per_s": n / t_pre,
+        "encode_rows_per_s": n_enc / t_enc, "encode_compute_only_rows_per_s": n_enc / t_enc_pre,
+        "cpu_model": cpu_model(), "hw_threads": hw, "rows_requested": rows, "rows_timed": n,
+        "compare_with": "train_rows_per_s_by_batch['512'] (the same batch_size = 512 regime), not `value` "
+                        "(one optimizer step per 1M-row batch)",
+        "sample": f"{n} of the {rows} requested rows x 24 cols (bounded to ~20 s per leg), 1 epoch of training.fit at "
+                  f"batch_size 512 through DataLoader (fp64, torch {torch.__version__}, {cores} of {hw} threads: the best "
+                  f"of 4..64), the same epoch on pre-sliced batches, and the encode loop of helper.compress on {n_enc} rows",
     }
 
 
@@ -216,46 +270,54 @@ def main():
         "config": {
             "workload": f"CMS 24-col AE(24,15) train step (fwd+loss+bwd+Adam), {a.rows} synthetic rows per GPU "
                         f"resident in HBM as float64, one optimizer step per pass (global batch = n_gpus x {a.rows}), "
-                        f"{a.mode} MFMA, random-init weights",
+                        f"{a.mode} MFMA (the 1e-5 parity mode), random-init weights",
             "rows_per_gpu": a.rows, "n_cols": 24, "latent": 15, "parallelism": f"dp{world}",
             "compute_mode": a.mode,
         },
         "train_rows_per_s": value, "last_batch_loss": final_loss,
         "rccl_ranks": bdist.rank_world()[1],
         "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
+        "source_hash": source_hash(),
     }
 
     achieved = FLOP_TRAIN_ROW * a.rows / (k_ms * 1e-3) / 1e12
-    # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
-    # separate runs, gfx950 x2 read correction), summarised under profiles/; counters cannot be read in-process
+    # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in separate
+    # runs, gfx950 x2 read correction; counters cannot be read in-process).  The committed summary is quoted only when it
+    # was taken on the kernel sources this library was built from; otherwise traffic is null.
     traffic = None
     try:
-        with open(os.path.join(REPO, "profiles", "r1_pmc_summary.json")) as f:
+        with open(os.path.join(REPO, "profiles", "pmc_summary.json")) as f:
             pm = json.load(f)
-        if pm.get("rows") == a.rows and a.mode == "fp32":
+        if pm.get("rows") == a.rows and a.mode == "fp32" and pm.get("source_hash") == out["source_hash"]:
             traffic = pm["fwd_bwd_hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
     out["roofline"] = {
         "bound": "mfma",
-        "kernel": "bamd_fwd_bwd = train_dec_kernel + train_enc_kernel (+ 0.02 ms partial-gradient reduction; the last 576 rows on the small-batch kernels)",
+        "kernel": "bamd_fwd_bwd = train_dec_kernel + train_enc_kernel + partial-gradient reduction",
         "achieved": achieved, "peak": PEAK_TFLOPS[a.mode], "unit": "TFLOP/s",
         "frac": achieved / PEAK_TFLOPS[a.mode], "traffic": traffic,
         "launch_ms": k_ms, "algorithmic_flop_per_row": FLOP_TRAIN_ROW, "rows_per_launch": a.rows,
     }
 
     if not a.no_extras:
+        extra_roof = {}
         # encode / decode passes over the same resident rows (no collectives: rows shard naturally)
         z = h.encode(x)
-        t_enc = timed(lambda: h.encode(x), max(3, a.steps // 2), world, dev)
         n_enc = max(3, a.steps // 2)
+        t_enc = timed(lambda: h.encode(x), n_enc, world, dev)
         out["encode_rows_per_s"] = world * a.rows * n_enc / t_enc
         t_dec = timed(lambda: h.decode(z), n_enc, world, dev)
         out["decode_rows_per_s"] = world * a.rows * n_enc / t_dec
         out["encode_tflops"] = FLOP_ENCODE_ROW * a.rows * n_enc / t_enc / 1e12
+        ms = event_ms(lambda: h.encode(x), 5)
+        extra_roof["encode_" + DTYPE_NAME[a.mode]] = {
+            "bound": "mfma", "kernel": "bamd_encode (infer2_kernel)", "launch_ms": ms, "unit": "TFLOP/s",
+            "achieved": FLOP_ENCODE_ROW * a.rows / ms / 1e9, "peak": PEAK_TFLOPS[a.mode],
+            "frac": FLOP_ENCODE_ROW * a.rows / ms / 1e9 / PEAK_TFLOPS[a.mode],
+            "hbm_gbs_algorithmic": BYTES_ENCODE_ROW * a.rows / ms / 1e6, "hbm_frac": BYTES_ENCODE_ROW * a.rows / ms / 1e6 / PEAK_HBM_GBS}
         if a.mode == "fp32":
-            # the bf16 inference mode on the same rows and weights (a throughput mode: ~2e-3 / 6e-3 rel. error on
-            # encode / decode, not the 1e-5 parity mode that `value` is measured in)
+            # ---- bf16 mode on the same rows and weights: a THROUGHPUT mode with its own 2e-2 bar (tests), never `value` ----
             hb = native.Handle(model.dims, "bf16")
             hb.load_params(flat)
             zb = hb.encode(x)
@@ -264,24 +326,73 @@ def main():
             out["bf16_encode_rows_per_s"] = world * a.rows * n_enc / t_b
             t_b = timed(lambda: hb.decode(z), n_enc, world, dev)
             out["bf16_decode_rows_per_s"] = world * a.rows * n_enc / t_b
+            ms = event_ms(lambda: hb.encode(x), 5)
+            extra_roof["encode_bf16"] = {
+                "bound": "hbm", "kernel": "bamd_encode (bf16_infer_kernel)", "launch_ms": ms, "unit": "GB/s",
+                "achieved": BYTES_ENCODE_ROW * a.rows / ms / 1e6, "peak": PEAK_HBM_GBS,
+                "frac": BYTES_ENCODE_ROW * a.rows / ms / 1e6 / PEAK_HBM_GBS,
+                "mfma_tflops": FLOP_ENCODE_ROW * a.rows / ms / 1e9, "mfma_frac": FLOP_ENCODE_ROW * a.rows / ms / 1e9 / PEAK_TFLOPS["bf16"]}
+            # bf16 MFMA TRAINING (BASELINE configs[1] names bf16): fp32 master weights + fp32 Adam, bf16 kernels
+            fb = flat.clone()
+            gb, mb, vb = torch.zeros_like(fb), torch.zeros_like(fb), torch.zeros_like(fb)
+            hb.load_params(fb)
+            tb = {"t": 0}
+
+            def bf16_step():
+                hb.fwd_bwd(x, gb)
+                if world > 1:
+                    bdist.allreduce_sum(gb)
+                tb["t"] += 1
+                hb.adam_step(fb, gb, mb, vb, tb["t"], 1e-3)
+            for _ in range(3):
+                bf16_step()
+            t_bt = timed(bf16_step, max(5, a.steps // 2), world, dev)
+            out["bf16_train_rows_per_s"] = world * a.rows * max(5, a.steps // 2) / t_bt
+            ms = event_ms(lambda: hb.fwd_bwd(x, gb), 5)
+            extra_roof["train_bf16"] = {
+                "bound": "mfma", "kernel": "bamd_fwd_bwd, BAMD_MODE_BF16 = bf16_train_kernel<PART 0> + <PART 1> + reduce_tiles_k",
+                "launch_ms": ms, "unit": "TFLOP/s", "achieved": FLOP_TRAIN_ROW * a.rows / ms / 1e9, "peak": PEAK_TFLOPS["bf16"],
+                "frac": FLOP_TRAIN_ROW * a.rows / ms / 1e9 / PEAK_TFLOPS["bf16"],
+                "hbm_gbs_algorithmic": BYTES_TRAIN_ROW * a.rows / ms / 1e6, "hbm_frac": BYTES_TRAIN_ROW * a.rows / ms / 1e6 / PEAK_HBM_GBS,
+                "last_batch_loss": float(gb[-1].item())}
             hb.close()
-        # strict reference batching: global batch 512 x n_gpus... kept at 512 rows per GPU, sequential steps
-        nb = 400
-        def bs512_pass():
-            for i in range(nb):
-                state["t"] += 1
-                if world == 1:      # what training.fit issues: one bamd_train_step per batch
-                    h.train_step(x[i * 512:(i + 1) * 512], flat, m, v, state["t"], 1e-3, loss_accum=loss_acc)
-                    continue
-                h.fwd_bwd(x[i * 512:(i + 1) * 512], grads)
-                bdist.allreduce_sum(grads)
-                h.adam_step(flat, grads, m, v, state["t"], 1e-3, loss_accum=loss_acc)
-        bs512_pass()
-        t512 = timed(bs512_pass, 1, world, dev)
-        out["train_bs512_rows_per_s"] = world * 512 * nb / t512
-        out["train_bs512_us_per_step"] = 1e6 * t512 / nb
+        # ---- the reference's batching regime and the curve up to the benchmarked batch: sequential optimizer steps ----
+        by_batch = {}
+        for bs in (512, 4096, 32768, 262144):
+            nb = max(2, min(400, a.rows // bs))
+            if bs * 2 > a.rows:
+                continue
+
+            def batch_pass():
+                for i in range(nb):
+                    state["t"] += 1
+                    xb = x[i * bs:(i + 1) * bs]
+                    if world == 1:      # what training.fit issues: one bamd_train_step per batch
+                        h.train_step(xb, flat, m, v, state["t"], 1e-3, loss_accum=loss_acc)
+                        continue
+                    h.fwd_bwd(xb, grads)
+                    bdist.allreduce_sum(grads)
+                    h.adam_step(flat, grads, m, v, state["t"], 1e-3, loss_accum=loss_acc)
+            batch_pass()
+            tb_ = timed(batch_pass, 1, world, dev)
+            by_batch[str(bs)] = {"rows_per_s": world * bs * nb / tb_, "us_per_step": 1e6 * tb_ / nb, "steps_timed": nb,
+                                 "tflops": FLOP_TRAIN_ROW * world * bs * nb / tb_ / 1e12,
+                                 "frac_of_mfma_peak": FLOP_TRAIN_ROW * bs * nb / tb_ / 1e12 / PEAK_TFLOPS[a.mode]}
+        out["train_rows_per_s_by_batch"] = by_batch
+        if "512" in by_batch:
+            out["train_bs512_rows_per_s"] = by_batch["512"]["rows_per_s"]
+            out["train_bs512_us_per_step"] = by_batch["512"]["us_per_step"]
+            extra_roof["train_bs512_" + DTYPE_NAME[a.mode]] = {
+                "bound": "latency", "kernel": "bamd_train_step at 512 rows (lat2_chain_kernel + lat2_dw_kernel<adam>)",
+                "launch_us": by_batch["512"]["us_per_step"] / 1.0, "unit": "TFLOP/s",
+                "achieved": by_batch["512"]["tflops"] / world, "peak": PEAK_TFLOPS[a.mode],
+                "frac": by_batch["512"]["frac_of_mfma_peak"]}
+        out["roofline_extra"] = extra_roof
         log(f"encode {out['encode_rows_per_s']:.4g} rows/s, decode {out['decode_rows_per_s']:.4g} rows/s, "
-            f"bs512 {out['train_bs512_rows_per_s']:.4g} rows/s ({out['train_bs512_us_per_step']:.1f} us/step)")
+            + ", ".join(f"bs{k} {v_['us_per_step']:.1f} us" for k, v_ in by_batch.items())
+            + (f", bf16 train {out['bf16_train_rows_per_s']:.4g} rows/s" if "bf16_train_rows_per_s" in out else ""))
+        if rank == 0 and world == 1 and a.mode == "fp32":
+            out["other_configs"] = other_configs(dev)
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_rows)
@@ -292,6 +403,37 @@ def main():
         import torch.distributed as td
         td.barrier()
         td.destroy_process_group()
+
+
+def other_configs(dev):
+    """BASELINE.json configs[3] (CFD 2-D field -> CFD_dense_AE(2500, 25)) and configs[4] (512-column table, encode only)
+    on one GPU, fp32 MFMA, so the driver's line carries them too (they are parity-test cases, not `value`)."""
+    from baler_amd import synth
+    from baler_amd.modules import models
+    res = {}
+    n = 32768
+    xc = torch.as_tensor(synth.cfd_field(n).reshape(n, 2500).astype(np.float32)).to(dev)
+    torch.manual_seed(0)
+    mc = models.CFD_dense_AE(2500, 25, mode="fp32").to(dev)
+    hc = mc.handle()
+    gc = torch.zeros_like(mc.flat)
+    ms_e = event_ms(lambda: hc.encode(xc), 3)
+    ms_t = event_ms(lambda: hc.fwd_bwd(xc, gc), 3)
+    res["c4_cfd_dense_2500_25"] = {
+        "frames": n, "encode_rows_per_s": n / ms_e * 1e3, "encode_frac_of_mfma_peak": FLOP_C4_ENCODE * n / ms_e / 1e9 / PEAK_TFLOPS["fp32"],
+        "train_fwd_bwd_rows_per_s": n / ms_t * 1e3, "train_frac_of_mfma_peak": FLOP_C4_TRAIN * n / ms_t / 1e9 / PEAK_TFLOPS["fp32"]}
+    hc.close()
+    del xc, gc
+    n = 262144
+    xw = torch.as_tensor(synth.wide_rows(n, 512).astype(np.float32)).to(dev)
+    mw = models.CFD_dense_AE(512, 6, mode="fp32").to(dev)
+    hw_ = mw.handle()
+    ms = event_ms(lambda: hw_.encode(xw), 3)
+    res["c5_encode_512col"] = {"rows": n, "encode_rows_per_s": n / ms * 1e3,
+                               "encode_frac_of_mfma_peak": FLOP_C5_ENCODE * n / ms / 1e9 / PEAK_TFLOPS["fp32"],
+                               "input_stream_gbs": 2048 * n / ms / 1e6}
+    hw_.close()
+    return res
 
 
 if __name__ == "__main__":
