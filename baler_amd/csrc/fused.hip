@@ -112,6 +112,9 @@ __device__ __forceinline__ WStream make_stream(const v4 *base, int bytes, int la
 __device__ __forceinline__ v4 frag(const WStream &ws, int idx) {
     return __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
 }
+__device__ __forceinline__ v4 frag_rt(const WStream &ws, int idx) {   // runtime (wave-uniform) fragment index
+    return __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
+}
 #ifndef BAMD_RING
 #define BAMD_RING 8
 #endif
@@ -285,6 +288,17 @@ template <class N> struct StreamTrainEnc {  // encoder-gradient kernel: forward 
     static constexpr int bwd_base(int l) { return (N::eb_off(l) - N::e_off()) / 64; }
     static constexpr int total = (N::eb_off(0) - N::e_off()) / 64;
     static constexpr int start_f4 = N::e_off();
+};
+
+template <class N> struct StreamWideEnc {   // wide models: forward fragments of layers 1..3 (layer 0 is streamed by its own loop)
+    static constexpr int fwd_base(int l) { return (N::wf_off(l) - N::wf_off(1)) / 64; }
+    static constexpr int total = (N::wf_off(4) - N::wf_off(1)) / 64;
+    static constexpr int start_f4 = N::wf_off(1);
+};
+template <class N> struct StreamWideDec {   // wide models: forward fragments of layers 4..6 (layer 7 is streamed by its own loop)
+    static constexpr int fwd_base(int l) { return (N::wf_off(l) - N::wf_off(4)) / 64; }
+    static constexpr int total = (N::wf_off(7) - N::wf_off(4)) / 64;
+    static constexpr int start_f4 = N::wf_off(4);
 };
 
 // ---- row I/O in slot order ------------------------------------------------------------------------------
@@ -567,6 +581,184 @@ __global__ void __launch_bounds__(256) infer2_kernel(const v4 *packed, const voi
             store_rows<F>(b8, out, out_f64, r1, v1, lane, feats, imask);
         }
         ring_tail<S::total>(ring, ws);
+    }
+}
+
+// ---- wide first / last layer (CFD_dense_AE(2500, 25): 2500 -> 200 -> ... -> 25 -> ... -> 200 -> 2500) ----------------------
+// 95 % of the model's work is en1 and de4, whose 2500-wide side cannot sit in registers the way the chain's tiles do.  They
+// are STREAMED: every wave owns 16 rows, keeps the 13 tiles of the 200-feature side in registers (the accumulators of en1,
+// the B operand of de4) and walks the wide dimension 16 features at a time -- one 16-byte row segment per lane and 13
+// 1-KiB weight fragments per 52 MFMAs (the register chain's ratio of one load per 4 MFMAs), fragments one chunk ahead in a
+// ping-pong register buffer.  The six narrow layers in between are the ordinary register chain.  One launch for encode,
+// one for decode; activations never touch HBM (the layer-wise path writes and re-reads 42 KB of them per row).
+template <int F>
+__device__ __forceinline__ v4 wide_x_chunk(const void *x, int in_f64, int64_t row, int kc, int g) {
+    // features 16 kc + 4 g .. + 3 of `row` (register r = MFMA step r, k = 4 g + r: the packed weights' order for full tiles);
+    // the partial last chunk is r-major (slot_feature): register 0 of lane group g = feature 16 kc + g, the rest padding
+    v4 v = (v4){0.f, 0.f, 0.f, 0.f};
+    if (16 * kc + 16 <= F) {
+        const int64_t i = row * F + 16 * kc + 4 * g;
+        if (in_f64) {
+            const double2 lo = *(const double2 *)((const double *)x + i), hi = *(const double2 *)((const double *)x + i + 2);
+            v = (v4){(float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y};
+        } else {
+            v = *(const v4 *)((const float *)x + i);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = slot_feature(F, kc, g, r);
+            if (f >= 0 && r < tile_steps(F, kc)) v[r] = in_f64 ? (float)((const double *)x)[row * F + f] : ((const float *)x)[row * F + f];
+        }
+    }
+    return v;
+}
+
+template <int F, int Z, int KIND>
+__global__ void __launch_bounds__(256) wide_infer_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
+                                                         void *__restrict__ out, int out_f64) {
+    using N = Net<F, Z>;
+    static_assert(KIND == K_ENCODE || KIND == K_DECODE, "encode or decode");
+    static_assert(N::dim(1) == 200 && N::dim(7) == 200, "13 register tiles on the narrow side of the wide layers");
+    using S = typename std::conditional<KIND == K_ENCODE, StreamWideEnc<N>, StreamWideDec<N>>::type;
+    constexpr int KC = tiles(F);                   // 16-feature chunks of the wide dimension
+    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
+    stage_bias<N>(bias_lds, packed);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int64_t ntile = (n + 15) / 16;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);                 // the chain's fragments
+    constexpr int WL = KIND == K_ENCODE ? 0 : 7;   // the streamed layer
+    WStream ww = make_stream(packed + N::wf_off(WL), N::wcount(WL) * 16, lane);                                  // its fragments: [q][t]
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 16 + (lane & 15);
+        const bool valid = row < n;
+        const int64_t rrow = valid ? row : 0;      // rows beyond n read row 0 (never stored)
+        asm volatile("" : "+v"(ws.voff), "+v"(ww.voff));   // keep the weight loads inside the loop (see infer_kernel)
+        if (KIND == K_ENCODE) {
+            // ---- en1, streamed over the 2500 input features: a1^T[13 tiles] += W[t][chunk] . x^T[chunk] ------------------
+            v4 a1[13];
+            init_bias(a1, bias_lds + (N::bf_off(0) - N::bf_off(0)), lane);
+            v4 wa[13], wb[13];
+            auto load_w = [&](v4 (&w)[13], int kc) {
+#pragma unroll
+                for (int t = 0; t < 13; ++t) w[t] = frag_rt(ww, kc * 13 + t);
+            };
+            auto mm = [&](const v4 (&w)[13], const v4 &xv, int kc) {
+                // 13 independent accumulators: consecutive MFMAs never wait on each other
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * kc + 16 <= F || r < tile_steps(F, KC - 1)) {
+#pragma unroll
+                        for (int t = 0; t < 13; ++t) a1[t] = mfma(w[t][r], xv[r], a1[t]);
+                    }
+            };
+            // x runs FOUR chunks ahead (first touch of a row segment comes from HBM: ~2 us against 0.8 us of MFMAs per chunk),
+            // the fragments (L2-resident) one chunk ahead; out-of-range prefetches re-read an earlier full chunk
+            v4 xr[4];
+            auto load_x = [&](int kc) { return wide_x_chunk<F>(xin, in_f64, rrow, kc < KC ? kc : 0, g); };
+            auto clampw = [&](int kc) { return kc < KC ? kc : KC - 1; };
+            load_w(wa, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xr[u] = load_x(u);
+            int kc = 0;
+            for (; kc + 4 <= KC; kc += 4) {              // chunks in fours (ping-pong fragment buffers, no register copies)
+                const int last = (F % 16) ? KC - 1 : -1; // index of the partial chunk
+                load_w(wb, clampw(kc + 1));
+                mm(wa, xr[0], kc == last ? KC - 1 : 0);
+                xr[0] = load_x(kc + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(wa, clampw(kc + 2));
+                mm(wb, xr[1], kc + 1 == last ? KC - 1 : 0);
+                xr[1] = load_x(kc + 5);
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(wb, clampw(kc + 3));
+                mm(wa, xr[2], kc + 2 == last ? KC - 1 : 0);
+                xr[2] = load_x(kc + 6);
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(wa, clampw(kc + 4));
+                mm(wb, xr[3], kc + 3 == last ? KC - 1 : 0);
+                xr[3] = load_x(kc + 7);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the last KC % 4 chunks: wa holds chunk kc's fragments, xr[u] chunk kc + u
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (kc + u < KC) {
+                    if (kc + u + 1 < KC) load_w(wb, kc + u + 1);
+                    mm(wa, xr[u], (kc + u == KC - 1 && F % 16) ? KC - 1 : 0);
+                    if (kc + u + 1 < KC) {
+#pragma unroll
+                        for (int t = 0; t < 13; ++t) wa[t] = wb[t];
+                    }
+                }
+            }
+            lrelu(a1);
+            // ---- layers 1..3: the register chain ---------------------------------------------------------------------------
+            Ring ring;
+            ring_prime<S::total>(ring, ws);
+            v4 a2[7], a3[4], a4[tiles(Z)];
+            fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
+            store_rows<Z>(a4, out, out_f64, row, valid, lane, nullptr, nullptr);
+        } else {
+            // ---- layers 4..6: the register chain -------------------------------------------------------------------------
+            Ring ring;
+            ring_prime<S::total>(ring, ws);
+            v4 a4[tiles(Z)], a5[4], a6[7], a7[13];
+            load_rows<Z>(a4, xin, in_f64, row, valid, lane, nullptr);
+            fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
+            // ---- de4, streamed over the 2500 output features, one tile at a time.  The 13 k tiles alternate between TWO
+            // accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, an independent one 32) that are added at the end
+            const v4 *bias7 = bias_lds + (N::bf_off(7) - N::bf_off(0));
+            v4 wa[13], wb[13];
+            auto load_w = [&](v4 (&w)[13], int t) {
+                t = t < KC ? t : KC - 1;
+#pragma unroll
+                for (int q = 0; q < 13; ++q) w[q] = frag_rt(ww, q * KC + t);
+            };
+            auto tile_out = [&](const v4 (&w)[13], int t) {
+                if (t >= KC) return;
+                v4 o0 = bias7[t * 4 + g], o1 = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 13; q += 2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (r < tile_steps(200, q)) o0 = mfma(w[q][r], a7[q][r], o0);
+                        if (q + 1 < 13 && r < tile_steps(200, q + 1)) o1 = mfma(w[q + 1][r], a7[q + 1][r], o1);
+                    }
+                const v4 o = o0 + o1;
+                if (!valid) return;
+                if (16 * t + 16 <= F) {              // full tile: the lane's 4 consecutive features as one vector store
+                    const int64_t i = row * F + 16 * t + 4 * g;
+                    if (out_f64) {
+                        *(double2 *)((double *)out + i) = make_double2((double)o[0], (double)o[1]);
+                        *(double2 *)((double *)out + i + 2) = make_double2((double)o[2], (double)o[3]);
+                    } else {
+                        *(v4 *)((float *)out + i) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = slot_feature(F, t, g, r);
+                        if (f >= 0) {
+                            if (out_f64) ((double *)out)[row * F + f] = (double)o[r]; else ((float *)out)[row * F + f] = o[r];
+                        }
+                    }
+                }
+            };
+            load_w(wa, 0);
+            for (int t0 = 0; t0 < KC; t0 += 2) {
+                load_w(wb, t0 + 1);
+                tile_out(wa, t0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(wa, t0 + 2);
+                tile_out(wb, t0 + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 }
 
@@ -986,9 +1178,6 @@ template <class N> struct Lat {
     static constexpr int xch_f4 = 13 * 64;                       // one exchange buffer: up to 13 tiles
 };
 
-__device__ __forceinline__ v4 frag_rt(const WStream &ws, int idx) {   // runtime (wave-uniform) fragment index
-    return __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
-}
 
 template <int NT> __device__ __forceinline__ void lat_collect(const v4 *xch, v4 (&all)[NT], int lane) {
 #pragma unroll
@@ -1730,6 +1919,76 @@ template <int F, int Z> struct ImplInfer {
     }
 };
 
+// Wide models (CFD_dense_AE(2500, 25), BASELINE.json configs[3]): encode and decode as ONE launch each on wide_infer_kernel;
+// training and forward_loss on the layer-wise path (the weight gradient of a 2500 x 200 layer is 2 MB of accumulators per
+// workgroup: it has to be a split-K GEMM).  Normalise-on-load / un-normalise-on-store go through a float32 staging buffer
+// (the per-feature min / range of 2500 features do not fit next to the chain's registers).
+template <int F, int Z> struct ImplWide {
+    using N = Net<F, Z>;
+    static constexpr int64_t kChunkRows = 1 << 18;     // staging chunk: 2.6 GB of float32 rows
+    static bool matches(const bamd_handle *h) {
+        if (h->L != 8) return false;
+        for (int i = 0; i <= 8; ++i)
+            if (h->dims[i] != N::dim(i)) return false;
+        return true;
+    }
+    static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, false>(h, st); }
+    static int grid_for(int64_t n) {
+        const int64_t wg = ((n + 15) / 16 + 3) / 4;
+        return (int)(wg < 1 ? 1 : (wg > 2048 ? 2048 : wg));
+    }
+    static int encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
+                      hipStream_t s) {
+        const size_t xes = x_dtype == BAMD_F64 ? 8 : 4, zes = z_dtype == BAMD_F64 ? 8 : 4;
+        for (int64_t r0 = 0; r0 < n; r0 += kChunkRows) {
+            const int64_t rows = n - r0 < kChunkRows ? n - r0 : kChunkRows;
+            const void *src = (const char *)x + (size_t)r0 * F * xes;
+            int src_f64 = x_dtype == BAMD_F64;
+            if (features) {
+                int rc = h->work.ensure((size_t)rows * F * sizeof(float));
+                if (rc) return rc;
+                rc = launch_normalize(src, x_dtype, rows, F, features, h->work.p, BAMD_F32, s);
+                if (rc) return rc;
+                src = h->work.p;
+                src_f64 = 0;
+            }
+            hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_ENCODE>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, src,
+                               src_f64, rows, (void *)((char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64);
+        }
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features, const uint8_t *int_mask,
+                      void *out, int out_dtype, hipStream_t s) {
+        const size_t zes = z_dtype == BAMD_F64 ? 8 : 4, oes = out_dtype == BAMD_F64 ? 8 : 4;
+        if (features && out_dtype != BAMD_F64) { set_error("decode with features needs a float64 output"); return BAMD_ERR_INVALID; }
+        for (int64_t r0 = 0; r0 < n; r0 += kChunkRows) {
+            const int64_t rows = n - r0 < kChunkRows ? n - r0 : kChunkRows;
+            void *dst = (char *)out + (size_t)r0 * F * oes;
+            void *kout = dst;
+            int kout_f64 = out_dtype == BAMD_F64;
+            if (features) {
+                int rc = h->work.ensure((size_t)rows * F * sizeof(float));
+                if (rc) return rc;
+                kout = h->work.p;
+                kout_f64 = 0;
+            }
+            hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_DECODE>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                               (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout, kout_f64);
+            if (features) {
+                int rc = launch_renormalize(kout, BAMD_F32, rows, F, features, int_mask, (double *)dst, s);
+                if (rc) return rc;
+            }
+        }
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static const FusedOps *ops() {
+        static const FusedOps o = {setup, encode, decode, nullptr, nullptr, nullptr};
+        return &o;
+    }
+};
+
 // Instantiated shapes: the CMS 24-column model at the usual compression ratios
 // (latent = ceil(24 / ratio): 1.6 -> 15, 2 -> 12, 3 -> 8, 4 -> 6).  Anything else runs on generic.hip.
 static const FusedOps *find_ops(const bamd_handle *h) {
@@ -1739,6 +1998,7 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     if (Impl<24, 8>::matches(h)) return Impl<24, 8>::ops();
     if (Impl<24, 6>::matches(h)) return Impl<24, 6>::ops();
     if (ImplInfer<512, 6>::matches(h)) return ImplInfer<512, 6>::ops();
+    if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();
     return nullptr;
 }
 

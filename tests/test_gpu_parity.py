@@ -308,6 +308,33 @@ def test_cfd_dense_golden(golden):
     assert rel(norms, g["grad_tensor_l2"]) < 1e-4
 
 
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 100, 1037])
+def test_cfd_dense_wide_layer_kernels_vs_oracle(n):
+    """CFD_dense_AE(2500, 25) encode / decode on the fused wide-layer kernels (en1 / de4 streamed, the six narrow layers on the
+    register chain) at ragged row counts, float32 and float64 rows, with and without the fused (un)normalisation, against the
+    oracle and against the layer-wise path (BALER_AMD_FORCE_GENERIC, the independent cross-check)."""
+    dims = orc.ae_dims(2500, 25)
+    flat = orc.formula_params(dims, 17)
+    h, _ = make_handle(dims, flat, "fp32")
+    raw = synth.cfd_field(n + 3)[3:].reshape(n, 2500)
+    mn, rg = raw.min(0) - 0.01, raw.max(0) - raw.min(0) + 0.02
+    xn = (raw - mn) / rg
+    z_ref = orc.encode(dims, flat, xn)
+    feats = dev(np.stack([mn, rg]))
+    for xin, f in ((dev(xn, torch.float32), None), (dev(xn), None), (dev(raw), feats), (dev(raw, torch.float32), feats)):
+        z = h.encode(xin, features=f, out_dtype=torch.float32)
+        assert rel(z.cpu().numpy(), z_ref) < (TOL32 if f is None or xin.dtype == torch.float64 else 2e-4), (xin.dtype, f is None)
+    rec_ref = orc.decode(dims, flat, z_ref)
+    for zin in (dev(z_ref, torch.float32), dev(z_ref)):
+        assert rel(h.decode(zin).cpu().numpy(), rec_ref) < TOL32
+    mask = np.zeros(2500, dtype=np.uint8)
+    mask[::7] = 1
+    dec = h.decode(dev(z_ref, torch.float32), features=feats, int_mask=torch.as_tensor(mask).cuda(), out_dtype=torch.float64).cpu().numpy()
+    want = rec_ref * rg + mn
+    want[:, mask == 1] = np.trunc(want[:, mask == 1])
+    assert np.isclose(dec, want, rtol=1e-4, atol=1e-6).mean() > 0.999        # a truncation may flip where want sits on an integer
+
+
 def test_wide_512_encoder_vs_oracle():
     dims = orc.ae_dims(512, 6)
     flat = orc.formula_params(dims, 41)
