@@ -652,40 +652,37 @@ __global__ void __launch_bounds__(256) wide_infer_kernel(const v4 *packed, const
                         for (int t = 0; t < 13; ++t) a1[t] = mfma(w[t][r], xv[r], a1[t]);
                     }
             };
-            // x runs FOUR chunks ahead (first touch of a row segment comes from HBM: ~2 us against 0.8 us of MFMAs per chunk),
-            // the fragments (L2-resident) one chunk ahead; out-of-range prefetches re-read an earlier full chunk
-            v4 xr[4];
+            // x runs kXA chunks ahead (first touch of a row segment comes from HBM: ~2 us against 0.8 us of MFMAs per chunk;
+            // 4 ahead left SQ_WAIT_ANY at 23 %), the fragments (L2-resident) one chunk ahead in ping-pong buffers (no register
+            // copies); out-of-range prefetches re-read chunk 0
+            constexpr int kXA = 8;
+            v4 xr[kXA];
             auto load_x = [&](int kc) { return wide_x_chunk<F>(xin, in_f64, rrow, kc < KC ? kc : 0, g); };
             auto clampw = [&](int kc) { return kc < KC ? kc : KC - 1; };
+            const int last = (F % 16) ? KC - 1 : -1;       // index of the partial chunk
             load_w(wa, 0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xr[u] = load_x(u);
+            for (int u = 0; u < kXA; ++u) xr[u] = load_x(u);
             int kc = 0;
-            for (; kc + 4 <= KC; kc += 4) {              // chunks in fours (ping-pong fragment buffers, no register copies)
-                const int last = (F % 16) ? KC - 1 : -1; // index of the partial chunk
-                load_w(wb, clampw(kc + 1));
-                mm(wa, xr[0], kc == last ? KC - 1 : 0);
-                xr[0] = load_x(kc + 4);
-                __builtin_amdgcn_sched_barrier(0);
-                load_w(wa, clampw(kc + 2));
-                mm(wb, xr[1], kc + 1 == last ? KC - 1 : 0);
-                xr[1] = load_x(kc + 5);
-                __builtin_amdgcn_sched_barrier(0);
-                load_w(wb, clampw(kc + 3));
-                mm(wa, xr[2], kc + 2 == last ? KC - 1 : 0);
-                xr[2] = load_x(kc + 6);
-                __builtin_amdgcn_sched_barrier(0);
-                load_w(wa, clampw(kc + 4));
-                mm(wb, xr[3], kc + 3 == last ? KC - 1 : 0);
-                xr[3] = load_x(kc + 7);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // the last KC % 4 chunks: wa holds chunk kc's fragments, xr[u] chunk kc + u
+            for (; kc + kXA <= KC; kc += kXA) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+                for (int p = 0; p < kXA / 2; ++p) {
+                    load_w(wb, clampw(kc + 2 * p + 1));
+                    mm(wa, xr[2 * p], kc + 2 * p == last ? KC - 1 : 0);
+                    xr[2 * p] = load_x(kc + 2 * p + kXA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_w(wa, clampw(kc + 2 * p + 2));
+                    mm(wb, xr[2 * p + 1], kc + 2 * p + 1 == last ? KC - 1 : 0);
+                    xr[2 * p + 1] = load_x(kc + 2 * p + 1 + kXA);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the last KC % kXA chunks: wa holds chunk kc's fragments, xr[u] chunk kc + u
+#pragma unroll
+            for (int u = 0; u < kXA - 1; ++u) {
                 if (kc + u < KC) {
                     if (kc + u + 1 < KC) load_w(wb, kc + u + 1);
-                    mm(wa, xr[u], (kc + u == KC - 1 && F % 16) ? KC - 1 : 0);
+                    mm(wa, xr[u], (kc + u == last) ? KC - 1 : 0);
                     if (kc + u + 1 < KC) {
 #pragma unroll
                         for (int t = 0; t < 13; ++t) wa[t] = wb[t];

@@ -418,9 +418,12 @@ def other_configs(dev):
     hc = mc.handle()
     gc = torch.zeros_like(mc.flat)
     ms_e = event_ms(lambda: hc.encode(xc), 3)
+    zc = hc.encode(xc)
+    ms_d = event_ms(lambda: hc.decode(zc), 3)
     ms_t = event_ms(lambda: hc.fwd_bwd(xc, gc), 3)
     res["c4_cfd_dense_2500_25"] = {
         "frames": n, "encode_rows_per_s": n / ms_e * 1e3, "encode_frac_of_mfma_peak": FLOP_C4_ENCODE * n / ms_e / 1e9 / PEAK_TFLOPS["fp32"],
+        "decode_rows_per_s": n / ms_d * 1e3, "decode_frac_of_mfma_peak": FLOP_C4_ENCODE * n / ms_d / 1e9 / PEAK_TFLOPS["fp32"],
         "train_fwd_bwd_rows_per_s": n / ms_t * 1e3, "train_frac_of_mfma_peak": FLOP_C4_TRAIN * n / ms_t / 1e9 / PEAK_TFLOPS["fp32"]}
     hc.close()
     del xc, gc

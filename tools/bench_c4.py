@@ -17,6 +17,9 @@ def timeit(fn, k=3):
     for _ in range(k): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / k
 te = timeit(lambda: h.encode(x))
+z = h.encode(x)
+td = timeit(lambda: h.decode(z))
 tt = timeit(lambda: h.fwd_bwd(x, grads))
 print(f"C4 N={n}: encode {n / te / 1e6:.2f} M rows/s ({1052500 * n / te / 1e12:.1f} TFLOP/s, {100 * 1052500 * n / te / 157.3e12:.0f}% of fp32 MFMA peak); "
+      f"decode {n / td / 1e6:.2f} M rows/s ({100 * 1052500 * n / td / 157.3e12:.0f}%); "
       f"train fwd_bwd {n / tt / 1e6:.2f} M rows/s ({5315000 * n / tt / 1e12:.1f} TFLOP/s, {100 * 5315000 * n / tt / 157.3e12:.0f}%), {tt * 1e3:.1f} ms")
