@@ -1994,7 +1994,10 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     if (Impl<24, 12>::matches(h)) return Impl<24, 12>::ops();
     if (Impl<24, 8>::matches(h)) return Impl<24, 8>::ops();
     if (Impl<24, 6>::matches(h)) return Impl<24, 6>::ops();
-    if (ImplInfer<512, 6>::matches(h)) return ImplInfer<512, 6>::ops();
+    if (ImplWide<512, 6>::matches(h)) {   // BALER_AMD_WIDE512=0: the all-in-registers chain (A/B runs)
+        const char *e = getenv("BALER_AMD_WIDE512");
+        return (e && e[0] == '0') ? ImplInfer<512, 6>::ops() : ImplWide<512, 6>::ops();
+    }
     if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();
     return nullptr;
 }

@@ -340,7 +340,11 @@ def test_wide_512_encoder_vs_oracle():
     flat = orc.formula_params(dims, 41)
     h, _ = make_handle(dims, flat, "fp32")
     x = synth.wide_rows(300, 512)
-    assert rel(h.encode(dev(x, torch.float32)).cpu().numpy(), orc.encode(dims, flat, x)) < TOL32
+    z = orc.encode(dims, flat, x)
+    assert rel(h.encode(dev(x, torch.float32)).cpu().numpy(), z) < TOL32
+    assert rel(h.encode(dev(x)).cpu().numpy(), z) < TOL32
+    # decode runs on the same streamed wide-layer kernel (de4: 200 -> 512)
+    assert rel(h.decode(dev(z, torch.float32)).cpu().numpy(), orc.decode(dims, flat, z)) < TOL32
 
 
 # ---- size-independent properties at BASELINE.json's full single-GPU size --------------------------
