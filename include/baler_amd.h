@@ -52,11 +52,14 @@ typedef enum bamd_dtype { BAMD_F32 = 0, BAMD_F64 = 1 } bamd_dtype;
 
 /* arithmetic the Linear layers run in.  F32 = v_mfma_f32_16x16x4_f32 (exact fp32, the parity mode:
  * outputs within 1e-5 rel. of the fp64 reference).  F64 = v_mfma_f64_16x16x4_f64 (long-horizon
- * training parity).  BF16 = inference (bamd_encode / bamd_decode / bamd_forward_loss) on
- * v_mfma_f32_16x16x32_bf16 with fp32 accumulation, weights rounded from the fp32 master copy and kept in
- * LDS: a THROUGHPUT mode for compress / decompress (outputs within ~1e-2 rel.; measured 2e-3 encode,
- * 6e-3 decode), 4-5x the F32 rate.  Available for the 24-column AE (latent 15/12/8/6); training
- * entry points of a BF16 handle run on the fp32 layer-wise kernels and re-pack the bf16 weights. */
+ * training parity).  BF16 = v_mfma_f32_16x16x32_bf16 with fp32 accumulation: a THROUGHPUT mode with its own 2e-2 bar.
+ * Inference (bamd_encode / bamd_decode / bamd_forward_loss): weights rounded from the fp32 master copy and kept in LDS,
+ * 4-5x the F32 rate (measured 2e-3 encode, 6e-3 decode).  Training (bamd_fwd_bwd / bamd_train_step): bf16 weights,
+ * activations and gradients through the chain, fp32 accumulation and fp32 partial gradients; params / m / v / grads stay
+ * FLOAT (the caller's fp32 master copy and Adam state); bamd_adam_step re-rounds the bf16 fragments.  3.3x the F32 training
+ * rate; one-step gradients within ~5e-3 rel-L2 of the fp64 reference.  Available for the 24-column AE (latent 15/12/8/6);
+ * other shapes of a BF16 handle are rejected by bamd_create.  bamd_fwd_bwd_latent and bamd_activation_means of a BF16
+ * handle run on the fp32 layer-wise kernels. */
 typedef enum bamd_mode { BAMD_MODE_F32 = 0, BAMD_MODE_F64 = 1, BAMD_MODE_BF16 = 2 } bamd_mode;
 
 /* Adam hyper-parameters of one step (torch.optim.Adam defaults are beta1=.9 beta2=.999 eps=1e-8). */
