@@ -105,6 +105,8 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
     if (rc) { delete h; return rc; }
     rc = fused_setup(h);
     if (rc) { bamd_destroy(h); return rc; }
+    rc = fused64_setup(h);
+    if (rc) { bamd_destroy(h); return rc; }
     if (mode == BAMD_MODE_BF16) {   // inference on bf16 MFMA; training calls of such a handle run on the fp32 layer-wise kernels
         rc = bf16_setup(h);
         if (rc) { bamd_destroy(h); return rc; }
@@ -119,6 +121,7 @@ void bamd_destroy(bamd_handle *h) {
     if (!h) return;
     DeviceGuard guard(h->device);
     fused_teardown(h);
+    fused64_teardown(h);
     bf16_teardown(h);
     bf16_train_teardown(h);
     h->params.release();
@@ -147,6 +150,7 @@ int bamd_load_params(bamd_handle *h, const void *params, int dtype, void *stream
         h->bf16_infer_stale = false;
         return rc ? rc : bf16_train_pack(h, s);
     }
+    if (h->mode == BAMD_MODE_F64) return fused64_pack(h, s);
     return fused_pack(h, s);
 }
 
@@ -226,6 +230,10 @@ int bamd_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, con
         return BAMD_OK;
     }
     if (h->fused_ok) return fused_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
+    if (h->mode == BAMD_MODE_F64) {   // small batches: fp64 chain + weight-gradient tiles; otherwise the layer-wise kernels
+        int rc = fused64_step(h, x, x_dtype, n_rows, features, grads, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+        if (rc != BAMD_ERR_UNSUPPORTED) return rc;
+    }
     if (h->mode == BAMD_MODE_BF16 && bf16_train_ok(h)) return bf16_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
     return generic_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
 }
@@ -254,6 +262,7 @@ int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, voi
     const int *sc_off = nullptr, *sc_idx = nullptr;
     void *packed = nullptr;
     fused_scatter(h, &sc_off, &sc_idx, &packed);   // Adam also refreshes the packed weight copy (one launch)
+    if (h->mode == BAMD_MODE_F64) fused64_scatter(h, &sc_off, &sc_idx, &packed);
     int rc = launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, sc_off, sc_idx, packed, s);
     if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16) {
         if (bf16_train_ok(h)) { h->bf16_infer_stale = true; rc = bf16_train_pack(h, s); }   // the next step's fragments now, the inference ones on demand
@@ -271,6 +280,10 @@ int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, 
     if (n_rows > 0) {
         int rc = fused_train_step(h, x, x_dtype, n_rows, features, grads, params, m, v, *hp, loss_accum, s);
         if (rc != BAMD_ERR_UNSUPPORTED) return rc;
+        if (h->mode == BAMD_MODE_F64) {
+            rc = fused64_step(h, x, x_dtype, n_rows, features, grads, params, m, v, hp, loss_accum, s);
+            if (rc != BAMD_ERR_UNSUPPORTED) return rc;
+        }
     }
     if (!grads) {
         int rc = h->gscratch.ensure((size_t)(h->nparams + 1) * h->esize);

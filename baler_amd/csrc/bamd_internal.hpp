@@ -62,6 +62,7 @@ struct bamd_handle {
     bool params_loaded = false;
     bool fused_ok = false;          // shape is served by the fused register-chained kernels
     void *fused_state = nullptr;    // index maps of the fused path (fused.hip)
+    void *fused64_state = nullptr;  // maps + packed fp64 weights of the fp64 small-batch step (fused64.hip)
     void *bf16_state = nullptr;     // packed bf16 weights + maps of the bf16 inference mode (bf16.hip)
     void *bf16_train_state = nullptr;   // packed bf16 weights + maps of the bf16 training kernels (bf16_train.hip)
     bool bf16_infer_stale = false;  // the inference fragments lag h->params (re-packed lazily by the next inference call)

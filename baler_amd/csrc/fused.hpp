@@ -20,4 +20,13 @@ int fused_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const d
 // batch size has no such path (the caller then runs fused_fwd_bwd / generic_fwd_bwd followed by launch_adam)
 int fused_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
                      void *params, void *m, void *v, const bamd_adam &hp, double *loss_accum, hipStream_t s);
+// fp64 small-batch step (fused64.hip): chain + weight-gradient tiles on v_mfma_f64_16x16x4_f64 for BAMD_MODE_F64 handles
+int fused64_setup(bamd_handle *h);               // leaves h->fused64_state null for shapes without an instantiation
+void fused64_teardown(bamd_handle *h);
+int fused64_pack(bamd_handle *h, hipStream_t s); // h->params (fp64) -> fragment-packed fp64 weights
+void fused64_scatter(bamd_handle *h, const int **sc_off, const int **sc_idx, void **packed);   // for the fused Adam + pack kernel
+// fwd + loss + bwd (hp == nullptr) or the whole training step (hp != nullptr) of a small batch; BAMD_ERR_UNSUPPORTED when this
+// handle / batch size has no such path (the caller then runs the layer-wise kernels)
+int fused64_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, void *params, void *m,
+                 void *v, const bamd_adam *hp, double *loss_accum, hipStream_t s);
 }  // namespace bamd

@@ -1,0 +1,547 @@
+// fp64 small-batch training step of AE(F, Z) on v_mfma_f64_16x16x4_f64 (BAMD_MODE_F64): the reference's own dtype
+// (models.py:128-136) at the reference's batch size -- the mode that pins 500-step CLI runs at 1e-9.  Same two-launch
+// structure as the fp32 small-batch step in fused.hip (a workgroup owns ONE 16-row block and its 4 waves split every
+// layer's output tiles, swapping tiles through a double-buffered LDS exchange; then one workgroup per weight-gradient
+// tile over the whole batch, optionally fused with Adam and the refresh of the packed weights), re-derived for the
+// f64 MFMA, whose C/D map is NOT the f32 one:
+//     f32 16x16x4:  D row = 4 (lane >> 4) + reg        f64 16x16x4:  D row = (lane >> 4) + 4 reg
+// so register r of an output tile on lane group g holds feature 16 t + 4 r + g, and -- because the B operand of MFMA
+// step r takes k = g from lane group g -- step r of the next layer consumes exactly features 16 q + 4 r .. + 3: the chain
+// closes with NATURAL feature order (slot s = feature s; no g-major / r-major distinction between full and partial tiles).
+// Batches above FusedState64::max_rows and the inference entry points stay on the layer-wise kernels (generic.hip).
+#include "fused.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <utility>
+
+namespace bamd {
+namespace {
+
+using d4 = double __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int tiles(int d) { return (d + 15) / 16; }
+__host__ __device__ constexpr int tile_steps(int d, int t) { return d - 16 * t >= 16 ? 4 : (d - 16 * t + 3) / 4; }
+// feature held by register r of tile t on lane group g (-1 = padding)
+__host__ __device__ constexpr int creg_feature(int d, int t, int g, int r) { return 16 * t + 4 * r + g < d ? 16 * t + 4 * r + g : -1; }
+
+template <int F, int Z> struct Net64 {
+    static constexpr int L = 8;
+    __host__ __device__ static constexpr int dim(int i) {
+        return i == 0 ? F : i == 1 ? 200 : i == 2 ? 100 : i == 3 ? 50 : i == 4 ? Z : i == 5 ? 50 : i == 6 ? 100 : i == 7 ? 200 : F;
+    }
+    __host__ __device__ static constexpr bool act(int l) { return !(l == 3 || l == 7); }
+    // packed buffer (d4 units = 32 bytes; a fragment = 64 lanes x d4 = 2 KiB): [ Wf(0..7) | Wb(7..1) | bias fragments ]
+    __host__ __device__ static constexpr int wcount(int l) { return tiles(dim(l)) * tiles(dim(l + 1)) * 64; }
+    __host__ __device__ static constexpr int wf_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += wcount(j); return s; }
+    __host__ __device__ static constexpr int wb_off(int l) { int s = wf_off(L); for (int j = L - 1; j > l; --j) s += wcount(j); return s; }
+    __host__ __device__ static constexpr int bf_off(int l) { int s = wb_off(0); for (int j = 0; j < l; ++j) s += tiles(dim(j + 1)) * 4; return s; }
+    __host__ __device__ static constexpr int packed_d4() { return bf_off(L) + 64; }
+    __host__ __device__ static constexpr int dw_tiles(int l) { return tiles(dim(l + 1)) * tiles(dim(l) + 1); }
+    __host__ __device__ static constexpr int slab_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += dw_tiles(j); return s; }
+    __host__ __device__ static constexpr int w_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += dim(j + 1) * dim(j) + dim(j + 1); return s; }
+    __host__ __device__ static constexpr int b_off(int l) { return w_off(l) + dim(l + 1) * dim(l); }
+    __host__ __device__ static constexpr int nparams() { return w_off(L); }
+    // global images of the chain: [16-row block][slot][16 rows]; X_l has 16 tiles(dim(l) + 1) slots (with the ones slot), dZ_l 16 tiles(dim(l+1))
+    __host__ __device__ static constexpr int x_rows(int l) { return 16 * tiles(dim(l) + 1); }
+    __host__ __device__ static constexpr int z_rows(int l) { return 16 * tiles(dim(l + 1)); }
+    __host__ __device__ static constexpr int x_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += x_rows(j); return s; }
+    __host__ __device__ static constexpr int z_off(int l) { int s = x_off(L); for (int j = 0; j < l; ++j) s += z_rows(j); return s; }
+    static constexpr int img_doubles = z_off(L) * 16;
+};
+
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;   // lane * 32
+};
+// fragment idx of the stream: two 16-byte halves per lane
+__device__ __forceinline__ d4 frag_rt(const WStream &ws, int idx) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const u4 lo = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 2048, 0);
+    const u4 hi = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff + 16, idx * 2048, 0);
+    const d2 a = __builtin_bit_cast(d2, lo), b = __builtin_bit_cast(d2, hi);
+    return (d4){a[0], a[1], b[0], b[1]};
+}
+
+// The 15 chain GEMMs of one step as ONE fragment sequence per wave (forward layers 0..7, then the transposed fragments
+// of layers 7..1); a register ring runs D fragments ahead of the MFMAs across layer boundaries (see fused.hip LatSeq).
+template <class N, int W, int D_> struct Seq {
+    static constexpr int D = D_, Wv = W, NG = 15;
+    __host__ __device__ static constexpr int layer(int g) { return g < 8 ? g : 15 - g; }
+    __host__ __device__ static constexpr int kd(int g) { return g < 8 ? N::dim(g) : N::dim(layer(g) + 1); }
+    __host__ __device__ static constexpr int nt(int g) { return tiles(g < 8 ? N::dim(g + 1) : N::dim(layer(g))); }
+    __host__ __device__ static constexpr int base(int g) { return (g < 8 ? N::wf_off(g) : N::wb_off(layer(g))) / 64; }
+    __host__ __device__ static constexpr int nl(int g) { return (nt(g) + W - 1) / W; }
+    __host__ __device__ static constexpr int nf(int g) { return tiles(kd(g)) * nl(g); }
+    __host__ __device__ static constexpr int start(int g) { int s = 0; for (int j = 0; j < g; ++j) s += nf(j); return s; }
+    static constexpr int total = start(NG);
+    __host__ __device__ static constexpr int gemm_of(int G) { int g = 0; for (int j = 1; j < NG; ++j) if (G >= start(j)) g = j; return g; }
+};
+template <class SQ, int G>
+__device__ __forceinline__ void seq_issue(d4 (&slot)[SQ::D], const WStream &ws, int wave) {
+    if constexpr (G < SQ::total) {
+        constexpr int g = SQ::gemm_of(G), f = G - SQ::start(g), NL = SQ::nl(g), q = f / NL, i = f % NL, NT = SQ::nt(g);
+        int t = wave + SQ::Wv * i;
+        t = t < NT ? t : NT - 1;
+        slot[G % SQ::D] = frag_rt(ws, SQ::base(g) + q * NT + t);
+    }
+}
+template <class SQ, int... G>
+__device__ __forceinline__ void seq_prologue(d4 (&slot)[SQ::D], const WStream &ws, int wave, std::integer_sequence<int, G...>) {
+    (seq_issue<SQ, G>(slot, ws, wave), ...);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class SQ, int g, int f>
+__device__ __forceinline__ void seq_one(const d4 (&in)[tiles(SQ::kd(g))], d4 (&out)[SQ::nl(g)], d4 (&slot)[SQ::D], const WStream &ws,
+                                        int wave) {
+    constexpr int NL = SQ::nl(g), S0 = SQ::start(g), KD = SQ::kd(g), q = f / NL, i = f % NL, s = (S0 + f) % SQ::D;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (r < tile_steps(KD, q)) out[i] = mfma(slot[s][r], in[q][r], out[i]);
+    seq_issue<SQ, S0 + f + SQ::D>(slot, ws, wave);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class SQ, int g, int... P>
+__device__ __forceinline__ void seq_mm_impl(const d4 (&in)[tiles(SQ::kd(g))], d4 (&out)[SQ::nl(g)], d4 (&slot)[SQ::D], const WStream &ws,
+                                            int wave, std::integer_sequence<int, P...>) {
+    (seq_one<SQ, g, P>(in, out, slot, ws, wave), ...);
+}
+template <class SQ, int g>
+__device__ __forceinline__ void seq_mm(const d4 (&in)[tiles(SQ::kd(g))], d4 (&out)[SQ::nl(g)], d4 (&slot)[SQ::D], const WStream &ws,
+                                       int wave) {
+    seq_mm_impl<SQ, g>(in, out, slot, ws, wave, std::make_integer_sequence<int, SQ::nf(g)>{});
+}
+
+template <int NT> __device__ __forceinline__ void collect(const d4 *xch, d4 (&all)[NT], int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) all[t] = xch[t * 64 + lane];
+}
+template <int NL> __device__ __forceinline__ void lrelu(d4 (&a)[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[i][r] = a[i][r] > 0.0 ? a[i][r] : a[i][r] * kSlope;
+}
+template <int NL> __device__ __forceinline__ void lrelu_bwd(d4 (&d)[NL], const d4 (&y)[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[i][r] = y[i][r] > 0.0 ? d[i][r] : d[i][r] * kSlope;
+}
+
+// own tiles -> LDS exchange buffer (C layout) and -> the global [slot][16 rows] image; slot of register (g, r) of tile t =
+// 16 t + g + 4 r (natural feature order).  ONES: the first padding slot of dimension D is the ones column that carries db.
+template <int D, bool ONES, int W>
+__device__ __forceinline__ void publish(d4 *xch, double *img, int slot0, const d4 (&loc)[(tiles(D) + W - 1) / W], int lane, int wave) {
+    constexpr int NT = tiles(D), NL = (NT + W - 1) / W;
+    constexpr int T1 = tiles(D) - 1, V = D - 16 * T1;      // V = slot of the ones column inside tile T1 (D % 16 != 0)
+    const int g = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int t = wave + W * i;
+        if (t < NT) {
+            if (xch) xch[t * 64 + lane] = loc[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = loc[i][r];
+                if (ONES && t == T1 && g + 4 * r == V) v = 1.0;
+                img[(slot0 + 16 * t + g + 4 * r) * 16 + col] = v;
+            }
+        }
+    }
+}
+
+template <int F, int Z, int W>
+__global__ void __launch_bounds__(64 * W) chain64_kernel(const d4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
+                                                         const double *__restrict__ feats, double *__restrict__ imgs,
+                                                         double *__restrict__ loss_part) {
+    using N = Net64<F, Z>;
+    constexpr int TF = tiles(F), TZ = tiles(Z);
+    static_assert(TF <= W && TZ == 1 && F % 16 != 0, "input / latent tiles");
+    constexpr int kNB = N::bf_off(N::L) - N::bf_off(0);
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    d4 *xchA = (d4 *)lds_raw, *xchB = xchA + 13 * 64, *bias_lds = xchB + 13 * 64;
+    __shared__ double loss_lds[W];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    WStream ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)packed, 0, N::packed_d4() * 32, 0x00020000);
+    ws.voff = lane * 32;
+    // rows first (layer 0 waits for them), then the ring's first fragments queue up behind them
+    const int64_t row = (int64_t)blockIdx.x * 16 + (lane & 15);
+    const bool valid = row < n;
+    const int64_t rbase = (valid ? row : 0) * F;
+    d4 a0[TF];
+#pragma unroll
+    for (int t = 0; t < TF; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = creg_feature(F, t, g, r);
+            const int fc = f >= 0 ? f : 0;                        // padding slots read feature 0 (finite, meets zero weights)
+            double v = in_f64 ? ((const double *)xin)[rbase + fc] : (double)((const float *)xin)[rbase + fc];
+            if (feats) v = (v - feats[fc]) / feats[F + fc];
+            a0[t][r] = f >= 0 ? v : 0.0;
+        }
+    using SQ = Seq<N, W, 12>;
+    d4 ring[SQ::D];
+    for (int i = threadIdx.x; i < kNB; i += 64 * W) bias_lds[i] = packed[N::bf_off(0) + i];
+    seq_prologue<SQ>(ring, ws, wave, std::make_integer_sequence<int, SQ::D>{});
+    __syncthreads();
+    double *img = imgs + (int64_t)blockIdx.x * N::img_doubles;
+#define BIAS64(loc, l, NTl)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < (NTl + W - 1) / W; ++i) {                                      \
+        int t_ = wave + W * i; t_ = t_ < NTl ? t_ : NTl - 1;                                             \
+        loc[i] = bias_lds[(N::bf_off(l) - N::bf_off(0)) + t_ * 4 + g];                                   \
+    }
+    constexpr int L13 = (13 + W - 1) / W, L7 = (7 + W - 1) / W, L4 = (4 + W - 1) / W, LF = (TF + W - 1) / W;
+    static_assert(LF == 1, "one input / output tile per wave");
+    // ---------------- forward ----------------
+    {
+        d4 own[LF];
+        own[0] = a0[wave < TF ? wave : TF - 1];
+        publish<F, true, W>(nullptr, img, N::x_off(0), own, lane, wave);
+    }
+    d4 s1[L13], s2[L7], s3[L4], s4[1], s5[L4], s6[L7], s7[L13], o8[LF];
+    BIAS64(s1, 0, 13) seq_mm<SQ, 0>(a0, s1, ring, ws, wave); lrelu(s1);
+    publish<200, true, W>(xchA, img, N::x_off(1), s1, lane, wave);
+    __syncthreads();
+    { d4 a1[13]; collect(xchA, a1, lane); BIAS64(s2, 1, 7) seq_mm<SQ, 1>(a1, s2, ring, ws, wave); lrelu(s2); }
+    publish<100, true, W>(xchB, img, N::x_off(2), s2, lane, wave);
+    __syncthreads();
+    { d4 a2[7]; collect(xchB, a2, lane); BIAS64(s3, 2, 4) seq_mm<SQ, 2>(a2, s3, ring, ws, wave); lrelu(s3); }
+    publish<50, true, W>(xchA, img, N::x_off(3), s3, lane, wave);
+    __syncthreads();
+    { d4 a3[4]; collect(xchA, a3, lane); BIAS64(s4, 3, TZ) seq_mm<SQ, 3>(a3, s4, ring, ws, wave); }          // en4: no activation
+    publish<Z, true, W>(xchB, img, N::x_off(4), s4, lane, wave);
+    __syncthreads();
+    { d4 a4[TZ]; collect(xchB, a4, lane); BIAS64(s5, 4, 4) seq_mm<SQ, 4>(a4, s5, ring, ws, wave); lrelu(s5); }
+    publish<50, true, W>(xchA, img, N::x_off(5), s5, lane, wave);
+    __syncthreads();
+    { d4 a5[4]; collect(xchA, a5, lane); BIAS64(s6, 5, 7) seq_mm<SQ, 5>(a5, s6, ring, ws, wave); lrelu(s6); }
+    publish<100, true, W>(xchB, img, N::x_off(6), s6, lane, wave);
+    __syncthreads();
+    { d4 a6[7]; collect(xchB, a6, lane); BIAS64(s7, 6, 13) seq_mm<SQ, 6>(a6, s7, ring, ws, wave); lrelu(s7); }
+    publish<200, true, W>(xchA, img, N::x_off(7), s7, lane, wave);
+    __syncthreads();
+    { d4 a7[13]; collect(xchA, a7, lane); BIAS64(o8, 7, TF) seq_mm<SQ, 7>(a7, o8, ring, ws, wave); }         // de4: no activation
+#undef BIAS64
+    // ---------------- loss, dL/drecon = 2 (r - x) / C (utils.py:195-199) ----------------
+    double lacc = 0.0;
+    {
+        const int t = wave < TF ? wave : TF - 1;
+        const d4 x0 = a0[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double d = o8[0][r] - x0[r];
+            const bool live = valid && wave < TF && creg_feature(F, t, g, r) >= 0;
+            if (live) lacc += d * d;
+            o8[0][r] = live ? d * (2.0 / (double)F) : 0.0;
+        }
+    }
+    // ---------------- backward chain (input gradients), publishing dZ images ----------------
+    publish<F, false, W>(xchB, img, N::z_off(7), o8, lane, wave);
+    __syncthreads();
+#define BWD64(GI, NIN, LOUT, SACT, XIN, XOUT, ZO, DOUT, MASK)                                            \
+    {                                                                                                    \
+        d4 din[NIN]; collect(XIN, din, lane);                                                            \
+        d4 dx[LOUT];                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < LOUT; ++i) dx[i] = (d4){0.0, 0.0, 0.0, 0.0};               \
+        seq_mm<SQ, GI>(din, dx, ring, ws, wave);                                                         \
+        if (MASK) lrelu_bwd(dx, SACT);                                                                   \
+        _Pragma("unroll") for (int i = 0; i < LOUT; ++i) SACT[i] = dx[i];                                \
+    }                                                                                                    \
+    publish<DOUT, false, W>(XOUT, img, ZO, SACT, lane, wave);                                            \
+    __syncthreads();
+    BWD64(8, TF, L13, s7, xchB, xchA, N::z_off(6), 200, true)
+    BWD64(9, 13, L7, s6, xchA, xchB, N::z_off(5), 100, true)
+    BWD64(10, 7, L4, s5, xchB, xchA, N::z_off(4), 50, true)
+    BWD64(11, 4, 1, s4, xchA, xchB, N::z_off(3), Z, false)                 // dL/dz: en4 has no activation
+    BWD64(12, TZ, L4, s3, xchB, xchA, N::z_off(2), 50, true)
+    BWD64(13, 4, L7, s2, xchA, xchB, N::z_off(1), 100, true)
+    BWD64(14, 7, L13, s1, xchB, (d4 *)nullptr, N::z_off(0), 200, true)
+#undef BWD64
+    // loss partial of this 16-row block: lanes of a wave, then waves 0..W-1 (fixed order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lacc += __shfl_down(lacc, off);
+    if (lane == 0) loss_lds[wave] = lacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) sum += loss_lds[w];
+        loss_part[blockIdx.x] = sum;
+    }
+}
+
+struct Adam64 {
+    double *params, *pcopy, *m, *v, *packed;
+    const int *sc_off, *sc_idx;
+    double *loss_accum;
+    double b1, b2, eps, step_size, bc2_sqrt;
+};
+
+// one workgroup per weight-gradient tile: contracts dZ^T (tile nt of layer l) with [X | 1] (tile kt) over all 16-row blocks
+// in a fixed order (wave w takes blocks w, w + 4, ..; then waves 0..3); optionally applies Adam to the parameters it owns.
+enum { DW_WRITE = 0, DW_ADAM = 1 };
+template <class N, int MODE>
+__global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ imgs, int nblk, const double *__restrict__ loss_part,
+                                                   const int *__restrict__ inv_map, double *__restrict__ grads, Adam64 ad) {
+    constexpr int T = N::slab_off(N::L), np = N::nparams();
+    constexpr int kPerXcd = (T + 1 + 7) / 8;
+    __shared__ __attribute__((aligned(32))) d4 red[4 * 64];
+    const int tile = (blockIdx.x & 7) * kPerXcd + (blockIdx.x >> 3);       // XCD c takes a contiguous tile range (see fused.hip)
+    if (tile > T) return;
+    if (tile == T) {   // loss: fixed-order sum of the per-block partials, / C
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int k = 0; k < nblk; ++k) s += loss_part[k];
+            const double gl = s * (1.0 / N::dim(0));
+            if (grads) grads[np] = gl;
+            if (MODE == DW_ADAM && ad.loss_accum) *ad.loss_accum += gl;
+        }
+        return;
+    }
+    const int p = inv_map[tile * 256 + threadIdx.x];
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < N::L; ++j) if (tile >= N::slab_off(j)) l = j;
+    int nt_count = tiles(N::dim(1)), soff = 0, xo = N::x_off(0), zo = N::z_off(0);
+#pragma unroll
+    for (int j = 1; j < N::L; ++j)
+        if (l == j) { nt_count = tiles(N::dim(j + 1)); soff = N::slab_off(j); xo = N::x_off(j); zo = N::z_off(j); }
+    const int idx = tile - soff, kt = idx / nt_count, nt = idx - kt * nt_count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    // A[i][k = g] of step r = dZ[slot 16 nt + i][batch row 4 g + r]: four consecutive rows of one image row per lane
+    const double *pz = imgs + ((zo + 16 * nt + i) * 16 + 4 * g);
+    const double *px = imgs + ((xo + 16 * kt + i) * 16 + 4 * g);
+    double pm = 0.0, pv = 0.0, pp = 0.0;
+    int s0 = 0, s1 = 0;
+    if (MODE == DW_ADAM && p >= 0) { pm = ad.m[p]; pv = ad.v[p]; pp = ad.params[p]; s0 = ad.sc_off[p]; s1 = ad.sc_off[p + 1]; }
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int b0 = wave; b0 < nblk; b0 += 16) {   // 4 blocks per wave in flight
+        d4 a[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + 4 * u;
+            const bool ok = b < nblk;
+            a[u] = ok ? *(const d4 *)(pz + (int64_t)b * N::img_doubles) : (d4){0.0, 0.0, 0.0, 0.0};
+            x[u] = ok ? *(const d4 *)(px + (int64_t)b * N::img_doubles) : (d4){0.0, 0.0, 0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = mfma(a[u][r], x[u][r], acc);
+    }
+    red[wave * 64 + lane] = acc;
+    __syncthreads();
+    // thread e = 4 lane' + r' owns D[n slot = g' + 4 r'][k slot = lane' & 15]  (f64 C/D map)
+    const double *rf = (const double *)red;
+    const int e = threadIdx.x;
+    const double gsum = ((rf[e] + rf[256 + e]) + rf[512 + e]) + rf[768 + e];
+    if (p < 0) return;
+    if (grads) grads[p] = gsum;
+    if (MODE == DW_ADAM) {   // elementwise.hip adam_k, on the parameters this tile owns
+        double mi = pm, vi = pv;
+        mi = mi + (gsum - mi) * (1.0 - ad.b1);
+        vi = vi * ad.b2 + (1.0 - ad.b2) * gsum * gsum;
+        const double denom = sqrt(vi) / ad.bc2_sqrt + ad.eps;
+        const double pn = pp - ad.step_size * (mi / denom);
+        ad.m[p] = mi;
+        ad.v[p] = vi;
+        ad.params[p] = pn;
+        if (ad.pcopy) ad.pcopy[p] = pn;
+        for (int k = s0; k < s1; ++k) ad.packed[ad.sc_idx[k]] = pn;
+    }
+}
+
+__global__ void __launch_bounds__(256) pack64_k(const double *__restrict__ params, const int *__restrict__ src, int count,
+                                                double *__restrict__ packed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) packed[i] = src[i] >= 0 ? params[src[i]] : 0.0;
+}
+
+struct Ops64;
+struct State64 {
+    const Ops64 *ops = nullptr;
+    DevBuf pack_src, inv_map, sc_off, sc_idx, packed, imgs;
+    int packed_doubles = 0;
+    int64_t max_rows = 12288;   // larger batches: layer-wise kernels (BALER_AMD_LATENCY_ROWS overrides, as for fp32)
+};
+struct Ops64 {
+    int (*setup)(bamd_handle *, State64 *);
+    int (*step)(bamd_handle *, State64 *, const void *, int, int64_t, const double *, double *, const Adam64 *, hipStream_t);
+};
+State64 *st64(bamd_handle *h) { return (State64 *)h->fused64_state; }
+
+template <int F, int Z> struct Impl64 {
+    using N = Net64<F, Z>;
+    static constexpr int kLds = (2 * 13 * 64 + (N::bf_off(N::L) - N::bf_off(0))) * 32;
+    static bool matches(const bamd_handle *h) {
+        if (h->L != 8) return false;
+        for (int i = 0; i <= 8; ++i)
+            if (h->dims[i] != N::dim(i)) return false;
+        return true;
+    }
+    static int setup(bamd_handle *, State64 *st) {
+        std::vector<int> src((size_t)N::packed_d4() * 4, -1);
+        for (int l = 0; l < N::L; ++l) {
+            const int K = N::dim(l), NN = N::dim(l + 1), KT = tiles(K), NT = tiles(NN);
+            // forward fragment (q, t): lane (i, g) component r = W[16 t + i][16 q + 4 r + g]
+            for (int q = 0; q < KT; ++q)
+                for (int t = 0; t < NT; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = 16 * t + (lane & 15), k = creg_feature(K, q, lane >> 4, r);
+                            if (n < NN && k >= 0) src[((size_t)N::wf_off(l) + (q * NT + t) * 64 + lane) * 4 + r] = N::w_off(l) + n * K + k;
+                        }
+            // backward fragment (tq, tk), l >= 1: lane (i, g) component r = W[16 tq + 4 r + g][16 tk + i]
+            for (int tq = 0; tq < NT && l >= 1; ++tq)
+                for (int tk = 0; tk < KT; ++tk)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = creg_feature(NN, tq, lane >> 4, r), k = 16 * tk + (lane & 15);
+                            if (n >= 0 && k < K) src[((size_t)N::wb_off(l) + (tq * KT + tk) * 64 + lane) * 4 + r] = N::w_off(l) + n * K + k;
+                        }
+            // bias fragment (t, g) component r = b[16 t + 4 r + g]
+            for (int t = 0; t < NT; ++t)
+                for (int g = 0; g < 4; ++g)
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = creg_feature(NN, t, g, r);
+                        if (n >= 0) src[((size_t)N::bf_off(l) + t * 4 + g) * 4 + r] = N::b_off(l) + n;
+                    }
+        }
+        // weight-gradient tile (kt, nt) of layer l: thread e = 4 lane + r holds dW[16 nt + g + 4 r][16 kt + (lane & 15)]; column K = db
+        const int ntiles = N::slab_off(N::L);
+        std::vector<int> inv((size_t)ntiles * 256, -1);
+        for (int l = 0; l < N::L; ++l) {
+            const int K = N::dim(l), NN = N::dim(l + 1), NT = tiles(NN);
+            for (int kt = 0; kt < tiles(K + 1); ++kt)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = creg_feature(NN, nt, lane >> 4, r), kc = 16 * kt + (lane & 15);
+                            if (n < 0) continue;
+                            const size_t o = ((size_t)(N::slab_off(l) + kt * NT + nt) * 64 + lane) * 4 + r;
+                            if (kc < K) inv[o] = N::w_off(l) + n * K + kc;
+                            else if (kc == K) inv[o] = N::b_off(l) + n;
+                        }
+        }
+        {
+            std::vector<char> seen(N::nparams(), 0);
+            for (int v : inv) if (v >= 0) seen[v]++;
+            for (char c : seen) if (c != 1) { set_error("fp64 fused step: incomplete gradient map"); return BAMD_ERR_INVALID; }
+        }
+        std::vector<int> off((size_t)N::nparams() + 1, 0), idx;
+        for (int v : src) if (v >= 0) off[v + 1]++;
+        for (int p = 0; p < N::nparams(); ++p) off[p + 1] += off[p];
+        idx.resize(off[N::nparams()]);
+        std::vector<int> cur(off.begin(), off.end() - 1);
+        for (size_t i = 0; i < src.size(); ++i) if (src[i] >= 0) idx[cur[src[i]]++] = (int)i;
+        st->packed_doubles = (int)src.size();
+        int rc = st->pack_src.ensure(src.size() * sizeof(int));
+        if (!rc) rc = st->inv_map.ensure(inv.size() * sizeof(int));
+        if (!rc) rc = st->sc_off.ensure(off.size() * sizeof(int));
+        if (!rc) rc = st->sc_idx.ensure(idx.size() * sizeof(int));
+        if (!rc) rc = st->packed.ensure(src.size() * sizeof(double));
+        if (rc) return rc;
+        BAMD_HIP(hipMemcpy(st->pack_src.p, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
+        BAMD_HIP(hipMemcpy(st->inv_map.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice));
+        BAMD_HIP(hipMemcpy(st->sc_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+        BAMD_HIP(hipMemcpy(st->sc_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        BAMD_HIP(hipFuncSetAttribute((const void *)chain64_kernel<F, Z, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        return BAMD_OK;
+    }
+    static int step(bamd_handle *h, State64 *st, const void *x, int x_dtype, int64_t n, const double *features, double *grads,
+                    const Adam64 *ad, hipStream_t s) {
+        const int nblk = (int)((n + 15) / 16);
+        int rc = st->imgs.ensure((size_t)N::img_doubles * sizeof(double) * (size_t)nblk);
+        if (rc) return rc;
+        rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk > 1024 ? nblk : 1024));
+        if (rc) return rc;
+        hipLaunchKernelGGL((chain64_kernel<F, Z, 4>), dim3(nblk), dim3(256), kLds, s, (const d4 *)st->packed.p, x, x_dtype == BAMD_F64, n,
+                           features, (double *)st->imgs.p, (double *)h->lossp.p);
+        const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
+        if (ad)
+            hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk, (const double *)h->lossp.p,
+                               (const int *)st->inv_map.p, grads, *ad);
+        else
+            hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk, (const double *)h->lossp.p,
+                               (const int *)st->inv_map.p, grads, Adam64{});
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static const Ops64 *ops() {
+        static const Ops64 o = {setup, step};
+        return &o;
+    }
+};
+
+const Ops64 *find64(const bamd_handle *h) {
+    if (h->mode != BAMD_MODE_F64) return nullptr;
+    if (Impl64<24, 15>::matches(h)) return Impl64<24, 15>::ops();
+    if (Impl64<24, 12>::matches(h)) return Impl64<24, 12>::ops();
+    if (Impl64<24, 8>::matches(h)) return Impl64<24, 8>::ops();
+    if (Impl64<24, 6>::matches(h)) return Impl64<24, 6>::ops();
+    return nullptr;
+}
+
+}  // namespace
+
+int fused64_setup(bamd_handle *h) {
+    const Ops64 *ops = find64(h);
+    if (!ops) return BAMD_OK;
+    const char *env = getenv("BALER_AMD_FORCE_GENERIC");
+    if (env && env[0] == '1') return BAMD_OK;
+    State64 *st = new State64();
+    st->ops = ops;
+    if (const char *lr = getenv("BALER_AMD_LATENCY_ROWS")) st->max_rows = atoll(lr);
+    h->fused64_state = st;
+    return ops->setup(h, st);
+}
+
+void fused64_teardown(bamd_handle *h) {
+    State64 *st = st64(h);
+    if (!st) return;
+    st->pack_src.release(); st->inv_map.release(); st->sc_off.release(); st->sc_idx.release(); st->packed.release(); st->imgs.release();
+    delete st;
+    h->fused64_state = nullptr;
+}
+
+int fused64_pack(bamd_handle *h, hipStream_t s) {
+    State64 *st = st64(h);
+    if (!st) return BAMD_OK;
+    hipLaunchKernelGGL(pack64_k, dim3((st->packed_doubles + 255) / 256), dim3(256), 0, s, (const double *)h->params.p,
+                       (const int *)st->pack_src.p, st->packed_doubles, (double *)st->packed.p);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
+void fused64_scatter(bamd_handle *h, const int **sc_off, const int **sc_idx, void **packed) {
+    State64 *st = st64(h);
+    if (!st) return;
+    *sc_off = (const int *)st->sc_off.p;
+    *sc_idx = (const int *)st->sc_idx.p;
+    *packed = st->packed.p;
+}
+
+// fwd + loss + bwd of a small batch (returns BAMD_ERR_UNSUPPORTED when this handle / batch size has no fp64 fused path);
+// with `hp`: also Adam and the refresh of the packed weights, in the weight-gradient kernel
+int fused64_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, void *params, void *m,
+                 void *v, const bamd_adam *hp, double *loss_accum, hipStream_t s) {
+    State64 *st = st64(h);
+    if (!st || n > st->max_rows || n <= 0) return BAMD_ERR_UNSUPPORTED;
+    if (!hp) return st->ops->step(h, st, x, x_dtype, n, features, (double *)grads, nullptr, s);
+    Adam64 ad;
+    ad.params = (double *)params; ad.pcopy = (double *)h->params.p; ad.m = (double *)m; ad.v = (double *)v;
+    ad.packed = (double *)st->packed.p;
+    ad.sc_off = (const int *)st->sc_off.p; ad.sc_idx = (const int *)st->sc_idx.p;
+    ad.loss_accum = loss_accum;
+    ad.b1 = hp->beta1; ad.b2 = hp->beta2; ad.eps = hp->eps;      // same scalars as launch_adam (elementwise.hip)
+    ad.step_size = hp->lr / (1.0 - pow(hp->beta1, (double)hp->step));
+    ad.bc2_sqrt = sqrt(1.0 - pow(hp->beta2, (double)hp->step));
+    return st->ops->step(h, st, x, x_dtype, n, features, (double *)grads, &ad, s);
+}
+
+}  // namespace bamd

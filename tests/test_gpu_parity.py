@@ -216,6 +216,40 @@ def test_gradients_ragged(n, path, data10k, monkeypatch):
     assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
 
 
+@pytest.mark.parametrize("n", [1, 7, 16, 17, 272, 513, 4099, 12288, 12289])
+def test_fp64_fused_step_ragged(n, data10k):
+    """fp64 mode: batches up to 12288 rows run on the fused fp64 step (chain + weight-gradient tiles on v_mfma_f64_16x16x4_f64,
+    fused64.hip), larger ones on the layer-wise kernels; both within 1e-11 of the scalar fp64 oracle, and
+    bamd_train_step == bamd_fwd_bwd + bamd_adam_step bit for bit."""
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 23)
+    x = data10k[:n] if n <= 10000 else orc.normalize(synth.cms_rows(n, row0=11))
+    h, p = make_handle(dims, flat, "fp64")
+    grads = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), grads)
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    gh = grads.cpu().numpy()
+    assert rel(gh[:-1], go) < TOL64 and abs(gh[-1] - lo) < TOL64 * lo
+    g2 = torch.zeros_like(p)
+    h.fwd_bwd(dev(x.astype(np.float32)), g2)                                 # float32 rows are widened on load
+    lo32, go32 = orc.fwd_bwd(dims, flat, x.astype(np.float32).astype(np.float64))
+    assert rel(g2.cpu().numpy()[:-1], go32) < TOL64
+    # one-call step == two-call step
+    m1, v1, m2, v2 = (torch.zeros_like(p) for _ in range(4))
+    p1, p2 = p.clone(), p.clone()
+    h1, _ = make_handle(dims, flat, "fp64")
+    h1.train_step(dev(x), p1, m1, v1, 1, 1e-3)
+    h.adam_step(p2, grads, m2, v2, 1, 1e-3)
+    assert torch.equal(p1[:-1], p2[:-1]) and torch.equal(m1[:-1], m2[:-1]) and torch.equal(v1[:-1], v2[:-1])
+    # ... and the next step uses the refreshed packed weights
+    g3, g4 = torch.zeros_like(p), torch.zeros_like(p)
+    h1.fwd_bwd(dev(x), g3)
+    h.fwd_bwd(dev(x), g4)
+    assert torch.equal(g3, g4)
+    _, go2 = orc.fwd_bwd(dims, p2.cpu().numpy()[:-1], x)
+    assert rel(g4.cpu().numpy()[:-1], go2) < TOL64
+
+
 def test_empty_shard_gives_zero_grad():
     dims = orc.ae_dims(24, 15)
     h, p = make_handle(dims, orc.formula_params(dims, 31), "fp32")
