@@ -56,3 +56,36 @@ def test_throughput_floors():
     assert t_enc < 0.70 and t_dec < 0.70, "fp32 encode / decode (profiles: 0.53 / 0.53 ms per 1M rows)"
     assert 1e3 * t_512 < 32.0, "small-batch step (profiles: 23.4 us)"
     assert t_benc < 0.20, "bf16 encode (profiles: 0.09-0.13 ms per 1M rows)"
+
+
+def test_round2_kernel_floors():
+    """bf16 training pair, fp64 fused small-batch step, fused wide-layer encode / decode (profiles/README.md, round 2)."""
+    n = 1_000_000
+    x = torch.rand((n, 24), dtype=torch.float64, device="cuda")
+    hb, pb = _handle("bf16")
+    gb = torch.zeros_like(pb)
+    t_b = _ms(lambda: hb.fwd_bwd(x, gb), 5)
+    dims = orc.ae_dims(24, 15)
+    h64 = native.Handle(dims, "fp64")
+    p64 = torch.from_numpy(np.concatenate([orc.formula_params(dims, 1), [0.0]])).cuda()
+    h64.load_params(p64)
+    m, v = torch.zeros_like(p64), torch.zeros_like(p64)
+    st = {"t": 0}
+
+    def steps64():
+        for i in range(100):
+            st["t"] += 1
+            h64.train_step(x[i * 512:(i + 1) * 512], p64, m, v, st["t"], 1e-3)
+    t_64 = _ms(steps64, 2) / 100
+    wd = orc.ae_dims(2500, 25)
+    hw = native.Handle(wd, "fp32")
+    hw.load_params(torch.from_numpy(np.concatenate([orc.formula_params(wd, 1), [0.0]]).astype(np.float32)).cuda())
+    xw = torch.rand((32768, 2500), dtype=torch.float32, device="cuda")
+    zw = hw.encode(xw)
+    t_we = _ms(lambda: hw.encode(xw), 3)
+    t_wd = _ms(lambda: hw.decode(zw), 3)
+    print(f"bf16 fwd_bwd {t_b:.3f} ms per 1M rows, fp64 bs512 step {1e3 * t_64:.1f} us, CFD_dense_AE(2500,25) encode {t_we:.3f} / decode {t_wd:.3f} ms "
+          f"per 32768 frames")
+    assert t_b < 1.35, "bf16 training kernels (profiles: ~1.0 ms per 1M rows)"
+    assert 1e3 * t_64 < 60.0, "fp64 fused small-batch step (profiles: 41 us; layer-wise: 768 us)"
+    assert t_we < 0.50 and t_wd < 0.60, "wide-layer encode / decode (profiles: 0.34 / 0.39 ms per 32768 frames; layer-wise 0.66)"
