@@ -415,6 +415,38 @@ def test_full_size_properties():
     assert rel(h.decode(h.encode(x[:4096])).cpu().numpy(), recon.cpu().numpy()) < 1e-6
 
 
+def test_c3_shard_size_properties():
+    """BASELINE configs[2] (100 M rows over 8 GPUs) at ONE rank's size: 12.5 M rows = 2.4 GB of float64 resident on one GPU
+    (the 8-GPU run itself needs an 8-GPU node).  Size-independent properties: training and encode over the shard equal the
+    sums / concatenations over its quarters, and sampled rows match the oracle; row offsets pass 2^31 bytes several times over."""
+    n = 12_500_000
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 77)
+    h, p = make_handle(dims, flat, "fp32")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand((n, 24), dtype=torch.float64, device="cuda", generator=gen)
+    g_full = torch.zeros_like(p)
+    h.fwd_bwd(x, g_full)
+    parts = torch.zeros_like(p, dtype=torch.float64)
+    q = n // 4
+    for k in range(4):
+        g = torch.zeros_like(p)
+        h.fwd_bwd(x[k * q:(k + 1) * q], g)
+        parts += g.double()
+    assert rel(parts.cpu().numpy(), g_full.cpu().numpy()) < 1e-5
+    z = h.encode(x, out_dtype=torch.float32)
+    zq = h.encode(x[3 * q:], out_dtype=torch.float32)
+    assert torch.equal(z[3 * q:], zq)
+    idx = torch.as_tensor(np.random.default_rng(1).choice(n, size=128, replace=False)).cuda()
+    assert rel(z[idx].cpu().numpy(), orc.encode(dims, flat, x[idx].cpu().numpy())) < TOL32
+    # the same shard through the bf16 training kernels: additive too, and within the bf16 bar of the fp32 gradient
+    hb, pb = make_handle(dims, flat, "bf16")
+    gb = torch.zeros_like(pb)
+    hb.fwd_bwd(x, gb)
+    assert rel(gb.cpu().numpy()[:-1], g_full.cpu().numpy()[:-1]) < 2e-2
+    assert abs(float(gb[-1]) - float(g_full[-1])) < 2e-3 * float(g_full[-1])
+
+
 @pytest.mark.parametrize("z", [6, 8, 12])
 def test_other_latent_sizes_fused(z, data10k):
     """The fused kernels are instantiated for the usual CMS compression ratios (latent 15, 12, 8, 6)."""
