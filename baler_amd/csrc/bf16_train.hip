@@ -66,6 +66,14 @@ template <int F, int Z> struct TNet {
     __host__ __device__ static constexpr int istride(int i) { int b = iblocks(i); return 64 * (b % 2 ? b : b + 1); }   // bytes, 64 x odd
     __host__ __device__ static constexpr int ioff(int i) { int s = 0; for (int j = 0; j < i; ++j) s += kRows * istride(j); return s; }
     __host__ __device__ static constexpr int img_bytes() { return ioff(L + 1); }
+    // Where dZ_l is written -- OUT OF PLACE, so that the epilogue of layer l + 1 may run while other waves still read X_{l+1} for
+    // that layer's weight-gradient tiles: ONE barrier per backward layer.  The network is symmetric (dim(8 - i) = dim(i) for the
+    // hidden widths), so the image of the MIRROR layer has exactly dZ_l's shape and is dead at that time: PART 0 (layers 7..4)
+    // no longer needs X_1..X_3 after the forward, PART 1 (layers 3..0) never fills images 5..8.
+    //   dZ_7 -> image 8;  dZ_6 -> image 1;  dZ_5 -> image 2;  dZ_4 -> image 3;  dZ_3 -> image 4 (loaded from the hand-off);
+    //   dZ_2 -> image 5;  dZ_1 -> image 6;  dZ_0 -> image 7
+    __host__ __device__ static constexpr int zimg_of(int l) { return l == 7 ? 8 : l >= 4 ? 7 - l : l == 3 ? 4 : 7 - l; }
+    __host__ __device__ static constexpr int zoff(int l) { return ioff(zimg_of(l)); }
     // weight-gradient tiles in the partial-gradient buffer
     __host__ __device__ static constexpr int dwt(int l) { return nt(l) * kt(l); }
     __host__ __device__ static constexpr int slab_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += dwt(j); return s; }
@@ -515,38 +523,28 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
             __syncthreads();
         }
 
-        // ---- backward: per layer  [input-gradient MFMAs | weight-gradient tiles]  barrier  [epilogue in place]  barrier -
-#ifdef BAMD_EXP_NO_BARRIER
-#define BAMD_EXP_BARRIER
-#else
-#define BAMD_EXP_BARRIER __syncthreads();
-#endif
+        // ---- backward: per layer  [input-gradient MFMAs] [mask + store dZ_{l-1} into its own region] [weight-gradient tiles]  barrier
 #define BAMD_BWD(l, G)                                                                                                       \
         if constexpr (P::has(l)) {                                                                                           \
-            constexpr int ZI = (l) + 1;   /* dZ_l lives where X_{l+1} was; dZ_7 in image 8 */                               \
+            constexpr int SZ = N::istride((l) + 1);   /* dZ_l has the shape of X_{l+1} */                                    \
+            const lds_p zimg = img + N::zoff(l);                                                                             \
             if constexpr ((l) >= 1) {                                                                                        \
                 ChainAcc<N::ntb(l)> acc;                                                                                     \
-                chain_mm<N, PART, SC::bstep(l), N::kbb(l), N::ntb(l), N::istride(ZI)>(                                       \
-                    acc, img + N::ioff(ZI) + lay_of<N::istride(ZI)>(ls).row, ring, ws, wave);                                \
-                dw_phase<N, l, N::istride(ZI), N::istride(l)>(G, img + N::ioff(ZI), img + N::ioff(l),                        \
-                                                             lay_of<N::istride(ZI)>(ls), lay_of<N::istride(l)>(ls), wave);   \
-                BAMD_EXP_BARRIER                                                                                             \
+                chain_mm<N, PART, SC::bstep(l), N::kbb(l), N::ntb(l), SZ>(acc, zimg + lay_of<SZ>(ls).row, ring, ws, wave);   \
                 if constexpr (PART == 0 && (l) == P::bwd_lo) {                                                               \
                     /* hand-off to the second launch: dL/dz, 4 bf16 per lane = 32 B per row (en4 has no activation) */       \
                     static_assert(N::ntb(l) == 1, "dL/dz is one tile per row");                                              \
                     dz[row * 4 + g] = pack4(acc.am[0]);                                                                      \
                 } else {                                                                                                     \
+                    constexpr int DELTA = N::zoff((l) - 1) - N::ioff(l);   /* same stride, same lane offsets: a constant shift */ \
                     acc_visit<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,              \
-                                                        [&](v4 &a, lds_p dst) {                                              \
-                                                            lds_w64(dst, N::act((l) - 1) ? lrelu_bwd_pack4(a, lds_b64(dst)) : pack4(a)); \
+                                                        [&](v4 &a, lds_p src) {                                              \
+                                                            lds_w64(src + DELTA, N::act((l) - 1) ? lrelu_bwd_pack4(a, lds_b64(src)) : pack4(a)); \
                                                         });                                                                  \
                 }                                                                                                            \
-                __syncthreads();                                                                                             \
-            } else {                                                                                                         \
-                dw_phase<N, l, N::istride(ZI), N::istride(l)>(G, img + N::ioff(ZI), img + N::ioff(l),                        \
-                                                             lay_of<N::istride(ZI)>(ls), lay_of<N::istride(l)>(ls), wave);   \
-                __syncthreads();                                                                                             \
             }                                                                                                                \
+            dw_phase<N, l, SZ, N::istride(l)>(G, zimg, img + N::ioff(l), lay_of<SZ>(ls), lay_of<N::istride(l)>(ls), wave);   \
+            __syncthreads();                                                                                                 \
         }
         BAMD_BWD(7, g7) BAMD_BWD(6, g6) BAMD_BWD(5, g5) BAMD_BWD(4, g4) BAMD_BWD(3, g3) BAMD_BWD(2, g2) BAMD_BWD(1, g1) BAMD_BWD(0, g0)
 #undef BAMD_FWD
