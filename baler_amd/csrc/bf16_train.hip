@@ -18,8 +18,9 @@
 //     no transposing stores.  The first padding slot of every image is a ONES column: it carries db through the
 //     weight-gradient product, and the forward product reads the bias through it (the packed weights hold b in input
 //     column K, and a 1 at [padding output K'][column K] so that every layer regenerates the next layer's ones column);
-//   * dZ_{l-1} overwrites X_l in place once layer l's weight-gradient tiles have been read (same shape, same owner
-//     wave and lane): 116 KB of images for the whole network at 64 rows, no second set of buffers.
+//   * dZ_{l-1} is written into the image of the MIRROR layer (same shape, dead at that time: see TNet::zoff), so the epilogue of
+//     layer l needs no barrier against the waves that still read X_l for its weight-gradient tiles: one barrier per backward
+//     layer, 132 KB of images for the whole network at 64 rows, no second set of buffers.
 // [dW | db] tiles stay in MFMA accumulators for the whole persistent loop (as in fused.hip) and are reduced over
 // workgroups in a fixed order: bitwise reproducible.  All 298 tiles x 256 floats do not fit one CU's registers
 // next to the chain, so training is two launches over the same rows (PART 0: forward, loss, decoder layers 7..4;
