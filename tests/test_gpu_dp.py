@@ -194,3 +194,57 @@ def test_bench_spawns_two_ranks_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "gloo" and d["value"] > 0
+
+
+_SPLIT_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["REPO"])
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from baler_amd import baler, dist as bdist
+from baler_amd.modules import helper, models
+from oracle import c_oracle as orc
+rank, world, local = bdist.init_from_env()
+torch.cuda.set_device(local)
+models.set_default_mode("fp64")
+init = orc.formula_params(orc.ae_dims(24, 15), 5)
+def factory(name):
+    cls = getattr(models, name)
+    return lambda n_features, z_dim: cls(n_features, z_dim).load_flat(init)
+helper.model_init = factory
+baler.main(["--project", "CMS_workspace", "CMS_project_v1", "--mode", "train"])
+'''
+
+
+def test_dp_validation_split_equals_single_process(tmp_path):
+    """test_size = 0.2 + activation extraction + early stopping off, 4 epochs, fp64: the 2-rank run (index-sharded train and
+    validation sets, per-batch validation losses and activation means combined by all-reduce) writes the SAME loss_data.npy,
+    activations.npy and model as the single-process run of the same config (sums are re-associated across ranks: 1e-10)."""
+    outs = {}
+    for world in (1, 2):
+        base = tmp_path / f"w{world}"
+        os.makedirs(base)
+        out = _dp_workspace(base, epochs=4, extra="\n_orig = set_config\ndef set_config(c):\n    _orig(c)\n    c.test_size = 0.2\n"
+                                                  "    c.early_stopping = False\n    c.batch_size = 500\n")
+        script = base / "w.py"
+        script.write_text(_SPLIT_WORKER)
+        env = dict(os.environ, REPO=REPO, BALER_AMD_FORCE_DEVICE="0", BALER_AMD_DIST_BACKEND="gloo")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        if world == 1:
+            cmd = [sys.executable, str(script)]
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(free_port()), str(script)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(base))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        import torch
+        sd = torch.load(out / "compressed_output" / "model.pt")
+        outs[world] = (np.load(out / "training" / "loss_data.npy"), np.load(out / "training" / "activations.npy"),
+                       np.concatenate([v.numpy().ravel() for v in sd.values()]))
+    l1, a1, p1 = outs[1]
+    l2, a2, p2 = outs[2]
+    assert l1.shape == (2, 4) and not np.array_equal(l1[0], l1[1])           # a real validation loss
+    assert np.allclose(l2, l1, rtol=1e-10, atol=0)
+    assert np.array_equal(np.isnan(a1), np.isnan(a2)) and np.allclose(np.nan_to_num(a2), np.nan_to_num(a1), rtol=1e-9, atol=1e-12)
+    assert np.linalg.norm(p2 - p1) / np.linalg.norm(p1) < 1e-10
