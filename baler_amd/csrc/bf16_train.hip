@@ -420,6 +420,13 @@ __device__ __forceinline__ void x_issue(RawX<F> &raw, const void *x, int is_f64,
     }
 }
 
+#ifdef BAMD_BF16_TRACE   // debug build: shader-clock stamps of workgroup 0, wave 0 at every phase boundary (tools/bf16_trace.py)
+__device__ unsigned long long g_bf16_trace[2][48];
+#define BT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bf16_trace[PART][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BT(i) do {} while (0)
+#endif
+
 template <int F, int Z, int PART>
 __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict__ wfrags, const void *__restrict__ xin, int in_f64, int64_t n,
                                                          const double *__restrict__ feats, v4 *__restrict__ slabs,
@@ -457,6 +464,7 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         // keep the weight loads and the LDS address arithmetic inside the loop (LICM would hoist hundreds of registers)
         asm volatile("" : "+v"(ws.voff), "+s"(wave), "+v"(lane));
+        BT(0);
         const int j = lane & 15, g = lane >> 4;
         Lays ls;
         ls.s1 = make_lay<64>(lane); ls.s3 = make_lay<192>(lane); ls.s5 = make_lay<320>(lane); ls.s7 = make_lay<448>(lane);
@@ -482,6 +490,7 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
         }
         x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);       // next iteration's rows, a whole iteration ahead
         __syncthreads();
+        BT(1);
 
         // ---- forward ------------------------------------------------------------------------------------------------
 #define BAMD_FWD(l)                                                                                                          \
@@ -492,6 +501,7 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
             acc_visit<N::nt(l), N::istride(l + 1)>(acc, img + N::ioff(l + 1), lay_of<N::istride(l + 1)>(ls), wave,           \
                                                    [&](v4 &a, lds_p dst) { if (N::act(l)) lrelu4(a); lds_w64(dst, pack4(a)); }); \
             __syncthreads();                                                                                                 \
+            BT(2 + (l));                                                                                                     \
         }
         BAMD_FWD(0) BAMD_FWD(1) BAMD_FWD(2)
         if constexpr (P::fwd_end == 8) {
@@ -517,6 +527,7 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                 lds_w64(img + N::ioff(8) + 16 * wave * N::istride(8) + l8.wr(t & 1) + 32 * (t & ~1), pack4(d));
             }
             __syncthreads();
+            BT(9);
         } else {
             // PART 1: dL/dz of these rows from the first launch -> image 4 (tile 0 of row tile `wave`)
             const u2 dzv = dz[row * 4 + g];                                 // rows beyond n: zeros (stored by PART 0)
@@ -544,8 +555,10 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                                                         });                                                                  \
                 }                                                                                                            \
             }                                                                                                                \
+            BT(20 + 2 * (l));                                                                                                \
             dw_phase<N, l, SZ, N::istride(l)>(G, zimg, img + N::ioff(l), lay_of<SZ>(ls), lay_of<N::istride(l)>(ls), wave);   \
             __syncthreads();                                                                                                 \
+            BT(21 + 2 * (l));                                                                                                \
         }
         BAMD_BWD(7, g7) BAMD_BWD(6, g6) BAMD_BWD(5, g5) BAMD_BWD(4, g4) BAMD_BWD(3, g3) BAMD_BWD(2, g2) BAMD_BWD(1, g1) BAMD_BWD(0, g0)
 #undef BAMD_FWD
@@ -736,6 +749,12 @@ const TrainOps *find_train(const bamd_handle *h) {
 }
 
 }  // namespace
+
+#ifdef BAMD_BF16_TRACE
+extern "C" int bamd_debug_bf16_trace(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_trace), sizeof(unsigned long long) * 96);
+}
+#endif
 
 int bf16_train_setup(bamd_handle *h) {
     const TrainOps *ops = find_train(h);
