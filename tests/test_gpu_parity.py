@@ -752,3 +752,59 @@ def test_persistent_loop_remainder_on_small_batch_kernels(monkeypatch):
         assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
         res.append(gh)
     assert rel(res[0], res[1]) < 1e-6 and not np.array_equal(res[0], res[1])     # two different summation orders
+
+
+# ---- round-2 boundary additions ---------------------------------------------------------------------
+def test_col_minmax_and_sharded_features_bit_exact():
+    """bamd_col_minmax on row shards + min / max combination == bamd_minmax of the whole table, bit for bit (what the
+    data-parallel helper.process does with one MIN and one MAX all-reduce)."""
+    raw = synth.cms_rows(100_003)
+    whole = native.minmax(dev(raw)).cpu().numpy()
+    cuts = [0, 1, 33_334, 66_668, 100_003]
+    mm = [native.col_minmax(dev(raw[a:b])).cpu().numpy() for a, b in zip(cuts[:-1], cuts[1:])]
+    mn = np.min([m[0] for m in mm], axis=0)
+    mx = np.max([m[1] for m in mm], axis=0)
+    assert np.array_equal(np.stack([mn, mx - mn]), whole)
+    assert np.array_equal(whole, np.stack([raw.min(0), raw.max(0) - raw.min(0)]))
+
+
+def test_handle_free_kernels_on_two_streams():
+    """The handle-free reductions keep their scratch per (device, stream): two streams reducing different tables at the same
+    time do not overwrite each other's partial results."""
+    a = dev(synth.cms_rows(400_000))
+    b = dev(synth.cms_rows(400_000, row0=1_000_000) * 3.0 + 1.0)
+    want_a, want_b = native.minmax(a).clone(), native.minmax(b).clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            ra = native.minmax(a)
+        with torch.cuda.stream(s2):
+            rb = native.minmax(b)
+        torch.cuda.synchronize()
+        assert torch.equal(ra, want_a) and torch.equal(rb, want_b)
+
+
+def test_hostio_round_trip_with_block_events():
+    """hostio on the device: rows go up through pinned staging (range, block-cyclic and index plans), come back with per-block
+    producer events, and chunk boundaries that cut blocks at odd places change nothing."""
+    from baler_amd import hostio
+    src = synth.cms_rows(50_000)
+    for plan, want in ((None, src), (hostio.RowPlan.contiguous(50_000, 1, 3), src[16_667:33_334]),
+                       (hostio.RowPlan.cyclic(50_000, 512, 2, 8), None)):
+        t = hostio.upload_rows(src, plan, "cuda:0", chunk_bytes=1 << 20)
+        if want is None:
+            want = hostio.upload_rows(src, plan, "cpu").numpy()
+        assert np.array_equal(t.cpu().numpy(), want)
+    x = dev(src)
+    out = torch.empty_like(x)
+    ready = []
+    for s in range(0, 50_000, 7_000):
+        e = min(s + 7_000, 50_000)
+        out[s:e] = x[s:e] * 2.0
+        ev = torch.cuda.Event()
+        ev.record()
+        ready.append((e, ev))
+    back = hostio.download_rows(out, ready=ready, chunk_bytes=3 << 20)
+    assert np.array_equal(back, src * 2.0)
+    assert np.array_equal(hostio.download_rows(out[:0]), src[:0] * 2.0)
