@@ -44,7 +44,7 @@ template <typename T> struct Opnd {
     }
 };
 
-enum { EPI_FWD = 0, EPI_DX = 1, EPI_DW = 2 };
+enum { EPI_FWD = 0, EPI_DX = 1, EPI_DW = 2, EPI_FWD_LOSS = 3 };   // FWD_LOSS: last layer of a training step: writes dL/drecon, sums the loss
 
 template <typename T> struct Epi {
     T *out;            // FWD/DX: output matrix
@@ -60,11 +60,23 @@ template <typename T> struct Epi {
     int64_t kin;       // DW: in-features (column kin of the product is db)
     int64_t slab_stride;
     int64_t rows_per_split;
+    const T *xref;     // FWD_LOSS: the (normalised) input rows the reconstruction is compared with, leading dimension ld
+    double *loss_part; // FWD_LOSS: one partial sum of (r - x)^2 per workgroup
+    double grad_scale; // FWD_LOSS: 2 / n_cols
 };
 
 template <typename T, int EPI>
-__device__ __forceinline__ void epilogue(const Epi<T> &e, int64_t row, int64_t col, T val) {
-    if (EPI == EPI_FWD) {
+__device__ __forceinline__ void epilogue(const Epi<T> &e, int64_t row, int64_t col, T val, double &lsum) {
+    if (EPI == EPI_FWD_LOSS) {
+        // utils.py:195-199 fused into de4's store: out = dL/drecon = 2 (r - x) / C, loss partial += (r - x)^2
+        if (row < e.n_rows && col < e.n_cols) {
+            val += e.bias[col];
+            if (e.act) val = val > (T)0 ? val : val * (T)kSlope;
+            const T d = val - e.xref[row * e.ld + col];
+            lsum += (double)d * (double)d;
+            e.out[row * e.ld + col] = (T)(e.grad_scale * (double)d);
+        }
+    } else if (EPI == EPI_FWD) {
         if (row < e.n_rows && col < e.n_cols) {
             val += e.bias[col];
             if (e.act) val = val > (T)0 ? val : val * (T)kSlope;
@@ -83,6 +95,18 @@ __device__ __forceinline__ void epilogue(const Epi<T> &e, int64_t row, int64_t c
             else if (col == e.kin) e.gb[so + row] = val;
         }
     }
+}
+
+// fixed-order workgroup sum of the per-thread loss terms -> one partial per workgroup (row-major over the grid)
+__device__ __forceinline__ void block_loss(double lsum, double *__restrict__ part) {
+    __shared__ double lsh[256];
+    lsh[threadIdx.x] = lsum;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) lsh[threadIdx.x] += lsh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = lsh[0];
 }
 
 template <typename T, int EPI, bool A_KFAST, bool B_KFAST>
@@ -134,6 +158,7 @@ __global__ void __launch_bounds__(256) gemm_k(Opnd<T> A, Opnd<T> B, int64_t kred
         __syncthreads();
     }
 
+    double lsum = 0.0;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -141,7 +166,8 @@ __global__ void __launch_bounds__(256) gemm_k(Opnd<T> A, Opnd<T> B, int64_t kred
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
                 epilogue<T, EPI>(e, i0 + wr * 32 + mt * 16 + MF<T>::crow(reg, lane), j0 + wc * 32 + nt * 16 + (lane & 15),
-                                 acc[mt][nt][reg]);
+                                 acc[mt][nt][reg], lsum);
+    if (EPI == EPI_FWD_LOSS) block_loss(lsum, e.loss_part);
 }
 
 // 128 x 128 x 16 tile, 2 x 2 waves of 4 x 4 MFMA tiles each, double-buffered LDS with register staging: the global
@@ -264,6 +290,7 @@ __global__ void __launch_bounds__(256) gemm_big_k(Opnd<T> A, Opnd<T> B, int64_t 
         if (more) lstore(buf ^ 1);
         __syncthreads();
     }
+    double lsum = 0.0;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -271,7 +298,8 @@ __global__ void __launch_bounds__(256) gemm_big_k(Opnd<T> A, Opnd<T> B, int64_t 
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
                 epilogue<T, EPI>(e, i0 + wr * 64 + mt * 16 + MF<T>::crow(reg, lane), j0 + wc * 64 + nt * 16 + (lane & 15),
-                                 acc[mt][nt][reg]);
+                                 acc[mt][nt][reg], lsum);
+    if (EPI == EPI_FWD_LOSS) block_loss(lsum, e.loss_part);
 }
 
 // dZ_L = 2 (R - X)/C and per-block partial sums of (R - X)^2 (utils.py:195-199 and its autograd).
@@ -352,7 +380,11 @@ __global__ void fill_nan_k(double *p, int n) {
 template <typename T, int EPI, bool AK, bool BK>
 static void launch_gemm(const Opnd<T> &A, const Opnd<T> &B, int64_t kred, const Epi<T> &e, int64_t outer_a, int64_t outer_b,
                         unsigned nz, hipStream_t s) {
-    if (outer_a >= 96 && outer_b >= 96) {
+    // weight-gradient products of narrow layers (e.g. 50 x 101 outputs) reduce over tens of thousands of rows: the 64 x 64
+    // kernel's element-wise K-slow loads made them the slowest launches of a CFD_dense_AE step (103 us each for 0.2 GFLOP);
+    // the big-tile kernel skips its dead 16-wide sub-tiles and loads 16 bytes per lane
+    const bool long_dw = EPI == EPI_DW && kred >= 4096 && outer_a >= 16 && outer_b >= 16;
+    if ((outer_a >= 96 && outer_b >= 96) || long_dw) {
         const int lds = 4 * 128 * 20 * (int)sizeof(T);
         static bool attr_set = false;
         if (!attr_set) {
@@ -521,14 +553,33 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
         rc = h->slabs.ensure((size_t)(nsplit * np) * sizeof(T));
         if (rc) return rc;
         T *slabs = (T *)h->slabs.p;
-        rc = stage_input<T>(h, x, x_dtype, r0, rows, c, features, wk.x0, s);
-        if (rc) return rc;
-        for (int l = 0; l < h->L; ++l) launch_fwd_layer<T>(h, l, wk.y[l], wk.y[l + 1], rows, s);
-        int64_t count = rows * c;
-        int nblk = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
+        // rows that already have the compute type are used where they lie (no staging copy: 328 MB per 32k CFD frames)
+        const bool in_place = !features && x_dtype == (sizeof(T) == 8 ? BAMD_F64 : BAMD_F32);
+        const T *x0 = in_place ? (const T *)x + r0 * c : wk.x0;
+        if (!in_place) {
+            rc = stage_input<T>(h, x, x_dtype, r0, rows, c, features, wk.x0, s);
+            if (rc) return rc;
+        }
+        launch_fwd_layer<T>(h, 0, x0, wk.y[1], rows, s);
+        for (int l = 1; l + 1 < h->L; ++l) launch_fwd_layer<T>(h, l, wk.y[l], wk.y[l + 1], rows, s);
         T *dz = wk.dza, *dz_next = wk.dzb;
-        hipLaunchKernelGGL(loss_grad_k<T>, dim3(nblk), dim3(256), 0, s, wk.y[h->L], wk.x0, count, 1.0 / c, dz,
-                           (double *)h->lossp.p);
+        int nblk = 0;
+        {   // last layer with the loss fused into its store: dz = 2 (r - x) / C, one loss partial per workgroup (the separate
+            // loss pass re-read r and x and wrote dz: 1 GB for 32k CFD frames)
+            const int l = h->L - 1, K = h->dims[l], N = h->dims[l + 1];
+            const bool big = rows >= 96 && N >= 96;
+            const int64_t tile = big ? 128 : 64;
+            nblk = (int)(((N + tile - 1) / tile) * ((rows + tile - 1) / tile));
+            rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk > 1024 ? nblk : 1024));
+            if (rc) return rc;
+            Opnd<T> A{wk.y[l], K, 1, rows, -1};
+            Opnd<T> B{P + h->w_off[l], K, 1, N, -1};
+            Epi<T> e{};
+            e.out = dz; e.ld = N; e.n_rows = rows; e.n_cols = N;
+            e.bias = P + h->b_off[l]; e.act = h->has_act(l) ? 1 : 0;
+            e.xref = x0; e.loss_part = (double *)h->lossp.p; e.grad_scale = 2.0 / c;
+            launch_gemm<T, EPI_FWD_LOSS, true, true>(A, B, (int64_t)K, e, rows, N, 1, s);
+        }
         hipLaunchKernelGGL(loss_final_k<T>, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk, 1.0 / c,
                            grads + np, chunk_i > 0 ? 1 : 0);
         for (int l = h->L - 1; l >= 0; --l) {
@@ -536,7 +587,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
             // [dW | db] = dZ^T [X | 1], reduced over this chunk's rows in nsplit fixed slabs
             {
                 Opnd<T> A{dz, 1, N, N, -1};
-                Opnd<T> B{wk.y[l], 1, K, K, K};
+                Opnd<T> B{l == 0 ? x0 : wk.y[l], 1, K, K, K};
                 Epi<T> e{};
                 e.n_rows = N; e.kin = K; e.gw = slabs + h->w_off[l]; e.gb = slabs + h->b_off[l];
                 e.slab_stride = np; e.rows_per_split = rps;

@@ -25,6 +25,7 @@ def rel(a, b):
 
 @pytest.fixture()
 def workspace(tmp_path, monkeypatch):
+    _reset_config()     # helper.Config keeps attributes of earlier projects (e.g. custom_loss_function of the SWAE test)
     ws = tmp_path / "workspaces"
     shutil.copytree(os.path.join(REPO, "workspaces", "CMS_workspace"), ws / "CMS_workspace")
     (ws / "__init__.py").write_text("")
