@@ -614,6 +614,126 @@ __device__ __forceinline__ v4 wide_x_chunk(const void *x, int in_f64, int64_t ro
     return v;
 }
 
+// acc[13 tiles of the 200-feature side] += sum over the wide dimension of frag(chunk kc, tile t) . x^T[chunk kc]: the streamed
+// product of en1 (fragments Wf(0), x = input rows) and of de4's input gradient (fragments Wb(7), x = dL/drecon rows).
+// x runs kXA chunks ahead (first touch of a row segment comes from HBM: ~2 us against 0.8 us of MFMAs per chunk; 4 ahead left
+// SQ_WAIT_ANY at 23 %), the fragments (L2-resident) one chunk ahead in ping-pong buffers (no register copies); out-of-range
+// prefetches re-read chunk 0.
+template <int F>
+__device__ __forceinline__ void wide_in_product(v4 (&acc)[13], const WStream &ww, const void *xin, int in_f64, int64_t rrow, int g) {
+    constexpr int KC = tiles(F);
+    v4 wa[13], wb[13];
+    auto load_w = [&](v4 (&w)[13], int kc) {
+#pragma unroll
+        for (int t = 0; t < 13; ++t) w[t] = frag_rt(ww, kc * 13 + t);
+    };
+    auto mm = [&](const v4 (&w)[13], const v4 &xv, int kc) {
+        // 13 independent accumulators: consecutive MFMAs never wait on each other
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (16 * kc + 16 <= F || r < tile_steps(F, KC - 1)) {
+#pragma unroll
+                for (int t = 0; t < 13; ++t) acc[t] = mfma(w[t][r], xv[r], acc[t]);
+            }
+    };
+    constexpr int kXA = 8;
+    v4 xr[kXA];
+    auto load_x = [&](int kc) { return wide_x_chunk<F>(xin, in_f64, rrow, kc < KC ? kc : 0, g); };
+    auto clampw = [&](int kc) { return kc < KC ? kc : KC - 1; };
+    const int last = (F % 16) ? KC - 1 : -1;       // index of the partial chunk
+    load_w(wa, 0);
+#pragma unroll
+    for (int u = 0; u < kXA; ++u) xr[u] = load_x(u);
+    int kc = 0;
+    for (; kc + kXA <= KC; kc += kXA) {
+#pragma unroll
+        for (int p = 0; p < kXA / 2; ++p) {
+            load_w(wb, clampw(kc + 2 * p + 1));
+            mm(wa, xr[2 * p], kc + 2 * p == last ? KC - 1 : 0);
+            xr[2 * p] = load_x(kc + 2 * p + kXA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wa, clampw(kc + 2 * p + 2));
+            mm(wb, xr[2 * p + 1], kc + 2 * p + 1 == last ? KC - 1 : 0);
+            xr[2 * p + 1] = load_x(kc + 2 * p + 1 + kXA);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the last KC % kXA chunks: wa holds chunk kc's fragments, xr[u] chunk kc + u
+#pragma unroll
+    for (int u = 0; u < kXA - 1; ++u) {
+        if (kc + u < KC) {
+            if (kc + u + 1 < KC) load_w(wb, kc + u + 1);
+            mm(wa, xr[u], (kc + u == last) ? KC - 1 : 0);
+            if (kc + u + 1 < KC) {
+#pragma unroll
+                for (int t = 0; t < 13; ++t) wa[t] = wb[t];
+            }
+        }
+    }
+}
+
+// out tile t of the wide side = bias + sum over the 13 tiles of the 200-feature side (de4): one tile at a time, fragments one
+// tile ahead in ping-pong buffers; `emit(o, t, slot)` consumes the finished tile (C layout: register r = slot_feature(F, t, g, r)).
+// The 13 k tiles alternate between TWO accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, an independent one 32).
+template <int F, class Emit>
+__device__ __forceinline__ void wide_out_product(const v4 (&a7)[13], const WStream &ww, const v4 *bias7, int g, Emit emit) {
+    constexpr int KC = tiles(F);
+    v4 wa[13], wb[13];
+    auto load_w = [&](v4 (&w)[13], int t) {
+        t = t < KC ? t : KC - 1;
+#pragma unroll
+        for (int q = 0; q < 13; ++q) w[q] = frag_rt(ww, q * KC + t);
+    };
+    auto tile_out = [&](const v4 (&w)[13], int t, auto slot) {
+        if (t >= KC) return;
+        v4 o0 = bias7[t * 4 + g], o1 = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 13; q += 2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < tile_steps(200, q)) o0 = mfma(w[q][r], a7[q][r], o0);
+                if (q + 1 < 13 && r < tile_steps(200, q + 1)) o1 = mfma(w[q + 1][r], a7[q + 1][r], o1);
+            }
+        emit(o0 + o1, t, slot);
+    };
+    load_w(wa, 0);
+    for (int t0 = 0; t0 < KC; t0 += 4) {       // unrolled by four: `emit` sees a compile-time slot t % 4 (prefetch rings of the caller)
+        load_w(wb, t0 + 1);
+        tile_out(wa, t0, std::integral_constant<int, 0>());
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(wa, t0 + 2);
+        tile_out(wb, t0 + 1, std::integral_constant<int, 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(wb, t0 + 3);
+        tile_out(wa, t0 + 2, std::integral_constant<int, 2>());
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(wa, t0 + 4);
+        tile_out(wb, t0 + 3, std::integral_constant<int, 3>());
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// store tile t of a wide row (C layout) as float / double
+template <int F>
+__device__ __forceinline__ void wide_store_tile(const v4 &o, void *out, int out_f64, int64_t row, int t, int g) {
+    if (16 * t + 16 <= F) {              // full tile: the lane's 4 consecutive features as one vector store
+        const int64_t i = row * F + 16 * t + 4 * g;
+        if (out_f64) {
+            *(double2 *)((double *)out + i) = make_double2((double)o[0], (double)o[1]);
+            *(double2 *)((double *)out + i + 2) = make_double2((double)o[2], (double)o[3]);
+        } else {
+            *(v4 *)((float *)out + i) = o;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = slot_feature(F, t, g, r);
+            if (f >= 0) {
+                if (out_f64) ((double *)out)[row * F + f] = (double)o[r]; else ((float *)out)[row * F + f] = o[r];
+            }
+        }
+    }
+}
+
 template <int F, int Z, int KIND>
 __global__ void __launch_bounds__(256) wide_infer_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
                                                          void *__restrict__ out, int out_f64) {
@@ -638,57 +758,7 @@ __global__ void __launch_bounds__(256) wide_infer_kernel(const v4 *packed, const
             // ---- en1, streamed over the 2500 input features: a1^T[13 tiles] += W[t][chunk] . x^T[chunk] ------------------
             v4 a1[13];
             init_bias(a1, bias_lds + (N::bf_off(0) - N::bf_off(0)), lane);
-            v4 wa[13], wb[13];
-            auto load_w = [&](v4 (&w)[13], int kc) {
-#pragma unroll
-                for (int t = 0; t < 13; ++t) w[t] = frag_rt(ww, kc * 13 + t);
-            };
-            auto mm = [&](const v4 (&w)[13], const v4 &xv, int kc) {
-                // 13 independent accumulators: consecutive MFMAs never wait on each other
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (16 * kc + 16 <= F || r < tile_steps(F, KC - 1)) {
-#pragma unroll
-                        for (int t = 0; t < 13; ++t) a1[t] = mfma(w[t][r], xv[r], a1[t]);
-                    }
-            };
-            // x runs kXA chunks ahead (first touch of a row segment comes from HBM: ~2 us against 0.8 us of MFMAs per chunk;
-            // 4 ahead left SQ_WAIT_ANY at 23 %), the fragments (L2-resident) one chunk ahead in ping-pong buffers (no register
-            // copies); out-of-range prefetches re-read chunk 0
-            constexpr int kXA = 8;
-            v4 xr[kXA];
-            auto load_x = [&](int kc) { return wide_x_chunk<F>(xin, in_f64, rrow, kc < KC ? kc : 0, g); };
-            auto clampw = [&](int kc) { return kc < KC ? kc : KC - 1; };
-            const int last = (F % 16) ? KC - 1 : -1;       // index of the partial chunk
-            load_w(wa, 0);
-#pragma unroll
-            for (int u = 0; u < kXA; ++u) xr[u] = load_x(u);
-            int kc = 0;
-            for (; kc + kXA <= KC; kc += kXA) {
-#pragma unroll
-                for (int p = 0; p < kXA / 2; ++p) {
-                    load_w(wb, clampw(kc + 2 * p + 1));
-                    mm(wa, xr[2 * p], kc + 2 * p == last ? KC - 1 : 0);
-                    xr[2 * p] = load_x(kc + 2 * p + kXA);
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_w(wa, clampw(kc + 2 * p + 2));
-                    mm(wb, xr[2 * p + 1], kc + 2 * p + 1 == last ? KC - 1 : 0);
-                    xr[2 * p + 1] = load_x(kc + 2 * p + 1 + kXA);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            // the last KC % kXA chunks: wa holds chunk kc's fragments, xr[u] chunk kc + u
-#pragma unroll
-            for (int u = 0; u < kXA - 1; ++u) {
-                if (kc + u < KC) {
-                    if (kc + u + 1 < KC) load_w(wb, kc + u + 1);
-                    mm(wa, xr[u], (kc + u == last) ? KC - 1 : 0);
-                    if (kc + u + 1 < KC) {
-#pragma unroll
-                        for (int t = 0; t < 13; ++t) wa[t] = wb[t];
-                    }
-                }
-            }
+            wide_in_product<F>(a1, ww, xin, in_f64, rrow, g);
             lrelu(a1);
             // ---- layers 1..3: the register chain ---------------------------------------------------------------------------
             Ring ring;
@@ -707,55 +777,166 @@ __global__ void __launch_bounds__(256) wide_infer_kernel(const v4 *packed, const
             fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
-            // ---- de4, streamed over the 2500 output features, one tile at a time.  The 13 k tiles alternate between TWO
-            // accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, an independent one 32) that are added at the end
-            const v4 *bias7 = bias_lds + (N::bf_off(7) - N::bf_off(0));
-            v4 wa[13], wb[13];
-            auto load_w = [&](v4 (&w)[13], int t) {
-                t = t < KC ? t : KC - 1;
+            // ---- de4, streamed over the 2500 output features -------------------------------------------------------------
+            wide_out_product<F>(a7, ww, bias_lds + (N::bf_off(7) - N::bf_off(0)), g,
+                                [&](const v4 &o, int t, auto) { if (valid) wide_store_tile<F>(o, out, out_f64, row, t, g); });
+        }
+    }
+}
+
+// ---- wide models: the row-local part of a training pass ---------------------------------------------------------------
+// The weight gradients of a wide model are split-K GEMMs over the whole chunk (generic.hip); everything that is LOCAL to a row --
+// the forward pass, the loss and its gradient, the input-gradient chain -- runs here, one launch each, with the activations and
+// the pre-activation gradients written once as row-major float32 for those GEMMs (no layer-by-layer round trips).
+template <class N> struct StreamWideMid {   // forward fragments of layers 1..6
+    static constexpr int fwd_base(int l) { return (N::wf_off(l) - N::wf_off(1)) / 64; }
+    static constexpr int total = (N::wf_off(7) - N::wf_off(1)) / 64;
+    static constexpr int start_f4 = N::wf_off(1);
+};
+template <class N> struct StreamWideMidBwd {   // transposed fragments of layers 6..1 (packed in that order)
+    static constexpr int bwd_base(int l) { return (N::wb_off(l) - N::wb_off(6)) / 64; }
+    static constexpr int total = (N::wb_off(0) - N::wb_off(6)) / 64;
+    static constexpr int start_f4 = N::wb_off(6);
+};
+// one activation / gradient row block in C layout from / to a row-major float32 matrix [rows][D]
+template <int D>
+__device__ __forceinline__ void load_act(v4 (&a)[tiles(D)], const float *__restrict__ y, int64_t rrow, int g) {
 #pragma unroll
-                for (int q = 0; q < 13; ++q) w[q] = frag_rt(ww, q * KC + t);
-            };
-            auto tile_out = [&](const v4 (&w)[13], int t) {
-                if (t >= KC) return;
-                v4 o0 = bias7[t * 4 + g], o1 = (v4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < tiles(D); ++t) {
+        if (D - 16 * t >= 16 && D % 4 == 0) {
+            a[t] = *(const v4 *)(y + rrow * D + 16 * t + 4 * g);
+        } else {
 #pragma unroll
-                for (int q = 0; q < 13; q += 2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (r < tile_steps(200, q)) o0 = mfma(w[q][r], a7[q][r], o0);
-                        if (q + 1 < 13 && r < tile_steps(200, q + 1)) o1 = mfma(w[q + 1][r], a7[q + 1][r], o1);
-                    }
-                const v4 o = o0 + o1;
-                if (!valid) return;
-                if (16 * t + 16 <= F) {              // full tile: the lane's 4 consecutive features as one vector store
-                    const int64_t i = row * F + 16 * t + 4 * g;
-                    if (out_f64) {
-                        *(double2 *)((double *)out + i) = make_double2((double)o[0], (double)o[1]);
-                        *(double2 *)((double *)out + i + 2) = make_double2((double)o[2], (double)o[3]);
-                    } else {
-                        *(v4 *)((float *)out + i) = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int f = slot_feature(F, t, g, r);
-                        if (f >= 0) {
-                            if (out_f64) ((double *)out)[row * F + f] = (double)o[r]; else ((float *)out)[row * F + f] = o[r];
-                        }
-                    }
-                }
-            };
-            load_w(wa, 0);
-            for (int t0 = 0; t0 < KC; t0 += 2) {
-                load_w(wb, t0 + 1);
-                tile_out(wa, t0);
-                __builtin_amdgcn_sched_barrier(0);
-                load_w(wa, t0 + 2);
-                tile_out(wb, t0 + 1);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < 4; ++r) {
+                const int f = slot_feature(D, t, g, r);
+                a[t][r] = f >= 0 ? y[rrow * D + f] : 0.f;
             }
         }
+    }
+}
+
+// forward + loss + dL/drecon of 16 rows per wave: en1 streamed, layers 1..6 chained in registers, de4 streamed tile by tile against
+// the x tile it reconstructs (re-read: the wave streamed that row block a few microseconds earlier).  y1..y7 = activations,
+// dz8 = 2 (recon - x) / F, loss_part[workgroup] = sum of squared errors (double, fixed order).
+template <int F, int Z>
+__global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, const float *__restrict__ x, int64_t n, float *__restrict__ y1,
+                                                             float *__restrict__ y2, float *__restrict__ y3, float *__restrict__ y4,
+                                                             float *__restrict__ y5, float *__restrict__ y6, float *__restrict__ y7,
+                                                             float *__restrict__ dz8, double *__restrict__ loss_part) {
+    using N = Net<F, Z>;
+    using S = StreamWideMid<N>;
+    constexpr int KC = tiles(F);
+    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
+    __shared__ double sh[256];
+    stage_bias<N>(bias_lds, packed);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int64_t ntile = (n + 15) / 16;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
+    WStream w0 = make_stream(packed + N::wf_off(0), N::wcount(0) * 16, lane);
+    WStream w7 = make_stream(packed + N::wf_off(7), N::wcount(7) * 16, lane);
+    const float gscale = 2.0f / F;
+    double lacc = 0.0;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 16 + (lane & 15);
+        const bool valid = row < n;
+        const int64_t rrow = valid ? row : 0;
+        asm volatile("" : "+v"(ws.voff), "+v"(w0.voff), "+v"(w7.voff));
+        v4 a7[13];
+        {
+            v4 a1[13];
+            init_bias(a1, bias_lds, lane);
+            wide_in_product<F>(a1, w0, x, 0, rrow, g);
+            lrelu(a1);
+            store_rows<200>(a1, y1, 0, row, valid, lane, nullptr, nullptr);
+            Ring ring;
+            ring_prime<S::total>(ring, ws);
+            v4 a2[7], a3[4], a4[tiles(Z)], a5[4], a6[7];
+            fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
+            store_rows<100>(a2, y2, 0, row, valid, lane, nullptr, nullptr);
+            fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
+            store_rows<50>(a3, y3, 0, row, valid, lane, nullptr, nullptr);
+            fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
+            store_rows<Z>(a4, y4, 0, row, valid, lane, nullptr, nullptr);
+            fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
+            store_rows<50>(a5, y5, 0, row, valid, lane, nullptr, nullptr);
+            fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
+            store_rows<100>(a6, y6, 0, row, valid, lane, nullptr, nullptr);
+            fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
+            store_rows<200>(a7, y7, 0, row, valid, lane, nullptr, nullptr);
+        }
+        // de4 + loss: the x tiles run four tiles ahead of the tile being multiplied
+        v4 xr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xr[u] = wide_x_chunk<F>(x, 0, rrow, u, g);
+        wide_out_product<F>(a7, w7, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, [&](const v4 &o, int t, auto slot) {
+            constexpr int SL = decltype(slot)::value;
+            const v4 d = o - xr[SL];     // padding slots: zero weights and bias against a zero x
+            xr[SL] = wide_x_chunk<F>(x, 0, rrow, t + 4 < KC ? t + 4 : 0, g);
+            if (valid) {
+                lacc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
+                wide_store_tile<F>(d * gscale, dz8, 0, row, t, g);
+            }
+        });
+    }
+    sh[threadIdx.x] = lacc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = sh[0];
+}
+
+// the input-gradient chain of 16 rows per wave: dZ_6 = (dZ_7 W_7) * lrelu'(y7) streamed over the wide dimension, then layers 6..1
+// chained in registers; every dZ_l (dL/d pre-activation of layer l) is stored for the weight-gradient GEMMs.
+template <int F, int Z>
+__global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, const float *__restrict__ dz7, int64_t n,
+                                                             const float *__restrict__ y1, const float *__restrict__ y2,
+                                                             const float *__restrict__ y3, const float *__restrict__ y5,
+                                                             const float *__restrict__ y6, const float *__restrict__ y7,
+                                                             float *__restrict__ dz0, float *__restrict__ dz1, float *__restrict__ dz2,
+                                                             float *__restrict__ dz3, float *__restrict__ dz4, float *__restrict__ dz5,
+                                                             float *__restrict__ dz6) {
+    using N = Net<F, Z>;
+    using S = StreamWideMidBwd<N>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int64_t ntile = (n + 15) / 16;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
+    WStream w7 = make_stream(packed + N::wb_off(7), N::wcount(7) * 16, lane);       // [wide chunk][tile of the 200 side]
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 16 + (lane & 15);
+        const bool valid = row < n;
+        const int64_t rrow = valid ? row : 0;
+        asm volatile("" : "+v"(ws.voff), "+v"(w7.voff));
+        v4 d6[13];
+        zero_tiles(d6);
+        wide_in_product<F>(d6, w7, dz7, 0, rrow, g);
+        Ring ring;
+        ring_prime<S::total>(ring, ws);
+        {
+            v4 a[13];
+            load_act<200>(a, y7, rrow, g);
+            lrelu_bwd(d6, a);
+        }
+        store_rows<200>(d6, dz6, 0, row, valid, lane, nullptr, nullptr);
+        v4 d5[7], d4[4], d3[tiles(Z)], d2[4], d1[7], d0[13];
+        bwd_layer<N, S, 6>(d6, d5, ring, ws);
+        { v4 a[7]; load_act<100>(a, y6, rrow, g); lrelu_bwd(d5, a); }
+        store_rows<100>(d5, dz5, 0, row, valid, lane, nullptr, nullptr);
+        bwd_layer<N, S, 5>(d5, d4, ring, ws);
+        { v4 a[4]; load_act<50>(a, y5, rrow, g); lrelu_bwd(d4, a); }
+        store_rows<50>(d4, dz4, 0, row, valid, lane, nullptr, nullptr);
+        bwd_layer<N, S, 4>(d4, d3, ring, ws);                      // the latent layer has no activation
+        store_rows<Z>(d3, dz3, 0, row, valid, lane, nullptr, nullptr);
+        bwd_layer<N, S, 3>(d3, d2, ring, ws);
+        { v4 a[4]; load_act<50>(a, y3, rrow, g); lrelu_bwd(d2, a); }
+        store_rows<50>(d2, dz2, 0, row, valid, lane, nullptr, nullptr);
+        bwd_layer<N, S, 2>(d2, d1, ring, ws);
+        { v4 a[7]; load_act<100>(a, y2, rrow, g); lrelu_bwd(d1, a); }
+        store_rows<100>(d1, dz1, 0, row, valid, lane, nullptr, nullptr);
+        bwd_layer<N, S, 1>(d1, d0, ring, ws);
+        { v4 a[13]; load_act<200>(a, y1, rrow, g); lrelu_bwd(d0, a); }
+        store_rows<200>(d0, dz0, 0, row, valid, lane, nullptr, nullptr);
     }
 }
 
@@ -1754,6 +1935,9 @@ struct FusedOps {
     int (*fwd_bwd)(bamd_handle *, const void *, int, int64_t, const double *, void *, hipStream_t);
     // fwd + bwd + Adam + pack in two launches (small batches only; returns BAMD_ERR_UNSUPPORTED when n is too large)
     int (*train_step)(bamd_handle *, const void *, int, int64_t, const double *, void *, const AdamArgs &, hipStream_t);
+    // wide models: the row-local parts of a layer-wise training pass (see wide_train_fwd_kernel / wide_train_bwd_kernel)
+    int (*wide_fwd)(bamd_handle *, const float *, int64_t, float *const *, float *, double *, int *, hipStream_t);
+    int (*wide_bwd)(bamd_handle *, int64_t, float *const *, float *const *, hipStream_t);
 };
 
 static FusedState *state_of(bamd_handle *h) { return (FusedState *)h->fused_state; }
@@ -1980,8 +2164,25 @@ template <int F, int Z> struct ImplWide {
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
+    // y[l] = activations entering layer l (row-major float32, y[0] unused), dz[l] = dL/d(pre-activation of layer l)
+    static int wide_fwd(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
+                        hipStream_t s) {
+        const int grid = grid_for(rows);
+        hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, y[1], y[2], y[3],
+                           y[4], y[5], y[6], y[7], dz_last, loss_part);
+        *nblk = grid;
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int wide_bwd(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, hipStream_t s) {
+        hipLaunchKernelGGL((wide_train_bwd_kernel<F, Z>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                           (const float *)dz[7], rows, (const float *)y[1], (const float *)y[2], (const float *)y[3], (const float *)y[5],
+                           (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6]);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
     static const FusedOps *ops() {
-        static const FusedOps o = {setup, encode, decode, nullptr, nullptr, nullptr};
+        static const FusedOps o = {setup, encode, decode, nullptr, nullptr, nullptr, wide_fwd, wide_bwd};
         return &o;
     }
 };
@@ -2050,6 +2251,23 @@ int fused_pack(bamd_handle *h, hipStream_t s) {
                        (const int *)st->pack_src.p, st->packed_floats, (float *)h->packed.p);
     BAMD_HIP(hipGetLastError());
     return BAMD_OK;
+}
+
+static bool wide_train_on() {   // BALER_AMD_WIDE_TRAIN=0: every layer of a wide model's training pass on the layer-wise kernels
+    const char *e = getenv("BALER_AMD_WIDE_TRAIN");      // read per call (a training pass is milliseconds): tests toggle it
+    return !(e && e[0] == '0');
+}
+bool fused_wide_train(const bamd_handle *h) {
+    return h->fused_ok && ((const FusedState *)h->fused_state)->ops->wide_fwd && wide_train_on();
+}
+int fused_wide_train_forward(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
+                             hipStream_t s) {
+    if (!fused_wide_train(h)) return BAMD_ERR_UNSUPPORTED;
+    return state_of(h)->ops->wide_fwd(h, x, rows, y, dz_last, loss_part, nblk, s);
+}
+int fused_wide_train_backward(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, hipStream_t s) {
+    if (!fused_wide_train(h)) return BAMD_ERR_UNSUPPORTED;
+    return state_of(h)->ops->wide_bwd(h, rows, y, dz, s);
 }
 
 int fused_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,

@@ -20,6 +20,13 @@ int fused_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const d
 // batch size has no such path (the caller then runs fused_fwd_bwd / generic_fwd_bwd followed by launch_adam)
 int fused_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
                      void *params, void *m, void *v, const bamd_adam &hp, double *loss_accum, hipStream_t s);
+// Wide models (CFD_dense_AE(2500, 25), the 512-column model) in the layer-wise training pass of generic.hip: the row-local work in
+// two launches.  forward: x -> activations y[1..7] (row-major float32), dz_last = 2 (recon - x) / F, one loss partial per
+// workgroup (*nblk of them); backward: dz[7] -> dz[6..0] (dL/d pre-activation of every layer).  The weight gradients stay GEMMs.
+bool fused_wide_train(const bamd_handle *h);
+int fused_wide_train_forward(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
+                             hipStream_t s);
+int fused_wide_train_backward(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, hipStream_t s);
 // fp64 small-batch step (fused64.hip): chain + weight-gradient tiles on v_mfma_f64_16x16x4_f64 for BAMD_MODE_F64 handles
 int fused64_setup(bamd_handle *h);               // leaves h->fused64_state null for shapes without an instantiation
 void fused64_teardown(bamd_handle *h);

@@ -8,6 +8,7 @@
 // The fused register-chained kernels in fused.hip are the fast path for narrow models; this path is
 // the general fallback and the independent cross-check for them.  gfx950 only.
 #include "bamd_internal.hpp"
+#include "fused.hpp"
 
 #include <cstdlib>
 
@@ -403,13 +404,13 @@ static void launch_gemm(const Opnd<T> &A, const Opnd<T> &B, int64_t kred, const 
 template <typename T> struct Work {
     T *x0;
     std::vector<T *> y;  // y[l] = output of layer l-1 (y[0] = x0)
-    T *dza, *dzb;
+    std::vector<T *> dz; // dz[l] = dL/d(pre-activation of layer l): rows x dims[l + 1] (training only)
     int64_t chunk;
 };
 
 template <typename T>
 static int carve(bamd_handle *h, int64_t n, bool need_grad, Work<T> &wk) {
-    int64_t per_row = h->dims[0] + h->sum_dims + (need_grad ? 2 * h->max_dim : 0);
+    int64_t per_row = h->dims[0] + h->sum_dims + (need_grad ? h->sum_dims : 0);
     // activation workspace budget: large enough that one chunk fills the chip even for wide models
     // (CFD_dense_AE: 42 KB of activations per row); 288 GB of HBM per GPU make 4 GB a small price
     static const int64_t budget = getenv("BALER_AMD_WORKSPACE_MB") ? atoll(getenv("BALER_AMD_WORKSPACE_MB")) << 20 : ((int64_t)4 << 30);
@@ -428,8 +429,11 @@ static int carve(bamd_handle *h, int64_t n, bool need_grad, Work<T> &wk) {
         p += chunk * h->dims[l];
     }
     wk.x0 = wk.y[0];
-    wk.dza = need_grad ? p : nullptr;
-    wk.dzb = need_grad ? p + chunk * h->max_dim : nullptr;
+    wk.dz.assign(h->L, nullptr);
+    for (int l = 0; l < h->L && need_grad; ++l) {
+        wk.dz[l] = p;
+        p += chunk * h->dims[l + 1];
+    }
     return BAMD_OK;
 }
 
@@ -560,30 +564,44 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
             rc = stage_input<T>(h, x, x_dtype, r0, rows, c, features, wk.x0, s);
             if (rc) return rc;
         }
-        launch_fwd_layer<T>(h, 0, x0, wk.y[1], rows, s);
-        for (int l = 1; l + 1 < h->L; ++l) launch_fwd_layer<T>(h, l, wk.y[l], wk.y[l + 1], rows, s);
-        T *dz = wk.dza, *dz_next = wk.dzb;
+        // wide models in float32: the row-local work (forward, loss, input-gradient chain) as two fused launches (fused.hip)
+        const bool wide = sizeof(T) == 4 && !latent_grad && fused_wide_train(h);
         int nblk = 0;
-        {   // last layer with the loss fused into its store: dz = 2 (r - x) / C, one loss partial per workgroup (the separate
-            // loss pass re-read r and x and wrote dz: 1 GB for 32k CFD frames)
-            const int l = h->L - 1, K = h->dims[l], N = h->dims[l + 1];
-            const bool big = rows >= 96 && N >= 96;
-            const int64_t tile = big ? 128 : 64;
-            nblk = (int)(((N + tile - 1) / tile) * ((rows + tile - 1) / tile));
-            rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk > 1024 ? nblk : 1024));
+        if (wide) {
+            rc = h->lossp.ensure(sizeof(double) * 4096);
             if (rc) return rc;
-            Opnd<T> A{wk.y[l], K, 1, rows, -1};
-            Opnd<T> B{P + h->w_off[l], K, 1, N, -1};
-            Epi<T> e{};
-            e.out = dz; e.ld = N; e.n_rows = rows; e.n_cols = N;
-            e.bias = P + h->b_off[l]; e.act = h->has_act(l) ? 1 : 0;
-            e.xref = x0; e.loss_part = (double *)h->lossp.p; e.grad_scale = 2.0 / c;
-            launch_gemm<T, EPI_FWD_LOSS, true, true>(A, B, (int64_t)K, e, rows, N, 1, s);
+            rc = fused_wide_train_forward(h, (const float *)x0, rows, (float *const *)wk.y.data(), (float *)wk.dz[h->L - 1],
+                                          (double *)h->lossp.p, &nblk, s);
+            if (rc) return rc;
+        } else {
+            launch_fwd_layer<T>(h, 0, x0, wk.y[1], rows, s);
+            for (int l = 1; l + 1 < h->L; ++l) launch_fwd_layer<T>(h, l, wk.y[l], wk.y[l + 1], rows, s);
+            {   // last layer with the loss fused into its store: dz = 2 (r - x) / C, one loss partial per workgroup (the separate
+                // loss pass re-read r and x and wrote dz: 1 GB for 32k CFD frames)
+                const int l = h->L - 1, K = h->dims[l], N = h->dims[l + 1];
+                const bool big = rows >= 96 && N >= 96;
+                const int64_t tile = big ? 128 : 64;
+                nblk = (int)(((N + tile - 1) / tile) * ((rows + tile - 1) / tile));
+                rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk > 1024 ? nblk : 1024));
+                if (rc) return rc;
+                Opnd<T> A{wk.y[l], K, 1, rows, -1};
+                Opnd<T> B{P + h->w_off[l], K, 1, N, -1};
+                Epi<T> e{};
+                e.out = wk.dz[l]; e.ld = N; e.n_rows = rows; e.n_cols = N;
+                e.bias = P + h->b_off[l]; e.act = h->has_act(l) ? 1 : 0;
+                e.xref = x0; e.loss_part = (double *)h->lossp.p; e.grad_scale = 2.0 / c;
+                launch_gemm<T, EPI_FWD_LOSS, true, true>(A, B, (int64_t)K, e, rows, N, 1, s);
+            }
         }
         hipLaunchKernelGGL(loss_final_k<T>, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk, 1.0 / c,
                            grads + np, chunk_i > 0 ? 1 : 0);
+        if (wide) {
+            rc = fused_wide_train_backward(h, rows, (float *const *)wk.y.data(), (float *const *)wk.dz.data(), s);
+            if (rc) return rc;
+        }
         for (int l = h->L - 1; l >= 0; --l) {
             int K = h->dims[l], N = h->dims[l + 1];
+            const T *dz = wk.dz[l];
             // [dW | db] = dZ^T [X | 1], reduced over this chunk's rows in nsplit fixed slabs
             {
                 Opnd<T> A{dz, 1, N, N, -1};
@@ -593,16 +611,15 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 e.slab_stride = np; e.rows_per_split = rps;
                 launch_gemm<T, EPI_DW, false, false>(A, B, rows, e, N, K + 1, (unsigned)nsplit, s);
             }
-            if (l > 0) {
+            if (l > 0 && !wide) {
                 // dZ_{l-1} = (dZ_l W_l) * lrelu'(Y_{l-1})
                 Opnd<T> A{dz, N, 1, rows, -1};
                 Opnd<T> B{P + h->w_off[l], 1, K, K, -1};
                 Epi<T> e{};
-                e.out = dz_next; e.ld = K; e.n_rows = rows; e.n_cols = K;
+                e.out = wk.dz[l - 1]; e.ld = K; e.n_rows = rows; e.n_cols = K;
                 e.ymask = h->has_act(l - 1) ? wk.y[l] : nullptr; e.ld_mask = K;
                 if (latent_grad && l == h->L / 2) { e.add = (const T *)latent_grad + r0 * K; e.ld_add = K; }   // dL/dz of the caller's regulariser
                 launch_gemm<T, EPI_DX, true, false>(A, B, (int64_t)N, e, rows, K, 1, s);
-                T *t = dz; dz = dz_next; dz_next = t;
             }
         }
         hipLaunchKernelGGL(reduce_slabs_k<T>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, slabs,

@@ -474,6 +474,35 @@ def test_other_latent_sizes_fused(z, data10k):
     assert rel(gg.cpu().numpy(), grads.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("shape,n", [((2500, 25), 1), ((2500, 25), 17), ((2500, 25), 300), ((2500, 25), 1037), ((512, 6), 65), ((512, 6), 1000)])
+def test_wide_training_pass_vs_oracle(shape, n, monkeypatch):
+    """Training pass of the wide models: forward + loss + input-gradient chain on the two fused wide-layer launches, weight
+    gradients as split-K GEMMs -- loss and every gradient against the oracle and against the all-layer-wise pass
+    (BALER_AMD_WIDE_TRAIN=0), float32 rows in place, float64 rows and normalise-on-load through the staging copy."""
+    dims = orc.ae_dims(*shape)
+    flat = orc.formula_params(dims, 23)
+    h, p = make_handle(dims, flat, "fp32")
+    rng = np.random.default_rng(n)
+    x = rng.random((n, shape[0]))
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    grads = torch.zeros_like(p)
+    for xin in (dev(x, torch.float32), dev(x)):
+        grads.fill_(7.0)
+        h.fwd_bwd(xin, grads)
+        gh = grads.cpu().numpy().astype(np.float64)
+        assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo, xin.dtype
+    monkeypatch.setenv("BALER_AMD_WIDE_TRAIN", "0")
+    gl = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), gl)
+    monkeypatch.delenv("BALER_AMD_WIDE_TRAIN")
+    assert rel(gl.cpu().numpy(), grads.cpu().numpy()) < 1e-5
+    mn, rg = x.min(0) - 0.5, x.max(0) - x.min(0) + 1.0
+    lo2, go2 = orc.fwd_bwd(dims, flat, (x - mn) / rg)
+    h.fwd_bwd(dev(x), grads, features=dev(np.stack([mn, rg])))
+    gh = grads.cpu().numpy().astype(np.float64)
+    assert rel(gh[:-1], go2) < 2e-5 and abs(gh[-1] - lo2) < 2e-5 * lo2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_wide_512_fused_encode_ragged(dtype):
     """Encode of the 512-column model runs on the fused register chain (vector row loads); decode/train on the
