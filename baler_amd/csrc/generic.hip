@@ -400,6 +400,180 @@ static void launch_gemm(const Opnd<T> &A, const Opnd<T> &B, int64_t kred, const 
     }
 }
 
+// ---- weight gradients with one short side (float32) --------------------------------------------------------------------------
+// [dW | db] = dZ^T [X | 1] of an autoencoder layer always has one side of at most a few hundred columns (200 x 2501, 2500 x 201,
+// 100 x 201 ...) and reduces over tens of thousands of rows.  The LDS-tiled kernel pays 128-wide tile padding on the short side
+// (201 -> 256) and needs many row splits to fill the chip with 128 x 128 tiles.  Here a wave keeps TQ x PT accumulator tiles in
+// registers -- ALL PT 16-column tiles of the short side "P" against TQ tiles of the other side "Q" -- for its whole row range, and
+// both operands are read in MFMA layout straight from the row-major matrices: the reduction index of v_mfma_f32_16x16x4_f32 is
+// the ROW (step s, lane group g -> row 4 s + g of a 16-row block), lane i of a group the column, so every operand register is
+// one coalesced dword load (64 contiguous bytes per lane group), no transpose and no LDS.  The four waves of a workgroup share
+// the P loads through the L1; operands of the next 16-row block are loaded while the current block multiplies (two register
+// sets, no copies).  P_IS_N: P = dZ (n side), Q = [X | 1]; otherwise P = [X | 1], Q = dZ.  The ones column is a select on the
+// tile that holds column K.  Output: this split's slab [n * K + k | n] (fixed order reduction by reduce_layers_k).
+template <int PT, int TQ, bool P_IS_N>
+__global__ void __launch_bounds__(256) dw_short_k(const float *__restrict__ dzm, const float *__restrict__ xm, int N, int K, int64_t rows,
+                                                  int64_t rps, float *__restrict__ slab, int64_t slab_size) {
+    using v4 = MF<float>::v4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const float *__restrict__ pm = P_IS_N ? dzm : xm;
+    const float *__restrict__ qm = P_IS_N ? xm : dzm;
+    const int DP = P_IS_N ? N : K, DQ = P_IS_N ? K : N;            // stored widths
+    const int CQ = P_IS_N ? K + 1 : N;                             // logical columns of Q
+    const int qt0 = ((int)blockIdx.x * 4 + wave) * TQ;
+    if (qt0 * 16 >= CQ) return;
+    const int64_t r_begin = (int64_t)blockIdx.y * rps;
+    const int64_t r_end = r_begin + rps < rows ? r_begin + rps : rows;
+    if (r_begin >= r_end) return;
+    // per-lane element offsets inside a 16-row block (columns beyond the stored width re-read the last column: their
+    // accumulators are padding and never stored)
+    // Operand loads go through buffer resources based at the split's first row: ONE byte offset per lane and operand side in a
+    // VGPR (tile t = +64 t bytes, an immediate; PT = tiles(logical columns), so only the LAST P tile can reach beyond the stored
+    // width and has its own clamped offset), block and step offsets in SGPRs -- no 64-bit address arithmetic on the vector unit
+    // (global loads cost one v_lshl_add_u64 each).  The host keeps rows-per-split x width below 2^29 elements.
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(pm + r_begin * DP), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(qm + r_begin * DQ), 0, 0x7fffffff, 0x00020000);
+    int offq[TQ];
+    const int offp0 = (g * DP + i) * 4;
+    const int offpl = (g * DP + (16 * (PT - 1) + i < DP ? 16 * (PT - 1) + i : DP - 1)) * 4;
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) { const int c = 16 * (qt0 + u) + i; offq[u] = (g * DQ + (c < DQ ? c : DQ - 1)) * 4; }
+    auto ldp = [&](int voff, int soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, voff, soff, 0)); };
+    auto ldq = [&](int voff, int soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, voff, soff, 0)); };
+    const bool p_one = !P_IS_N && 16 * (PT - 1) + i == K;          // this lane's column of the LAST P tile is the ones column
+    bool q_one[TQ];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) q_one[u] = P_IS_N && 16 * (qt0 + u) + i == K;
+    v4 acc[TQ][PT];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[u][t] = (v4){0.f, 0.f, 0.f, 0.f};
+    struct Frags { v4 p[PT]; v4 q[TQ]; };
+    auto load = [&](Frags &f, int64_t rb, bool tail) {      // rb = first row of the block, relative to r_begin
+        const int sp = (int)rb * DP * 4, sq = (int)rb * DQ * 4;
+        if (!tail) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+                for (int u = 0; u < TQ; ++u) f.q[u][s4] = ldq(offq[u], sq + s4 * 16 * DQ);
+#pragma unroll
+                for (int t = 0; t < PT; ++t) f.p[t][s4] = ldp(t == PT - 1 ? offpl : offp0 + 64 * t, sp + s4 * 16 * DP);
+            }
+        } else {            // last block of the range: rows beyond it read the last row and contribute zero through dZ
+            const int64_t nr = r_end - r_begin;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const bool ok = rb + 4 * s4 + g < nr;
+                const int back = ok ? 0 : (int)(rb + 4 * s4 + g - (nr - 1));
+#pragma unroll
+                for (int u = 0; u < TQ; ++u) {
+                    const float v = ldq(offq[u] - back * DQ * 4, sq + s4 * 16 * DQ);
+                    f.q[u][s4] = (!P_IS_N && !ok) ? 0.f : v;
+                }
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    const float v = ldp((t == PT - 1 ? offpl : offp0 + 64 * t) - back * DP * 4, sp + s4 * 16 * DP);
+                    f.p[t][s4] = (P_IS_N && !ok) ? 0.f : v;
+                }
+            }
+        }
+    };
+    auto mma = [&](Frags &f) {
+        if (!P_IS_N) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) f.p[PT - 1][s4] = p_one ? 1.0f : f.p[PT - 1][s4];
+        } else {
+#pragma unroll
+            for (int u = 0; u < TQ; ++u)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) f.q[u][s4] = q_one[u] ? 1.0f : f.q[u][s4];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int u = 0; u < TQ; ++u)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[u][t] = MF<float>::mma(f.q[u][s4], f.p[t][s4], acc[u][t]);
+    };
+    Frags fa, fb;
+    const int64_t nfull = (r_end - r_begin) >> 4;          // full 16-row blocks; the loop below never sees the ragged one
+    if (nfull > 0) {
+        load(fa, 0, false);
+        int64_t b = 0;
+        for (; b + 2 < nfull; b += 2) {
+            load(fb, 16 * (b + 1), false);
+            mma(fa);
+            __builtin_amdgcn_sched_barrier(0);
+            load(fa, 16 * (b + 2), false);
+            mma(fb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (b + 2 == nfull) {
+            load(fb, 16 * (b + 1), false);
+            mma(fa);
+            mma(fb);
+        } else {
+            mma(fa);
+        }
+    }
+    if ((r_end - r_begin) & 15) {
+        load(fa, 16 * nfull, true);
+        mma(fa);
+    }
+    // C map: register r of lane (g, i) = (q column 4 g + r of the tile, p column i)
+    float *out = slab + (int64_t)blockIdx.y * slab_size;
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const int q0 = 16 * (qt0 + u) + 4 * g;
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int pc = 16 * t + i;
+            if (P_IS_N) {                                   // n = p column, k = q column: the lane's 4 registers are 4 consecutive k
+                if (pc < N) {
+                    if ((K & 3) == 0 && q0 + 3 < K) {
+                        *(v4 *)(out + (int64_t)pc * K + q0) = acc[u][t];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (q0 + r < K) out[(int64_t)pc * K + q0 + r] = acc[u][t][r];
+                            else if (q0 + r == K) out[(int64_t)N * K + pc] = acc[u][t][r];
+                        }
+                    }
+                }
+            } else {                                        // n = q column, k = p column: lanes i are 16 consecutive k
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (q0 + r < N) {
+                        if (pc < K) out[(int64_t)(q0 + r) * K + pc] = acc[u][t][r];
+                        else if (pc == K) out[(int64_t)N * K + q0 + r] = acc[u][t][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// grads[off + j] (+)= sum over the layer's splits of slab_l[split][j], splits in fixed order
+struct ReducePlan {
+    int64_t off[9];        // parameter offsets of the layers (off[L] = parameter count); at most 8 layers
+    int64_t base[8];       // float offset of layer l's slabs
+    int nsplit[8];
+    int L;
+};
+__global__ void __launch_bounds__(256) reduce_layers_k(const float *__restrict__ slabs, ReducePlan pl, float *__restrict__ gout, int accumulate) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= pl.off[pl.L]) return;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) l += (k < pl.L && j >= pl.off[k]) ? 1 : 0;
+    const int64_t size = pl.off[l + 1] - pl.off[l];
+    const float *p = slabs + pl.base[l] + (j - pl.off[l]);
+    float acc = accumulate ? gout[j] : 0.f;
+    for (int k = 0; k < pl.nsplit[l]; ++k) acc += p[(int64_t)k * size];
+    gout[j] = acc;
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 template <typename T> struct Work {
     T *x0;
@@ -532,6 +706,75 @@ int generic_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, 
     return forward_loss_T<float>(h, x, x_dtype, n, features, recon, recon_dtype, loss_sum, s);
 }
 
+// short-side weight-gradient kernels: usable when every layer has a side of 1, 2, 4, 7 or 13 16-column tiles
+static int short_tiles(int cols) {
+    const int t = (cols + 15) / 16;
+    return (t == 1 || t == 2 || t == 4 || t == 7 || t == 13) ? t : 0;
+}
+struct ShortPlan {
+    bool ok = false;
+    bool p_is_n[8];
+    int pt[8], ncol[8], nsplit[8];
+    int64_t rps[8];
+    ReducePlan rp;
+    int64_t total = 0;     // slab floats
+};
+static ShortPlan plan_short_dw(const bamd_handle *h, int64_t rows) {
+    ShortPlan pl;
+    const char *e = getenv("BALER_AMD_SHORT_DW");
+    if ((e && e[0] == '0') || h->L > 8 || rows < 2048) return pl;
+    constexpr int TQ = 2;
+    int64_t base = 0;
+    for (int l = 0; l < h->L; ++l) {
+        const int K = h->dims[l], N = h->dims[l + 1];
+        // P = the side with fewer tiles among those that fit (more Q tiles = more workgroup columns)
+        const int tk = short_tiles(K + 1), tn = short_tiles(N);
+        if (!tk && !tn) return pl;
+        const bool pn = tk == 0 || (tn != 0 && N < K + 1);
+        pl.p_is_n[l] = pn;
+        pl.pt[l] = pn ? tn : tk;
+        const int cq = pn ? K + 1 : N;
+        pl.ncol[l] = ((cq + 15) / 16 + 4 * TQ - 1) / (4 * TQ);
+        // two workgroups per CU, every split at least 64 rows and a multiple of 16
+        int64_t ns = (512 + pl.ncol[l] - 1) / pl.ncol[l];
+        ns = ns > rows / 64 ? rows / 64 : ns;
+        ns = ns < 1 ? 1 : (ns > 256 ? 256 : ns);
+        int64_t rps = ((rows + ns - 1) / ns + 15) & ~(int64_t)15;
+        const int64_t wmax = K > N ? K : N;
+        if (rps * wmax >= ((int64_t)1 << 29)) return pl;       // 32-bit byte offsets inside a split
+        ns = (rows + rps - 1) / rps;
+        pl.nsplit[l] = (int)ns;
+        pl.rps[l] = rps;
+        pl.rp.off[l] = h->w_off[l];
+        pl.rp.base[l] = base;
+        pl.rp.nsplit[l] = (int)ns;
+        base += ns * ((int64_t)N * K + N);
+    }
+    pl.rp.off[h->L] = h->nparams;
+    pl.rp.L = h->L;
+    pl.total = base;
+    pl.ok = true;
+    return pl;
+}
+template <int PT>
+static void launch_dw_short(bool p_is_n, const float *dz, const float *xm, int N, int K, int64_t rows, int64_t rps, float *slab, dim3 grid,
+                            hipStream_t s) {
+    const int64_t size = (int64_t)N * K + N;
+    if (p_is_n) hipLaunchKernelGGL((dw_short_k<PT, 2, true>), grid, dim3(256), 0, s, dz, xm, N, K, rows, rps, slab, size);
+    else hipLaunchKernelGGL((dw_short_k<PT, 2, false>), grid, dim3(256), 0, s, dz, xm, N, K, rows, rps, slab, size);
+}
+static void run_dw_short(const ShortPlan &pl, int l, const float *dz, const float *xm, int N, int K, int64_t rows, float *slabs, hipStream_t s) {
+    const dim3 grid((unsigned)pl.ncol[l], (unsigned)pl.nsplit[l]);
+    float *slab = slabs + pl.rp.base[l];
+    switch (pl.pt[l]) {
+    case 1: launch_dw_short<1>(pl.p_is_n[l], dz, xm, N, K, rows, pl.rps[l], slab, grid, s); break;
+    case 2: launch_dw_short<2>(pl.p_is_n[l], dz, xm, N, K, rows, pl.rps[l], slab, grid, s); break;
+    case 4: launch_dw_short<4>(pl.p_is_n[l], dz, xm, N, K, rows, pl.rps[l], slab, grid, s); break;
+    case 7: launch_dw_short<7>(pl.p_is_n[l], dz, xm, N, K, rows, pl.rps[l], slab, grid, s); break;
+    default: launch_dw_short<13>(pl.p_is_n[l], dz, xm, N, K, rows, pl.rps[l], slab, grid, s); break;
+    }
+}
+
 template <typename T>
 static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
                      void *grads_v, const void *latent_grad, hipStream_t s) {
@@ -554,7 +797,9 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
         nsplit = nsplit > max_split ? max_split : nsplit;
         int64_t rps = ((rows + nsplit - 1) / nsplit + 15) & ~(int64_t)15;
         nsplit = (rows + rps - 1) / rps;
-        rc = h->slabs.ensure((size_t)(nsplit * np) * sizeof(T));
+        ShortPlan sp;
+        if constexpr (sizeof(T) == 4) sp = plan_short_dw(h, rows);
+        rc = h->slabs.ensure(sp.ok ? (size_t)sp.total * sizeof(float) : (size_t)(nsplit * np) * sizeof(T));
         if (rc) return rc;
         T *slabs = (T *)h->slabs.p;
         // rows that already have the compute type are used where they lie (no staging copy: 328 MB per 32k CFD frames)
@@ -603,7 +848,9 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
             int K = h->dims[l], N = h->dims[l + 1];
             const T *dz = wk.dz[l];
             // [dW | db] = dZ^T [X | 1], reduced over this chunk's rows in nsplit fixed slabs
-            {
+            if (sp.ok) {
+                if constexpr (sizeof(T) == 4) run_dw_short(sp, l, dz, l == 0 ? x0 : wk.y[l], N, K, rows, slabs, s);
+            } else {
                 Opnd<T> A{dz, 1, N, N, -1};
                 Opnd<T> B{l == 0 ? x0 : wk.y[l], 1, K, K, K};
                 Epi<T> e{};
@@ -622,8 +869,14 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 launch_gemm<T, EPI_DX, true, false>(A, B, (int64_t)N, e, rows, K, 1, s);
             }
         }
-        hipLaunchKernelGGL(reduce_slabs_k<T>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, slabs,
-                           (int)nsplit, np, np, grads, chunk_i > 0 ? 1 : 0);
+        if (sp.ok) {
+            if constexpr (sizeof(T) == 4)
+                hipLaunchKernelGGL(reduce_layers_k, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const float *)slabs, sp.rp, grads,
+                                   chunk_i > 0 ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL(reduce_slabs_k<T>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, slabs,
+                               (int)nsplit, np, np, grads, chunk_i > 0 ? 1 : 0);
+        }
     }
     BAMD_HIP(hipGetLastError());
     return BAMD_OK;

@@ -474,7 +474,30 @@ def test_other_latent_sizes_fused(z, data10k):
     assert rel(gg.cpu().numpy(), grads.cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("shape,n", [((2500, 25), 1), ((2500, 25), 17), ((2500, 25), 300), ((2500, 25), 1037), ((512, 6), 65), ((512, 6), 1000)])
+@pytest.mark.parametrize("z,n", [(15, 2048), (15, 5003), (6, 20000)])
+def test_layer_wise_training_short_side_weight_gradients(z, n, data10k, monkeypatch):
+    """Layer-wise float32 training pass at >= 2048 rows: the weight gradients run on the short-side kernels (1, 2, 4, 7 and 13
+    tiles on the short side, ones column on either side, ragged last block) -- against the oracle and against the LDS-tiled
+    GEMM path (BALER_AMD_SHORT_DW=0)."""
+    dims = orc.ae_dims(24, z)
+    flat = orc.formula_params(dims, 31)
+    x = np.concatenate([data10k, data10k[::-1] * 0.5])[:n]
+    monkeypatch.setenv("BALER_AMD_FORCE_GENERIC", "1")
+    h, p = make_handle(dims, flat, "fp32")
+    monkeypatch.delenv("BALER_AMD_FORCE_GENERIC")
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    grads = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), grads)
+    gh = grads.cpu().numpy().astype(np.float64)
+    assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
+    monkeypatch.setenv("BALER_AMD_SHORT_DW", "0")
+    g2 = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), g2)
+    assert rel(g2.cpu().numpy(), grads.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("shape,n", [((2500, 25), 1), ((2500, 25), 17), ((2500, 25), 300), ((2500, 25), 1037), ((2500, 25), 2100), ((512, 6), 65),
+                                     ((512, 6), 1000), ((512, 6), 4099)])
 def test_wide_training_pass_vs_oracle(shape, n, monkeypatch):
     """Training pass of the wide models: forward + loss + input-gradient chain on the two fused wide-layer launches, weight
     gradients as split-K GEMMs -- loss and every gradient against the oracle and against the all-layer-wise pass
