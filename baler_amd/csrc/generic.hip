@@ -502,10 +502,12 @@ __global__ void __launch_bounds__(256) dw_short_k(const float *__restrict__ dzm,
         load(fa, 0, false);
         int64_t b = 0;
         for (; b + 2 < nfull; b += 2) {
-            load(fb, 16 * (b + 1), false);
+            load(fb, 16 * (b + 1), false);          // issue the next block's loads BEFORE this block's MFMAs (hipcc sinks them otherwise)
+            __builtin_amdgcn_sched_barrier(0);
             mma(fa);
             __builtin_amdgcn_sched_barrier(0);
             load(fa, 16 * (b + 2), false);
+            __builtin_amdgcn_sched_barrier(0);
             mma(fb);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -551,6 +553,160 @@ __global__ void __launch_bounds__(256) dw_short_k(const float *__restrict__ dzm,
                 }
             }
         }
+    }
+}
+
+// The two WIDE weight gradients of a wide model (200 x 2501, 2500 x 201): the same structure with 16-byte operand loads.  The
+// vector-memory pipe issues one wave instruction per ~16 cycles whatever its width, so dword operand loads (60 per 104 MFMAs and
+// wave above) make the four waves of a CU VMEM-issue bound (measured: MFMA busy 45 %, 8 % of the cycles in s_waitcnt).  Here lane
+// (g, i) loads FOUR consecutive columns 4 i .. 4 i + 3 of row 4 s + g: register j of that load is the step-s operand of the
+// "strided tile" {64 G + 4 i + j : i = 0..15} of column group G -- a legal MFMA operand, since the column-to-lane map of an
+// operand is free as long as the epilogue knows it.  The short side (193..208 logical columns) is 3 groups (12 strided tiles) +
+// 1 plain tile of dword loads, the other side one group per wave: 20 loads per 208 MFMAs.  52 accumulator tiles (AGPRs), two
+// operand sets of 68 registers.  Needs widths and K divisible by 4 (16-byte rows; the ones column starts a 4-column group).
+template <bool P_IS_N>
+__global__ void __launch_bounds__(256) dw_wide_k(const float *__restrict__ dzm, const float *__restrict__ xm, int N, int K, int64_t rows,
+                                                 int64_t rps, float *__restrict__ slab, int64_t slab_size) {
+    using v4 = MF<float>::v4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const float *__restrict__ pm = P_IS_N ? dzm : xm;
+    const float *__restrict__ qm = P_IS_N ? xm : dzm;
+    const int DP = P_IS_N ? N : K, DQ = P_IS_N ? K : N;
+    const int CQ = P_IS_N ? K + 1 : N;
+    const int gq = (int)blockIdx.x * 4 + wave;                     // this wave's column group of Q
+    if (64 * gq >= CQ) return;
+    const int64_t r_begin = (int64_t)blockIdx.y * rps;
+    const int64_t r_end = r_begin + rps < rows ? r_begin + rps : rows;
+    if (r_begin >= r_end) return;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(pm + r_begin * DP), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(qm + r_begin * DQ), 0, 0x7fffffff, 0x00020000);
+    // columns beyond the stored width re-read the last 4 columns (padding accumulators, never stored)
+    const int cq = 64 * gq + 4 * i;
+    const int offq = (g * DQ + (cq + 4 <= DQ ? cq : DQ - 4)) * 4;
+    const int offpg = (g * DP + 4 * i) * 4;                                       // group G: + 256 G bytes
+    const int offpl = (g * DP + (192 + i < DP ? 192 + i : DP - 1)) * 4;           // the plain tile: columns 192 + i
+    const bool q_one = P_IS_N && cq == K;            // register 0 of this lane's Q load is the ones column
+    const bool p_one = !P_IS_N && 192 + i == K;
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t &r, int voff, int soff) {
+        return __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    v4 acc[4][13];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 13; ++t) acc[u][t] = (v4){0.f, 0.f, 0.f, 0.f};
+    struct Frags { v4 pg[3][4]; v4 pl; v4 q[4]; };                 // [group][step], plain tile [step], [step]
+    auto load = [&](Frags &f, int64_t rb, bool tail) {
+#ifdef BAMD_DW_NOLOAD        // ablation: operands of the first block only (pure MFMA time)
+        if (rb > 16) return;
+#endif
+        const int sp = (int)rb * DP * 4, sq = (int)rb * DQ * 4;
+        const int64_t nr = r_end - r_begin;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            int back_p = 0, back_q = 0;
+            bool ok = true;
+            if (tail) {                                            // rows beyond the range read its last row, dZ zeroed
+                ok = rb + 4 * s4 + g < nr;
+                const int back = ok ? 0 : (int)(rb + 4 * s4 + g - (nr - 1));
+                back_p = back * DP * 4;
+                back_q = back * DQ * 4;
+            }
+            f.q[s4] = ld4(rq, offq - back_q, sq + s4 * 16 * DQ);
+#pragma unroll
+            for (int G = 0; G < 3; ++G) f.pg[G][s4] = ld4(rp, offpg + 256 * G - back_p, sp + s4 * 16 * DP);
+            f.pl[s4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, offpl - back_p, sp + s4 * 16 * DP, 0));
+            if (tail && !ok) {
+                if (P_IS_N) {
+#pragma unroll
+                    for (int G = 0; G < 3; ++G) f.pg[G][s4] = (v4){0.f, 0.f, 0.f, 0.f};
+                    f.pl[s4] = 0.f;
+                } else {
+                    f.q[s4] = (v4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    };
+    auto mma = [&](Frags &f) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            if (P_IS_N) f.q[s4][0] = q_one ? 1.0f : f.q[s4][0];
+            else f.pl[s4] = p_one ? 1.0f : f.pl[s4];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int G = 0; G < 3; ++G)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[u][4 * G + j] = MF<float>::mma(f.q[s4][u], f.pg[G][s4][j], acc[u][4 * G + j]);
+                acc[u][12] = MF<float>::mma(f.q[s4][u], f.pl[s4], acc[u][12]);
+            }
+    };
+    Frags fa, fb;
+    const int64_t nfull = (r_end - r_begin) >> 4;
+    if (nfull > 0) {
+        load(fa, 0, false);
+        int64_t b = 0;
+        for (; b + 2 < nfull; b += 2) {
+            load(fb, 16 * (b + 1), false);          // issue the next block's loads BEFORE this block's MFMAs (hipcc sinks them otherwise)
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa);
+            __builtin_amdgcn_sched_barrier(0);
+            load(fa, 16 * (b + 2), false);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (b + 2 == nfull) {
+            load(fb, 16 * (b + 1), false);
+            mma(fa);
+            mma(fb);
+        } else {
+            mma(fa);
+        }
+    }
+    if ((r_end - r_begin) & 15) {
+        load(fa, 16 * nfull, true);
+        mma(fa);
+    }
+    // C map: register r of lane (g, i) in accumulator (u, t): Q column 64 gq + 16 g + 4 r + u; P column 64 G + 4 i + j for the
+    // strided tile t = 4 G + j, 192 + i for the plain tile t = 12
+    float *out = slab + (int64_t)blockIdx.y * slab_size;
+    if (P_IS_N) {                  // n = P column, k = Q column: the four Q tiles of a register are 4 consecutive k
+#pragma unroll
+        for (int t = 0; t < 13; ++t) {
+            const int n = t < 12 ? 64 * (t >> 2) + 4 * i + (t & 3) : 192 + i;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k0 = 64 * gq + 16 * g + 4 * r;
+                if (k0 + 3 < K) {
+                    *(v4 *)(out + (int64_t)n * K + k0) = (v4){acc[0][t][r], acc[1][t][r], acc[2][t][r], acc[3][t][r]};
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (k0 + u < K) out[(int64_t)n * K + k0 + u] = acc[u][t][r];
+                        else if (k0 + u == K) out[(int64_t)N * K + n] = acc[u][t][r];
+                    }
+                }
+            }
+        }
+    } else {                       // n = Q column, k = P column: the four strided tiles of a group are 4 consecutive k
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 64 * gq + 16 * g + 4 * r + u;
+                if (n >= N) continue;
+#pragma unroll
+                for (int G = 0; G < 3; ++G)
+                    *(v4 *)(out + (int64_t)n * K + 64 * G + 4 * i) = (v4){acc[u][4 * G][r], acc[u][4 * G + 1][r], acc[u][4 * G + 2][r], acc[u][4 * G + 3][r]};
+                const int k = 192 + i;
+                if (k < K) out[(int64_t)n * K + k] = acc[u][12][r];
+                else if (k == K) out[(int64_t)N * K + n] = acc[u][12][r];
+            }
     }
 }
 
@@ -713,7 +869,7 @@ static int short_tiles(int cols) {
 }
 struct ShortPlan {
     bool ok = false;
-    bool p_is_n[8];
+    bool p_is_n[8], wide[8];
     int pt[8], ncol[8], nsplit[8];
     int64_t rps[8];
     ReducePlan rp;
@@ -734,9 +890,14 @@ static ShortPlan plan_short_dw(const bamd_handle *h, int64_t rows) {
         pl.p_is_n[l] = pn;
         pl.pt[l] = pn ? tn : tk;
         const int cq = pn ? K + 1 : N;
-        pl.ncol[l] = ((cq + 15) / 16 + 4 * TQ - 1) / (4 * TQ);
-        // two workgroups per CU, every split at least 64 rows and a multiple of 16
-        int64_t ns = (512 + pl.ncol[l] - 1) / pl.ncol[l];
+        // 13 tiles on the short side and 16-byte rows: the kernel with 16-byte operand loads (one 64-column group of Q per wave,
+        // one workgroup per CU); otherwise two 16-column tiles of Q per wave, two workgroups per CU
+        static const bool wide_on = !(getenv("BALER_AMD_DW_WIDE") && getenv("BALER_AMD_DW_WIDE")[0] == '0');
+        pl.wide[l] = wide_on && pl.pt[l] == 13 && K % 4 == 0 && N % 4 == 0 && (pn ? N : K) >= 192;
+        const int per_wg = pl.wide[l] ? 256 : 16 * 4 * TQ;
+        pl.ncol[l] = (cq + per_wg - 1) / per_wg;
+        // every split at least 64 rows and a multiple of 16
+        int64_t ns = (pl.wide[l] ? 256 : 512) / pl.ncol[l];        // rounded DOWN: one workgroup more than the chip holds doubles the time
         ns = ns > rows / 64 ? rows / 64 : ns;
         ns = ns < 1 ? 1 : (ns > 256 ? 256 : ns);
         int64_t rps = ((rows + ns - 1) / ns + 15) & ~(int64_t)15;
@@ -766,6 +927,12 @@ static void launch_dw_short(bool p_is_n, const float *dz, const float *xm, int N
 static void run_dw_short(const ShortPlan &pl, int l, const float *dz, const float *xm, int N, int K, int64_t rows, float *slabs, hipStream_t s) {
     const dim3 grid((unsigned)pl.ncol[l], (unsigned)pl.nsplit[l]);
     float *slab = slabs + pl.rp.base[l];
+    if (pl.wide[l]) {
+        const int64_t size = (int64_t)N * K + N;
+        if (pl.p_is_n[l]) hipLaunchKernelGGL((dw_wide_k<true>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
+        else hipLaunchKernelGGL((dw_wide_k<false>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
+        return;
+    }
     switch (pl.pt[l]) {
     case 1: launch_dw_short<1>(pl.p_is_n[l], dz, xm, N, K, rows, pl.rps[l], slab, grid, s); break;
     case 2: launch_dw_short<2>(pl.p_is_n[l], dz, xm, N, K, rows, pl.rps[l], slab, grid, s); break;
