@@ -726,7 +726,16 @@ __global__ void __launch_bounds__(256) reduce_layers_k(const float *__restrict__
     const int64_t size = pl.off[l + 1] - pl.off[l];
     const float *p = slabs + pl.base[l] + (j - pl.off[l]);
     float acc = accumulate ? gout[j] : 0.f;
-    for (int k = 0; k < pl.nsplit[l]; ++k) acc += p[(int64_t)k * size];
+    const int ns = pl.nsplit[l];
+    int k = 0;
+    for (; k + 8 <= ns; k += 8) {          // eight loads in flight, added in split order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u) * size];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; k < ns; ++k) acc += p[(int64_t)k * size];
     gout[j] = acc;
 }
 
