@@ -2101,8 +2101,9 @@ template <int F, int Z> struct ImplInfer {
 };
 
 // Wide models (CFD_dense_AE(2500, 25), BASELINE.json configs[3]): encode and decode as ONE launch each on wide_infer_kernel;
-// training and forward_loss on the layer-wise path (the weight gradient of a 2500 x 200 layer is 2 MB of accumulators per
-// workgroup: it has to be a split-K GEMM).  Normalise-on-load / un-normalise-on-store go through a float32 staging buffer
+// training = the two row-local launches wide_fwd / wide_bwd inside generic.hip's layer-wise pass (the weight gradient of a
+// 2500 x 200 layer is 2 MB of accumulators per workgroup: it has to be a split-K product, generic.hip's dw_wide_k); forward_loss
+// layer-wise.  Normalise-on-load / un-normalise-on-store go through a float32 staging buffer
 // (the per-feature min / range of 2500 features do not fit next to the chain's registers).
 template <int F, int Z> struct ImplWide {
     using N = Net<F, Z>;

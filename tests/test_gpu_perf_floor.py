@@ -84,8 +84,11 @@ def test_round2_kernel_floors():
     zw = hw.encode(xw)
     t_we = _ms(lambda: hw.encode(xw), 3)
     t_wd = _ms(lambda: hw.decode(zw), 3)
+    gw = torch.zeros(orc.nparams(wd) + 1, dtype=torch.float32, device="cuda")
+    t_wt = _ms(lambda: hw.fwd_bwd(xw, gw), 3)
     print(f"bf16 fwd_bwd {t_b:.3f} ms per 1M rows, fp64 bs512 step {1e3 * t_64:.1f} us, CFD_dense_AE(2500,25) encode {t_we:.3f} / decode {t_wd:.3f} ms "
-          f"per 32768 frames")
+          f"/ fwd_bwd {t_wt:.3f} ms per 32768 frames")
     assert t_b < 1.35, "bf16 training kernels (profiles: ~1.0 ms per 1M rows)"
     assert 1e3 * t_64 < 60.0, "fp64 fused small-batch step (profiles: 41 us; layer-wise: 768 us)"
     assert t_we < 0.50 and t_wd < 0.60, "wide-layer encode / decode (profiles: 0.34 / 0.39 ms per 32768 frames; layer-wise 0.66)"
+    assert t_wt < 2.6, "wide-model training pass (profiles: 1.9 ms per 32768 frames; all layer-wise 3.3)"
