@@ -818,11 +818,13 @@ __device__ __forceinline__ void load_act(v4 (&a)[tiles(D)], const float *__restr
 // forward + loss + dL/drecon of 16 rows per wave: en1 streamed, layers 1..6 chained in registers, de4 streamed tile by tile against
 // the x tile it reconstructs (re-read: the wave streamed that row block a few microseconds earlier).  y1..y7 = activations,
 // dz8 = 2 (recon - x) / F, loss_part[workgroup] = sum of squared errors (double, fixed order).
-template <int F, int Z>
+// TRAIN = false is the validation pass (training.py:104-137): no activation stores, `dz8` (may be null) receives the
+// reconstruction itself as float32 / float64.
+template <int F, int Z, bool TRAIN>
 __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, const float *__restrict__ x, int64_t n, float *__restrict__ y1,
                                                              float *__restrict__ y2, float *__restrict__ y3, float *__restrict__ y4,
                                                              float *__restrict__ y5, float *__restrict__ y6, float *__restrict__ y7,
-                                                             float *__restrict__ dz8, double *__restrict__ loss_part) {
+                                                             void *__restrict__ dz8, int out_f64, double *__restrict__ loss_part) {
     using N = Net<F, Z>;
     using S = StreamWideMid<N>;
     constexpr int KC = tiles(F);
@@ -847,22 +849,22 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
             init_bias(a1, bias_lds, lane);
             wide_in_product<F>(a1, w0, x, 0, rrow, g);
             lrelu(a1);
-            store_rows<200>(a1, y1, 0, row, valid, lane, nullptr, nullptr);
+            if (TRAIN) store_rows<200>(a1, y1, 0, row, valid, lane, nullptr, nullptr);
             Ring ring;
             ring_prime<S::total>(ring, ws);
             v4 a2[7], a3[4], a4[tiles(Z)], a5[4], a6[7];
             fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
-            store_rows<100>(a2, y2, 0, row, valid, lane, nullptr, nullptr);
+            if (TRAIN) store_rows<100>(a2, y2, 0, row, valid, lane, nullptr, nullptr);
             fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
-            store_rows<50>(a3, y3, 0, row, valid, lane, nullptr, nullptr);
+            if (TRAIN) store_rows<50>(a3, y3, 0, row, valid, lane, nullptr, nullptr);
             fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
-            store_rows<Z>(a4, y4, 0, row, valid, lane, nullptr, nullptr);
+            if (TRAIN) store_rows<Z>(a4, y4, 0, row, valid, lane, nullptr, nullptr);
             fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
-            store_rows<50>(a5, y5, 0, row, valid, lane, nullptr, nullptr);
+            if (TRAIN) store_rows<50>(a5, y5, 0, row, valid, lane, nullptr, nullptr);
             fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
-            store_rows<100>(a6, y6, 0, row, valid, lane, nullptr, nullptr);
+            if (TRAIN) store_rows<100>(a6, y6, 0, row, valid, lane, nullptr, nullptr);
             fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
-            store_rows<200>(a7, y7, 0, row, valid, lane, nullptr, nullptr);
+            if (TRAIN) store_rows<200>(a7, y7, 0, row, valid, lane, nullptr, nullptr);
         }
         // de4 + loss: the x tiles run four tiles ahead of the tile being multiplied
         v4 xr[4];
@@ -874,7 +876,8 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
             xr[SL] = wide_x_chunk<F>(x, 0, rrow, t + 4 < KC ? t + 4 : 0, g);
             if (valid) {
                 lacc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
-                wide_store_tile<F>(d * gscale, dz8, 0, row, t, g);
+                if (TRAIN) wide_store_tile<F>(d * gscale, dz8, 0, row, t, g);
+                else if (dz8) wide_store_tile<F>(o, dz8, out_f64, row, t, g);
             }
         });
     }
@@ -1815,6 +1818,20 @@ __global__ void sum_loss_k(const double *__restrict__ part, int n, double scale,
     }
 }
 
+// the same for thousands of partials: 256 strided fixed-order sums, then a fixed tree
+__global__ void __launch_bounds__(256) sum_loss_wide_k(const double *__restrict__ part, int n, double scale, double *__restrict__ out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0] * scale;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 struct FusedOps;
 struct FusedState {
@@ -2169,9 +2186,40 @@ template <int F, int Z> struct ImplWide {
     static int wide_fwd(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
                         hipStream_t s) {
         const int grid = grid_for(rows);
-        hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, y[1], y[2], y[3],
-                           y[4], y[5], y[6], y[7], dz_last, loss_part);
+        hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, true>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, y[1], y[2], y[3],
+                           y[4], y[5], y[6], y[7], (void *)dz_last, 0, loss_part);
         *nblk = grid;
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    // validation pass: sum of squared errors / F into *loss_sum, optional reconstruction (float32 staging for non-float32 rows and
+    // normalise-on-load, as in encode)
+    static int forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *recon, int recon_dtype,
+                            double *loss_sum, hipStream_t s) {
+        const size_t xes = x_dtype == BAMD_F64 ? 8 : 4, oes = recon_dtype == BAMD_F64 ? 8 : 4;
+        const int64_t chunk = 1 << 16;
+        int rc = h->lossp.ensure(sizeof(double) * 4096 * ((n + chunk - 1) / chunk > 0 ? (n + chunk - 1) / chunk : 1));
+        if (rc) return rc;
+        int nblk = 0;
+        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+            const int64_t rows = n - r0 < chunk ? n - r0 : chunk;
+            const void *src = (const char *)x + (size_t)r0 * F * xes;
+            if (features || x_dtype != BAMD_F32) {
+                rc = h->work.ensure((size_t)rows * F * sizeof(float));
+                if (rc) return rc;
+                rc = features ? launch_normalize(src, x_dtype, rows, F, features, h->work.p, BAMD_F32, s)
+                              : launch_convert(src, x_dtype, h->work.p, BAMD_F32, rows * F, s);
+                if (rc) return rc;
+                src = h->work.p;
+            }
+            const int grid = grid_for(rows);
+            hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, false>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
+                               rows, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr,
+                               (float *)nullptr, (float *)nullptr, recon ? (void *)((char *)recon + (size_t)r0 * F * oes) : nullptr,
+                               recon_dtype == BAMD_F64, (double *)h->lossp.p + nblk);
+            nblk += grid;
+        }
+        hipLaunchKernelGGL(sum_loss_wide_k, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk, 1.0 / F, loss_sum);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
@@ -2183,7 +2231,7 @@ template <int F, int Z> struct ImplWide {
         return BAMD_OK;
     }
     static const FusedOps *ops() {
-        static const FusedOps o = {setup, encode, decode, nullptr, nullptr, nullptr, wide_fwd, wide_bwd};
+        static const FusedOps o = {setup, encode, decode, forward_loss, nullptr, nullptr, wide_fwd, wide_bwd};
         return &o;
     }
 };

@@ -526,6 +526,32 @@ def test_wide_training_pass_vs_oracle(shape, n, monkeypatch):
     assert rel(gh[:-1], go2) < 2e-5 and abs(gh[-1] - lo2) < 2e-5 * lo2
 
 
+@pytest.mark.parametrize("shape,n", [((2500, 25), 1), ((2500, 25), 333), ((2500, 25), 70001), ((512, 6), 1000)])
+def test_wide_validation_pass_vs_oracle(shape, n):
+    """forward_loss (training.py:104-137) of the wide models on the fused forward kernel: loss and reconstruction, float32 and
+    float64 rows, normalise-on-load, several 65536-row chunks."""
+    dims = orc.ae_dims(*shape)
+    flat = orc.formula_params(dims, 29)
+    h, _ = make_handle(dims, flat, "fp32")
+    rng = np.random.default_rng(n)
+    x = rng.random((n, shape[0])).astype(np.float32).astype(np.float64)
+    m = min(n, 2000)                                   # the oracle on a head and a tail slice; the loss on all rows
+    rec_ref = np.concatenate([orc.forward(dims, flat, x[:m]), orc.forward(dims, flat, x[-m:])])
+    for xin in (dev(x, torch.float32), dev(x)):
+        rec, loss = h.forward_loss(xin)
+        r = rec.cpu().numpy().astype(np.float64)
+        assert rel(np.concatenate([r[:m], r[-m:]]), rec_ref) < TOL32
+        want = ((r - x) ** 2).sum() / shape[0]
+        assert abs(loss.item() - want) < 1e-5 * want
+    _, loss2 = h.forward_loss(dev(x, torch.float32), want_recon=False)
+    assert abs(loss2.item() - want) < 1e-5 * want
+    mn, rg = x.min(0) - 0.5, x.max(0) - x.min(0) + 1.0
+    rec3, loss3 = h.forward_loss(dev(x[:m]), features=dev(np.stack([mn, rg])))
+    xn = (x[:m] - mn) / rg
+    assert rel(rec3.cpu().numpy(), orc.forward(dims, flat, xn)) < 2e-5
+    assert abs(loss3.item() - orc.loss(xn, orc.forward(dims, flat, xn))) < 2e-5 * loss3.item()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_wide_512_fused_encode_ragged(dtype):
     """Encode of the 512-column model runs on the fused register chain (vector row loads); decode/train on the
