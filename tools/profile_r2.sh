@@ -21,6 +21,13 @@ $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/bpmc_f -o
 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/bpmc_w -o run -- $X > $O/bpmc_w.log 2>&1
 $T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $O/bpmc_m -o run -- $X > $O/bpmc_m.log 2>&1
 $T rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $O/bpmc_l -o run -- $X > $O/bpmc_l.log 2>&1
+# CFD_dense_AE(2500, 25) (BASELINE configs[3]): wide-layer encode / decode / training kernels, 32768 frames
+C="python3 $R/tools/bench_c4.py 32768"
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/cstats -o run -- $C > $O/cstats.log 2>&1
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cpmc_f -o run -- $C > $O/cpmc_f.log 2>&1
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cpmc_w -o run -- $C > $O/cpmc_w.log 2>&1
+$T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $O/cpmc_m -o run -- $C > $O/cpmc_m.log 2>&1
 python3 $R/tools/kstats.py $O/stats 8
+python3 $R/tools/kstats.py $O/cstats 8
 python3 $R/tools/kstats.py $O/bstats 6
 tail -1 $O/bench.json | cut -c1-400

@@ -17,7 +17,10 @@ R = os.path.join(REPO, "gpurun_out", "r2")
 KEYS = (("train_dec_kernel", "train_dec"), ("train_enc_kernel", "train_enc"), ("reduce_slabs_k", "reduce_slabs"),
         ("lat2_chain_kernel", "lat2_chain"), ("lat2_dw_kernel", "lat2_dw"), ("adam_k", "adam_k"),
         ("bf16_train_kernel<PART 0>", "bf16_train_kernel<24, 15, 0>"), ("bf16_train_kernel<PART 1>", "bf16_train_kernel<24, 15, 1>"),
-        ("reduce_tiles_k", "reduce_tiles_k"))
+        ("reduce_tiles_k", "reduce_tiles_k"),
+        ("wide_infer_kernel<ENCODE>", "wide_infer_kernel<2500, 25, 0>"), ("wide_infer_kernel<DECODE>", "wide_infer_kernel<2500, 25, 1>"),
+        ("wide_train_fwd_kernel", "wide_train_fwd_kernel<2500, 25, true>"), ("wide_train_bwd_kernel", "wide_train_bwd_kernel<2500, 25>"),
+        ("dw_wide_k<P = dZ>", "dw_wide_k<true>"), ("dw_wide_k<P = [X|1]>", "dw_wide_k<false>"), ("reduce_layers_k", "reduce_layers_k"))
 
 
 def load(pattern):
@@ -51,6 +54,7 @@ import bench  # noqa: E402  (source_hash)
 
 fp32 = merge("")
 bf16 = merge("b")
+c4 = merge("c")
 lds = load(f"{R}/bpmc_l/**/*counter_collection.csv")
 for k, v in lds.items():
     bf16.setdefault(k, {}).update(v)
@@ -62,23 +66,26 @@ out = {
             "passes, --kernel-trace only); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half of a wide "
             "coalesced read, MI355X_MICROARCH.md; checked on minmax_partial: 96 MB reported for a 192 MB read)",
     "source_hash": bench.source_hash(), "rows": 1000000, "kernels": fp32, "bf16_kernels": bf16,
+    "c4_note": "CFD_dense_AE(2500, 25), 32768 frames per launch, `python3 tools/bench_c4.py 32768`", "c4_kernels": c4,
     "fwd_bwd_hbm_bytes_per_launch": sum(fp32[k]["hbm_bytes"] for k in ("train_dec_kernel", "train_enc_kernel", "reduce_slabs_k") if k in fp32),
     "bf16_fwd_bwd_hbm_bytes_per_launch": sum(bf16[k]["hbm_bytes"] for k in ("bf16_train_kernel<PART 0>", "bf16_train_kernel<PART 1>", "reduce_tiles_k") if k in bf16),
 }
 json.dump(out, open(os.path.join(REPO, "profiles", "pmc_summary.json"), "w"), indent=1)
 shutil.copy(glob.glob(f"{R}/stats/**/*kernel_stats.csv", recursive=True)[0], os.path.join(REPO, "profiles", "r2_kernel_stats.csv"))
 shutil.copy(glob.glob(f"{R}/bstats/**/*kernel_stats.csv", recursive=True)[0], os.path.join(REPO, "profiles", "r2_bf16_kernel_stats.csv"))
+if glob.glob(f"{R}/cstats/**/*kernel_stats.csv", recursive=True):
+    shutil.copy(glob.glob(f"{R}/cstats/**/*kernel_stats.csv", recursive=True)[0], os.path.join(REPO, "profiles", "r2_c4_kernel_stats.csv"))
 d = json.loads(open(f"{R}/bench.json").read().strip().splitlines()[-1])
 if d.get("source_hash") == out["source_hash"]:
     d["roofline"]["traffic"] = out["fwd_bwd_hbm_bytes_per_launch"]
 json.dump(d, open(os.path.join(REPO, "profiles", "r2_bench.json"), "w"), indent=1)
-for name, tab in (("fp32", fp32), ("bf16", bf16)):
+for name, tab in (("fp32", fp32), ("bf16", bf16), ("c4", c4)):
     for k, v in tab.items():
         print(f"{name} {k:28s} busy {100 * v.get('mfma_busy', 0):5.1f}%  valu/mfma {v.get('valu_per_mfma', 0):.2f}  wait_any {v.get('wait_any_frac', 0):.3f}  "
               f"hbm {v['hbm_bytes'] / 1e6:7.1f} MB  mfma {v.get('SQ_INSTS_MFMA', 0) / 1e6:.1f} M  lds_conflict {v.get('lds_conflict_frac', 0):.2f}")
 print("fp32 fwd_bwd traffic MB", out["fwd_bwd_hbm_bytes_per_launch"] / 1e6, " bf16", out["bf16_fwd_bwd_hbm_bytes_per_launch"] / 1e6)
-for f in ("r2_kernel_stats.csv", "r2_bf16_kernel_stats.csv"):
-    for r in list(csv.DictReader(open(os.path.join(REPO, "profiles", f))))[:5]:
+for f in ("r2_kernel_stats.csv", "r2_bf16_kernel_stats.csv", "r2_c4_kernel_stats.csv"):
+    for r in list(csv.DictReader(open(os.path.join(REPO, "profiles", f))))[:7]:
         print(r["Name"].split("(")[0][-46:], r["Calls"], f"{float(r['AverageNs']) / 1e6:.4f} ms")
 print({k: d.get(k) for k in ("value", "ms_per_step", "encode_rows_per_s", "decode_rows_per_s", "bf16_train_rows_per_s", "train_bs512_us_per_step")})
 print(d["roofline"])
