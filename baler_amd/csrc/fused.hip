@@ -675,9 +675,10 @@ __device__ __forceinline__ void wide_in_product(v4 (&acc)[13], const WStream &ww
 // out tile t of the wide side = bias + sum over the 13 tiles of the 200-feature side (de4): one tile at a time, fragments one
 // tile ahead in ping-pong buffers; `emit(o, t, slot)` consumes the finished tile (C layout: register r = slot_feature(F, t, g, r)).
 // The 13 k tiles alternate between TWO accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, an independent one 32).
-template <int F, class Emit>
+template <int F, int NS, class Emit>
 __device__ __forceinline__ void wide_out_product(const v4 (&a7)[13], const WStream &ww, const v4 *bias7, int g, Emit emit) {
     constexpr int KC = tiles(F);
+    static_assert(NS == 4 || NS == 8, "slots of the caller's prefetch ring");
     v4 wa[13], wb[13];
     auto load_w = [&](v4 (&w)[13], int t) {
         t = t < KC ? t : KC - 1;
@@ -696,20 +697,23 @@ __device__ __forceinline__ void wide_out_product(const v4 (&a7)[13], const WStre
             }
         emit(o0 + o1, t, slot);
     };
+    auto pair = [&](int t0, auto jj) {          // tiles t0 + 2 j (fragments in wa) and t0 + 2 j + 1 (wb); `emit` sees the slot t % NS
+        constexpr int j = decltype(jj)::value;
+        load_w(wb, t0 + 2 * j + 1);
+        tile_out(wa, t0 + 2 * j, std::integral_constant<int, 2 * j>());
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(wa, t0 + 2 * j + 2);
+        tile_out(wb, t0 + 2 * j + 1, std::integral_constant<int, 2 * j + 1>());
+        __builtin_amdgcn_sched_barrier(0);
+    };
     load_w(wa, 0);
-    for (int t0 = 0; t0 < KC; t0 += 4) {       // unrolled by four: `emit` sees a compile-time slot t % 4 (prefetch rings of the caller)
-        load_w(wb, t0 + 1);
-        tile_out(wa, t0, std::integral_constant<int, 0>());
-        __builtin_amdgcn_sched_barrier(0);
-        load_w(wa, t0 + 2);
-        tile_out(wb, t0 + 1, std::integral_constant<int, 1>());
-        __builtin_amdgcn_sched_barrier(0);
-        load_w(wb, t0 + 3);
-        tile_out(wa, t0 + 2, std::integral_constant<int, 2>());
-        __builtin_amdgcn_sched_barrier(0);
-        load_w(wa, t0 + 4);
-        tile_out(wb, t0 + 3, std::integral_constant<int, 3>());
-        __builtin_amdgcn_sched_barrier(0);
+    for (int t0 = 0; t0 < KC; t0 += NS) {
+        pair(t0, std::integral_constant<int, 0>());
+        pair(t0, std::integral_constant<int, 1>());
+        if constexpr (NS == 8) {
+            pair(t0, std::integral_constant<int, 2>());
+            pair(t0, std::integral_constant<int, 3>());
+        }
     }
 }
 // store tile t of a wide row (C layout) as float / double
@@ -778,7 +782,7 @@ __global__ void __launch_bounds__(256) wide_infer_kernel(const v4 *packed, const
             fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
             // ---- de4, streamed over the 2500 output features -------------------------------------------------------------
-            wide_out_product<F>(a7, ww, bias_lds + (N::bf_off(7) - N::bf_off(0)), g,
+            wide_out_product<F, 4>(a7, ww, bias_lds + (N::bf_off(7) - N::bf_off(0)), g,
                                 [&](const v4 &o, int t, auto) { if (valid) wide_store_tile<F>(o, out, out_f64, row, t, g); });
         }
     }
@@ -866,16 +870,22 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
             fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
             if (TRAIN) store_rows<200>(a7, y7, 0, row, valid, lane, nullptr, nullptr);
         }
-        // de4 + loss: the x tiles run four tiles ahead of the tile being multiplied
-        v4 xr[4];
+        // de4 + loss: the x tiles run kXT tiles ahead of the tile being multiplied (HBM again: 327 MB of rows do not stay in the
+        // 256-MB MALL between the two passes; four ahead left 94 us of a 839-us launch waiting for them)
+        constexpr int kXT = 8;
+        v4 xr[kXT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xr[u] = wide_x_chunk<F>(x, 0, rrow, u, g);
-        wide_out_product<F>(a7, w7, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, [&](const v4 &o, int t, auto slot) {
+        for (int u = 0; u < kXT; ++u) xr[u] = wide_x_chunk<F>(x, 0, rrow, u, g);
+        wide_out_product<F, kXT>(a7, w7, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, [&](const v4 &o, int t, auto slot) {
             constexpr int SL = decltype(slot)::value;
             const v4 d = o - xr[SL];     // padding slots: zero weights and bias against a zero x
-            xr[SL] = wide_x_chunk<F>(x, 0, rrow, t + 4 < KC ? t + 4 : 0, g);
+#ifndef BAMD_WT_ABL_X
+            xr[SL] = wide_x_chunk<F>(x, 0, rrow, t + kXT < KC ? t + kXT : 0, g);
+#endif
             if (valid) {
+#ifndef BAMD_WT_ABL_LOSS
                 lacc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
+#endif
                 if (TRAIN) wide_store_tile<F>(d * gscale, dz8, 0, row, t, g);
                 else if (dz8) wide_store_tile<F>(o, dz8, out_f64, row, t, g);
             }
