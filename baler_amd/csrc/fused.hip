@@ -738,6 +738,110 @@ __device__ __forceinline__ void wide_store_tile(const v4 &o, void *out, int out_
     }
 }
 
+// Two 16-row tiles per wave: every fragment feeds both tiles' accumulators (half the fragment traffic per MFMA), and the 13
+// fragments of a chunk are fetched in two halves (tiles 0..6 / 7..12) so that two row tiles cost the registers of one:
+// 104 accumulators + 52 fragment + 32 x registers.  Each half multiplies 56 / 48 MFMAs while the other half loads.
+template <int F>
+__device__ __forceinline__ void wide_in_product2(v4 (&acc0)[13], v4 (&acc1)[13], const WStream &ww, const void *xin, int in_f64,
+                                                 int64_t rrow0, int64_t rrow1, int g) {
+    constexpr int KC = tiles(F);
+    v4 wlo[7], whi[6];
+    auto load_lo = [&](int kc) {
+        kc = kc < KC ? kc : KC - 1;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) wlo[t] = frag_rt(ww, kc * 13 + t);
+    };
+    auto load_hi = [&](int kc) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) whi[t] = frag_rt(ww, kc * 13 + 7 + t);
+    };
+    auto steps_of = [&](int kc) { return (F % 16 != 0 && kc == KC - 1) ? tile_steps(F, KC - 1) : 4; };
+    auto mm_lo = [&](const v4 &x0, const v4 &x1, int steps) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < steps) {
+#pragma unroll
+                for (int t = 0; t < 7; ++t) {
+                    acc0[t] = mfma(wlo[t][r], x0[r], acc0[t]);
+                    acc1[t] = mfma(wlo[t][r], x1[r], acc1[t]);
+                }
+            }
+    };
+    auto mm_hi = [&](const v4 &x0, const v4 &x1, int steps) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < steps) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    acc0[7 + t] = mfma(whi[t][r], x0[r], acc0[7 + t]);
+                    acc1[7 + t] = mfma(whi[t][r], x1[r], acc1[7 + t]);
+                }
+            }
+    };
+    constexpr int kXA = 4;
+    v4 x0r[kXA], x1r[kXA];
+    auto load_x0 = [&](int kc) { return wide_x_chunk<F>(xin, in_f64, rrow0, kc < KC ? kc : 0, g); };
+    auto load_x1 = [&](int kc) { return wide_x_chunk<F>(xin, in_f64, rrow1, kc < KC ? kc : 0, g); };
+    load_lo(0);
+#pragma unroll
+    for (int u = 0; u < kXA; ++u) { x0r[u] = load_x0(u); x1r[u] = load_x1(u); }
+    auto chunk = [&](int kc, auto slot) {
+        constexpr int SL = decltype(slot)::value;
+        const int steps = steps_of(kc);
+        load_hi(kc);
+        mm_lo(x0r[SL], x1r[SL], steps);
+        __builtin_amdgcn_sched_barrier(0);
+        load_lo(kc + 1);
+        mm_hi(x0r[SL], x1r[SL], steps);
+        x0r[SL] = load_x0(kc + kXA);
+        x1r[SL] = load_x1(kc + kXA);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kc = 0;
+    for (; kc + kXA <= KC; kc += kXA) {
+        chunk(kc, std::integral_constant<int, 0>());
+        chunk(kc + 1, std::integral_constant<int, 1>());
+        chunk(kc + 2, std::integral_constant<int, 2>());
+        chunk(kc + 3, std::integral_constant<int, 3>());
+    }
+    if (kc < KC) chunk(kc, std::integral_constant<int, 0>());
+    if (kc + 1 < KC) chunk(kc + 1, std::integral_constant<int, 1>());
+    if (kc + 2 < KC) chunk(kc + 2, std::integral_constant<int, 2>());
+}
+
+template <int F, int Z>
+__global__ void __launch_bounds__(256) wide_encode2_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
+                                                           void *__restrict__ out, int out_f64) {
+    using N = Net<F, Z>;
+    using S = StreamWideEnc<N>;
+    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
+    stage_bias<N>(bias_lds, packed);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int64_t npair = (n + 31) / 32;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
+    WStream ww = make_stream(packed + N::wf_off(0), N::wcount(0) * 16, lane);
+    for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < npair; pr += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = pr * 32 + (lane & 15), r1 = r0 + 16;
+        const bool v0 = r0 < n, v1 = r1 < n;
+        asm volatile("" : "+v"(ws.voff), "+v"(ww.voff));
+        v4 a1[13], b1[13];
+        init_bias(a1, bias_lds, lane);
+#pragma unroll
+        for (int t = 0; t < 13; ++t) b1[t] = a1[t];
+        wide_in_product2<F>(a1, b1, ww, xin, in_f64, v0 ? r0 : 0, v1 ? r1 : 0, g);
+        lrelu(a1);
+        lrelu(b1);
+        Ring ring;
+        ring_prime<S::total>(ring, ws);
+        v4 a2[7], b2[7], a3[4], b3[4], a4[tiles(Z)], b4[tiles(Z)];
+        fwd_layer2<N, S, 1>(a1, b1, a2, b2, ring, ws, bias_lds, lane);
+        fwd_layer2<N, S, 2>(a2, b2, a3, b3, ring, ws, bias_lds, lane);
+        fwd_layer2<N, S, 3>(a3, b3, a4, b4, ring, ws, bias_lds, lane);
+        store_rows<Z>(a4, out, out_f64, r0, v0, lane, nullptr, nullptr);
+        store_rows<Z>(b4, out, out_f64, r1, v1, lane, nullptr, nullptr);
+    }
+}
+
 template <int F, int Z, int KIND>
 __global__ void __launch_bounds__(256) wide_infer_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
                                                          void *__restrict__ out, int out_f64) {
@@ -2161,8 +2265,17 @@ template <int F, int Z> struct ImplWide {
                 src = h->work.p;
                 src_f64 = 0;
             }
-            hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_ENCODE>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, src,
-                               src_f64, rows, (void *)((char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64);
+            // two row tiles per wave once that still leaves two workgroups per CU (measured: 512-column model, 524288 rows
+            // 384 -> 419 M rows/s; C4 131072 frames 87.6 -> 91.8 M, but 32768 frames 96 -> 72 M: half the chip's wave slots empty);
+            // BALER_AMD_WIDE2=0 / 1 forces one / two tiles
+            const char *e2 = getenv("BALER_AMD_WIDE2");
+            const bool two = e2 ? e2[0] == '1' : rows >= 32 * 4 * 512;
+            if (two)
+                hipLaunchKernelGGL((wide_encode2_kernel<F, Z>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src,
+                                   src_f64, rows, (void *)((char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64);
+            else
+                hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_ENCODE>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, src,
+                                   src_f64, rows, (void *)((char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64);
         }
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;

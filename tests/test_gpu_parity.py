@@ -552,6 +552,25 @@ def test_wide_validation_pass_vs_oracle(shape, n):
     assert abs(loss3.item() - orc.loss(xn, orc.forward(dims, flat, xn))) < 2e-5 * loss3.item()
 
 
+@pytest.mark.parametrize("shape,n", [((2500, 25), 1), ((2500, 25), 31), ((2500, 25), 33), ((2500, 25), 1000), ((512, 6), 17), ((512, 6), 70000)])
+def test_wide_encode_two_row_tiles_per_wave(shape, n, monkeypatch):
+    """The two-tile encode kernel of the wide models (taken from 65536 rows on; forced here) against the one-tile kernel (same
+    fragments; the one-tile chain interleaves the steps of fragment pairs, so a one-tile-wide layer sums in another order) and
+    within 1e-5 of the oracle, ragged pair counts, float32 / float64 rows."""
+    dims = orc.ae_dims(*shape)
+    flat = orc.formula_params(dims, 37)
+    h, _ = make_handle(dims, flat, "fp32")
+    x = np.random.default_rng(n).random((n, shape[0]))
+    m = min(n, 1500)
+    for xin in (dev(x, torch.float32), dev(x)):
+        monkeypatch.setenv("BALER_AMD_WIDE2", "1")
+        z2 = h.encode(xin, out_dtype=torch.float32)
+        monkeypatch.setenv("BALER_AMD_WIDE2", "0")
+        z1 = h.encode(xin, out_dtype=torch.float32)
+        assert rel(z1.cpu().numpy(), z2.cpu().numpy()) < 2e-6
+        assert rel(z2[:m].cpu().numpy(), orc.encode(dims, flat, x[:m].astype(np.float32 if xin.dtype == torch.float32 else np.float64))) < TOL32
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_wide_512_fused_encode_ragged(dtype):
     """Encode of the 512-column model runs on the fused register chain (vector row loads); decode/train on the
