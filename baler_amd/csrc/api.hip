@@ -107,7 +107,7 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
     if (rc) { bamd_destroy(h); return rc; }
     rc = fused64_setup(h);
     if (rc) { bamd_destroy(h); return rc; }
-    if (mode == BAMD_MODE_BF16) {   // inference on bf16 MFMA; training calls of such a handle run on the fp32 layer-wise kernels
+    if (mode == BAMD_MODE_BF16 && !h->fused_ok) {   // (wide models in the bf16 mode are served by fused.hip: h->fused_ok)
         rc = bf16_setup(h);
         if (rc) { bamd_destroy(h); return rc; }
         rc = bf16_train_setup(h);
@@ -145,7 +145,7 @@ int bamd_load_params(bamd_handle *h, const void *params, int dtype, void *stream
     int rc = launch_convert(params, dtype, h->params.p, h->esize == 8 ? BAMD_F64 : BAMD_F32, h->nparams, s);
     if (rc) return rc;
     h->params_loaded = true;
-    if (h->mode == BAMD_MODE_BF16) {
+    if (h->mode == BAMD_MODE_BF16 && h->bf16_state) {
         rc = bf16_pack(h, s);
         h->bf16_infer_stale = false;
         return rc ? rc : bf16_train_pack(h, s);
@@ -174,7 +174,7 @@ int bamd_renormalize(const void *x, int dtype, int64_t n_rows, int n_cols, const
 
 // bf16 handles re-round the INFERENCE fragments lazily: a training step refreshes only what the next step reads
 static int bf16_sync(bamd_handle *h, hipStream_t s) {
-    if (h->mode != BAMD_MODE_BF16 || !h->bf16_infer_stale) return BAMD_OK;
+    if (h->mode != BAMD_MODE_BF16 || !h->bf16_state || !h->bf16_infer_stale) return BAMD_OK;
     h->bf16_infer_stale = false;
     return bf16_pack(h, s);
 }
@@ -192,7 +192,7 @@ int bamd_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, cons
     if (n_rows == 0) return BAMD_OK;
     hipStream_t s = (hipStream_t)stream;
     if (int rc = bf16_sync(h, s)) return rc;
-    if (h->mode == BAMD_MODE_BF16) return bf16_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
+    if (h->mode == BAMD_MODE_BF16 && h->bf16_state) return bf16_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
     if (h->fused_ok) return fused_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
     return generic_forward(h, x, x_dtype, n_rows, features, 0, h->L / 2, z, z_dtype, nullptr, nullptr, s);
 }
@@ -204,7 +204,7 @@ int bamd_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n_rows, cons
     if (n_rows == 0) return BAMD_OK;
     hipStream_t s = (hipStream_t)stream;
     if (int rc = bf16_sync(h, s)) return rc;
-    if (h->mode == BAMD_MODE_BF16) return bf16_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);
+    if (h->mode == BAMD_MODE_BF16 && h->bf16_state) return bf16_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);
     if (h->fused_ok) return fused_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);
     return generic_forward(h, z, z_dtype, n_rows, nullptr, h->L / 2, h->L, out, out_dtype, features, int_mask, s);
 }
@@ -215,7 +215,7 @@ int bamd_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows
     BAMD_REQUIRE(x && loss_sum && n_rows > 0, "bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (int rc = bf16_sync(h, s)) return rc;
-    if (h->mode == BAMD_MODE_BF16) return bf16_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
+    if (h->mode == BAMD_MODE_BF16 && h->bf16_state) return bf16_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
     if (h->fused_ok) return fused_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
     return generic_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
 }
@@ -264,7 +264,8 @@ int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, voi
     fused_scatter(h, &sc_off, &sc_idx, &packed);   // Adam also refreshes the packed weight copy (one launch)
     if (h->mode == BAMD_MODE_F64) fused64_scatter(h, &sc_off, &sc_idx, &packed);
     int rc = launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, sc_off, sc_idx, packed, s);
-    if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16) {
+    if (rc == BAMD_OK) fused_params_changed(h);
+    if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16 && h->bf16_state) {
         if (bf16_train_ok(h)) { h->bf16_infer_stale = true; rc = bf16_train_pack(h, s); }   // the next step's fragments now, the inference ones on demand
         else rc = bf16_pack(h, s);
     }

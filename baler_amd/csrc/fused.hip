@@ -809,9 +809,10 @@ __device__ __forceinline__ void wide_in_product2(v4 (&acc0)[13], v4 (&acc1)[13],
     if (kc + 2 < KC) chunk(kc + 2, std::integral_constant<int, 2>());
 }
 
-template <int F, int Z>
-__global__ void __launch_bounds__(256) wide_encode2_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
+template <int F, int Z, bool IN64>       // IN64: the row type is a template parameter (no branch in front of the row loads)
+__global__ void __launch_bounds__(256) wide_encode2_kernel(const v4 *packed, const void *__restrict__ xin, int64_t n,
                                                            void *__restrict__ out, int out_f64) {
+    constexpr int in_f64 = IN64 ? 1 : 0;
     using N = Net<F, Z>;
     using S = StreamWideEnc<N>;
     __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
@@ -842,9 +843,318 @@ __global__ void __launch_bounds__(256) wide_encode2_kernel(const v4 *packed, con
     }
 }
 
-template <int F, int Z, int KIND>
-__global__ void __launch_bounds__(256) wide_infer_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
+// ---- wide models in the bf16 mode: en1 / de4 on v_mfma_f32_16x16x32_bf16, the six narrow layers on the fp32 chain ------------
+// 95 % of the work of CFD_dense_AE(2500, 25) is the two wide layers.  On the bf16 MFMA (16 cycles for 16 x 16 x 32) they stop
+// being the bound: a frame is 10 KB of float32 input (encode) or output (decode), so the kernels are HBM-BOUND at
+// 8 TB/s / 10 KB = 0.8 G frames/s (fp32 MFMA bound: 0.15 G).  Two 16-row tiles per wave share every 1-KiB bf16 fragment
+// (16 outputs x 32 k; one tile per wave would need 250 B/clk/CU of fragments through a 64 B/clk L1).
+//   encode: B operand = 8 consecutive floats of the row per lane (k = 32 c + 8 g + j: natural order, a full 128-byte line per
+//           row and chunk), converted with four v_cvt_pk_bf16_f32; A = W0 fragments [chunk][tile][lane].
+//   decode: the fp32 chain leaves a7 in C layout (tile q, register r = feature slot (q, g, r)); k slot (g, j) of chunk c is
+//           DEFINED as (tile 2 c + j / 4, register j % 4), so a lane's 8 k values are its own registers of two tiles -- no
+//           cross-lane movement; W7's fragments are packed in that k order.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v4 mfma_bf(bf8 a, bf8 b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf8 to_bf8(const v4 &lo, const v4 &hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const bf2 p0 = {(__bf16)lo[0], (__bf16)lo[1]}, p1 = {(__bf16)lo[2], (__bf16)lo[3]};     // pair by pair: v_cvt_pk_bf16_f32
+    const bf2 p2 = {(__bf16)hi[0], (__bf16)hi[1]}, p3 = {(__bf16)hi[2], (__bf16)hi[3]};
+    const u4v u = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1), __builtin_bit_cast(unsigned, p2),
+                   __builtin_bit_cast(unsigned, p3)};
+    return __builtin_bit_cast(bf8, u);
+}
+__device__ __forceinline__ bf8 frag_bf(const WStream &ws, int idx) {
+    return __builtin_bit_cast(bf8, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
+}
+struct XPair { v4 lo, hi; };          // 8 consecutive features of one row (k = 8 g .. 8 g + 7 of a 32-feature chunk)
+template <int F>
+__device__ __forceinline__ XPair wide_x_chunk32(const void *x, int in_f64, int64_t row, int c, int g) {
+    XPair p;
+    const int k0 = 32 * c + 8 * g;
+    if (32 * c + 32 <= F) {
+        const int64_t i = row * F + k0;
+        if (in_f64) {
+            const double *d = (const double *)x + i;
+            const double2 a = *(const double2 *)d, b = *(const double2 *)(d + 2), e = *(const double2 *)(d + 4), f = *(const double2 *)(d + 6);
+            p.lo = (v4){(float)a.x, (float)a.y, (float)b.x, (float)b.y};
+            p.hi = (v4){(float)e.x, (float)e.y, (float)f.x, (float)f.y};
+        } else {
+            p.lo = *(const v4 *)((const float *)x + i);
+            p.hi = *(const v4 *)((const float *)x + i + 4);
+        }
+    } else {                      // the last, partial chunk: element by element, zero beyond the row
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            if (k0 + j < F) v = in_f64 ? (float)((const double *)x)[row * F + k0 + j] : ((const float *)x)[row * F + k0 + j];
+            if (j < 4) p.lo[j] = v; else p.hi[j - 4] = v;
+        }
+    }
+    return p;
+}
+
+// Encode.  All loads of a wave retire in order (vmcnt), so a weight fragment fetched "just ahead" would wait for every row chunk
+// fetched "far ahead" before it: the first version (fragments half a chunk ahead in registers, rows three chunks ahead) spent one
+// HBM round trip per chunk (1.9 us; 216 M frames/s).  Here EVERY load has the same lead: the four waves of a workgroup walk the
+// chunks in lockstep and share the chunk's 13 fragments through a double-buffered LDS stage -- each wave fetches its 3-4
+// fragments three chunks ahead (16 registers per chunk in flight), stores them one chunk ahead, one barrier per chunk -- and the
+// rows are fetched three chunks ahead.  Fragment traffic through the L1 drops four times as well.
+// the same through a buffer resource based at the workgroup's first row: one byte offset per lane (row and lane group) in a
+// VGPR, the chunk offset in an SGPR -- no 64-bit address arithmetic per load
+template <int F>
+__device__ __forceinline__ XPair wide_x_chunk32_buf(__amdgpu_buffer_rsrc_t rs, int voff, int in_f64, int c, int g) {
+    XPair p;
+    if (32 * c + 32 <= F) {
+        if (in_f64) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * k, c * 256, 0));
+            p.lo = (v4){(float)q[0][0], (float)q[0][1], (float)q[1][0], (float)q[1][1]};
+            p.hi = (v4){(float)q[2][0], (float)q[2][1], (float)q[3][0], (float)q[3][1]};
+        } else {
+            p.lo = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, c * 128, 0));
+            p.hi = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, c * 128, 0));
+        }
+    } else {                      // the last, partial chunk: element by element, zero beyond the row
+        const int k0 = 32 * c + 8 * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            if (k0 + j < F) {
+                if (in_f64) v = (float)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 8 * j, c * 256, 0));
+                else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * j, c * 128, 0));
+            }
+            if (j < 4) p.lo[j] = v; else p.hi[j - 4] = v;
+        }
+    }
+    return p;
+}
+
+// (IN64 is a template parameter: as a run-time flag every row load sat behind a branch and hipcc joined the paths with
+// s_waitcnt vmcnt(0), i.e. no load stayed in flight across a chunk)
+template <int F, int Z, bool IN64>
+__global__ void __launch_bounds__(256) wide_bf16_encode_kernel(const v4 *packed, const v4 *w0b, const void *__restrict__ xin, int64_t n,
+                                                               void *__restrict__ out, int out_f64) {
+    constexpr int in_f64 = IN64 ? 1 : 0;
+    using N = Net<F, Z>;
+    using S = StreamWideEnc<N>;
+    constexpr int KB = (F + 31) / 32;
+    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
+    __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];       // the chunk's fragments, [slot][tile][lane]
+    stage_bias<N>(bias_lds, packed);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 127) / 128;                          // 4 waves x 2 tiles x 16 rows
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
+    WStream ww = make_stream(w0b, KB * 13 * 1024, lane);
+    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+        const int64_t r0 = (grp * 4 + wave) * 32 + (lane & 15), r1 = r0 + 16;
+        const bool v0 = r0 < n, v1 = r1 < n;
+        // rows beyond n read the group's first row (never stored)
+        const int es = in_f64 ? 8 : 4;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)xin + (size_t)(grp * 128) * F * es), 0,
+                                                                             0x7fffffff, 0x00020000);
+        const int lr0 = wave * 32 + (lane & 15);
+        const int xo0 = ((v0 ? lr0 : 0) * F + 8 * g) * es, xo1 = ((v1 ? lr0 + 16 : 0) * F + 8 * g) * es;
+        asm volatile("" : "+v"(ws.voff), "+v"(ww.voff));
+        v4 a1[13], b1[13];
+        init_bias(a1, bias_lds, lane);
+#pragma unroll
+        for (int t = 0; t < 13; ++t) b1[t] = a1[t];
+        {
+            bf8 wq[2][4];                 // this wave's share (tiles wave, wave + 4, wave + 8, 12 for wave 0) of two chunks in flight
+            XPair x0r[3], x1r[3];
+            auto wload = [&](bf8 (&w)[4], int c) {
+                c = c < KB ? c : KB - 1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = wave + 4 * k;
+                    w[k] = frag_bf(ww, c * 13 + (t < 13 ? t : 12));
+                }
+            };
+            auto wstore = [&](const bf8 (&w)[4], int slot) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = wave + 4 * k;
+                    if (t < 13) wst[slot][t][lane] = __builtin_bit_cast(v4, w[k]);
+                }
+            };
+            auto lx0 = [&](int c) { return wide_x_chunk32_buf<F>(xrs, xo0, in_f64, c < KB ? c : 0, g); };
+            auto lx1 = [&](int c) { return wide_x_chunk32_buf<F>(xrs, xo1, in_f64, c < KB ? c : 0, g); };
+            // prologue: chunk 0 staged, chunks 1, 2 in flight; rows of chunks 0..2 in flight
+            wload(wq[0], 0);
+            wload(wq[1], 1);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { x0r[u] = lx0(u); x1r[u] = lx1(u); }
+            __syncthreads();              // the previous group's last chunk has been read
+            wstore(wq[0], 0);
+            wload(wq[0], 2);
+            auto iter = [&](int c, auto wsl, auto xsl) {
+                constexpr int WS = decltype(wsl)::value, XS = decltype(xsl)::value;      // c % 2, c % 3
+                __syncthreads();          // fragments of chunk c visible in stage slot WS; stage slot WS ^ 1 free
+                wstore(wq[WS ^ 1], WS ^ 1);                                              // chunk c + 1 (fetched two chunks ago)
+                const bf8 q0 = to_bf8(x0r[XS].lo, x0r[XS].hi), q1 = to_bf8(x1r[XS].lo, x1r[XS].hi);
+                wload(wq[WS ^ 1], c + 3);
+                x0r[XS] = lx0(c + 3);
+                x1r[XS] = lx1(c + 3);
+                // the chunk's fragments from the stage, four at a time (two register sets: 32 instead of 52 registers -- with
+                // all 13 resident the kernel needed 304 registers, one wave per SIMD)
+                bf8 wl[2][4];
+                auto rd = [&](bf8 (&w)[4], int t0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w[k] = __builtin_bit_cast(bf8, wst[WS][t0 + k < 13 ? t0 + k : 12][lane]);
+                };
+                auto mm = [&](const bf8 (&w)[4], int t0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (t0 + k < 13) { a1[t0 + k] = mfma_bf(w[k], q0, a1[t0 + k]); b1[t0 + k] = mfma_bf(w[k], q1, b1[t0 + k]); }
+                };
+                rd(wl[0], 0);
+                rd(wl[1], 4);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wl[0], 0);
+                rd(wl[0], 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wl[1], 4);
+                rd(wl[1], 12);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wl[0], 8);
+                mm(wl[1], 12);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            int c = 0;
+            for (; c + 6 <= KB; c += 6) {
+                iter(c, I0(), I0()); iter(c + 1, I1(), I1()); iter(c + 2, I0(), I2());
+                iter(c + 3, I1(), I0()); iter(c + 4, I0(), I1()); iter(c + 5, I1(), I2());
+            }
+            if (c < KB) iter(c, I0(), I0());
+            if (c + 1 < KB) iter(c + 1, I1(), I1());
+            if (c + 2 < KB) iter(c + 2, I0(), I2());
+            if (c + 3 < KB) iter(c + 3, I1(), I0());
+            if (c + 4 < KB) iter(c + 4, I0(), I1());
+        }
+        // the narrow layers one row tile after the other (the two-tile chain needs 300 registers next to the other tile's
+        // accumulators: one wave per SIMD for the whole kernel; they are 4 % of the work)
+        lrelu(a1);
+        lrelu(b1);
+        {
+            Ring ring;
+            ring_prime<S::total>(ring, ws);
+            v4 a2[7], a3[4], a4[tiles(Z)];
+            fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
+            store_rows<Z>(a4, out, out_f64, r0, v0, lane, nullptr, nullptr);
+        }
+        {
+            Ring ring;
+            ring_prime<S::total>(ring, ws);
+            v4 b2[7], b3[4], b4[tiles(Z)];
+            fwd_layer<N, S, 1>(b1, b2, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 2>(b2, b3, ring, ws, bias_lds, lane);
+            fwd_layer<N, S, 3>(b3, b4, ring, ws, bias_lds, lane);
+            store_rows<Z>(b4, out, out_f64, r1, v1, lane, nullptr, nullptr);
+        }
+    }
+}
+
+template <int F, int Z, bool OUT64>
+__global__ void __launch_bounds__(256) wide_bf16_decode_kernel(const v4 *packed, const v4 *w7b, const void *__restrict__ zin, int in_f64,
+                                                               int64_t n, void *__restrict__ out) {
+    constexpr int out_f64 = OUT64 ? 1 : 0;
+    using N = Net<F, Z>;
+    using S = StreamWideDec<N>;
+    constexpr int KT = tiles(F);                   // output tiles
+    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
+    stage_bias<N>(bias_lds, packed);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int64_t npair = (n + 31) / 32;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
+    WStream ww = make_stream(w7b, KT * 7 * 1024, lane);
+    const v4 *bias7 = bias_lds + (N::bf_off(7) - N::bf_off(0));
+    for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < npair; pr += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = pr * 32 + (lane & 15), r1 = r0 + 16;
+        const bool v0 = r0 < n, v1 = r1 < n;
+        asm volatile("" : "+v"(ws.voff), "+v"(ww.voff));
+        bf8 qa[7], qb[7];                          // a7 of both row tiles as bf16 B operands (k chunk c = tiles 2 c, 2 c + 1)
+        {
+            Ring ring;
+            ring_prime<S::total>(ring, ws);
+            v4 a4[tiles(Z)], b4[tiles(Z)], a5[4], b5[4], a6[7], b6[7], a7[13], b7[13];
+            load_rows<Z>(a4, zin, in_f64, r0, v0, lane, nullptr);
+            load_rows<Z>(b4, zin, in_f64, r1, v1, lane, nullptr);
+            fwd_layer2<N, S, 4>(a4, b4, a5, b5, ring, ws, bias_lds, lane);
+            fwd_layer2<N, S, 5>(a5, b5, a6, b6, ring, ws, bias_lds, lane);
+            fwd_layer2<N, S, 6>(a6, b6, a7, b7, ring, ws, bias_lds, lane);
+            const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                qa[c] = to_bf8(a7[2 * c], 2 * c + 1 < 13 ? a7[2 * c + 1 < 13 ? 2 * c + 1 : 12] : zero);
+                qb[c] = to_bf8(b7[2 * c], 2 * c + 1 < 13 ? b7[2 * c + 1 < 13 ? 2 * c + 1 : 12] : zero);
+            }
+        }
+        // fragments three output tiles ahead in four rotating register buffers (a tile is 14 MFMAs: one tile ahead left every
+        // tile waiting for an L2 round trip, 185 M frames/s)
+        bf8 wr[4][7];
+        auto load_w = [&](bf8 (&w)[7], int t) {
+            t = t < KT ? t : KT - 1;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) w[c] = frag_bf(ww, t * 7 + c);
+        };
+        auto tile_out = [&](const bf8 (&w)[7], int t) {
+            if (t >= KT) return;
+            v4 o0 = bias7[t * 4 + g], o1 = o0;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) { o0 = mfma_bf(w[c], qa[c], o0); o1 = mfma_bf(w[c], qb[c], o1); }
+#if defined(BAMD_WB_ABL) && BAMD_WB_ABL == 1
+            asm volatile("" :: "v"(o0), "v"(o1));
+#elif defined(BAMD_WB_ABL) && BAMD_WB_ABL == 2
+            {   // ablation: the same bytes as ONE contiguous 2-KB run per wave and tile
+                float *lin = (float *)out + ((pr * (F / 16) + (t < F / 16 ? t : 0)) * 2) * 256 + lane * 4;
+                *(v4 *)lin = o0;
+                *(v4 *)(lin + 256) = o1;
+            }
+#else
+            if (v0) wide_store_tile<F>(o0, out, out_f64, r0, t, g);
+            if (v1) wide_store_tile<F>(o1, out, out_f64, r1, t, g);
+#endif
+        };
+        load_w(wr[0], 0);
+        load_w(wr[1], 1);
+        load_w(wr[2], 2);
+        for (int t0 = 0; t0 < KT; t0 += 4) {
+            load_w(wr[3], t0 + 3);
+            tile_out(wr[0], t0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wr[0], t0 + 4);
+            tile_out(wr[1], t0 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wr[1], t0 + 5);
+            tile_out(wr[2], t0 + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wr[2], t0 + 6);
+            tile_out(wr[3], t0 + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// params (fp32) -> bf16 fragments through an index map (-1: zero)
+__global__ void __launch_bounds__(256) pack_wide_bf16_k(const float *__restrict__ params, const int *__restrict__ src, int count,
+                                                        __bf16 *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = (__bf16)(src[i] >= 0 ? params[src[i]] : 0.f);
+}
+
+// IN64 = type of the rows that encode reads, as a template parameter: as a run-time flag every row load of the streamed loop
+// sat behind a branch, and hipcc joins such paths with conservative waits (C4 encode at 131072 frames 91.8 -> 97.6 M rows/s;
+// the same treatment of decode's stores measured 5 % SLOWER and is not applied: decode ignores IN64)
+template <int F, int Z, int KIND, bool IN64>
+__global__ void __launch_bounds__(256) wide_infer_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64_, int64_t n,
                                                          void *__restrict__ out, int out_f64) {
+    const int in_f64 = KIND == K_ENCODE ? (IN64 ? 1 : 0) : in_f64_;
     using N = Net<F, Z>;
     static_assert(KIND == K_ENCODE || KIND == K_DECODE, "encode or decode");
     static_assert(N::dim(1) == 200 && N::dim(7) == 200, "13 register tiles on the narrow side of the wide layers");
@@ -1959,6 +2269,9 @@ struct FusedState {
     // <= this many rows: small-batch kernels (BALER_AMD_LATENCY_ROWS overrides).  Measured us/step small-batch vs
     // throughput pair: 1024 rows 27 / 74, 4096 44 / 88, 8192 76 / 101, 16384 133 / 131
     int64_t latency_max_rows = 12288;
+    DevBuf wb_src[2], wb[2];           // wide models in the bf16 mode: index maps and bf16 fragments of W0 / W7
+    int wb_count[2] = {0, 0};
+    bool wb_stale = false;             // the bf16 fragments lag the parameters (re-rounded before the next encode / decode)
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
     bool tail_split = true;            // short remainder of the persistent loop on the small-batch kernels (BALER_AMD_TAIL_SPLIT=0: off)
 };
@@ -2069,6 +2382,7 @@ struct FusedOps {
     // wide models: the row-local parts of a layer-wise training pass (see wide_train_fwd_kernel / wide_train_bwd_kernel)
     int (*wide_fwd)(bamd_handle *, const float *, int64_t, float *const *, float *, double *, int *, hipStream_t);
     int (*wide_bwd)(bamd_handle *, int64_t, float *const *, float *const *, hipStream_t);
+    int (*pack_extra)(bamd_handle *, FusedState *, hipStream_t);    // further packed copies of the parameters (bf16 fragments)
 };
 
 static FusedState *state_of(bamd_handle *h) { return (FusedState *)h->fused_state; }
@@ -2270,12 +2584,16 @@ template <int F, int Z> struct ImplWide {
             // BALER_AMD_WIDE2=0 / 1 forces one / two tiles
             const char *e2 = getenv("BALER_AMD_WIDE2");
             const bool two = e2 ? e2[0] == '1' : rows >= 32 * 4 * 512;
-            if (two)
-                hipLaunchKernelGGL((wide_encode2_kernel<F, Z>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src,
-                                   src_f64, rows, (void *)((char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64);
+            void *zo = (void *)((char *)z + (size_t)r0 * Z * zes);
+            const int z64 = z_dtype == BAMD_F64;
+            if (two && src_f64)
+                hipLaunchKernelGGL((wide_encode2_kernel<F, Z, true>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
+            else if (two)
+                hipLaunchKernelGGL((wide_encode2_kernel<F, Z, false>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
+            else if (src_f64)
+                hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_ENCODE, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, src, 1, rows, zo, z64);
             else
-                hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_ENCODE>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, src,
-                                   src_f64, rows, (void *)((char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64);
+                hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_ENCODE, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, src, 0, rows, zo, z64);
         }
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
@@ -2295,7 +2613,7 @@ template <int F, int Z> struct ImplWide {
                 kout = h->work.p;
                 kout_f64 = 0;
             }
-            hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_DECODE>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+            hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_DECODE, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
                                (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout, kout_f64);
             if (features) {
                 int rc = launch_renormalize(kout, BAMD_F32, rows, F, features, int_mask, (double *)dst, s);
@@ -2359,9 +2677,130 @@ template <int F, int Z> struct ImplWide {
     }
 };
 
+// The same models on a BAMD_MODE_BF16 handle: encode / decode on the bf16 kernels above (HBM-bound), training and validation on the
+// fp32 wide-layer kernels (fp32 master weights, as in the 24-column bf16 mode).
+template <int F, int Z> struct ImplWideBf16 {
+    using N = Net<F, Z>;
+    using W = ImplWide<F, Z>;
+    static constexpr int KB = (F + 31) / 32, KT = tiles(F);
+    static int setup(bamd_handle *h, FusedState *st) {
+        int rc = build_maps<F, Z, false>(h, st);
+        if (rc) return rc;
+        std::vector<int> s0((size_t)KB * 13 * 64 * 8, -1), s7((size_t)KT * 7 * 64 * 8, -1);
+        for (int c = 0; c < KB; ++c)
+            for (int t = 0; t < 13; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = lane & 15, g = lane >> 4;
+                        const int nf = slot_feature(200, t, i / 4, i % 4), kf = 32 * c + 8 * g + j;
+                        if (nf >= 0 && kf < F) s0[(((size_t)c * 13 + t) * 64 + lane) * 8 + j] = N::w_off(0) + nf * F + kf;
+                    }
+        for (int t = 0; t < KT; ++t)
+            for (int c = 0; c < 7; ++c)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = lane & 15, g = lane >> 4, q = 2 * c + j / 4;
+                        const int nf = slot_feature(F, t, i / 4, i % 4), kf = q < 13 ? slot_feature(200, q, g, j % 4) : -1;
+                        if (nf >= 0 && kf >= 0) s7[(((size_t)t * 7 + c) * 64 + lane) * 8 + j] = N::w_off(7) + nf * 200 + kf;
+                    }
+        const std::vector<int> *srcs[2] = {&s0, &s7};
+        for (int k = 0; k < 2; ++k) {
+            st->wb_count[k] = (int)srcs[k]->size();
+            rc = st->wb_src[k].ensure(srcs[k]->size() * sizeof(int));
+            if (rc) return rc;
+            rc = st->wb[k].ensure(srcs[k]->size() * sizeof(__bf16) + 4096);
+            if (rc) return rc;
+            BAMD_HIP(hipMemcpy(st->wb_src[k].p, srcs[k]->data(), srcs[k]->size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+        return BAMD_OK;
+    }
+    static int pack_extra(bamd_handle *h, FusedState *st, hipStream_t s) {
+        for (int k = 0; k < 2; ++k)
+            hipLaunchKernelGGL(pack_wide_bf16_k, dim3((st->wb_count[k] + 255) / 256), dim3(256), 0, s, (const float *)h->params.p,
+                               (const int *)st->wb_src[k].p, st->wb_count[k], (__bf16 *)st->wb[k].p);
+        st->wb_stale = false;
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int grid_for(int64_t n) {
+        const int64_t wg = ((n + 31) / 32 + 3) / 4;
+        return (int)(wg < 1 ? 1 : (wg > 2048 ? 2048 : wg));
+    }
+    static int encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
+                      hipStream_t s) {
+        FusedState *st = state_of(h);
+        if (st->wb_stale) { int rc = pack_extra(h, st, s); if (rc) return rc; }
+        const size_t xes = x_dtype == BAMD_F64 ? 8 : 4, zes = z_dtype == BAMD_F64 ? 8 : 4;
+        for (int64_t r0 = 0; r0 < n; r0 += W::kChunkRows) {
+            const int64_t rows = n - r0 < W::kChunkRows ? n - r0 : W::kChunkRows;
+            const void *src = (const char *)x + (size_t)r0 * F * xes;
+            int src_f64 = x_dtype == BAMD_F64;
+            if (features) {
+                int rc = h->work.ensure((size_t)rows * F * sizeof(float));
+                if (rc) return rc;
+                rc = launch_normalize(src, x_dtype, rows, F, features, h->work.p, BAMD_F32, s);
+                if (rc) return rc;
+                src = h->work.p;
+                src_f64 = 0;
+            }
+            const int64_t ngroup = (rows + 127) / 128;
+            const dim3 grid((unsigned)(ngroup > 2048 ? 2048 : ngroup));
+            void *zo = (void *)((char *)z + (size_t)r0 * Z * zes);
+            if (src_f64)
+                hipLaunchKernelGGL((wide_bf16_encode_kernel<F, Z, true>), grid, dim3(256), 0, s, (const v4 *)h->packed.p,
+                                   (const v4 *)st->wb[0].p, src, rows, zo, z_dtype == BAMD_F64);
+            else
+                hipLaunchKernelGGL((wide_bf16_encode_kernel<F, Z, false>), grid, dim3(256), 0, s, (const v4 *)h->packed.p,
+                                   (const v4 *)st->wb[0].p, src, rows, zo, z_dtype == BAMD_F64);
+        }
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features, const uint8_t *int_mask,
+                      void *out, int out_dtype, hipStream_t s) {
+        FusedState *st = state_of(h);
+        if (st->wb_stale) { int rc = pack_extra(h, st, s); if (rc) return rc; }
+        const size_t zes = z_dtype == BAMD_F64 ? 8 : 4, oes = out_dtype == BAMD_F64 ? 8 : 4;
+        if (features && out_dtype != BAMD_F64) { set_error("decode with features needs a float64 output"); return BAMD_ERR_INVALID; }
+        for (int64_t r0 = 0; r0 < n; r0 += W::kChunkRows) {
+            const int64_t rows = n - r0 < W::kChunkRows ? n - r0 : W::kChunkRows;
+            void *dst = (char *)out + (size_t)r0 * F * oes;
+            void *kout = dst;
+            int kout_f64 = out_dtype == BAMD_F64;
+            if (features) {
+                int rc = h->work.ensure((size_t)rows * F * sizeof(float));
+                if (rc) return rc;
+                kout = h->work.p;
+                kout_f64 = 0;
+            }
+            if (kout_f64)
+                hipLaunchKernelGGL((wide_bf16_decode_kernel<F, Z, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                                   (const v4 *)st->wb[1].p, (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout);
+            else
+                hipLaunchKernelGGL((wide_bf16_decode_kernel<F, Z, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                                   (const v4 *)st->wb[1].p, (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout);
+            if (features) {
+                int rc = launch_renormalize(kout, BAMD_F32, rows, F, features, int_mask, (double *)dst, s);
+                if (rc) return rc;
+            }
+        }
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static const FusedOps *ops() {
+        static const FusedOps o = {setup, encode, decode, W::forward_loss, nullptr, nullptr, W::wide_fwd, W::wide_bwd, pack_extra};
+        return &o;
+    }
+};
+
 // Instantiated shapes: the CMS 24-column model at the usual compression ratios
 // (latent = ceil(24 / ratio): 1.6 -> 15, 2 -> 12, 3 -> 8, 4 -> 6).  Anything else runs on generic.hip.
 static const FusedOps *find_ops(const bamd_handle *h) {
+    if (h->mode == BAMD_MODE_BF16) {      // wide models only: the 24-column model's bf16 mode lives in bf16.hip / bf16_train.hip
+        if (ImplWide<2500, 25>::matches(h)) return ImplWideBf16<2500, 25>::ops();
+        if (ImplWide<512, 6>::matches(h)) return ImplWideBf16<512, 6>::ops();
+        return nullptr;
+    }
     if (h->mode != BAMD_MODE_F32) return nullptr;
     if (Impl<24, 15>::matches(h)) return Impl<24, 15>::ops();
     if (Impl<24, 12>::matches(h)) return Impl<24, 12>::ops();
@@ -2401,6 +2840,7 @@ void fused_teardown(bamd_handle *h) {
     st->slab_map.release();
     st->dz.release();
     st->imgs.release();
+    for (int k = 0; k < 2; ++k) { st->wb_src[k].release(); st->wb[k].release(); }
     st->sc_off.release();
     st->sc_idx.release();
     delete st;
@@ -2422,7 +2862,12 @@ int fused_pack(bamd_handle *h, hipStream_t s) {
     hipLaunchKernelGGL(pack_k, dim3((st->packed_floats + 255) / 256), dim3(256), 0, s, (const float *)h->params.p,
                        (const int *)st->pack_src.p, st->packed_floats, (float *)h->packed.p);
     BAMD_HIP(hipGetLastError());
+    if (st->ops->pack_extra) return st->ops->pack_extra(h, st, s);
     return BAMD_OK;
+}
+
+void fused_params_changed(bamd_handle *h) {   // after an optimiser step: further packed copies are refreshed on demand
+    if (h->fused_ok && state_of(h)->ops->pack_extra) state_of(h)->wb_stale = true;
 }
 
 static bool wide_train_on() {   // BALER_AMD_WIDE_TRAIN=0: every layer of a wide model's training pass on the layer-wise kernels

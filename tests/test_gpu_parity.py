@@ -763,7 +763,42 @@ def test_train_step_empty_batch_and_generic_fallback():
 
 def test_bf16_mode_unsupported_shape():
     with pytest.raises(native.NativeError):
-        native.Handle(orc.ae_dims(2500, 25), "bf16")
+        native.Handle(orc.ae_dims(100, 10), "bf16")
+
+
+@pytest.mark.parametrize("shape,n", [((2500, 25), 1), ((2500, 25), 33), ((2500, 25), 1000), ((512, 6), 17), ((512, 6), 4100)])
+def test_bf16_mode_wide_models(shape, n):
+    """BAMD_MODE_BF16 on the wide models: en1 / de4 on the bf16 MFMA (HBM-bound kernels), the narrow layers on the fp32 chain;
+    bf16-level agreement with the oracle (inputs and the two wide weight matrices are rounded to bf16), ragged pair counts,
+    float32 / float64 rows, fused (un)normalisation; training calls of such a handle run the fp32 wide-layer kernels (exact) and
+    re-round the bf16 fragments before the next encode."""
+    dims = orc.ae_dims(*shape)
+    flat = orc.formula_params(dims, 41)
+    h, p = make_handle(dims, flat, "bf16")
+    x = np.random.default_rng(n).random((n, shape[0]))
+    z_ref = orc.encode(dims, flat, x)
+    for xin in (dev(x, torch.float32), dev(x)):
+        assert rel(h.encode(xin, out_dtype=torch.float32).cpu().numpy(), z_ref) < 6e-3
+    rec_ref = orc.decode(dims, flat, z_ref)
+    for zin in (dev(z_ref, torch.float32), dev(z_ref)):
+        assert rel(h.decode(zin).cpu().numpy(), rec_ref) < 6e-3
+    mn, rg = x.min(0) - 0.5, x.max(0) - x.min(0) + 1.0
+    feats = dev(np.stack([mn, rg]))
+    zn = orc.encode(dims, flat, (x - mn) / rg)
+    assert rel(h.encode(dev(x), features=feats, out_dtype=torch.float32).cpu().numpy(), zn) < 6e-3
+    dec = h.decode(dev(zn, torch.float32), features=feats, out_dtype=torch.float64).cpu().numpy()
+    assert rel(dec, orc.decode(dims, flat, zn) * rg + mn) < 6e-3
+    # training pass in fp32 (exact), then an optimiser step: the next encode must see the new weights
+    grads = torch.zeros_like(p)
+    h.fwd_bwd(dev(x, torch.float32), grads)
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    gh = grads.cpu().numpy().astype(np.float64)
+    assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    h.adam_step(p, grads, m, v, 1, 1e-2)
+    z_new = orc.encode(dims, p.cpu().numpy().astype(np.float64)[:-1], x)
+    assert rel(h.encode(dev(x), out_dtype=torch.float32).cpu().numpy(), z_new) < 6e-3
+    assert rel(z_new, z_ref) > 2e-2          # the step moved the latents by far more than the bf16 tolerance
 
 
 def test_two_handles_two_streams(data10k):
