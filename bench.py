@@ -426,7 +426,20 @@ def other_configs(dev):
         "decode_rows_per_s": n / ms_d * 1e3, "decode_frac_of_mfma_peak": FLOP_C4_ENCODE * n / ms_d / 1e9 / PEAK_TFLOPS["fp32"],
         "train_fwd_bwd_rows_per_s": n / ms_t * 1e3, "train_frac_of_mfma_peak": FLOP_C4_TRAIN * n / ms_t / 1e9 / PEAK_TFLOPS["fp32"]}
     hc.close()
-    del xc, gc
+    del gc
+    # the same model in the bf16 mode: en1 / de4 on the bf16 MFMA, HBM-bound (10 KB of float32 per frame)
+    from baler_amd import native
+    hb = native.Handle([2500, 200, 100, 50, 25, 50, 100, 200, 2500], "bf16")
+    hb.load_params(mc.flat)
+    zb = hb.encode(xc, out_dtype=torch.float32)
+    ms_be = event_ms(lambda: hb.encode(xc, out_dtype=torch.float32), 3)
+    ms_bd = event_ms(lambda: hb.decode(zb), 3)
+    res["c4_cfd_dense_2500_25"].update({
+        "bf16_encode_rows_per_s": n / ms_be * 1e3, "bf16_encode_frac_of_hbm": 10100 * n / ms_be / 1e6 / PEAK_HBM_GBS,
+        "bf16_decode_rows_per_s": n / ms_bd * 1e3, "bf16_decode_frac_of_hbm": 10100 * n / ms_bd / 1e6 / PEAK_HBM_GBS,
+        "bf16_encode_rel_err_vs_fp32": float(torch.linalg.norm(zb.double() - zc.double()) / torch.linalg.norm(zc.double()))})
+    hb.close()
+    del xc
     n = 262144
     xw = torch.as_tensor(synth.wide_rows(n, 512).astype(np.float32)).to(dev)
     mw = models.CFD_dense_AE(512, 6, mode="fp32").to(dev)

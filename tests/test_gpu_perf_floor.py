@@ -92,3 +92,11 @@ def test_round2_kernel_floors():
     assert 1e3 * t_64 < 60.0, "fp64 fused small-batch step (profiles: 41 us; layer-wise: 768 us)"
     assert t_we < 0.50 and t_wd < 0.60, "wide-layer encode / decode (profiles: 0.34 / 0.39 ms per 32768 frames; layer-wise 0.66)"
     assert t_wt < 2.6, "wide-model training pass (profiles: 1.9 ms per 32768 frames; all layer-wise 3.3)"
+    hb = native.Handle(wd, "bf16")
+    hb.load_params(torch.from_numpy(np.concatenate([orc.formula_params(wd, 1), [0.0]]).astype(np.float32)).cuda())
+    xb = torch.rand((131072, 2500), dtype=torch.float32, device="cuda")
+    zb = hb.encode(xb, out_dtype=torch.float32)
+    t_be = _ms(lambda: hb.encode(xb, out_dtype=torch.float32), 3)
+    t_bd = _ms(lambda: hb.decode(zb), 3)
+    print(f"bf16 mode, 131072 frames: encode {t_be:.3f} ms, decode {t_bd:.3f} ms")
+    assert t_be < 0.60 and t_bd < 1.0, "bf16 wide-layer encode / decode (profiles: 0.40 / 0.73 ms per 131072 frames; fp32 1.34 / 1.22)"
