@@ -286,6 +286,38 @@ def test_cli_cfd_dense_2d(tmp_path, monkeypatch):
     assert rel(dec.reshape(60, 2500), orc.decode(dims, final, comp["data"].astype(np.float64))) < 1e-5
 
 
+def test_cli_cfd_dense_2d_bf16_mode(tmp_path, monkeypatch):
+    """The same CFD project with BALER_AMD_MODE=bf16: training runs the fp32 wide-layer kernels (fp32 master weights: the loss
+    curve stays at the float32 bar), compress / decompress run en1 / de4 on the bf16 MFMA (bf16-level agreement)."""
+    from baler_amd import baler
+    from baler_amd.modules import helper, models
+    field = synth.cfd_field(60)
+    out = _write_project(tmp_path, monkeypatch, "CFD", "anim", _CFD_CONFIG, field, np.array([]))
+    models.set_default_mode("bf16")
+    try:
+        dims = orc.ae_dims(2500, 25)
+        init = orc.formula_params(dims, 78)
+        monkeypatch.setattr(helper, "model_init",
+                            lambda name: (lambda n_features, z_dim: getattr(models, name)(n_features, z_dim).load_flat(init)))
+        for mode in ("train", "compress", "decompress"):
+            baler.main(["--project", "CFD", "anim", "--mode", mode])
+    finally:
+        models.set_default_mode("fp32")
+    loss = np.load(out / "training" / "loss_data.npy")
+    x = field.astype(np.float32).astype(np.float64).reshape(60, 2500)
+    st = orc.FitState(dims, init.astype(np.float32).astype(np.float64))
+    want = [orc.fit_epoch(st, x, 6000, 1e-3)[0] for _ in range(3)]
+    assert rel(loss[0], want) < 1e-4
+    sd = torch.load(out / "compressed_output" / "model.pt")
+    comp = np.load(out / "compressed_output" / "compressed.npz")
+    final = np.concatenate([v.numpy().ravel().astype(np.float64) for v in sd.values()])
+    assert comp["data"].shape == (60, 25)
+    assert rel(comp["data"], orc.encode(dims, final, x)) < 6e-3
+    dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
+    assert dec.shape == (60, 50, 50)
+    assert rel(dec.reshape(60, 2500), orc.decode(dims, final, comp["data"].astype(np.float64))) < 6e-3
+
+
 def test_cli_blocks_2d_with_validation_split(tmp_path, monkeypatch):
     """The reference's exafel1/exafel2 shape of run (public_datasets/exafel1 config): 2-D frames cut into 25x25
     blocks (convert_to_blocks = [1, 25, 25], data_processing.py:26-34), CFD_dense_AE(625, 7) in float32,
