@@ -1148,6 +1148,121 @@ __global__ void __launch_bounds__(256) pack_wide_bf16_k(const float *__restrict_
     if (i < count) dst[i] = (__bf16)(src[i] >= 0 ? params[src[i]] : 0.f);
 }
 
+// The streamed wide -> 200 product with the chunk's 13 fragments SHARED by the four waves of the workgroup through a
+// double-buffered LDS stage (see wide_bf16_encode_kernel: every load of a wave then has the same lead -- fragments and rows three
+// chunks ahead -- so the in-order vmcnt never makes an L2 hit wait for an HBM miss; fragment traffic through the L1 drops 4x;
+// 32 + 32 fragment registers instead of 104).  All four waves must call it together (one barrier per chunk).
+template <int F, bool IN64, int RT = 1>
+__device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13], v4 (*wst)[13][64], const WStream &ww, const void *xin,
+                                                    int64_t rrow, int64_t rrow1, int g, int lane, int wave) {
+    constexpr int KC = tiles(F);
+    v4 wq[2][4], xr[3], xs[3];            // xs / acc1: the second row tile (RT == 2)
+    auto wload = [&](v4 (&w)[4], int kc) {
+        kc = kc < KC ? kc : KC - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = wave + 4 * k;
+            w[k] = frag_rt(ww, kc * 13 + (t < 13 ? t : 12));
+        }
+    };
+    auto wstore = [&](const v4 (&w)[4], int slot) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = wave + 4 * k;
+            if (t < 13) wst[slot][t][lane] = w[k];
+        }
+    };
+    auto lx = [&](int kc) { return wide_x_chunk<F>(xin, IN64 ? 1 : 0, rrow, kc < KC ? kc : 0, g); };
+    auto ly = [&](int kc) { return RT == 2 ? wide_x_chunk<F>(xin, IN64 ? 1 : 0, rrow1, kc < KC ? kc : 0, g) : (v4){0.f, 0.f, 0.f, 0.f}; };
+    wload(wq[0], 0);
+    wload(wq[1], 1);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { xr[u] = lx(u); xs[u] = ly(u); }
+    __syncthreads();                      // the previous row group's last chunk has been read
+    wstore(wq[0], 0);
+    wload(wq[0], 2);
+    auto iter = [&](int kc, auto wsl, auto xsl) {
+        constexpr int WS = decltype(wsl)::value, XS = decltype(xsl)::value;      // kc % 2, kc % 3
+        __syncthreads();                  // fragments of chunk kc visible in stage slot WS; slot WS ^ 1 free
+        wstore(wq[WS ^ 1], WS ^ 1);       // chunk kc + 1 (fetched two chunks ago)
+        const v4 xv = xr[XS], yv = xs[XS];
+        wload(wq[WS ^ 1], kc + 3);
+        xr[XS] = lx(kc + 3);
+        xs[XS] = ly(kc + 3);
+        const int steps = (F % 16 != 0 && kc == KC - 1) ? tile_steps(F, KC - 1) : 4;
+        v4 wl[2][4];
+        auto rd = [&](v4 (&w)[4], int t0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = wst[WS][t0 + k < 13 ? t0 + k : 12][lane];
+        };
+        auto mm = [&](const v4 (&w)[4], int t0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < steps) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (t0 + k < 13) {
+                            acc[t0 + k] = mfma(w[k][r], xv[r], acc[t0 + k]);
+                            if (RT == 2) acc1[t0 + k] = mfma(w[k][r], yv[r], acc1[t0 + k]);
+                        }
+                }
+        };
+        rd(wl[0], 0);
+        rd(wl[1], 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wl[0], 0);
+        rd(wl[0], 8);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wl[1], 4);
+        rd(wl[1], 12);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wl[0], 8);
+        mm(wl[1], 12);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    int kc = 0;
+    for (; kc + 6 <= KC; kc += 6) {
+        iter(kc, I0(), I0()); iter(kc + 1, I1(), I1()); iter(kc + 2, I0(), I2());
+        iter(kc + 3, I1(), I0()); iter(kc + 4, I0(), I1()); iter(kc + 5, I1(), I2());
+    }
+    if (kc < KC) iter(kc, I0(), I0());
+    if (kc + 1 < KC) iter(kc + 1, I1(), I1());
+    if (kc + 2 < KC) iter(kc + 2, I0(), I2());
+    if (kc + 3 < KC) iter(kc + 3, I1(), I0());
+    if (kc + 4 < KC) iter(kc + 4, I0(), I1());
+}
+
+template <int F, int Z, bool IN64>
+__global__ void __launch_bounds__(256) wide_encode_lds_kernel(const v4 *packed, const void *__restrict__ xin, int64_t n,
+                                                              void *__restrict__ out, int out_f64) {
+    using N = Net<F, Z>;
+    using S = StreamWideEnc<N>;
+    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
+    __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
+    stage_bias<N>(bias_lds, packed);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 63) / 64;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
+    WStream ww = make_stream(packed + N::wf_off(0), N::wcount(0) * 16, lane);
+    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+        const int64_t row = (grp * 4 + wave) * 16 + (lane & 15);
+        const bool valid = row < n;
+        asm volatile("" : "+v"(ws.voff), "+v"(ww.voff));
+        v4 a1[13];
+        init_bias(a1, bias_lds, lane);
+        wide_in_product_lds<F, IN64, 1>(a1, a1, wst, ww, xin, valid ? row : 0, 0, g, lane, wave);
+        lrelu(a1);
+        Ring ring;
+        ring_prime<S::total>(ring, ws);
+        v4 a2[7], a3[4], a4[tiles(Z)];
+        fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
+        fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
+        fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
+        store_rows<Z>(a4, out, out_f64, row, valid, lane, nullptr, nullptr);
+    }
+}
+
 // IN64 = type of the rows that encode reads, as a template parameter: as a run-time flag every row load of the streamed loop
 // sat behind a branch, and hipcc joins such paths with conservative waits (C4 encode at 131072 frames 91.8 -> 97.6 M rows/s;
 // the same treatment of decode's stores measured 5 % SLOWER and is not applied: decode ignores IN64)
@@ -1249,15 +1364,16 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
     __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
     __shared__ double sh[256];
     stage_bias<N>(bias_lds, packed);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int64_t ntile = (n + 15) / 16;
+    __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];      // en1's fragments, shared by the four waves (wide_in_product_lds)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 63) / 64;
     WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
     WStream w0 = make_stream(packed + N::wf_off(0), N::wcount(0) * 16, lane);
     WStream w7 = make_stream(packed + N::wf_off(7), N::wcount(7) * 16, lane);
     const float gscale = 2.0f / F;
     double lacc = 0.0;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
-        const int64_t row = tile * 16 + (lane & 15);
+    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {      // workgroup-uniform trip count: the product has barriers
+        const int64_t row = (grp * 4 + wave) * 16 + (lane & 15);
         const bool valid = row < n;
         const int64_t rrow = valid ? row : 0;
         asm volatile("" : "+v"(ws.voff), "+v"(w0.voff), "+v"(w7.voff));
@@ -1265,7 +1381,7 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
         {
             v4 a1[13];
             init_bias(a1, bias_lds, lane);
-            wide_in_product<F>(a1, w0, x, 0, rrow, g);
+            wide_in_product_lds<F, false, 1>(a1, a1, wst, w0, x, rrow, 0, g, lane, wave);
             lrelu(a1);
             if (TRAIN) store_rows<200>(a1, y1, 0, row, valid, lane, nullptr, nullptr);
             Ring ring;
@@ -1326,18 +1442,19 @@ __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, c
                                                              float *__restrict__ dz6) {
     using N = Net<F, Z>;
     using S = StreamWideMidBwd<N>;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int64_t ntile = (n + 15) / 16;
+    __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 63) / 64;
     WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
     WStream w7 = make_stream(packed + N::wb_off(7), N::wcount(7) * 16, lane);       // [wide chunk][tile of the 200 side]
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
-        const int64_t row = tile * 16 + (lane & 15);
+    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+        const int64_t row = (grp * 4 + wave) * 16 + (lane & 15);
         const bool valid = row < n;
         const int64_t rrow = valid ? row : 0;
         asm volatile("" : "+v"(ws.voff), "+v"(w7.voff));
         v4 d6[13];
         zero_tiles(d6);
-        wide_in_product<F>(d6, w7, dz7, 0, rrow, g);
+        wide_in_product_lds<F, false, 1>(d6, d6, wst, w7, dz7, rrow, 0, g, lane, wave);
         Ring ring;
         ring_prime<S::total>(ring, ws);
         {
@@ -2590,7 +2707,13 @@ template <int F, int Z> struct ImplWide {
                 hipLaunchKernelGGL((wide_encode2_kernel<F, Z, true>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
             else if (two)
                 hipLaunchKernelGGL((wide_encode2_kernel<F, Z, false>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
-            else if (src_f64)
+            else if (!(getenv("BALER_AMD_WIDE_LDS") && getenv("BALER_AMD_WIDE_LDS")[0] == '0')) {
+                // fragments shared through LDS (C4, 32768 frames: 92.5 -> 98.5 M rows/s; BALER_AMD_WIDE_LDS=0: per-wave fragments)
+                const int64_t ng = (rows + 63) / 64;
+                const dim3 gl((unsigned)(ng > 2048 ? 2048 : ng));
+                if (src_f64) hipLaunchKernelGGL((wide_encode_lds_kernel<F, Z, true>), gl, dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
+                else hipLaunchKernelGGL((wide_encode_lds_kernel<F, Z, false>), gl, dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
+            } else if (src_f64)
                 hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_ENCODE, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, src, 1, rows, zo, z64);
             else
                 hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_ENCODE, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, src, 0, rows, zo, z64);
