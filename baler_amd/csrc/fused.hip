@@ -591,12 +591,15 @@ __global__ void __launch_bounds__(256) infer2_kernel(const v4 *packed, const voi
 // 1-KiB weight fragments per 52 MFMAs (the register chain's ratio of one load per 4 MFMAs), fragments one chunk ahead in a
 // ping-pong register buffer.  The six narrow layers in between are the ordinary register chain.  One launch for encode,
 // one for decode; activations never touch HBM (the layer-wise path writes and re-reads 42 KB of them per row).
-template <int F>
+// FULL: the caller guarantees a full chunk (kc < F / 16).  The streamed loops only ever load full chunks and treat the
+// remainder of the wide dimension as an epilogue: with the "full chunk?" test inside the loop every row load sat behind a branch
+// whose other side is a different load sequence, and hipcc joins such paths with conservative waits.
+template <int F, bool FULL = false>
 __device__ __forceinline__ v4 wide_x_chunk(const void *x, int in_f64, int64_t row, int kc, int g) {
     // features 16 kc + 4 g .. + 3 of `row` (register r = MFMA step r, k = 4 g + r: the packed weights' order for full tiles);
     // the partial last chunk is r-major (slot_feature): register 0 of lane group g = feature 16 kc + g, the rest padding
     v4 v = (v4){0.f, 0.f, 0.f, 0.f};
-    if (16 * kc + 16 <= F) {
+    if (FULL || 16 * kc + 16 <= F) {
         const int64_t i = row * F + 16 * kc + 4 * g;
         if (in_f64) {
             const double2 lo = *(const double2 *)((const double *)x + i), hi = *(const double2 *)((const double *)x + i + 2);
@@ -902,10 +905,10 @@ __device__ __forceinline__ XPair wide_x_chunk32(const void *x, int in_f64, int64
 // rows are fetched three chunks ahead.  Fragment traffic through the L1 drops four times as well.
 // the same through a buffer resource based at the workgroup's first row: one byte offset per lane (row and lane group) in a
 // VGPR, the chunk offset in an SGPR -- no 64-bit address arithmetic per load
-template <int F>
+template <int F, bool FULL = false>
 __device__ __forceinline__ XPair wide_x_chunk32_buf(__amdgpu_buffer_rsrc_t rs, int voff, int in_f64, int c, int g) {
     XPair p;
-    if (32 * c + 32 <= F) {
+    if (FULL || 32 * c + 32 <= F) {
         if (in_f64) {
             typedef double d2 __attribute__((ext_vector_type(2)));
             d2 q[4];
@@ -940,14 +943,14 @@ __global__ void __launch_bounds__(256) wide_bf16_encode_kernel(const v4 *packed,
     constexpr int in_f64 = IN64 ? 1 : 0;
     using N = Net<F, Z>;
     using S = StreamWideEnc<N>;
-    constexpr int KB = (F + 31) / 32;
+    constexpr int KB = F / 32, KBT = (F + 31) / 32;      // full chunks (the loop) / all chunks (a remainder chunk is the epilogue)
     __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
     __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];       // the chunk's fragments, [slot][tile][lane]
     stage_bias<N>(bias_lds, packed);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
     const int64_t ngroup = (n + 127) / 128;                          // 4 waves x 2 tiles x 16 rows
     WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
-    WStream ww = make_stream(w0b, KB * 13 * 1024, lane);
+    WStream ww = make_stream(w0b, KBT * 13 * 1024, lane);
     for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
         const int64_t r0 = (grp * 4 + wave) * 32 + (lane & 15), r1 = r0 + 16;
         const bool v0 = r0 < n, v1 = r1 < n;
@@ -980,8 +983,8 @@ __global__ void __launch_bounds__(256) wide_bf16_encode_kernel(const v4 *packed,
                     if (t < 13) wst[slot][t][lane] = __builtin_bit_cast(v4, w[k]);
                 }
             };
-            auto lx0 = [&](int c) { return wide_x_chunk32_buf<F>(xrs, xo0, in_f64, c < KB ? c : 0, g); };
-            auto lx1 = [&](int c) { return wide_x_chunk32_buf<F>(xrs, xo1, in_f64, c < KB ? c : 0, g); };
+            auto lx0 = [&](int c) { return wide_x_chunk32_buf<F, true>(xrs, xo0, in_f64, c < KB ? c : 0, g); };
+            auto lx1 = [&](int c) { return wide_x_chunk32_buf<F, true>(xrs, xo1, in_f64, c < KB ? c : 0, g); };
             // prologue: chunk 0 staged, chunks 1, 2 in flight; rows of chunks 0..2 in flight
             wload(wq[0], 0);
             wload(wq[1], 1);
@@ -1034,6 +1037,16 @@ __global__ void __launch_bounds__(256) wide_bf16_encode_kernel(const v4 *packed,
             if (c + 2 < KB) iter(c + 2, I0(), I2());
             if (c + 3 < KB) iter(c + 3, I1(), I0());
             if (c + 4 < KB) iter(c + 4, I0(), I1());
+            if (F % 32 != 0) {            // the remaining F % 32 features: one partial chunk, fragments straight from L2
+                const XPair p0 = wide_x_chunk32_buf<F>(xrs, xo0, in_f64, KB, g), p1 = wide_x_chunk32_buf<F>(xrs, xo1, in_f64, KB, g);
+                const bf8 q0 = to_bf8(p0.lo, p0.hi), q1 = to_bf8(p1.lo, p1.hi);
+#pragma unroll
+                for (int t = 0; t < 13; ++t) {
+                    const bf8 w = frag_bf(ww, KB * 13 + t);
+                    a1[t] = mfma_bf(w, q0, a1[t]);
+                    b1[t] = mfma_bf(w, q1, b1[t]);
+                }
+            }
         }
         // the narrow layers one row tile after the other (the two-tile chain needs 300 registers next to the other tile's
         // accumulators: one wave per SIMD for the whole kernel; they are 4 % of the work)
@@ -1155,7 +1168,8 @@ __global__ void __launch_bounds__(256) pack_wide_bf16_k(const float *__restrict_
 template <int F, bool IN64, int RT = 1>
 __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13], v4 (*wst)[13][64], const WStream &ww, const void *xin,
                                                     int64_t rrow, int64_t rrow1, int g, int lane, int wave) {
-    constexpr int KC = tiles(F);
+    constexpr int KC = F / 16;            // FULL chunks: the loop; the remainder F % 16 is the epilogue below
+    static_assert(KC >= 3, "at least three full chunks");
     v4 wq[2][4], xr[3], xs[3];            // xs / acc1: the second row tile (RT == 2)
     auto wload = [&](v4 (&w)[4], int kc) {
         kc = kc < KC ? kc : KC - 1;
@@ -1172,8 +1186,8 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
             if (t < 13) wst[slot][t][lane] = w[k];
         }
     };
-    auto lx = [&](int kc) { return wide_x_chunk<F>(xin, IN64 ? 1 : 0, rrow, kc < KC ? kc : 0, g); };
-    auto ly = [&](int kc) { return RT == 2 ? wide_x_chunk<F>(xin, IN64 ? 1 : 0, rrow1, kc < KC ? kc : 0, g) : (v4){0.f, 0.f, 0.f, 0.f}; };
+    auto lx = [&](int kc) { return wide_x_chunk<F, true>(xin, IN64 ? 1 : 0, rrow, kc < KC ? kc : 0, g); };
+    auto ly = [&](int kc) { return RT == 2 ? wide_x_chunk<F, true>(xin, IN64 ? 1 : 0, rrow1, kc < KC ? kc : 0, g) : (v4){0.f, 0.f, 0.f, 0.f}; };
     wload(wq[0], 0);
     wload(wq[1], 1);
 #pragma unroll
@@ -1189,7 +1203,6 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
         wload(wq[WS ^ 1], kc + 3);
         xr[XS] = lx(kc + 3);
         xs[XS] = ly(kc + 3);
-        const int steps = (F % 16 != 0 && kc == KC - 1) ? tile_steps(F, KC - 1) : 4;
         v4 wl[2][4];
         auto rd = [&](v4 (&w)[4], int t0) {
 #pragma unroll
@@ -1197,15 +1210,14 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
         };
         auto mm = [&](const v4 (&w)[4], int t0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < steps) {
+            for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (t0 + k < 13) {
-                            acc[t0 + k] = mfma(w[k][r], xv[r], acc[t0 + k]);
-                            if (RT == 2) acc1[t0 + k] = mfma(w[k][r], yv[r], acc1[t0 + k]);
-                        }
-                }
+                for (int k = 0; k < 4; ++k)
+                    if (t0 + k < 13) {
+                        acc[t0 + k] = mfma(w[k][r], xv[r], acc[t0 + k]);
+                        if (RT == 2) acc1[t0 + k] = mfma(w[k][r], yv[r], acc1[t0 + k]);
+                    }
+            }
         };
         rd(wl[0], 0);
         rd(wl[1], 4);
@@ -1231,6 +1243,21 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
     if (kc + 2 < KC) iter(kc + 2, I0(), I2());
     if (kc + 3 < KC) iter(kc + 3, I1(), I0());
     if (kc + 4 < KC) iter(kc + 4, I0(), I1());
+    if (F % 16 != 0) {                    // the remaining F % 16 features: one partial chunk, fragments straight from L2
+        constexpr int KL = F / 16, ST = tile_steps(F, KL);
+        const v4 xv = wide_x_chunk<F>(xin, IN64 ? 1 : 0, rrow, KL, g);
+        const v4 yv = RT == 2 ? wide_x_chunk<F>(xin, IN64 ? 1 : 0, rrow1, KL, g) : xv;
+        v4 wt[13];
+#pragma unroll
+        for (int t = 0; t < 13; ++t) wt[t] = frag_rt(ww, KL * 13 + t);
+#pragma unroll
+        for (int r = 0; r < ST; ++r)
+#pragma unroll
+            for (int t = 0; t < 13; ++t) {
+                acc[t] = mfma(wt[t][r], xv[r], acc[t]);
+                if (RT == 2) acc1[t] = mfma(wt[t][r], yv[r], acc1[t]);
+            }
+    }
 }
 
 template <int F, int Z, bool IN64>
@@ -1401,8 +1428,9 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
             if (TRAIN) store_rows<200>(a7, y7, 0, row, valid, lane, nullptr, nullptr);
         }
         // de4 + loss: the x tiles run kXT tiles ahead of the tile being multiplied (HBM again: 327 MB of rows do not stay in the
-        // 256-MB MALL between the two passes; four ahead left 94 us of a 839-us launch waiting for them)
-        constexpr int kXT = 8;
+        // 256-MB MALL between the two passes).  Eight ahead measured 2 % faster than four while en1 kept its fragments in
+        // registers; with en1 on the LDS stage four keeps the kernel at two waves per SIMD (786 -> 776 us)
+        constexpr int kXT = 4;
         v4 xr[kXT];
 #pragma unroll
         for (int u = 0; u < kXT; ++u) xr[u] = wide_x_chunk<F>(x, 0, rrow, u, g);
