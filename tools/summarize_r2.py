@@ -18,7 +18,7 @@ KEYS = (("train_dec_kernel", "train_dec"), ("train_enc_kernel", "train_enc"), ("
         ("lat2_chain_kernel", "lat2_chain"), ("lat2_dw_kernel", "lat2_dw"), ("adam_k", "adam_k"),
         ("bf16_train_kernel<PART 0>", "bf16_train_kernel<24, 15, 0>"), ("bf16_train_kernel<PART 1>", "bf16_train_kernel<24, 15, 1>"),
         ("reduce_tiles_k", "reduce_tiles_k"),
-        ("wide_infer_kernel<ENCODE>", "wide_infer_kernel<2500, 25, 0>"), ("wide_infer_kernel<DECODE>", "wide_infer_kernel<2500, 25, 1>"),
+        ("wide_encode_lds_kernel", "wide_encode_lds_kernel<2500, 25"), ("wide_infer_kernel<DECODE>", "wide_infer_kernel<2500, 25, 1"),
         ("wide_train_fwd_kernel", "wide_train_fwd_kernel<2500, 25, true>"), ("wide_train_bwd_kernel", "wide_train_bwd_kernel<2500, 25>"),
         ("dw_wide_k<P = dZ>", "dw_wide_k<true>"), ("dw_wide_k<P = [X|1]>", "dw_wide_k<false>"), ("reduce_layers_k", "reduce_layers_k"))
 
