@@ -720,9 +720,9 @@ __device__ __forceinline__ void wide_out_product(const v4 (&a7)[13], const WStre
     }
 }
 // store tile t of a wide row (C layout) as float / double
-template <int F>
+template <int F, bool FULL = false>
 __device__ __forceinline__ void wide_store_tile(const v4 &o, void *out, int out_f64, int64_t row, int t, int g) {
-    if (16 * t + 16 <= F) {              // full tile: the lane's 4 consecutive features as one vector store
+    if (FULL || 16 * t + 16 <= F) {      // full tile: the lane's 4 consecutive features as one vector store
         const int64_t i = row * F + 16 * t + 4 * g;
         if (out_f64) {
             *(double2 *)((double *)out + i) = make_double2((double)o[0], (double)o[1]);
@@ -1260,6 +1260,90 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
     }
 }
 
+// The streamed 200 -> wide product (de4) the same way: the 13 fragments of an output tile shared through the LDS stage, fetched
+// three tiles ahead; `pre(t, slot, full)` issues the caller's own loads for tile t (three tiles ahead as well, slot = t % 3),
+// `emit(o, t, slot, full)` consumes output tile t; full = std::true_type in the main loop, where every tile touched is a full one
+// (no "partial tile?" test in front of the loads and stores), std::false_type for the last tiles.  All four waves together; one
+// barrier per tile.
+template <int F, class Pre, class Emit>
+__device__ __forceinline__ void wide_out_product_lds(const v4 (&a7)[13], v4 (*wst)[13][64], const WStream &ww, const v4 *bias7, int g,
+                                                     int lane, int wave, Pre pre, Emit emit) {
+    constexpr int KC = tiles(F), KF = F / 16;      // all / full output tiles
+    static_assert(KF >= 3, "at least three full tiles");
+    v4 wq[2][4];
+    auto wload = [&](v4 (&w)[4], int t) {
+        t = t < KC ? t : KC - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = wave + 4 * k;
+            w[k] = frag_rt(ww, (q < 13 ? q : 12) * KC + t);
+        }
+    };
+    auto wstore = [&](const v4 (&w)[4], int slot) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = wave + 4 * k;
+            if (q < 13) wst[slot][q][lane] = w[k];
+        }
+    };
+    wload(wq[0], 0);
+    wload(wq[1], 1);
+    pre(0, std::integral_constant<int, 0>(), std::true_type());
+    pre(1, std::integral_constant<int, 1>(), std::true_type());
+    pre(2, std::integral_constant<int, 2>(), std::true_type());
+    __syncthreads();
+    wstore(wq[0], 0);
+    wload(wq[0], 2);
+    auto iter = [&](int t, auto wsl, auto xsl, auto full) {
+        constexpr int WS = decltype(wsl)::value;
+        __syncthreads();
+        wstore(wq[WS ^ 1], WS ^ 1);
+        wload(wq[WS ^ 1], t + 3);
+        v4 o0 = bias7[t * 4 + g], o1 = (v4){0.f, 0.f, 0.f, 0.f};
+        v4 wl[2][4];
+        auto rd = [&](v4 (&w)[4], int q0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = wst[WS][q0 + k < 13 ? q0 + k : 12][lane];
+        };
+        auto mm = [&](const v4 (&w)[4], int q0) {       // k tiles alternate between two accumulators (dependent MFMAs: 40 cycles)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (q0 + k < 13 && r < tile_steps(200, q0 + k)) {
+                        if (k & 1) o1 = mfma(w[k][r], a7[q0 + k][r], o1); else o0 = mfma(w[k][r], a7[q0 + k][r], o0);
+                    }
+        };
+        rd(wl[0], 0);
+        rd(wl[1], 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wl[0], 0);
+        rd(wl[0], 8);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wl[1], 4);
+        rd(wl[1], 12);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wl[0], 8);
+        mm(wl[1], 12);
+        emit(o0 + o1, t, xsl, full);
+        pre(t + 3, xsl, full);                          // into the slot just consumed
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using TT = std::true_type;
+    using FT = std::false_type;
+    int t = 0;
+    for (; t + 9 <= KF; t += 6) {                       // tiles t .. t + 5 and the prefetched t + 3 .. t + 8 are all full
+        iter(t, I0(), I0(), TT()); iter(t + 1, I1(), I1(), TT()); iter(t + 2, I0(), I2(), TT());
+        iter(t + 3, I1(), I0(), TT()); iter(t + 4, I0(), I1(), TT()); iter(t + 5, I1(), I2(), TT());
+    }
+    // the last <= 14 tiles (the partial one among them) on the general path; slots keep following t % 2 / t % 3
+    auto tail = [&](int k, auto wsl, auto xsl) { if (t + k < KC) iter(t + k, wsl, xsl, FT()); };
+    tail(0, I0(), I0()); tail(1, I1(), I1()); tail(2, I0(), I2()); tail(3, I1(), I0()); tail(4, I0(), I1()); tail(5, I1(), I2());
+    tail(6, I0(), I0()); tail(7, I1(), I1()); tail(8, I0(), I2()); tail(9, I1(), I0()); tail(10, I0(), I1()); tail(11, I1(), I2());
+    tail(12, I0(), I0()); tail(13, I1(), I1());
+}
+
 template <int F, int Z, bool IN64>
 __global__ void __launch_bounds__(256) wide_encode_lds_kernel(const v4 *packed, const void *__restrict__ xin, int64_t n,
                                                               void *__restrict__ out, int out_f64) {
@@ -1287,6 +1371,36 @@ __global__ void __launch_bounds__(256) wide_encode_lds_kernel(const v4 *packed, 
         fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
         fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
         store_rows<Z>(a4, out, out_f64, row, valid, lane, nullptr, nullptr);
+    }
+}
+
+template <int F, int Z, bool OUT64>
+__global__ void __launch_bounds__(256) wide_decode_lds_kernel(const v4 *packed, const void *__restrict__ zin, int in_f64, int64_t n,
+                                                              void *__restrict__ out) {
+    using N = Net<F, Z>;
+    using S = StreamWideDec<N>;
+    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
+    __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
+    stage_bias<N>(bias_lds, packed);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 63) / 64;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
+    WStream ww = make_stream(packed + N::wf_off(7), N::wcount(7) * 16, lane);
+    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+        const int64_t row = (grp * 4 + wave) * 16 + (lane & 15);
+        const bool valid = row < n;
+        asm volatile("" : "+v"(ws.voff), "+v"(ww.voff));
+        Ring ring;
+        ring_prime<S::total>(ring, ws);
+        v4 a4[tiles(Z)], a5[4], a6[7], a7[13];
+        load_rows<Z>(a4, zin, in_f64, row, valid, lane, nullptr);
+        fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
+        fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
+        fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
+        wide_out_product_lds<F>(a7, wst, ww, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, lane, wave, [&](int, auto, auto) {},
+                                [&](const v4 &o, int t, auto, auto full) {
+                                    if (valid) wide_store_tile<F, decltype(full)::value>(o, out, OUT64 ? 1 : 0, row, t, g);
+                                });
     }
 }
 
@@ -1427,27 +1541,31 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
             fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
             if (TRAIN) store_rows<200>(a7, y7, 0, row, valid, lane, nullptr, nullptr);
         }
-        // de4 + loss: the x tiles run kXT tiles ahead of the tile being multiplied (HBM again: 327 MB of rows do not stay in the
-        // 256-MB MALL between the two passes).  Eight ahead measured 2 % faster than four while en1 kept its fragments in
-        // registers; with en1 on the LDS stage four keeps the kernel at two waves per SIMD (786 -> 776 us)
-        constexpr int kXT = 4;
-        v4 xr[kXT];
-#pragma unroll
-        for (int u = 0; u < kXT; ++u) xr[u] = wide_x_chunk<F>(x, 0, rrow, u, g);
-        wide_out_product<F, kXT>(a7, w7, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, [&](const v4 &o, int t, auto slot) {
-            constexpr int SL = decltype(slot)::value;
-            const v4 d = o - xr[SL];     // padding slots: zero weights and bias against a zero x
+        // de4 + loss: the x tiles are re-read three tiles ahead of the tile being multiplied, like the fragments (HBM again:
+        // 327 MB of rows do not stay in the 256-MB MALL between the two passes)
+        v4 xr[3];
+        wide_out_product_lds<F>(a7, wst, w7, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, lane, wave,
+            [&](int t, auto slot, auto full) {
+                constexpr int SL = decltype(slot)::value;
 #ifndef BAMD_WT_ABL_X
-            xr[SL] = wide_x_chunk<F>(x, 0, rrow, t + kXT < KC ? t + kXT : 0, g);
+                if (decltype(full)::value) xr[SL] = wide_x_chunk<F, true>(x, 0, rrow, t, g);
+                else xr[SL] = wide_x_chunk<F>(x, 0, rrow, t < KC ? t : 0, g);
+#else
+                xr[SL] = (v4){0.f, 0.f, 0.f, 0.f};
 #endif
-            if (valid) {
+            },
+            [&](const v4 &o, int t, auto slot, auto full) {
+                constexpr int SL = decltype(slot)::value;
+                constexpr bool FL = decltype(full)::value;
+                const v4 d = o - xr[SL];     // padding slots: zero weights and bias against a zero x
+                if (valid) {
 #ifndef BAMD_WT_ABL_LOSS
-                lacc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
+                    lacc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
 #endif
-                if (TRAIN) wide_store_tile<F>(d * gscale, dz8, 0, row, t, g);
-                else if (dz8) wide_store_tile<F>(o, dz8, out_f64, row, t, g);
-            }
-        });
+                    if (TRAIN) wide_store_tile<F, FL>(d * gscale, dz8, 0, row, t, g);
+                    else if (dz8) wide_store_tile<F, FL>(o, dz8, out_f64, row, t, g);
+                }
+            });
     }
     sh[threadIdx.x] = lacc;
     __syncthreads();
@@ -2764,8 +2882,16 @@ template <int F, int Z> struct ImplWide {
                 kout = h->work.p;
                 kout_f64 = 0;
             }
-            hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_DECODE, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
-                               (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout, kout_f64);
+            const void *zi = (const void *)((const char *)z + (size_t)r0 * Z * zes);
+            if (getenv("BALER_AMD_WIDE_LDS") && getenv("BALER_AMD_WIDE_LDS")[0] == '0')
+                hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_DECODE, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                                   zi, z_dtype == BAMD_F64, rows, kout, kout_f64);
+            else if (kout_f64)
+                hipLaunchKernelGGL((wide_decode_lds_kernel<F, Z, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, zi,
+                                   z_dtype == BAMD_F64, rows, kout);
+            else
+                hipLaunchKernelGGL((wide_decode_lds_kernel<F, Z, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, zi,
+                                   z_dtype == BAMD_F64, rows, kout);
             if (features) {
                 int rc = launch_renormalize(kout, BAMD_F32, rows, F, features, int_mask, (double *)dst, s);
                 if (rc) return rc;
