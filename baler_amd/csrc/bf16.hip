@@ -504,7 +504,7 @@ const Bf16Ops *find_bf16(const bamd_handle *h) {
 int bf16_setup(bamd_handle *h) {
     const Bf16Ops *ops = find_bf16(h);
     if (!ops) {
-        set_error("BAMD_MODE_BF16 is instantiated for the 24-column AE (latent 15/12/8/6) only; use BAMD_MODE_F32");
+        set_error("BAMD_MODE_BF16 is instantiated for the 24-column AE (latent 15/12/8/6) and the wide models (2500-25, 512-6) only; use BAMD_MODE_F32");
         return BAMD_ERR_UNSUPPORTED;
     }
     Bf16State *st = new Bf16State();
