@@ -887,7 +887,8 @@ struct ShortPlan {
 static ShortPlan plan_short_dw(const bamd_handle *h, int64_t rows) {
     ShortPlan pl;
     const char *e = getenv("BALER_AMD_SHORT_DW");
-    if ((e && e[0] == '0') || h->L > 8 || rows < 2048) return pl;
+    static const int64_t min_rows = getenv("BALER_AMD_SHORT_DW_MIN") ? atoll(getenv("BALER_AMD_SHORT_DW_MIN")) : 128;   // C4 at 512 frames: 796 -> 580 us per pass; 60 frames: no difference
+    if ((e && e[0] == '0') || h->L > 8 || rows < min_rows) return pl;
     constexpr int TQ = 2;
     int64_t base = 0;
     for (int l = 0; l < h->L; ++l) {

@@ -474,9 +474,9 @@ def test_other_latent_sizes_fused(z, data10k):
     assert rel(gg.cpu().numpy(), grads.cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("z,n", [(15, 2048), (15, 5003), (6, 20000)])
+@pytest.mark.parametrize("z,n", [(15, 130), (15, 2048), (15, 5003), (6, 20000)])
 def test_layer_wise_training_short_side_weight_gradients(z, n, data10k, monkeypatch):
-    """Layer-wise float32 training pass at >= 2048 rows: the weight gradients run on the short-side kernels (1, 2, 4, 7 and 13
+    """Layer-wise float32 training pass (>= 128 rows): the weight gradients run on the short-side kernels (1, 2, 4, 7 and 13
     tiles on the short side, ones column on either side, ragged last block) -- against the oracle and against the LDS-tiled
     GEMM path (BALER_AMD_SHORT_DW=0)."""
     dims = orc.ae_dims(24, z)
