@@ -591,11 +591,14 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
 
 // Fixed-order reduction of the per-workgroup partial gradients ([tile][workgroup][64 lanes] float4) into the canonical
 // (state-dict) layout; block `ntiles`: grads[np] = sum of the loss partials / C.  One wave per tile (see fused.hip).
-__global__ void __launch_bounds__(64) reduce_tiles_k(const v4 *__restrict__ slabs, int nslab, int ntiles, const int *__restrict__ inv_map,
-                                                     int np, double inv_c, float *__restrict__ grads) {
-    const int tile = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(256) reduce_tiles_k(const v4 *__restrict__ slabs, int nslab, int ntiles, const int *__restrict__ inv_map,
+                                                      int np, double inv_c, float *__restrict__ grads) {
+    // one workgroup per tile: wave w sums the w-th quarter of the workgroups' slabs in order, the four partial sums are added
+    // in wave order (fixed => bitwise reproducible)
+    __shared__ v4 part[4][64];
+    const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (tile == ntiles) {
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             const double *lp = (const double *)(slabs + (int64_t)ntiles * nslab * 64);
             double l = 0.0;
             for (int k = 0; k < nslab; ++k) l += lp[k];
@@ -603,17 +606,22 @@ __global__ void __launch_bounds__(64) reduce_tiles_k(const v4 *__restrict__ slab
         }
         return;
     }
+    const int q = (nslab + 3) / 4, k0 = wave * q, k1 = k0 + q < nslab ? k0 + q : nslab;
     const v4 *src = slabs + (int64_t)tile * nslab * 64 + lane;
     v4 s = (v4){0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 8 <= nslab; k += 8) {
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
         v4 t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = src[(k + u) * 64];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += t[u];
     }
-    for (; k < nslab; ++k) s += src[k * 64];
+    for (; k < k1; ++k) s += src[k * 64];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0) return;
+    s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int p = inv_map[(tile * 64 + lane) * 4 + c];
@@ -729,7 +737,7 @@ template <int F, int Z> struct TImpl {
         if (rc) return rc;
         hipLaunchKernelGGL((bf16_train_kernel<F, Z, 0>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
         hipLaunchKernelGGL((bf16_train_kernel<F, Z, 1>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
-        hipLaunchKernelGGL(reduce_tiles_k, dim3(st->ntiles + 1), dim3(64), 0, s, (const v4 *)h->slabs.p, grid, st->ntiles,
+        hipLaunchKernelGGL(reduce_tiles_k, dim3(st->ntiles + 1), dim3(256), 0, s, (const v4 *)h->slabs.p, grid, st->ntiles,
                            (const int *)st->inv.p, st->nparams, 1.0 / F, grads);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
