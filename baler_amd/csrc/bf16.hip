@@ -87,15 +87,25 @@ __device__ __forceinline__ void blayer(const bf8 (&in)[KB][kMB], bf8 (&out)[(NT 
         const v4 b1 = has1 ? bias[(2 * p + 1) * 4 + g] : (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mb = 0; mb < kMB; ++mb) { acc0[mb] = b0; acc1[mb] = b1; }
+        // fragment reads one step ahead of their MFMAs (hipcc placed every ds_read_b128 right in front of its use: a full LDS
+        // round trip before each group of four MFMAs, SQ_WAIT_ANY 45-51 %); sched_barrier pins the order
+        bf8 a0 = w[(2 * p) * 64], a1 = has1 ? w[(2 * p + 1) * 64] : a0;
 #pragma unroll
         for (int q = 0; q < KB; ++q) {
-            const bf8 a0 = w[(q * NT + 2 * p) * 64];
-            const bf8 a1 = has1 ? w[(q * NT + 2 * p + 1) * 64] : a0;
+            bf8 n0 = a0, n1 = a1;
+            if (q + 1 < KB) {
+                n0 = w[((q + 1) * NT + 2 * p) * 64];
+                n1 = has1 ? w[((q + 1) * NT + 2 * p + 1) * 64] : n0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mb = 0; mb < kMB; ++mb) {
                 acc0[mb] = mfma_bf16(a0, in[q][mb], acc0[mb]);
                 if (has1) acc1[mb] = mfma_bf16(a1, in[q][mb], acc1[mb]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0;
+            a1 = n1;
         }
 #pragma unroll
         for (int mb = 0; mb < kMB; ++mb) {
@@ -126,15 +136,25 @@ __device__ __forceinline__ void blayer_pair(const bf8 (&in)[KB][kMB], bf8 (&out)
         const v4 b1 = has1 ? bias[(2 * p + 1) * 4 + g] : (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mb = 0; mb < kMB; ++mb) { acc0[mb] = b0; acc1[mb] = b1; }
+        // fragment reads one step ahead of their MFMAs (hipcc placed every ds_read_b128 right in front of its use: a full LDS
+        // round trip before each group of four MFMAs, SQ_WAIT_ANY 45-51 %); sched_barrier pins the order
+        bf8 a0 = w[(2 * p) * 64], a1 = has1 ? w[(2 * p + 1) * 64] : a0;
 #pragma unroll
         for (int q = 0; q < KB; ++q) {
-            const bf8 a0 = w[(q * NT + 2 * p) * 64];
-            const bf8 a1 = has1 ? w[(q * NT + 2 * p + 1) * 64] : a0;
+            bf8 n0 = a0, n1 = a1;
+            if (q + 1 < KB) {
+                n0 = w[((q + 1) * NT + 2 * p) * 64];
+                n1 = has1 ? w[((q + 1) * NT + 2 * p + 1) * 64] : n0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mb = 0; mb < kMB; ++mb) {
                 acc0[mb] = mfma_bf16(a0, in[q][mb], acc0[mb]);
                 if (has1) acc1[mb] = mfma_bf16(a1, in[q][mb], acc1[mb]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0;
+            a1 = n1;
         }
         bf8 blk[kMB];
 #pragma unroll
@@ -143,11 +163,18 @@ __device__ __forceinline__ void blayer_pair(const bf8 (&in)[KB][kMB], bf8 (&out)
             if (has1) lrelu4(acc1[mb]);
             blk[mb] = pack8(acc0[mb], acc1[mb]);
         }
+        {
+            bf8 a = w1[(p * NT1) * 64];
 #pragma unroll
-        for (int t = 0; t < NT1; ++t) {
-            const bf8 a = w1[(p * NT1 + t) * 64];
+            for (int t = 0; t < NT1; ++t) {
+                bf8 nx = a;
+                if (t + 1 < NT1) nx = w1[(p * NT1 + t + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mb = 0; mb < kMB; ++mb) acc[t][mb] = mfma_bf16(a, blk[mb], acc[t][mb]);
+                for (int mb = 0; mb < kMB; ++mb) acc[t][mb] = mfma_bf16(a, blk[mb], acc[t][mb]);
+                __builtin_amdgcn_sched_barrier(0);
+                a = nx;
+            }
         }
     }
 #pragma unroll
@@ -184,15 +211,25 @@ __device__ __forceinline__ void blayer_then_last(const bf8 (&in)[KB][kMB], v4 (&
         const v4 b1 = has1 ? bias[(2 * p + 1) * 4 + g] : (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mb = 0; mb < kMB; ++mb) { acc0[mb] = b0; acc1[mb] = b1; }
+        // fragment reads one step ahead of their MFMAs (hipcc placed every ds_read_b128 right in front of its use: a full LDS
+        // round trip before each group of four MFMAs, SQ_WAIT_ANY 45-51 %); sched_barrier pins the order
+        bf8 a0 = w[(2 * p) * 64], a1 = has1 ? w[(2 * p + 1) * 64] : a0;
 #pragma unroll
         for (int q = 0; q < KB; ++q) {
-            const bf8 a0 = w[(q * NT + 2 * p) * 64];
-            const bf8 a1 = has1 ? w[(q * NT + 2 * p + 1) * 64] : a0;
+            bf8 n0 = a0, n1 = a1;
+            if (q + 1 < KB) {
+                n0 = w[((q + 1) * NT + 2 * p) * 64];
+                n1 = has1 ? w[((q + 1) * NT + 2 * p + 1) * 64] : n0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mb = 0; mb < kMB; ++mb) {
                 acc0[mb] = mfma_bf16(a0, in[q][mb], acc0[mb]);
                 if (has1) acc1[mb] = mfma_bf16(a1, in[q][mb], acc1[mb]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0;
+            a1 = n1;
         }
         bf8 blk[kMB];
 #pragma unroll
@@ -201,11 +238,18 @@ __device__ __forceinline__ void blayer_then_last(const bf8 (&in)[KB][kMB], v4 (&
             if (has1) lrelu4(acc1[mb]);
             blk[mb] = pack8(acc0[mb], acc1[mb]);
         }
+        {
+            bf8 a = w2[(p * NT2) * 64];
 #pragma unroll
-        for (int t = 0; t < NT2; ++t) {
-            const bf8 a = w2[(p * NT2 + t) * 64];
+            for (int t = 0; t < NT2; ++t) {
+                bf8 nx = a;
+                if (t + 1 < NT2) nx = w2[(p * NT2 + t + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mb = 0; mb < kMB; ++mb) y[t][mb] = mfma_bf16(a, blk[mb], y[t][mb]);
+                for (int mb = 0; mb < kMB; ++mb) y[t][mb] = mfma_bf16(a, blk[mb], y[t][mb]);
+                __builtin_amdgcn_sched_barrier(0);
+                a = nx;
+            }
         }
     }
 }
@@ -253,11 +297,56 @@ __device__ __forceinline__ bf8 load_block(const void *x, int is_f64, int64_t row
     return o;
 }
 
+// The same in two halves, so that the NEXT pass's rows can be requested while this pass computes: `issue` only loads (raw
+// values stay in registers: 8 or 16 per batch tile), `finish` normalises, rounds and packs.  IN64 is a template parameter (a
+// run-time dtype branch in front of the loads makes hipcc join the paths with conservative waits).
+template <int D, bool IN64> struct RawBlock { typename std::conditional<IN64, double, float>::type v[8]; };
+template <int D, bool IN64>
+__device__ __forceinline__ void load_block_issue(RawBlock<D, IN64> &raw, const void *x, int64_t row, bool valid, int g) {
+    using T = typename std::conditional<IN64, double, float>::type;
+    const int64_t base = (valid ? row : 0) * D;
+    if (D % 8 == 0) {
+        const int f0 = 8 * g < D ? 8 * g : 0;
+        if (IN64) {
+            const double2 *p = (const double2 *)((const double *)x + base + f0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double2 t = p[e]; raw.v[2 * e] = (T)t.x; raw.v[2 * e + 1] = (T)t.y; }
+        } else {
+            const float4 *p = (const float4 *)((const float *)x + base + f0);
+            const float4 t0 = p[0], t1 = p[1];
+            raw.v[0] = (T)t0.x; raw.v[1] = (T)t0.y; raw.v[2] = (T)t0.z; raw.v[3] = (T)t0.w;
+            raw.v[4] = (T)t1.x; raw.v[5] = (T)t1.y; raw.v[6] = (T)t1.z; raw.v[7] = (T)t1.w;
+        }
+    } else {   // narrow, unaligned rows (the latent codes): element loads; lane groups that hold no feature re-read feature 0
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int f = 8 * g + e < D ? 8 * g + e : 0;
+            raw.v[e] = ((const T *)x)[base + f];
+        }
+    }
+}
+template <int D, bool IN64>
+__device__ __forceinline__ bf8 load_block_finish(const RawBlock<D, IN64> &raw, int g, const double *feats_lds) {
+    float v[8];
+    const int f0 = 8 * g < D ? 8 * g : 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        double d = (double)raw.v[e];
+        const int f = D % 8 == 0 ? f0 + e : (8 * g + e < D ? 8 * g + e : 0);
+        if (feats_lds) d = (d - feats_lds[f]) / feats_lds[32 + f];
+        v[e] = (D % 8 == 0 || 8 * g + e < D) ? (float)d : 0.f;
+    }
+    bf8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+    return o;
+}
+
 // DEC = false: z = encode(x).  DEC = true: out = decode(z) (+ un-normalise / int truncation), and with xref the
 // squared-error partial of out against (normalised) xref rows (forward_loss).
-template <int F, int Z, bool DEC>
+template <int F, int Z, bool DEC, bool IN64>
 __global__ void __launch_bounds__(64 * kWaves) bf16_infer_kernel(const uint4 *__restrict__ wfrags, const v4 *__restrict__ bias_g,
-                                                                 const void *__restrict__ xin, int in_f64, int64_t n,
+                                                                 const void *__restrict__ xin, int64_t n,
                                                                  const double *__restrict__ feats, void *__restrict__ out, int out_f64,
                                                                  const uint8_t *__restrict__ imask, const void *__restrict__ xref,
                                                                  int xref_f64, const double *__restrict__ xref_feats,
@@ -283,7 +372,21 @@ __global__ void __launch_bounds__(64 * kWaves) bf16_infer_kernel(const uint4 *__
     const int64_t npass = (n + kRowsPerPass - 1) / kRowsPerPass;
     double lacc = 0.0;
     int lane_off = lane;
-    for (int64_t pass = (int64_t)blockIdx.x * kWaves + wave; pass < npass; pass += (int64_t)gridDim.x * kWaves) {
+    // The rows of the NEXT pass are requested while this pass computes (they used to be loaded at the top of the pass and used at
+    // once: SQ_WAIT_ANY 45-51 %); requested BEFORE this pass's stores, so the in-order vmcnt makes the next pass wait for its
+    // loads only, not for the stores to drain.
+    constexpr int DIN = DEC ? Z : F;
+    RawBlock<DIN, IN64> raw[kMB];
+    const int64_t pass0 = (int64_t)blockIdx.x * kWaves + wave, pstride = (int64_t)gridDim.x * kWaves;
+    auto prefetch = [&](int64_t pass) {
+#pragma unroll
+        for (int mb = 0; mb < kMB; ++mb) {
+            const int64_t r = pass * kRowsPerPass + 16 * mb + j;
+            load_block_issue<DIN, IN64>(raw[mb], xin, r, pass < npass && r < n, g);
+        }
+    };
+    if (pass0 < npass) prefetch(pass0);
+    for (int64_t pass = pass0; pass < npass; pass += pstride) {
         asm volatile("" : "+v"(lane_off));              // keep the LDS fragment reads inside the loop (LICM would spill the model)
         const bf8 *w = (const bf8 *)wl + lane_off;
         int64_t row[kMB];
@@ -293,9 +396,11 @@ __global__ void __launch_bounds__(64 * kWaves) bf16_infer_kernel(const uint4 *__
         if (!DEC) {
             bf8 a0[1][kMB], a2[N::kb(2)][kMB];
 #pragma unroll
-            for (int mb = 0; mb < kMB; ++mb) a0[0][mb] = load_block<F>(xin, in_f64, row[mb], valid[mb], g, feats ? fl : nullptr);
+            for (int mb = 0; mb < kMB; ++mb) a0[0][mb] = load_block_finish<DIN, IN64>(raw[mb], g, feats ? fl : nullptr);
+            if (!IN64) prefetch(pass + pstride);          // float64 rows (16 registers per batch tile): after the widest layer pair
             blayer_pair<N::kb(0), N::nt(0), N::nt(1)>(a0, a2, w + N::f_off(0) * 64, bias + N::b_off(0), w + N::f_off(1) * 64,
                                                       bias + N::b_off(1), g);
+            if (IN64) prefetch(pass + pstride);
             v4 z[N::nt(3)][kMB];
             blayer_then_last<N::kb(2), N::nt(2), N::nt(3)>(a2, z, w + N::f_off(2) * 64, bias + N::b_off(2), w + N::f_off(3) * 64,
                                                            bias + N::b_off(3), g);
@@ -321,12 +426,14 @@ __global__ void __launch_bounds__(64 * kWaves) bf16_infer_kernel(const uint4 *__
         } else {
             bf8 a4[1][kMB], a5[N::kb(5)][kMB], a6[N::kb(6)][kMB];
 #pragma unroll
-            for (int mb = 0; mb < kMB; ++mb) a4[0][mb] = load_block<Z>(xin, in_f64, row[mb], valid[mb], g, nullptr);
+            for (int mb = 0; mb < kMB; ++mb) a4[0][mb] = load_block_finish<DIN, IN64>(raw[mb], g, nullptr);
+            if (!IN64) prefetch(pass + pstride);
             blayer<N::kb(4), N::nt(4), true>(a4, a5, w + N::f_off(4) * 64, bias + N::b_off(4), g);
             blayer<N::kb(5), N::nt(5), true>(a5, a6, w + N::f_off(5) * 64, bias + N::b_off(5), g);
             v4 y[N::nt(7)][kMB];
             blayer_then_last<N::kb(6), N::nt(6), N::nt(7)>(a6, y, w + N::f_off(6) * 64, bias + N::b_off(6), w + N::f_off(7) * 64,
                                                            bias + N::b_off(7), g);
+            if (IN64) prefetch(pass + pstride);           // still before this pass's stores
 #pragma unroll
             for (int mb = 0; mb < kMB; ++mb)
 #pragma unroll
@@ -462,9 +569,13 @@ template <int F, int Z> struct BImpl {
             BAMD_HIP(hipMemcpy(st->wsrc[hf].p, wsrc.data(), wsrc.size() * sizeof(int), hipMemcpyHostToDevice));
             BAMD_HIP(hipMemcpy(st->bsrc[hf].p, bsrc.data(), bsrc.size() * sizeof(int), hipMemcpyHostToDevice));
         }
-        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_infer_kernel<F, Z, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_infer_kernel<F, Z, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)N::lds_bytes(0)));
-        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_infer_kernel<F, Z, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_infer_kernel<F, Z, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)N::lds_bytes(0)));
+        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_infer_kernel<F, Z, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)N::lds_bytes(1)));
+        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_infer_kernel<F, Z, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)N::lds_bytes(1)));
         return BAMD_OK;
     }
@@ -474,14 +585,16 @@ template <int F, int Z> struct BImpl {
         const int64_t npass = (n + kRowsPerPass - 1) / kRowsPerPass;
         int64_t wg = (npass + kWaves - 1) / kWaves;
         const int grid = (int)(wg < 1 ? 1 : (wg > st->grid ? st->grid : wg));
-        if (dec)
-            hipLaunchKernelGGL((bf16_infer_kernel<F, Z, true>), dim3(grid), dim3(64 * kWaves), N::lds_bytes(1), s,
-                               (const uint4 *)st->w[1].p, (const v4 *)st->b[1].p, xin, in_f64, n, feats, out, out_f64, imask, xref,
+        auto go = [&](auto decv, auto inv) {
+            constexpr bool D_ = decltype(decv)::value, I_ = decltype(inv)::value;
+            hipLaunchKernelGGL((bf16_infer_kernel<F, Z, D_, I_>), dim3(grid), dim3(64 * kWaves), N::lds_bytes(D_ ? 1 : 0), s,
+                               (const uint4 *)st->w[D_ ? 1 : 0].p, (const v4 *)st->b[D_ ? 1 : 0].p, xin, n, feats, out, out_f64, imask, xref,
                                xref_f64, xref_feats, loss_part);
-        else
-            hipLaunchKernelGGL((bf16_infer_kernel<F, Z, false>), dim3(grid), dim3(64 * kWaves), N::lds_bytes(0), s,
-                               (const uint4 *)st->w[0].p, (const v4 *)st->b[0].p, xin, in_f64, n, feats, out, out_f64, imask, xref,
-                               xref_f64, xref_feats, loss_part);
+        };
+        if (dec && in_f64) go(std::true_type(), std::true_type());
+        else if (dec) go(std::true_type(), std::false_type());
+        else if (in_f64) go(std::false_type(), std::true_type());
+        else go(std::false_type(), std::false_type());
         BAMD_HIP(hipGetLastError());
         return grid;
     }
