@@ -257,47 +257,7 @@ __device__ __forceinline__ void blayer_then_last(const bf8 (&in)[KB][kMB], v4 (&
 // rows -> first k block: lane (j, g) reads features 8g .. 8g+7 of its row (64 contiguous bytes in fp64).  Branch-free:
 // lanes beyond the last row read row 0 and lane groups / elements beyond D read feature 0 -- always inside the table, and
 // never used (those k slots meet zero weights; rows beyond n are not stored and carry no loss).
-template <int D>
-__device__ __forceinline__ bf8 load_block(const void *x, int is_f64, int64_t row, bool valid, int g, const double *feats_lds) {
-    float v[8];
-    const int64_t base = (valid ? row : 0) * D;
-    if (D % 8 == 0) {
-        const int f0 = 8 * g < D ? 8 * g : 0;
-        double d[8];
-        if (is_f64) {
-            const double2 *p = (const double2 *)((const double *)x + base + f0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const double2 t = p[e]; d[2 * e] = t.x; d[2 * e + 1] = t.y; }
-        } else {
-            const float4 *p = (const float4 *)((const float *)x + base + f0);
-            const float4 t0 = p[0], t1 = p[1];
-            d[0] = t0.x; d[1] = t0.y; d[2] = t0.z; d[3] = t0.w; d[4] = t1.x; d[5] = t1.y; d[6] = t1.z; d[7] = t1.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (feats_lds) d[e] = (d[e] - feats_lds[f0 + e]) / feats_lds[32 + f0 + e];
-            v[e] = (float)d[e];
-        }
-    } else {   // narrow, unaligned rows (the latent codes): element loads, skipped by the lane groups that hold no feature
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        if (8 * g < D) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int f = 8 * g + e < D ? 8 * g + e : 0;
-                double d = is_f64 ? ((const double *)x)[base + f] : (double)((const float *)x)[base + f];
-                if (feats_lds) d = (d - feats_lds[f]) / feats_lds[32 + f];
-                v[e] = (float)d;
-            }
-        }
-    }
-    bf8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-    return o;
-}
-
-// The same in two halves, so that the NEXT pass's rows can be requested while this pass computes: `issue` only loads (raw
+// In two halves, so that the NEXT pass's rows can be requested while this pass computes: `issue` only loads (raw
 // values stay in registers: 8 or 16 per batch tile), `finish` normalises, rounds and packs.  IN64 is a template parameter (a
 // run-time dtype branch in front of the loads makes hipcc join the paths with conservative waits).
 template <int D, bool IN64> struct RawBlock { typename std::conditional<IN64, double, float>::type v[8]; };
