@@ -350,12 +350,24 @@ __device__ __forceinline__ void dw_phase(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p
         for (int i = 0; i < NI; ++i) {
             if (wave + 4 * i >= NT) continue;
             const bf8 a0 = tr_operand<SZ>(za + 128 * i, 0), a1 = tr_operand<SZ>(za + 128 * i, 1);
+            // the transposed reads of tile k + 1 are issued before the MFMAs of tile k (hipcc put every read right in front of
+            // its MFMA: one LDS round trip per pair of MFMAs); sched_barrier pins the order
+            const lds_p xb0 = ximg + lx.tr(0);
+            bf8 b0 = tr_operand<SX>(xb0, 0), b1 = tr_operand<SX>(xb0, 1);
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                const lds_p xb = ximg + lx.tr(k & 1) + 32 * (k & ~1);
-                const bf8 b0 = tr_operand<SX>(xb, 0), b1 = tr_operand<SX>(xb, 1);
+                bf8 n0 = b0, n1 = b1;
+                if (k + 1 < KT) {
+                    const lds_p xb = ximg + lx.tr((k + 1) & 1) + 32 * ((k + 1) & ~1);
+                    n0 = tr_operand<SX>(xb, 0);
+                    n1 = tr_operand<SX>(xb, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 acc[i * KT + k] = mfma(a0, b0, acc[i * KT + k]);
                 acc[i * KT + k] = mfma(a1, b1, acc[i * KT + k]);
+                __builtin_amdgcn_sched_barrier(0);
+                b0 = n0;
+                b1 = n1;
             }
         }
     } else {
@@ -365,12 +377,22 @@ __device__ __forceinline__ void dw_phase(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p
         for (int i = 0; i < KI; ++i) {
             if (wave + 4 * i >= KT) continue;
             const bf8 b0 = tr_operand<SX>(xb + 128 * i, 0), b1 = tr_operand<SX>(xb + 128 * i, 1);
+            const lds_p za0 = zimg + lz.tr(0);
+            bf8 a0 = tr_operand<SZ>(za0, 0), a1 = tr_operand<SZ>(za0, 1);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const lds_p za = zimg + lz.tr(t & 1) + 32 * (t & ~1);
-                const bf8 a0 = tr_operand<SZ>(za, 0), a1 = tr_operand<SZ>(za, 1);
+                bf8 n0 = a0, n1 = a1;
+                if (t + 1 < NT) {
+                    const lds_p za = zimg + lz.tr((t + 1) & 1) + 32 * ((t + 1) & ~1);
+                    n0 = tr_operand<SZ>(za, 0);
+                    n1 = tr_operand<SZ>(za, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 acc[i * NT + t] = mfma(a0, b0, acc[i * NT + t]);
                 acc[i * NT + t] = mfma(a1, b1, acc[i * NT + t]);
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = n0;
+                a1 = n1;
             }
         }
     }
