@@ -334,6 +334,50 @@ __device__ __forceinline__ void acc_visit(ChainAcc<NT> &acc, lds_p img, const La
     }
 }
 
+// The backward epilogue reads, per tile, the 8 bytes the image holds at the place it is about to write (the sign mask of the
+// activation).  Same visits as acc_visit, with those reads issued one group of four tiles AHEAD of the arithmetic that needs
+// them (read-then-use per tile left one LDS round trip per tile exposed): `pre(addr)` reads, `fn(tile, addr, value)` consumes.
+template <int NT, int SOUT, class Pre, class Fn>
+__device__ __forceinline__ void acc_visit_pre(ChainAcc<NT> &acc, lds_p img, const Lay &lay, int wave, Pre pre, Fn fn) {
+    using SP = Split<NT>;
+#ifdef BAMD_ABLATE_EPILOGUE
+    return;
+#endif
+    const lds_p wn = img + lay.wr(wave & 1) + 32 * (wave & ~1);
+    const lds_p wm0 = img + 16 * wave * SOUT;
+    u2 ym[SP::MS > 0 ? SP::MS : 1];
+#pragma unroll
+    for (int k = 0; k < SP::MS; ++k) {
+        const int t = SP::m0 + k;
+        ym[k] = pre(wm0 + lay.wr(t & 1) + 32 * (t & ~1));
+    }
+    u2 yc[4], yn[4];
+    if (SP::NS > 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) yc[m] = pre(wn + 16 * m * SOUT);
+    }
+#pragma unroll
+    for (int k = 0; k < SP::NS; ++k) {
+        if (k + 1 < SP::NS) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) yn[m] = pre(wn + 128 * (k + 1) + 16 * m * SOUT);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(SP::ragged && k == SP::NS - 1 && wave + 4 * k >= NT)) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) fn(acc.an[k][m], wn + 128 * k + 16 * m * SOUT, yc[m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) yc[m] = yn[m];
+    }
+#pragma unroll
+    for (int k = 0; k < SP::MS; ++k) {
+        const int t = SP::m0 + k;
+        fn(acc.am[k], wm0 + lay.wr(t & 1) + 32 * (t & ~1), ym[k]);
+    }
+}
+
 // ---- weight-gradient tiles of layer l --------------------------------------------------------------------------------
 // A operand: dZ_l^T (image ZI, stride SZ), B operand: [X_l | 1] (image XI, stride SX), both by transposed reads;
 // contraction over the 64 rows = 2 MFMAs per tile.  Tiles owned by this wave: see TNet::by_nt.
@@ -571,10 +615,13 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                     dz[row * 4 + g] = pack4(acc.am[0]);                                                                      \
                 } else {                                                                                                     \
                     constexpr int DELTA = N::zoff((l) - 1) - N::ioff(l);   /* same stride, same lane offsets: a constant shift */ \
-                    acc_visit<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,              \
-                                                        [&](v4 &a, lds_p src) {                                              \
-                                                            lds_w64(src + DELTA, N::act((l) - 1) ? lrelu_bwd_pack4(a, lds_b64(src)) : pack4(a)); \
-                                                        });                                                                  \
+                    if constexpr (N::act((l) - 1))                                                                           \
+                        acc_visit_pre<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,      \
+                                                                [&](lds_p src) { return lds_b64(src); },                     \
+                                                                [&](v4 &a, lds_p src, u2 y) { lds_w64(src + DELTA, lrelu_bwd_pack4(a, y)); }); \
+                    else                                                                                                     \
+                        acc_visit<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,          \
+                                                            [&](v4 &a, lds_p src) { lds_w64(src + DELTA, pack4(a)); });      \
                 }                                                                                                            \
             }                                                                                                                \
             BT(20 + 2 * (l));                                                                                                \
