@@ -394,24 +394,32 @@ __device__ __forceinline__ void dw_phase(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p
         for (int i = 0; i < NI; ++i) {
             if (wave + 4 * i >= NT) continue;
             const bf8 a0 = tr_operand<SZ>(za + 128 * i, 0), a1 = tr_operand<SZ>(za + 128 * i, 1);
-            // the transposed reads of tile k + 1 are issued before the MFMAs of tile k (hipcc put every read right in front of
-            // its MFMA: one LDS round trip per pair of MFMAs); sched_barrier pins the order
-            const lds_p xb0 = ximg + lx.tr(0);
-            bf8 b0 = tr_operand<SX>(xb0, 0), b1 = tr_operand<SX>(xb0, 1);
+            // (hipcc put every transposed read right in front of its MFMA: one LDS round trip per pair of MFMAs; sched_barrier
+            // pins the order below)
+            // two tiles per step: their MFMAs alternate between two accumulators (a dependent v_mfma waits for its predecessor),
+            // the reads of the next pair are issued before the MFMAs of this one
+            auto rdb = [&](bf8 (&b)[2][2], int k) {
 #pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                bf8 n0 = b0, n1 = b1;
-                if (k + 1 < KT) {
-                    const lds_p xb = ximg + lx.tr((k + 1) & 1) + 32 * ((k + 1) & ~1);
-                    n0 = tr_operand<SX>(xb, 0);
-                    n1 = tr_operand<SX>(xb, 1);
+                for (int u = 0; u < 2; ++u) {
+                    const int kk = k + u < KT ? k + u : KT - 1;
+                    const lds_p xb = ximg + lx.tr(kk & 1) + 32 * (kk & ~1);
+                    b[u][0] = tr_operand<SX>(xb, 0);
+                    b[u][1] = tr_operand<SX>(xb, 1);
                 }
+            };
+            bf8 bc[2][2], bn[2][2];
+            rdb(bc, 0);
+#pragma unroll
+            for (int k = 0; k < KT; k += 2) {
+                if (k + 2 < KT) rdb(bn, k + 2);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[i * KT + k] = mfma(a0, b0, acc[i * KT + k]);
-                acc[i * KT + k] = mfma(a1, b1, acc[i * KT + k]);
+                acc[i * KT + k] = mfma(a0, bc[0][0], acc[i * KT + k]);
+                if (k + 1 < KT) acc[i * KT + k + 1] = mfma(a0, bc[1][0], acc[i * KT + k + 1]);
+                acc[i * KT + k] = mfma(a1, bc[0][1], acc[i * KT + k]);
+                if (k + 1 < KT) acc[i * KT + k + 1] = mfma(a1, bc[1][1], acc[i * KT + k + 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                b0 = n0;
-                b1 = n1;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
             }
         }
     } else {
@@ -421,22 +429,28 @@ __device__ __forceinline__ void dw_phase(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p
         for (int i = 0; i < KI; ++i) {
             if (wave + 4 * i >= KT) continue;
             const bf8 b0 = tr_operand<SX>(xb + 128 * i, 0), b1 = tr_operand<SX>(xb + 128 * i, 1);
-            const lds_p za0 = zimg + lz.tr(0);
-            bf8 a0 = tr_operand<SZ>(za0, 0), a1 = tr_operand<SZ>(za0, 1);
+            auto rda = [&](bf8 (&a)[2][2], int t) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                bf8 n0 = a0, n1 = a1;
-                if (t + 1 < NT) {
-                    const lds_p za = zimg + lz.tr((t + 1) & 1) + 32 * ((t + 1) & ~1);
-                    n0 = tr_operand<SZ>(za, 0);
-                    n1 = tr_operand<SZ>(za, 1);
+                for (int u = 0; u < 2; ++u) {
+                    const int tt = t + u < NT ? t + u : NT - 1;
+                    const lds_p za = zimg + lz.tr(tt & 1) + 32 * (tt & ~1);
+                    a[u][0] = tr_operand<SZ>(za, 0);
+                    a[u][1] = tr_operand<SZ>(za, 1);
                 }
+            };
+            bf8 ac[2][2], an[2][2];
+            rda(ac, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t += 2) {
+                if (t + 2 < NT) rda(an, t + 2);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[i * NT + t] = mfma(a0, b0, acc[i * NT + t]);
-                acc[i * NT + t] = mfma(a1, b1, acc[i * NT + t]);
+                acc[i * NT + t] = mfma(ac[0][0], b0, acc[i * NT + t]);
+                if (t + 1 < NT) acc[i * NT + t + 1] = mfma(ac[1][0], b0, acc[i * NT + t + 1]);
+                acc[i * NT + t] = mfma(ac[0][1], b1, acc[i * NT + t]);
+                if (t + 1 < NT) acc[i * NT + t + 1] = mfma(ac[1][1], b1, acc[i * NT + t + 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                a0 = n0;
-                a1 = n1;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { ac[u][0] = an[u][0]; ac[u][1] = an[u][1]; }
             }
         }
     }
