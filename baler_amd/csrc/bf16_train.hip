@@ -101,6 +101,10 @@ template <int PART> struct Part {
 // A STEP is one k block of one chain product; every wave loads at most 4 fragments per step, two steps ahead of the
 // MFMAs, into a ring of 3 step buffers.  The step count is padded to a multiple of 3 so that the ring wraps across
 // persistent iterations (padding steps load nothing).
+#ifndef BAMD_BF16_RING
+#define BAMD_BF16_RING 3
+#endif
+constexpr int kRD = BAMD_BF16_RING;      // step buffers of the fragment ring (fragments run kRD - 1 k-blocks ahead; 4 and 5 measured within 0.5 % of 3)
 struct StepInfo { int bwd, l, q, valid; };
 template <class N, int PART> struct Sched {
     using P = Part<PART>;
@@ -108,7 +112,7 @@ template <class N, int PART> struct Sched {
     __host__ __device__ static constexpr int fstep(int l) { int s = 0; for (int j = 0; j < l; ++j) s += N::kb(j); return s; }
     __host__ __device__ static constexpr int bstep(int l) { int s = fstep(P::fwd_end); for (int j = P::bwd_hi; j > l; --j) s += N::kbb(j); return s; }
     static constexpr int real = bstep(chain_lo()) + N::kbb(chain_lo());
-    static constexpr int total = cdiv(real, 3) * 3;
+    static constexpr int total = cdiv(real, kRD) * kRD;
     __host__ __device__ static constexpr StepInfo info(int s) {
         s %= total;
         if (s >= real) return {0, 0, 0, 0};
@@ -141,7 +145,7 @@ struct WStream {
 __device__ __forceinline__ bf8 frag_rt(const WStream &ws, int idx) {
     return __builtin_bit_cast(bf8, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
 }
-struct Ring { bf8 buf[3][4]; };
+struct Ring { bf8 buf[kRD][4]; };
 
 template <class N, int PART, int STEP>
 __device__ __forceinline__ void issue(Ring &ring, const WStream &ws, int wave) {
@@ -154,7 +158,7 @@ __device__ __forceinline__ void issue(Ring &ring, const WStream &ws, int wave) {
         for (int k = 0; k < SP::NF; ++k) {
             int t = k < SP::NS ? wave + 4 * k : SP::m0 + (k - SP::NS);
             if (SP::ragged && k == SP::NS - 1) t = t < NT ? t : NT - 1;      // empty slot: load a valid fragment, unused
-            ring.buf[STEP % 3][k] = frag_rt(ws, base + t);
+            ring.buf[STEP % kRD][k] = frag_rt(ws, base + t);
         }
     }
 }
@@ -271,7 +275,7 @@ template <class N, int PART, int STEP0, int KB, int NT, int SIN, int Q>
 __device__ __forceinline__ void chain_step(ChainAcc<NT> &acc, bf8 (&b)[2][4], lds_p in_row, Ring &ring, const WStream &ws, int wave,
                                            bool last_ok) {
     using SP = Split<NT>;
-    issue<N, PART, STEP0 + Q + 2>(ring, ws, wave);
+    issue<N, PART, STEP0 + Q + kRD - 1>(ring, ws, wave);
     if (Q + 1 < KB) chain_load_b<NT, SIN>(b[(Q + 1) & 1], in_row, wave, Q + 1);
     const bf8 (&bq)[4] = b[Q & 1];
     // k block 0 starts from a literal zero C operand (no accumulator initialisation; the bias arrives through the
@@ -281,14 +285,14 @@ __device__ __forceinline__ void chain_step(ChainAcc<NT> &acc, bf8 (&b)[2][4], ld
     for (int k = 0; k < SP::NS; ++k) {
         if (SP::ragged && k == SP::NS - 1 && !last_ok) continue;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc.an[k][m] = mfma(ring.buf[(STEP0 + Q) % 3][k], bq[m], Q == 0 ? zero : acc.an[k][m]);
+        for (int m = 0; m < 4; ++m) acc.an[k][m] = mfma(ring.buf[(STEP0 + Q) % kRD][k], bq[m], Q == 0 ? zero : acc.an[k][m]);
     }
     if (SP::MS > 0) {
         // M-split tiles use this wave's OWN row tile: with N-split tiles present it is read once more (a wave-uniform
         // address) rather than selected from the four with 12 v_cndmask
         const bf8 bw = SP::NS > 0 ? lds_b128(in_row + 16 * wave * SIN + 64 * Q) : bq[0];
 #pragma unroll
-        for (int k = 0; k < SP::MS; ++k) acc.am[k] = mfma(ring.buf[(STEP0 + Q) % 3][SP::NS + k], bw, Q == 0 ? zero : acc.am[k]);
+        for (int k = 0; k < SP::MS; ++k) acc.am[k] = mfma(ring.buf[(STEP0 + Q) % kRD][SP::NS + k], bw, Q == 0 ? zero : acc.am[k]);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -538,6 +542,8 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     Ring ring;
     issue<N, PART, 0>(ring, ws, wave);
     issue<N, PART, 1>(ring, ws, wave);
+    if constexpr (kRD > 3) issue<N, PART, 2>(ring, ws, wave);
+    if constexpr (kRD > 4) issue<N, PART, 3>(ring, ws, wave);
     RawX<F> xraw;
     x_issue<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15), n, lane >> 4);
 
@@ -648,8 +654,11 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
 #undef BAMD_BWD
         // step over the padding steps and prime the ring for the next iteration (steps total, total + 1 = its steps 0, 1:
         // already issued by the last two real steps when there is no padding)
-        if constexpr (SC::total - SC::real == 2) { issue<N, PART, SC::total>(ring, ws, wave); issue<N, PART, SC::total + 1>(ring, ws, wave); }
-        if constexpr (SC::total - SC::real == 1) { issue<N, PART, SC::total + 1>(ring, ws, wave); }
+        // (step total + j is issued by real step total + j - (kRD - 1) when that one exists)
+        if constexpr (SC::total + 0 - (kRD - 1) >= SC::real) issue<N, PART, SC::total + 0>(ring, ws, wave);
+        if constexpr (kRD > 2 && SC::total + 1 - (kRD - 1) >= SC::real) issue<N, PART, SC::total + 1>(ring, ws, wave);
+        if constexpr (kRD > 3 && SC::total + 2 - (kRD - 1) >= SC::real) issue<N, PART, SC::total + 2>(ring, ws, wave);
+        if constexpr (kRD > 4 && SC::total + 3 - (kRD - 1) >= SC::real) issue<N, PART, SC::total + 3>(ring, ws, wave);
     }
     if constexpr (P::has(7)) dw_flush<N, 7>(slab, g7, lane, wave);
     if constexpr (P::has(6)) dw_flush<N, 6>(slab, g6, lane, wave);
