@@ -1768,6 +1768,12 @@ __device__ __forceinline__ void dw_phase(const float *__restrict__ qdz, const fl
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (u + 1 < U) lds_frags(u + 1, fa[(u + 1) & 1], fb[(u + 1) & 1]);
+#ifndef BAMD_DW_LOOSE
+        // pin the reads of step u + 1 in front of the MFMAs of step u: left free, hipcc sank the second tile's reads to one MFMA
+        // before their first use (it reuses the registers of the buffer in use).  Measured neutral (298 M rows/s either way:
+        // one MFMA covers most of an LDS round trip here); kept because the schedule no longer depends on the allocator's mood
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         const int it0 = 2 * (u >> 2), it1 = it0 + 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
