@@ -107,7 +107,7 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
     if (rc) { bamd_destroy(h); return rc; }
     rc = fused64_setup(h);
     if (rc) { bamd_destroy(h); return rc; }
-    if (mode == BAMD_MODE_BF16 && !h->fused_ok) {   // (wide models in the bf16 mode are served by fused.hip: h->fused_ok)
+    if (mode == BAMD_MODE_BF16 && !fused_serves_bf16_inference(h)) {   // (wide models in the bf16 mode are served by fused.hip)
         rc = bf16_setup(h);
         if (rc) { bamd_destroy(h); return rc; }
         rc = bf16_train_setup(h);
@@ -148,7 +148,9 @@ int bamd_load_params(bamd_handle *h, const void *params, int dtype, void *stream
     if (h->mode == BAMD_MODE_BF16 && h->bf16_state) {
         rc = bf16_pack(h, s);
         h->bf16_infer_stale = false;
-        return rc ? rc : bf16_train_pack(h, s);
+        h->bf16_train_stale = false;
+        if (!rc) rc = bf16_train_pack(h, s);
+        return rc ? rc : fused_pack(h, s);           // fp32 fragments of the small-batch kernels (no-op without them)
     }
     if (h->mode == BAMD_MODE_F64) return fused64_pack(h, s);
     return fused_pack(h, s);
@@ -170,6 +172,22 @@ int bamd_normalize(const void *x, int dtype, int64_t n_rows, int n_cols, const d
 int bamd_renormalize(const void *x, int dtype, int64_t n_rows, int n_cols, const double *features,
                      const uint8_t *int_mask, double *out, void *stream) {
     return launch_renormalize(x, dtype, n_rows, n_cols, features, int_mask, out, (hipStream_t)stream);
+}
+
+// BF16 handles of the 24-column model train SMALL batches on the fp32 small-batch kernels: measured us per bamd_train_step,
+// fp32 / bf16 kernels: 512 rows 23 / 34, 2048 rows 34 / 37, 8192 rows 72 / 51, 32768 rows 161 / 80 -- the bf16 pair needs ~3000
+// rows to win (its workgroups own 64 rows each: a 512-row batch occupies 8 CUs).  BALER_AMD_BF16_SMALL_ROWS overrides (0: never).
+static int64_t bf16_small_rows() {
+    const char *e = getenv("BALER_AMD_BF16_SMALL_ROWS");       // read per call: tests toggle it
+    return e ? atoll(e) : 3072;
+}
+static bool bf16_kernels_train(const bamd_handle *h, int64_t n_rows) {
+    return h->mode == BAMD_MODE_BF16 && bf16_train_ok(h) && !(h->fused_ok && n_rows <= bf16_small_rows());
+}
+static int bf16_train_sync(bamd_handle *h, hipStream_t s) {   // the bf16 training fragments are re-rounded on demand
+    if (!h->bf16_train_stale) return BAMD_OK;
+    h->bf16_train_stale = false;
+    return bf16_train_pack(h, s);
 }
 
 // bf16 handles re-round the INFERENCE fragments lazily: a training step refreshes only what the next step reads
@@ -229,12 +247,15 @@ int bamd_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, con
         BAMD_HIP(hipMemsetAsync(grads, 0, (size_t)(h->nparams + 1) * h->esize, s));
         return BAMD_OK;
     }
+    if (bf16_kernels_train(h, n_rows)) {
+        if (int rc = bf16_train_sync(h, s)) return rc;
+        return bf16_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
+    }
     if (h->fused_ok) return fused_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
     if (h->mode == BAMD_MODE_F64) {   // small batches: fp64 chain + weight-gradient tiles; otherwise the layer-wise kernels
         int rc = fused64_step(h, x, x_dtype, n_rows, features, grads, nullptr, nullptr, nullptr, nullptr, nullptr, s);
         if (rc != BAMD_ERR_UNSUPPORTED) return rc;
     }
-    if (h->mode == BAMD_MODE_BF16 && bf16_train_ok(h)) return bf16_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
     return generic_fwd_bwd(h, x, x_dtype, n_rows, features, grads, s);
 }
 
@@ -266,7 +287,7 @@ int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, voi
     int rc = launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, sc_off, sc_idx, packed, s);
     if (rc == BAMD_OK) fused_params_changed(h);
     if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16 && h->bf16_state) {
-        if (bf16_train_ok(h)) { h->bf16_infer_stale = true; rc = bf16_train_pack(h, s); }   // the next step's fragments now, the inference ones on demand
+        if (bf16_train_ok(h)) { h->bf16_infer_stale = true; h->bf16_train_stale = true; }   // both sets of bf16 fragments on demand
         else rc = bf16_pack(h, s);
     }
     return rc;
@@ -278,9 +299,12 @@ int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, 
     BAMD_REQUIRE(params && m && v && hp && n_rows >= 0 && (x || n_rows == 0), "bad arguments");
     BAMD_REQUIRE(hp->step >= 1, "step must be >= 1");
     hipStream_t s = (hipStream_t)stream;
-    if (n_rows > 0) {
+    if (n_rows > 0 && !bf16_kernels_train(h, n_rows)) {
         int rc = fused_train_step(h, x, x_dtype, n_rows, features, grads, params, m, v, *hp, loss_accum, s);
-        if (rc != BAMD_ERR_UNSUPPORTED) return rc;
+        if (rc != BAMD_ERR_UNSUPPORTED) {
+            if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16) { h->bf16_infer_stale = true; h->bf16_train_stale = true; fused_params_changed(h); }
+            return rc;
+        }
         if (h->mode == BAMD_MODE_F64) {
             rc = fused64_step(h, x, x_dtype, n_rows, features, grads, params, m, v, hp, loss_accum, s);
             if (rc != BAMD_ERR_UNSUPPORTED) return rc;

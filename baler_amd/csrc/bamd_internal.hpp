@@ -66,6 +66,7 @@ struct bamd_handle {
     void *bf16_state = nullptr;     // packed bf16 weights + maps of the bf16 inference mode (bf16.hip)
     void *bf16_train_state = nullptr;   // packed bf16 weights + maps of the bf16 training kernels (bf16_train.hip)
     bool bf16_infer_stale = false;  // the inference fragments lag h->params (re-packed lazily by the next inference call)
+    bool bf16_train_stale = false;  // the bf16 TRAINING fragments lag h->params (re-packed by the next bf16 training launch)
 
     bool has_act(int l) const { return !(l == L / 2 - 1 || l == L - 1); }
 };

@@ -3117,9 +3117,15 @@ template <int F, int Z> struct ImplWideBf16 {
 // Instantiated shapes: the CMS 24-column model at the usual compression ratios
 // (latent = ceil(24 / ratio): 1.6 -> 15, 2 -> 12, 3 -> 8, 4 -> 6).  Anything else runs on generic.hip.
 static const FusedOps *find_ops(const bamd_handle *h) {
-    if (h->mode == BAMD_MODE_BF16) {      // wide models only: the 24-column model's bf16 mode lives in bf16.hip / bf16_train.hip
+    if (h->mode == BAMD_MODE_BF16) {
         if (ImplWide<2500, 25>::matches(h)) return ImplWideBf16<2500, 25>::ops();
         if (ImplWide<512, 6>::matches(h)) return ImplWideBf16<512, 6>::ops();
+        // the 24-column model's bf16 kernels live in bf16.hip / bf16_train.hip; the fp32 kernels here serve its SMALL batches
+        // (api.hip: the bf16 training kernels need ~3000 rows to beat the fp32 small-batch step)
+        if (Impl<24, 15>::matches(h)) return Impl<24, 15>::ops();
+        if (Impl<24, 12>::matches(h)) return Impl<24, 12>::ops();
+        if (Impl<24, 8>::matches(h)) return Impl<24, 8>::ops();
+        if (Impl<24, 6>::matches(h)) return Impl<24, 6>::ops();
         return nullptr;
     }
     if (h->mode != BAMD_MODE_F32) return nullptr;
@@ -3185,6 +3191,10 @@ int fused_pack(bamd_handle *h, hipStream_t s) {
     BAMD_HIP(hipGetLastError());
     if (st->ops->pack_extra) return st->ops->pack_extra(h, st, s);
     return BAMD_OK;
+}
+
+bool fused_serves_bf16_inference(const bamd_handle *h) {   // wide models in the bf16 mode: encode / decode live in fused.hip
+    return h->fused_ok && ((const FusedState *)h->fused_state)->ops->pack_extra != nullptr;
 }
 
 void fused_params_changed(bamd_handle *h) {   // after an optimiser step: further packed copies are refreshed on demand

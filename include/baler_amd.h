@@ -57,7 +57,8 @@ typedef enum bamd_dtype { BAMD_F32 = 0, BAMD_F64 = 1 } bamd_dtype;
  * 4-5x the F32 rate (measured 2e-3 encode, 6e-3 decode).  Training (bamd_fwd_bwd / bamd_train_step): bf16 weights,
  * activations and gradients through the chain, fp32 accumulation and fp32 partial gradients; params / m / v / grads stay
  * FLOAT (the caller's fp32 master copy and Adam state); bamd_adam_step re-rounds the bf16 fragments.  3.3x the F32 training
- * rate; one-step gradients within ~5e-3 rel-L2 of the fp64 reference.  Available for the 24-column AE (latent 15/12/8/6)
+ * rate; one-step gradients within ~5e-3 rel-L2 of the fp64 reference; batches of <= 3072 rows run on the F32 small-batch
+ * kernels instead (exact fp32, and faster there: 23 vs 34 us per 512-row step).  Available for the 24-column AE (latent 15/12/8/6)
  * and, for bamd_encode / bamd_decode, for the wide models CFD_dense_AE(2500, 25) and the 512-column model (their two wide
  * layers on the bf16 MFMA, HBM-bound; the narrow layers, training and validation of such a handle run in fp32);
  * other shapes of a BF16 handle are rejected by bamd_create.  bamd_fwd_bwd_latent and bamd_activation_means of a BF16

@@ -29,6 +29,13 @@ def handle(flat, mode="bf16", dims=DIMS):
     return h, p
 
 
+@pytest.fixture(autouse=True)
+def _bf16_kernels_for_every_batch(monkeypatch):
+    """BF16 handles train batches of <= 3072 rows on the fp32 small-batch kernels (faster there); these tests are about the bf16
+    kernels, at every size."""
+    monkeypatch.setenv("BALER_AMD_BF16_SMALL_ROWS", "0")
+
+
 @pytest.fixture(scope="module")
 def data():
     raw = synth.cms_rows(20000)
@@ -134,3 +141,35 @@ def test_full_size_and_rate():
     ms = e0.elapsed_time(e1) / 5
     print(f"bf16 fwd_bwd: {ms:.3f} ms per 1M rows = {n / ms / 1e3:.0f} M rows/s")
     assert ms < 1.35, "bf16 training kernels fell off their fast path (profiles: ~1.0 ms per 1M rows)"
+
+
+@pytest.mark.parametrize("n", [1, 512, 3072, 3073])
+def test_small_batches_of_a_bf16_handle_run_the_fp32_kernels(n, data, monkeypatch):
+    """Up to 3072 rows a BF16 handle's training calls run the fp32 small-batch kernels (23 us against 34 us per 512-row step):
+    gradients at the fp32 bar there, at the bf16 bar above; an optimiser step taken on either path is seen by the other and by the
+    bf16 inference kernels (the bf16 fragments are re-rounded on demand)."""
+    monkeypatch.delenv("BALER_AMD_BF16_SMALL_ROWS")
+    raw, x = data
+    flat = orc.formula_params(DIMS, 11)
+    h, p = handle(flat)
+    g = torch.zeros_like(p)
+    xb = torch.as_tensor(x[:n]).cuda()
+    h.fwd_bwd(xb, g)
+    loss_ref, g_ref = orc.fwd_bwd(DIMS, flat, x[:n])
+    gh = g.cpu().numpy().astype(np.float64)
+    tol = 1e-5 if n <= 3072 else 2e-2
+    assert rel(gh[:-1], g_ref) < tol and abs(gh[-1] - loss_ref) < max(tol, 2e-3 if n > 3072 else 0) * loss_ref
+    # train_step on this path, then a large (bf16) and a small (fp32) gradient and an encode with the NEW parameters
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    h.train_step(xb, p, m, v, 1, 1e-2)
+    new = p.cpu().numpy().astype(np.float64)[:-1]
+    assert rel(new, flat) > 1e-3
+    big = torch.as_tensor(x[:8000]).cuda()
+    h.fwd_bwd(big, g)
+    _, gb = orc.fwd_bwd(DIMS, new, x[:8000])
+    assert rel(g.cpu().numpy().astype(np.float64)[:-1], gb) < 2e-2
+    small = torch.as_tensor(x[:300]).cuda()
+    h.fwd_bwd(small, g)
+    _, gs = orc.fwd_bwd(DIMS, new, x[:300])
+    assert rel(g.cpu().numpy().astype(np.float64)[:-1], gs) < 1e-5
+    assert rel(h.encode(big).cpu().numpy(), orc.encode(DIMS, new, x[:8000])) < 6e-3
