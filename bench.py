@@ -355,6 +355,21 @@ def main():
                 "frac": FLOP_TRAIN_ROW * a.rows / ms / 1e9 / PEAK_TFLOPS["bf16"],
                 "hbm_gbs_algorithmic": BYTES_TRAIN_ROW * a.rows / ms / 1e6, "hbm_frac": BYTES_TRAIN_ROW * a.rows / ms / 1e6 / PEAK_HBM_GBS,
                 "last_batch_loss": float(gb[-1].item())}
+            if world == 1:      # the bf16 handle's optimizer steps by batch size (<= 3072 rows: the fp32 small-batch kernels)
+                bb = {}
+                for bs in (512, 8192, 32768):
+                    if bs * 2 > a.rows:
+                        continue
+                    nb = max(2, min(200, a.rows // bs))
+
+                    def bpass():
+                        for i in range(nb):
+                            tb["t"] += 1
+                            hb.train_step(x[i * bs:(i + 1) * bs], fb, mb, vb, tb["t"], 1e-3)
+                    bpass()
+                    t_ = timed(bpass, 1, world, dev)
+                    bb[str(bs)] = {"rows_per_s": bs * nb / t_, "us_per_step": 1e6 * t_ / nb}
+                out["bf16_train_rows_per_s_by_batch"] = bb
             hb.close()
         # ---- the reference's batching regime and the curve up to the benchmarked batch: sequential optimizer steps ----
         by_batch = {}
