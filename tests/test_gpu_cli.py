@@ -97,7 +97,7 @@ def test_cli_train_compress_decompress(workspace, golden, monkeypatch, compute_m
         # fp32 parity mode: 1e-5 while the trajectories are still numerically comparable, then loss-curve
         # agreement.  fp32-vs-fp64 training diverges chaotically; WHEN it leaves 1e-5 depends
         # on rounding details: measured epoch-4 deviation 2e-7 (throughput kernels) .. 6e-5 (latency kernel),
-        # with per-step gradient errors of 1e-7 in both (tools/debug_graderr.py), so pin the first 60 steps
+        # with per-step gradient errors of 1e-7 in both, so pin the first 60 steps
         assert rel(loss[0][:3], g["loss_data"][0][:3]) < 1e-5
         assert np.max(np.abs(loss[0] / g["loss_data"][0] - 1)) < 0.05
         # compress/decompress of this run's own model agree with the oracle at 1e-5

@@ -163,12 +163,13 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` outside torchrun: the parent (which must not touch the GPU) starts two ranks as a child
     process and relays the child's exit code.  Here there is no GPU, so the ranks fail loudly -- what is checked is that
     two ranks were started (WORLD_SIZE=2 in the children) and that the parent returns the failure."""
-    env = dict(os.environ, BALER_AMD_DIST_BACKEND="gloo", BALER_AMD_FORCE_DEVICE="0")
-    env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       env=env, capture_output=True, text=True, timeout=600)
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by tests/test_gpu_dp.py")
+    env = dict(os.environ, BALER_AMD_DIST_BACKEND="gloo", BALER_AMD_FORCE_DEVICE="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert "no MI355X" in r.stderr and "nproc" not in r.stdout
     assert r.stderr.count("NativeError") >= 2 or "local_rank: 1" in r.stderr or "rank: 1" in r.stderr
