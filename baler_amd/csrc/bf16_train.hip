@@ -23,8 +23,14 @@
 //     layer, 132 KB of images for the whole network at 64 rows, no second set of buffers.
 // [dW | db] tiles stay in MFMA accumulators for the whole persistent loop (as in fused.hip) and are reduced over
 // workgroups in a fixed order: bitwise reproducible.  All 298 tiles x 256 floats do not fit one CU's registers
-// next to the chain, so training is two launches over the same rows (PART 0: forward, loss, decoder layers 7..4;
-// PART 1: encoder forward recomputed, layers 3..0, dL/dz handed over as 32 B per row).
+// next to the chain, so training is two launches over the same rows.  The cut sits BELOW layer 1: PART 0 = forward, loss,
+// the whole input-gradient chain down to dZ_1 and the weight gradients of layers 7..2 (181 tiles); PART 1 = layer 0's
+// forward recomputed (one k block), dZ_1 handed over as 224 B per row, layers 1..0 (117 tiles).  (Round 2 cut at the
+// bottleneck -- 32 B per row -- and PART 1 recomputed the forward of layers 0..2: a third of its time.)
+// The four NARROW layers in the middle (100 -> 50 -> Z -> 50 -> 100, forward and backward) run as a per-wave REGISTER chain
+// ("M-split": every wave computes ALL output tiles of ITS 16 rows, a C tile pair is the next layer's B operand after
+// v_cvt_pk_bf16_f32, the packed weights carry the k permutation): no barrier between them -- as N-split phases each of them
+// cost 500-1300 cycles for 32-256 cycles of MFMAs (barrier, LDS round trip, lock step of the four waves).
 #include "bf16.hpp"
 
 #include <cmath>
@@ -67,14 +73,23 @@ template <int F, int Z> struct TNet {
     __host__ __device__ static constexpr int istride(int i) { int b = iblocks(i); return 64 * (b % 2 ? b : b + 1); }   // bytes, 64 x odd
     __host__ __device__ static constexpr int ioff(int i) { int s = 0; for (int j = 0; j < i; ++j) s += kRows * istride(j); return s; }
     __host__ __device__ static constexpr int img_bytes() { return ioff(L + 1); }
-    // Where dZ_l is written -- OUT OF PLACE, so that the epilogue of layer l + 1 may run while other waves still read X_{l+1} for
-    // that layer's weight-gradient tiles: ONE barrier per backward layer.  The network is symmetric (dim(8 - i) = dim(i) for the
-    // hidden widths), so the image of the MIRROR layer has exactly dZ_l's shape and is dead at that time: PART 0 (layers 7..4)
-    // no longer needs X_1..X_3 after the forward, PART 1 (layers 3..0) never fills images 5..8.
-    //   dZ_7 -> image 8;  dZ_6 -> image 1;  dZ_5 -> image 2;  dZ_4 -> image 3;  dZ_3 -> image 4 (loaded from the hand-off);
-    //   dZ_2 -> image 5;  dZ_1 -> image 6;  dZ_0 -> image 7
-    __host__ __device__ static constexpr int zimg_of(int l) { return l == 7 ? 8 : l >= 4 ? 7 - l : l == 3 ? 4 : 7 - l; }
+    // Where dZ_l lives -- OUT OF PLACE, in an image region that is dead by then, so that the epilogue of layer l + 1 may run while
+    // other waves still read X_{l+1} for that layer's weight-gradient tiles: ONE barrier per backward layer, no second set of
+    // buffers.  A region is reused with the stride of the image whose SHAPE dZ_l has (X_{l+1}'s), which is never larger.
+    //   PART 0:  dZ_7 -> image 8;  dZ_6 -> region 1 (X_1 is dead after layer 1's forward: its weight gradient is PART 1's);
+    //            dZ_5 -> region 7 (X_7 dead after layer 7);  dZ_4 -> region 6 (X_6 dead after layer 6);  dZ_3 -> region 0;
+    //            dZ_2 -> region 1 (dZ_6 dead after layer 6);  dZ_1 -> global memory (the hand-off)
+    //   PART 1:  dZ_1 -> region 2 (loaded from the hand-off);  dZ_0 -> region 7
+    __host__ __device__ static constexpr int zimg_of(int l) { return l == 7 ? 8 : l == 6 ? 1 : l == 5 ? 7 : l == 4 ? 6 : l == 3 ? 0 : l == 2 ? 1 : l == 1 ? 2 : 7; }
     __host__ __device__ static constexpr int zoff(int l) { return ioff(zimg_of(l)); }
+    // M-split (per-wave register chain) products: forward layers 2..5, input-gradient products of layers 5..2.  The first of
+    // each run reads its B operand from the image (natural k order); the others take it from the previous product's packed
+    // C tiles: k slot (g, e) <-> feature 32 q + 16 (e >> 2) + 4 g + (e & 3) (TImpl::setup packs the fragments that way).
+    __host__ __device__ static constexpr bool mf(int l) { return l >= 2 && l <= 5; }
+    __host__ __device__ static constexpr bool mb(int l) { return l >= 2 && l <= 5; }
+    __host__ __device__ static constexpr bool regfed_f(int l) { return l >= 3 && l <= 5; }
+    __host__ __device__ static constexpr bool regfed_b(int l) { return l >= 2 && l <= 4; }
+    static constexpr int hand_tiles = 7;                 // dZ_1: cdiv(100, 16) tiles = 224 B per row
     // weight-gradient tiles in the partial-gradient buffer
     __host__ __device__ static constexpr int dwt(int l) { return nt(l) * kt(l); }
     __host__ __device__ static constexpr int slab_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += dwt(j); return s; }
@@ -85,15 +100,15 @@ template <int F, int Z> struct TNet {
     __host__ __device__ static constexpr int w_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += dim(j + 1) * dim(j) + dim(j + 1); return s; }
     __host__ __device__ static constexpr int b_off(int l) { return w_off(l) + dim(l + 1) * dim(l); }
     __host__ __device__ static constexpr int nparams() { return w_off(L); }
-    static_assert(F % 8 == 0 && F < 32 && Z < 32, "input rows are read as 8-feature chunks of one 32-slot block");
+    static_assert(F % 8 == 0 && F < 32 && Z < 16, "input rows are read as 8-feature chunks of one 32-slot block; the latent is one tile");
 };
 
-// Which layers a launch covers.  PART 0: forward 0..7, loss, backward 7..4.  PART 1: forward 0..2, backward 3..0.
-// PART 2: everything in one launch (needs all 298 tiles in registers: kept for experiments).
+// Which layers a launch covers.  PART 0: forward 0..7, loss, backward 7..2 (input-gradient chain down to dZ_1).
+// PART 1: forward 0, backward 1..0.
 template <int PART> struct Part {
-    static constexpr int fwd_end = PART == 1 ? 3 : 8;        // forward layers [0, fwd_end)
-    static constexpr int bwd_hi = PART == 1 ? 3 : 7;         // backward layers bwd_hi .. bwd_lo
-    static constexpr int bwd_lo = PART == 0 ? 4 : 0;
+    static constexpr int fwd_end = PART == 1 ? 1 : 8;        // forward layers [0, fwd_end)
+    static constexpr int bwd_hi = PART == 1 ? 1 : 7;         // backward layers bwd_hi .. bwd_lo
+    static constexpr int bwd_lo = PART == 0 ? 2 : 0;
     __host__ __device__ static constexpr bool has(int l) { return l <= bwd_hi && l >= bwd_lo; }
 };
 
@@ -101,28 +116,33 @@ template <int PART> struct Part {
 // A STEP is one k block of one chain product; every wave loads at most 4 fragments per step, two steps ahead of the
 // MFMAs, into a ring of 3 step buffers.  The step count is padded to a multiple of 3 so that the ring wraps across
 // persistent iterations (padding steps load nothing).
-#ifndef BAMD_BF16_RING
-#define BAMD_BF16_RING 3
+#undef BAMD_BF16_RING
+#ifndef BAMD_BF16_RINGD
+#define BAMD_BF16_RINGD 4
 #endif
-constexpr int kRD = BAMD_BF16_RING;      // step buffers of the fragment ring (fragments run kRD - 1 k-blocks ahead; 4 and 5 measured within 0.5 % of 3)
-struct StepInfo { int bwd, l, q, valid; };
+struct StepInfo { int bwd, l, q, valid, msplit; };
+// steps of a product: N-split = one per k block (<= 4 fragments per wave); M-split = its kb x nt fragments, in MFMA order
+// [k block][tile], four per step (every wave loads all of them)
 template <class N, int PART> struct Sched {
     using P = Part<PART>;
     __host__ __device__ static constexpr int chain_lo() { return P::bwd_lo < 1 ? 1 : P::bwd_lo; }   // layer 0 has no input gradient
-    __host__ __device__ static constexpr int fstep(int l) { int s = 0; for (int j = 0; j < l; ++j) s += N::kb(j); return s; }
-    __host__ __device__ static constexpr int bstep(int l) { int s = fstep(P::fwd_end); for (int j = P::bwd_hi; j > l; --j) s += N::kbb(j); return s; }
-    static constexpr int real = bstep(chain_lo()) + N::kbb(chain_lo());
-    static constexpr int total = cdiv(real, kRD) * kRD;
+    __host__ __device__ static constexpr int nf(int l) { return N::mf(l) ? cdiv(N::kb(l) * N::nt(l), 4) : N::kb(l); }
+    __host__ __device__ static constexpr int nb(int l) { return N::mb(l) ? cdiv(N::kbb(l) * N::ntb(l), 4) : N::kbb(l); }
+    __host__ __device__ static constexpr int fstep(int l) { int s = 0; for (int j = 0; j < l; ++j) s += nf(j); return s; }
+    __host__ __device__ static constexpr int bstep(int l) { int s = fstep(P::fwd_end); for (int j = P::bwd_hi; j > l; --j) s += nb(j); return s; }
+    static constexpr int real = bstep(chain_lo()) + nb(chain_lo());
+    static constexpr int total = cdiv(real, BAMD_BF16_RINGD) * BAMD_BF16_RINGD;
     __host__ __device__ static constexpr StepInfo info(int s) {
         s %= total;
-        if (s >= real) return {0, 0, 0, 0};
+        if (s >= real) return {0, 0, 0, 0, 0};
         for (int l = 0; l < P::fwd_end; ++l)
-            if (s < fstep(l) + N::kb(l)) return {0, l, s - fstep(l), 1};
+            if (s < fstep(l) + nf(l)) return {0, l, s - fstep(l), 1, N::mf(l) ? 1 : 0};
         for (int l = P::bwd_hi; l >= chain_lo(); --l)
-            if (s < bstep(l) + N::kbb(l)) return {1, l, s - bstep(l), 1};
-        return {0, 0, 0, 0};
+            if (s < bstep(l) + nb(l)) return {1, l, s - bstep(l), 1, N::mb(l) ? 1 : 0};
+        return {0, 0, 0, 0, 0};
     }
 };
+constexpr int kRD = BAMD_BF16_RINGD;      // step buffers of the fragment ring (fragments run kRD - 1 steps ahead)
 
 // How the NT output tiles of a chain product are split over the 4 waves.  N-split slot i: tile wave + 4 i for ALL four
 // row tiles (the fragment is loaded by one wave only); M-split tile k: every wave computes it for ITS row tile (fragment
@@ -150,7 +170,13 @@ struct Ring { bf8 buf[kRD][4]; };
 template <class N, int PART, int STEP>
 __device__ __forceinline__ void issue(Ring &ring, const WStream &ws, int wave) {
     constexpr StepInfo si = Sched<N, PART>::info(STEP);
-    if constexpr (si.valid) {
+    if constexpr (si.valid && si.msplit) {
+        constexpr int cnt = si.bwd ? N::kbb(si.l) * N::ntb(si.l) : N::kb(si.l) * N::nt(si.l);
+        constexpr int base = (si.bwd ? N::bfo(si.l) : N::ffo(si.l)) + 4 * si.q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * si.q + k < cnt) ring.buf[STEP % kRD][k] = frag_rt(ws, base + k);
+    } else if constexpr (si.valid) {
         constexpr int NT = si.bwd ? N::ntb(si.l) : N::nt(si.l);
         using SP = Split<NT>;
         constexpr int base = (si.bwd ? N::bfo(si.l) : N::ffo(si.l)) + si.q * NT;
@@ -261,23 +287,30 @@ template <int NT> struct ChainAcc {
     v4 am[SP::MS > 0 ? SP::MS : 1];
 };
 
+#ifndef BAMD_BF16_BDEPTH
+#define BAMD_BF16_BDEPTH 2
+#endif
+constexpr int kBD = BAMD_BF16_BDEPTH;      // k blocks the B operand reads run ahead of the MFMAs (LDS latency under load: 150-200 cycles)
+// B operands of one k block: [0..3] the four row tiles (N-split slots), [4] this wave's own row tile (M-split tiles)
 template <int NT, int SIN>
-__device__ __forceinline__ void chain_load_b(bf8 (&dst)[4], lds_p in_row, int wave, int q) {
-    if (Split<NT>::NS > 0) {
+__device__ __forceinline__ void chain_load_b(bf8 (&dst)[5], lds_p in_row, int wave, int q) {
+    using SP = Split<NT>;
+    if (SP::NS > 0) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) dst[m] = lds_b128(in_row + 16 * m * SIN + 64 * q);
-    } else {
-        dst[0] = lds_b128(in_row + 16 * wave * SIN + 64 * q);              // M-split only: this wave's row tile
     }
+    // M-split tiles use this wave's OWN row tile: read once more (a wave-uniform address) rather than selected from the four
+    // with 12 v_cndmask -- and read AHEAD like the others (read at its use, every k block paid one LDS round trip)
+    if (SP::MS > 0) dst[4] = lds_b128(in_row + 16 * wave * SIN + 64 * q);
 }
 // k block Q of the product (every index a template constant: the ring and the B buffers stay in registers)
 template <class N, int PART, int STEP0, int KB, int NT, int SIN, int Q>
-__device__ __forceinline__ void chain_step(ChainAcc<NT> &acc, bf8 (&b)[2][4], lds_p in_row, Ring &ring, const WStream &ws, int wave,
+__device__ __forceinline__ void chain_step(ChainAcc<NT> &acc, bf8 (&b)[kBD + 1][5], lds_p in_row, Ring &ring, const WStream &ws, int wave,
                                            bool last_ok) {
     using SP = Split<NT>;
     issue<N, PART, STEP0 + Q + kRD - 1>(ring, ws, wave);
-    if (Q + 1 < KB) chain_load_b<NT, SIN>(b[(Q + 1) & 1], in_row, wave, Q + 1);
-    const bf8 (&bq)[4] = b[Q & 1];
+    if (Q + kBD < KB) chain_load_b<NT, SIN>(b[(Q + kBD) % (kBD + 1)], in_row, wave, Q + kBD);
+    const bf8 (&bq)[5] = b[Q % (kBD + 1)];
     // k block 0 starts from a literal zero C operand (no accumulator initialisation; the bias arrives through the
     // ones slot of the input image, whose weight column holds it)
     const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
@@ -287,13 +320,8 @@ __device__ __forceinline__ void chain_step(ChainAcc<NT> &acc, bf8 (&b)[2][4], ld
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc.an[k][m] = mfma(ring.buf[(STEP0 + Q) % kRD][k], bq[m], Q == 0 ? zero : acc.an[k][m]);
     }
-    if (SP::MS > 0) {
-        // M-split tiles use this wave's OWN row tile: with N-split tiles present it is read once more (a wave-uniform
-        // address) rather than selected from the four with 12 v_cndmask
-        const bf8 bw = SP::NS > 0 ? lds_b128(in_row + 16 * wave * SIN + 64 * Q) : bq[0];
 #pragma unroll
-        for (int k = 0; k < SP::MS; ++k) acc.am[k] = mfma(ring.buf[(STEP0 + Q) % kRD][SP::NS + k], bw, Q == 0 ? zero : acc.am[k]);
-    }
+    for (int k = 0; k < SP::MS; ++k) acc.am[k] = mfma(ring.buf[(STEP0 + Q) % kRD][SP::NS + k], bq[4], Q == 0 ? zero : acc.am[k]);
     __builtin_amdgcn_sched_barrier(0);
 }
 template <class N, int PART, int STEP0, int KB, int NT, int SIN, int... Q>
@@ -304,8 +332,9 @@ __device__ __forceinline__ void chain_mm_impl(ChainAcc<NT> &acc, lds_p in_row, R
 #ifdef BAMD_ABLATE_CHAIN
     return;
 #endif
-    bf8 b[2][4];
-    chain_load_b<NT, SIN>(b[0], in_row, wave, 0);
+    bf8 b[kBD + 1][5];
+#pragma unroll
+    for (int q = 0; q < kBD && q < KB; ++q) chain_load_b<NT, SIN>(b[q], in_row, wave, q);
     (chain_step<N, PART, STEP0, KB, NT, SIN, Q>(acc, b, in_row, ring, ws, wave, last_ok), ...);
 }
 template <class N, int PART, int STEP0, int KB, int NT, int SIN>
@@ -385,79 +414,78 @@ __device__ __forceinline__ void acc_visit_pre(ChainAcc<NT> &acc, lds_p img, cons
 // ---- weight-gradient tiles of layer l --------------------------------------------------------------------------------
 // A operand: dZ_l^T (image ZI, stride SZ), B operand: [X_l | 1] (image XI, stride SX), both by transposed reads;
 // contraction over the 64 rows = 2 MFMAs per tile.  Tiles owned by this wave: see TNet::by_nt.
+// The wave OWNS the tiles {wave + 4 i} of one side (output tiles when by_nt, input tiles otherwise) and streams over all tiles
+// of the other side.  Its own operands (NO x 2 halves) are read once and stay in registers; every streamed operand feeds the
+// MFMAs of all NO owned tiles (the first version re-read the streamed side per owned tile: twice to four times the LDS traffic),
+// and the streamed reads run kDWD tiles ahead of their MFMAs: one tile ahead = 64 MFMA cycles left every step waiting for an
+// LDS round trip of 150-200 cycles (13 steps of dW_6 took 2,280 cycles for 832 cycles of MFMAs).
+// An owned slot that does not exist on this wave (13 tiles over 4 waves) is computed on a clamped address and never flushed:
+// uniform code, and that wave would wait at the barrier anyway.
+#ifndef BAMD_BF16_DWDEPTH
+#define BAMD_BF16_DWDEPTH 3
+#endif
+constexpr int kDWD = BAMD_BF16_DWDEPTH;
+template <class N, int l> struct DwGeo {
+    static constexpr int NT = N::nt(l), KT = N::kt(l);
+    static constexpr bool BYN = N::by_nt(l);
+    static constexpr int NO = BYN ? cdiv(NT, 4) : cdiv(KT, 4);      // owned slots
+    static constexpr int OWN = BYN ? NT : KT;                       // tiles on the owned side
+    static constexpr int NS = BYN ? KT : NT;                        // streamed tiles
+};
+template <class N, int l, int SZ, int SX, int S>
+__device__ __forceinline__ void dw_step(v4 (&acc)[N::dwn(l)], const bf8 (&own)[DwGeo<N, l>::NO][2], bf8 (&ring)[kDWD + 1][2], lds_p sbase0,
+                                        lds_p sbase1) {
+    using G = DwGeo<N, l>;
+    constexpr int SS = G::BYN ? SX : SZ;          // stride of the streamed image
+    if constexpr (S + kDWD < G::NS) {
+        constexpr int t = S + kDWD;
+        const lds_p sb = ((t & 1) ? sbase1 : sbase0) + 32 * (t & ~1);
+        ring[t % (kDWD + 1)][0] = tr_operand<SS>(sb, 0);
+        ring[t % (kDWD + 1)][1] = tr_operand<SS>(sb, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bf8 (&st)[2] = ring[S % (kDWD + 1)];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < G::NO; ++i) {
+            v4 &c = acc[i * G::NS + S];
+            c = G::BYN ? mfma(own[i][h], st[h], c) : mfma(st[h], own[i][h], c);      // A = dZ^T tile, B = [X | 1] tile
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class N, int l, int SZ, int SX, int... S>
+__device__ __forceinline__ void dw_phase_impl(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave,
+                                              std::integer_sequence<int, S...>) {
+    using G = DwGeo<N, l>;
+    constexpr int SO = G::BYN ? SZ : SX, SS = G::BYN ? SX : SZ;
+    const lds_p oimg = G::BYN ? zimg : ximg, simg = G::BYN ? ximg : zimg;
+    const Lay &lo = G::BYN ? lz : lx, &lst = G::BYN ? lx : lz;
+    const lds_p ob = oimg + lo.tr(wave & 1) + 32 * (wave & ~1);      // owned tile wave + 4 i -> + 128 i
+    bf8 own[G::NO][2];
+#pragma unroll
+    for (int i = 0; i < G::NO; ++i) {
+        const int ii = (i == 0 || wave + 4 * i < G::OWN) ? i : i - 1;      // wave-uniform clamp
+        own[i][0] = tr_operand<SO>(ob + 128 * ii, 0);
+        own[i][1] = tr_operand<SO>(ob + 128 * ii, 1);
+    }
+    const lds_p sb0 = simg + lst.tr0, sb1 = simg + lst.tr1;
+    bf8 ring[kDWD + 1][2];
+#pragma unroll
+    for (int t = 0; t < kDWD && t < G::NS; ++t) {
+        const lds_p sb = ((t & 1) ? sb1 : sb0) + 32 * (t & ~1);
+        ring[t][0] = tr_operand<SS>(sb, 0);
+        ring[t][1] = tr_operand<SS>(sb, 1);
+    }
+    (dw_step<N, l, SZ, SX, S>(acc, own, ring, sb0, sb1), ...);
+}
 template <class N, int l, int SZ, int SX>
 __device__ __forceinline__ void dw_phase(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave) {
-    constexpr int NT = N::nt(l), KT = N::kt(l);
 #ifdef BAMD_ABLATE_DW
     return;
 #endif
-    if constexpr (N::by_nt(l)) {
-        constexpr int NI = cdiv(NT, 4);
-        const lds_p za = zimg + lz.tr(wave & 1) + 32 * (wave & ~1);      // tile nt = wave + 4 i -> + 128 i
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (wave + 4 * i >= NT) continue;
-            const bf8 a0 = tr_operand<SZ>(za + 128 * i, 0), a1 = tr_operand<SZ>(za + 128 * i, 1);
-            // (hipcc put every transposed read right in front of its MFMA: one LDS round trip per pair of MFMAs; sched_barrier
-            // pins the order below)
-            // two tiles per step: their MFMAs alternate between two accumulators (a dependent v_mfma waits for its predecessor),
-            // the reads of the next pair are issued before the MFMAs of this one
-            auto rdb = [&](bf8 (&b)[2][2], int k) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int kk = k + u < KT ? k + u : KT - 1;
-                    const lds_p xb = ximg + lx.tr(kk & 1) + 32 * (kk & ~1);
-                    b[u][0] = tr_operand<SX>(xb, 0);
-                    b[u][1] = tr_operand<SX>(xb, 1);
-                }
-            };
-            bf8 bc[2][2], bn[2][2];
-            rdb(bc, 0);
-#pragma unroll
-            for (int k = 0; k < KT; k += 2) {
-                if (k + 2 < KT) rdb(bn, k + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[i * KT + k] = mfma(a0, bc[0][0], acc[i * KT + k]);
-                if (k + 1 < KT) acc[i * KT + k + 1] = mfma(a0, bc[1][0], acc[i * KT + k + 1]);
-                acc[i * KT + k] = mfma(a1, bc[0][1], acc[i * KT + k]);
-                if (k + 1 < KT) acc[i * KT + k + 1] = mfma(a1, bc[1][1], acc[i * KT + k + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
-            }
-        }
-    } else {
-        constexpr int KI = cdiv(KT, 4);
-        const lds_p xb = ximg + lx.tr(wave & 1) + 32 * (wave & ~1);      // tile kt = wave + 4 i
-#pragma unroll
-        for (int i = 0; i < KI; ++i) {
-            if (wave + 4 * i >= KT) continue;
-            const bf8 b0 = tr_operand<SX>(xb + 128 * i, 0), b1 = tr_operand<SX>(xb + 128 * i, 1);
-            auto rda = [&](bf8 (&a)[2][2], int t) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int tt = t + u < NT ? t + u : NT - 1;
-                    const lds_p za = zimg + lz.tr(tt & 1) + 32 * (tt & ~1);
-                    a[u][0] = tr_operand<SZ>(za, 0);
-                    a[u][1] = tr_operand<SZ>(za, 1);
-                }
-            };
-            bf8 ac[2][2], an[2][2];
-            rda(ac, 0);
-#pragma unroll
-            for (int t = 0; t < NT; t += 2) {
-                if (t + 2 < NT) rda(an, t + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[i * NT + t] = mfma(ac[0][0], b0, acc[i * NT + t]);
-                if (t + 1 < NT) acc[i * NT + t + 1] = mfma(ac[1][0], b0, acc[i * NT + t + 1]);
-                acc[i * NT + t] = mfma(ac[0][1], b1, acc[i * NT + t]);
-                if (t + 1 < NT) acc[i * NT + t + 1] = mfma(ac[1][1], b1, acc[i * NT + t + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) { ac[u][0] = an[u][0]; ac[u][1] = an[u][1]; }
-            }
-        }
-    }
+    static_assert(N::dwn(l) == DwGeo<N, l>::NO * DwGeo<N, l>::NS, "accumulator count");
+    dw_phase_impl<N, l, SZ, SX>(acc, zimg, ximg, lz, lx, wave, std::make_integer_sequence<int, DwGeo<N, l>::NS>{});
 }
 
 template <class N, int l>
@@ -505,11 +533,50 @@ __device__ __forceinline__ void x_issue(RawX<F> &raw, const void *x, int is_f64,
 }
 
 #ifdef BAMD_BF16_TRACE   // debug build: shader-clock stamps of workgroup 0, wave 0 at every phase boundary (tools/bf16_trace.py)
-__device__ unsigned long long g_bf16_trace[2][48];
-#define BT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bf16_trace[PART][i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_bf16_trace[2][4][128];
+// stamps go to LDS (a global store per stamp sat in front of every later counted vmcnt wait: in-order retirement) and are
+// copied out once after the loop
+#define BT(i) do { if ((threadIdx.x & 63) == 0) bt_lds[(threadIdx.x >> 6) * 128 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define BT(i) do {} while (0)
 #endif
+
+// ---- M-split products: this wave computes ALL NT output tiles of ITS 16 rows; the KB B operands are in registers ----------
+// fragment f = q NT + t of the product's stream feeds MFMA (k block q, tile t); four fragments per ring step
+template <class N, int PART, int STEP0, int KB, int NT, int F_>
+__device__ __forceinline__ void mstep(v4 (&acc)[NT], const bf8 (&b)[KB], Ring &ring, const WStream &ws, int wave) {
+    constexpr int q = F_ / NT, t = F_ % NT, st = STEP0 + F_ / 4, slot = F_ % 4;
+    if constexpr (slot == 0) issue<N, PART, st + kRD - 1>(ring, ws, wave);
+    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+    acc[t] = mfma(ring.buf[st % kRD][slot], b[q], q == 0 ? zero : acc[t]);
+    if constexpr (slot == 3) __builtin_amdgcn_sched_barrier(0);
+}
+template <class N, int PART, int STEP0, int KB, int NT, int... F_>
+__device__ __forceinline__ void mchain_impl(v4 (&acc)[NT], const bf8 (&b)[KB], Ring &ring, const WStream &ws, int wave,
+                                            std::integer_sequence<int, F_...>) {
+    (mstep<N, PART, STEP0, KB, NT, F_>(acc, b, ring, ws, wave), ...);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class N, int PART, int STEP0, int KB, int NT>
+__device__ __forceinline__ void mchain(v4 (&acc)[NT], const bf8 (&b)[KB], Ring &ring, const WStream &ws, int wave) {
+    mchain_impl<N, PART, STEP0, KB, NT>(acc, b, ring, ws, wave, std::make_integer_sequence<int, KB * NT>{});
+}
+// B operands of the next product from this product's packed C tiles: k block q = tiles 2 q, 2 q + 1 (missing tile: zeros)
+template <int KB, int NT>
+__device__ __forceinline__ void regfeed(bf8 (&b)[KB], const u2 (&pk)[NT]) {
+    typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int q = 0; q < KB; ++q) {
+        const u2 lo = 2 * q < NT ? pk[2 * q] : (u2){0u, 0u}, hi = 2 * q + 1 < NT ? pk[2 * q + 1] : (u2){0u, 0u};
+        b[q] = __builtin_bit_cast(bf8, (u4_){lo[0], lo[1], hi[0], hi[1]});
+    }
+}
+// B operands from image rows of THIS wave's row tile (`own` = image base + lane row part + 16 wave S)
+template <int KB>
+__device__ __forceinline__ void imgfeed(bf8 (&b)[KB], lds_p own) {
+#pragma unroll
+    for (int q = 0; q < KB; ++q) b[q] = lds_b128(own + 64 * q);
+}
 
 template <int F, int Z, int PART>
 __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict__ wfrags, const void *__restrict__ xin, int in_f64, int64_t n,
@@ -522,6 +589,9 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     const lds_p img = (lds_p)lds_raw;
     float *xf = (float *)(lds_raw + N::img_bytes());          // fp32 copy of the normalised input rows: [64][32]
     double *fl = (double *)(xf + kRows * 32);                 // [0..31] min, [32..63] range
+#ifdef BAMD_BF16_TRACE
+    unsigned long long *bt_lds = (unsigned long long *)(fl + 64);
+#endif
     for (int i = threadIdx.x; i < N::img_bytes() / 16; i += 256) ((uint4 *)lds_raw)[i] = make_uint4(0, 0, 0, 0);   // finite padding slots
     if (threadIdx.x < 64) {
         const int f = threadIdx.x & 31, which = threadIdx.x >> 5;
@@ -541,9 +611,11 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     double lacc = 0.0;
     Ring ring;
     issue<N, PART, 0>(ring, ws, wave);
-    issue<N, PART, 1>(ring, ws, wave);
+    if constexpr (kRD > 2) issue<N, PART, 1>(ring, ws, wave);
     if constexpr (kRD > 3) issue<N, PART, 2>(ring, ws, wave);
     if constexpr (kRD > 4) issue<N, PART, 3>(ring, ws, wave);
+    if constexpr (kRD > 5) issue<N, PART, 4>(ring, ws, wave);
+    static_assert(kRD >= 2 && kRD <= 6, "ring depth");
     RawX<F> xraw;
     x_issue<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15), n, lane >> 4);
 
@@ -570,28 +642,82 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
             *(bf8 __attribute__((address_space(3))) *)(img + N::ioff(0) + lay_of<N::istride(0)>(ls).row + 16 * wave * N::istride(0)) = o;
-            float *xr = xf + (16 * wave + j) * 32 + 8 * g;
-            *(float4 *)xr = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4 *)(xr + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            if constexpr (PART == 0) {
+                float *xr = xf + (16 * wave + j) * 32 + 8 * g;
+                *(float4 *)xr = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4 *)(xr + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
         }
         x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);       // next iteration's rows, a whole iteration ahead
+        if constexpr (PART == 1) {
+            // dZ_1 of these rows from the first launch (row-major, 224 B per row) -> region 2: thread (r, p) moves chunks
+            // p, p + 4, p + 8 (and p + 12 for p < 2) of row r to their swizzled places
+            constexpr int HB = N::hand_tiles * 32, S2 = N::istride(2);
+            static_assert(N::iblocks(2) * 64 >= HB, "hand-off row fits the image row");
+            const int r = threadIdx.x >> 2, pp = threadIdx.x & 3;
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            const u4v *src = (const u4v *)((const unsigned char *)dz + (grp * kRows + r) * HB) + pp;
+            const lds_p dst = img + N::zoff(1) + r * S2 + ((pp ^ ((r >> 1) & 3)) << 4);
+            u4v c[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = src[(16 * (pp + 4 * i) < HB) ? 4 * i : 0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (16 * (pp + 4 * i) < HB) *(u4v __attribute__((address_space(3))) *)(dst + 64 * i) = c[i];
+        }
         __syncthreads();
         BT(1);
 
-        // ---- forward ------------------------------------------------------------------------------------------------
+        // ---- forward, N-split layers ------------------------------------------------------------------------------------
 #define BAMD_FWD(l)                                                                                                          \
         {                                                                                                                    \
             ChainAcc<N::nt(l)> acc;                                                                                          \
             chain_mm<N, PART, SC::fstep(l), N::kb(l), N::nt(l), N::istride(l)>(                                              \
                 acc, img + N::ioff(l) + lay_of<N::istride(l)>(ls).row, ring, ws, wave);                                      \
+            BT(40 + 2 * (l));                                                                                                \
             acc_visit<N::nt(l), N::istride(l + 1)>(acc, img + N::ioff(l + 1), lay_of<N::istride(l + 1)>(ls), wave,           \
                                                    [&](v4 &a, lds_p dst) { if (N::act(l)) lrelu4(a); lds_w64(dst, pack4(a)); }); \
+            BT(41 + 2 * (l));                                                                                                \
             __syncthreads();                                                                                                 \
             BT(2 + (l));                                                                                                     \
         }
-        BAMD_FWD(0) BAMD_FWD(1) BAMD_FWD(2)
+        // ---- forward, M-split layer: B operands `bin` -> packed output tiles `pk` (also stored into image l + 1, own rows) ---
+#define BAMD_FWD_M(l, bin, pk)                                                                                               \
+        u2 pk[N::nt(l)];                                                                                                     \
+        {                                                                                                                    \
+            v4 acc[N::nt(l)];                                                                                                \
+            mchain<N, PART, SC::fstep(l), N::kb(l), N::nt(l)>(acc, bin, ring, ws, wave);                                     \
+            const Lay &lo = lay_of<N::istride((l) + 1)>(ls);                                                                 \
+            const lds_p ob = img + N::ioff((l) + 1) + 16 * wave * N::istride((l) + 1);                                       \
+            _Pragma("unroll") for (int t = 0; t < N::nt(l); ++t) {                                                           \
+                if (N::act(l)) lrelu4(acc[t]);                                                                               \
+                pk[t] = pack4(acc[t]);                                                                                       \
+                lds_w64(ob + lo.wr(t & 1) + 32 * (t & ~1), pk[t]);                                                           \
+            }                                                                                                                \
+        }
+        BAMD_FWD(0)
         if constexpr (P::fwd_end == 8) {
-            BAMD_FWD(3) BAMD_FWD(4) BAMD_FWD(5) BAMD_FWD(6)
+            BAMD_FWD(1)
+            {
+                static_assert(N::mf(2) && N::mf(3) && N::mf(4) && N::mf(5) && !N::regfed_f(2), "register chain 2..5");
+                bf8 b2[N::kb(2)];
+                imgfeed<N::kb(2)>(b2, img + N::ioff(2) + lay_of<N::istride(2)>(ls).row + 16 * wave * N::istride(2));
+                BAMD_FWD_M(2, b2, p3)
+                bf8 b3[N::kb(3)];
+                regfeed<N::kb(3), N::nt(2)>(b3, p3);
+                BAMD_FWD_M(3, b3, p4)
+                bf8 b4[N::kb(4)];
+                regfeed<N::kb(4), N::nt(3)>(b4, p4);
+                BAMD_FWD_M(4, b4, p5)
+                bf8 b5[N::kb(5)];
+                regfeed<N::kb(5), N::nt(4)>(b5, p5);
+                BAMD_FWD_M(5, b5, p6)
+                (void)p6;
+                BT(54);
+                __syncthreads();
+                BT(55);
+            }
+            BAMD_FWD(6)
             // layer 7 + loss: NT = 2 -> this wave holds both output tiles of ITS 16 rows
             ChainAcc<N::nt(7)> acc;
             static_assert(N::nt(7) < 4, "loss epilogue expects the M-split form");
@@ -614,14 +740,9 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
             }
             __syncthreads();
             BT(9);
-        } else {
-            // PART 1: dL/dz of these rows from the first launch -> image 4 (tile 0 of row tile `wave`)
-            const u2 dzv = dz[row * 4 + g];                                 // rows beyond n: zeros (stored by PART 0)
-            lds_w64(img + N::ioff(4) + 16 * wave * N::istride(4) + lay_of<N::istride(4)>(ls).wr0, dzv);
-            __syncthreads();
         }
 
-        // ---- backward: per layer  [input-gradient MFMAs] [mask + store dZ_{l-1} into its own region] [weight-gradient tiles]  barrier
+        // ---- backward, N-split: per layer  [input-gradient MFMAs] [mask + store dZ_{l-1} into its own region] [weight-gradient tiles]  barrier
 #define BAMD_BWD(l, G)                                                                                                       \
         if constexpr (P::has(l)) {                                                                                           \
             constexpr int SZ = N::istride((l) + 1);   /* dZ_l has the shape of X_{l+1} */                                    \
@@ -629,37 +750,93 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
             if constexpr ((l) >= 1) {                                                                                        \
                 ChainAcc<N::ntb(l)> acc;                                                                                     \
                 chain_mm<N, PART, SC::bstep(l), N::kbb(l), N::ntb(l), SZ>(acc, zimg + lay_of<SZ>(ls).row, ring, ws, wave);   \
-                if constexpr (PART == 0 && (l) == P::bwd_lo) {                                                               \
-                    /* hand-off to the second launch: dL/dz, 4 bf16 per lane = 32 B per row (en4 has no activation) */       \
-                    static_assert(N::ntb(l) == 1, "dL/dz is one tile per row");                                              \
-                    dz[row * 4 + g] = pack4(acc.am[0]);                                                                      \
-                } else {                                                                                                     \
-                    constexpr int DELTA = N::zoff((l) - 1) - N::ioff(l);   /* same stride, same lane offsets: a constant shift */ \
-                    if constexpr (N::act((l) - 1))                                                                           \
-                        acc_visit_pre<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,      \
-                                                                [&](lds_p src) { return lds_b64(src); },                     \
-                                                                [&](v4 &a, lds_p src, u2 y) { lds_w64(src + DELTA, lrelu_bwd_pack4(a, y)); }); \
-                    else                                                                                                     \
-                        acc_visit<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,          \
-                                                            [&](v4 &a, lds_p src) { lds_w64(src + DELTA, pack4(a)); });      \
-                }                                                                                                            \
+                BT(70 + 2 * (l));                                                                                            \
+                constexpr int DELTA = N::zoff((l) - 1) - N::ioff(l);   /* same stride, same lane offsets: a constant shift */ \
+                if constexpr (N::act((l) - 1))                                                                               \
+                    acc_visit_pre<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,          \
+                                                            [&](lds_p src) { return lds_b64(src); },                         \
+                                                            [&](v4 &a, lds_p src, u2 y) { lds_w64(src + DELTA, lrelu_bwd_pack4(a, y)); }); \
+                else                                                                                                         \
+                    acc_visit<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,              \
+                                                        [&](v4 &a, lds_p src) { lds_w64(src + DELTA, pack4(a)); });          \
             }                                                                                                                \
             BT(20 + 2 * (l));                                                                                                \
             dw_phase<N, l, SZ, N::istride(l)>(G, zimg, img + N::ioff(l), lay_of<SZ>(ls), lay_of<N::istride(l)>(ls), wave);   \
+            BT(71 + 2 * (l));                                                                                                \
             __syncthreads();                                                                                                 \
             BT(21 + 2 * (l));                                                                                                \
         }
-        BAMD_BWD(7, g7) BAMD_BWD(6, g6) BAMD_BWD(5, g5) BAMD_BWD(4, g4) BAMD_BWD(3, g3) BAMD_BWD(2, g2) BAMD_BWD(1, g1) BAMD_BWD(0, g0)
+        // ---- backward, M-split product of layer l: B operands `bin` (dZ_l) -> packed dZ_{l-1} tiles `pk`, stored into their region
+        //      (own rows), masked with the sign of X_l where layer l - 1 has an activation
+#define BAMD_BWD_M(l, bin, pk)                                                                                               \
+        u2 pk[N::ntb(l)];                                                                                                    \
+        {                                                                                                                    \
+            const Lay &lo = lay_of<N::istride(l)>(ls);                                                                       \
+            const lds_p xb = img + N::ioff(l) + 16 * wave * N::istride(l);                                                   \
+            constexpr int DELTA = N::zoff((l) - 1) - N::ioff(l);                                                             \
+            u2 y[N::ntb(l)];                                                                                                 \
+            if constexpr (N::act((l) - 1)) {                                                                                 \
+                _Pragma("unroll") for (int t = 0; t < N::ntb(l); ++t) y[t] = lds_b64(xb + lo.wr(t & 1) + 32 * (t & ~1));     \
+            }                                                                                                                \
+            v4 acc[N::ntb(l)];                                                                                               \
+            mchain<N, PART, SC::bstep(l), N::kbb(l), N::ntb(l)>(acc, bin, ring, ws, wave);                                   \
+            _Pragma("unroll") for (int t = 0; t < N::ntb(l); ++t) {                                                          \
+                if constexpr (N::act((l) - 1)) pk[t] = lrelu_bwd_pack4(acc[t], y[t]);                                        \
+                else pk[t] = pack4(acc[t]);                                                                                  \
+                if constexpr ((l) - 1 >= P::bwd_lo) lds_w64(xb + DELTA + lo.wr(t & 1) + 32 * (t & ~1), pk[t]);               \
+            }                                                                                                                \
+        }
+        BAMD_BWD(7, g7) BAMD_BWD(6, g6)
+        if constexpr (PART == 0) {
+            static_assert(N::mb(5) && N::mb(4) && N::mb(3) && N::mb(2) && !N::regfed_b(5), "register chain 5..2");
+            bf8 c5[N::kbb(5)];
+            imgfeed<N::kbb(5)>(c5, img + N::zoff(5) + lay_of<N::istride(6)>(ls).row + 16 * wave * N::istride(6));
+            BAMD_BWD_M(5, c5, q4)
+            bf8 c4[N::kbb(4)];
+            regfeed<N::kbb(4), N::ntb(5)>(c4, q4);
+            BAMD_BWD_M(4, c4, q3)
+            bf8 c3[N::kbb(3)];
+            regfeed<N::kbb(3), N::ntb(4)>(c3, q3);
+            BAMD_BWD_M(3, c3, q2)
+            bf8 c2[N::kbb(2)];
+            regfeed<N::kbb(2), N::ntb(3)>(c2, q2);
+            BAMD_BWD_M(2, c2, q1)
+            // hand-off to the second launch: dZ_1, row-major, 8 bytes (features 16 t + 4 g ..) per lane and tile; rows beyond n
+            // carry zeros (their dL/drecon is zero)
+            static_assert(N::ntb(2) == N::hand_tiles, "hand-off width");
+#pragma unroll
+            for (int t = 0; t < N::ntb(2); ++t) dz[row * (4 * N::hand_tiles) + 4 * t + g] = q1[t];
+            BT(56);
+            __syncthreads();
+            BT(57);
+            // weight-gradient tiles of the four narrow layers (images complete for all 64 rows now)
+#define BAMD_DW(l, G) dw_phase<N, l, N::istride((l) + 1), N::istride(l)>(G, img + N::zoff(l), img + N::ioff(l), lay_of<N::istride((l) + 1)>(ls), \
+                                                                        lay_of<N::istride(l)>(ls), wave);
+            BAMD_DW(5, g5) BAMD_DW(4, g4) BAMD_DW(3, g3) BAMD_DW(2, g2)
+#undef BAMD_DW
+            BT(58);
+            __syncthreads();     // the next iteration's rows overwrite region 0 (dZ_3), its layer 0 region 1 (dZ_2)
+            BT(59);
+        } else {
+            BAMD_BWD(1, g1) BAMD_BWD(0, g0)
+        }
 #undef BAMD_FWD
+#undef BAMD_FWD_M
 #undef BAMD_BWD
-        // step over the padding steps and prime the ring for the next iteration (steps total, total + 1 = its steps 0, 1:
-        // already issued by the last two real steps when there is no padding)
-        // (step total + j is issued by real step total + j - (kRD - 1) when that one exists)
+#undef BAMD_BWD_M
+        // step over the padding steps and prime the ring for the next iteration (step total + j is issued by real step
+        // total + j - (kRD - 1) when that one exists)
         if constexpr (SC::total + 0 - (kRD - 1) >= SC::real) issue<N, PART, SC::total + 0>(ring, ws, wave);
         if constexpr (kRD > 2 && SC::total + 1 - (kRD - 1) >= SC::real) issue<N, PART, SC::total + 1>(ring, ws, wave);
         if constexpr (kRD > 3 && SC::total + 2 - (kRD - 1) >= SC::real) issue<N, PART, SC::total + 2>(ring, ws, wave);
         if constexpr (kRD > 4 && SC::total + 3 - (kRD - 1) >= SC::real) issue<N, PART, SC::total + 3>(ring, ws, wave);
+        if constexpr (kRD > 5 && SC::total + 4 - (kRD - 1) >= SC::real) issue<N, PART, SC::total + 4>(ring, ws, wave);
     }
+#ifdef BAMD_BF16_TRACE
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 512; i += 256) g_bf16_trace[PART][i >> 7][i & 127] = bt_lds[i];
+#endif
     if constexpr (P::has(7)) dw_flush<N, 7>(slab, g7, lane, wave);
     if constexpr (P::has(6)) dw_flush<N, 6>(slab, g6, lane, wave);
     if constexpr (P::has(5)) dw_flush<N, 5>(slab, g5, lane, wave);
@@ -745,7 +922,11 @@ TrainState *tstate(bamd_handle *h) { return (TrainState *)h->bf16_train_state; }
 
 template <int F, int Z> struct TImpl {
     using N = TNet<F, Z>;
+#ifdef BAMD_BF16_TRACE
+    static constexpr size_t lds_bytes() { return (size_t)N::img_bytes() + kRows * 32 * 4 + 64 * 8 + 4096; }
+#else
     static constexpr size_t lds_bytes() { return (size_t)N::img_bytes() + kRows * 32 * 4 + 64 * 8; }
+#endif
     static_assert(lds_bytes() <= 160 * 1024, "LDS images exceed one CU");
     static bool matches(const bamd_handle *h) {
         if (h->L != 8) return false;
@@ -764,7 +945,8 @@ template <int F, int Z> struct TImpl {
                 for (int t = 0; t < N::nt(l); ++t)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
-                            const int n = 16 * t + (lane & 15), k = 32 * q + 8 * (lane >> 4) + e;
+                            const int g = lane >> 4;
+                            const int n = 16 * t + (lane & 15), k = N::regfed_f(l) ? 32 * q + 16 * (e >> 2) + 4 * g + (e & 3) : 32 * q + 8 * g + e;
                             int v = -1;
                             if (n < NN && k < K) v = N::w_off(l) + n * K + k;
                             else if (n < NN && k == K) v = N::b_off(l) + n;
@@ -776,7 +958,8 @@ template <int F, int Z> struct TImpl {
                 for (int t = 0; t < N::ntb(l); ++t)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
-                            const int n = 32 * q + 8 * (lane >> 4) + e, k = 16 * t + (lane & 15);
+                            const int g = lane >> 4;
+                            const int n = N::regfed_b(l) ? 32 * q + 16 * (e >> 2) + 4 * g + (e & 3) : 32 * q + 8 * g + e, k = 16 * t + (lane & 15);
                             if (n < NN && k < K) src[((size_t)(N::bfo(l) + q * N::ntb(l) + t) * 64 + lane) * 8 + e] = N::w_off(l) + n * K + k;
                         }
             static_assert(N::dim(0) % 32 && N::dim(1) % 32 && N::dim(2) % 32 && N::dim(3) % 32 && N::dim(4) % 32,
@@ -825,7 +1008,7 @@ template <int F, int Z> struct TImpl {
         // tiles + one double per workgroup for the loss
         int rc = h->slabs.ensure(((size_t)st->ntiles * 1024 + 16) * (size_t)grid);
         if (rc) return rc;
-        rc = st->dz.ensure((size_t)ngroups * kRows * 32);          // dL/dz hand-off: 16 bf16 per row, whole row groups
+        rc = st->dz.ensure((size_t)ngroups * kRows * N::hand_tiles * 32);          // dZ_1 hand-off: 112 bf16 per row, whole row groups
         if (rc) return rc;
         hipLaunchKernelGGL((bf16_train_kernel<F, Z, 0>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
         hipLaunchKernelGGL((bf16_train_kernel<F, Z, 1>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
@@ -852,7 +1035,7 @@ const TrainOps *find_train(const bamd_handle *h) {
 
 #ifdef BAMD_BF16_TRACE
 extern "C" int bamd_debug_bf16_trace(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_trace), sizeof(unsigned long long) * 96);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_trace), sizeof(unsigned long long) * 2 * 4 * 128);
 }
 #endif
 

@@ -23,25 +23,35 @@ g = torch.zeros_like(model.flat)
 for _ in range(3):
     h.fwd_bwd(x, g)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 96)()
+buf = (ctypes.c_ulonglong * 1024)()
 L = native.lib()
 L.bamd_debug_bf16_trace.argtypes = [ctypes.c_void_p]
 print("rc", L.bamd_debug_bf16_trace(buf))
-t = np.array(buf[:], dtype=np.int64).reshape(2, 48)
-for part in (0, 1):
-    tt = t[part]
-    print(f"PART {part}: iteration total {tt[21 + 2 * (4 if part == 0 else 0)] - tt[0]} cycles")
-    print(f"  rows -> image 0 + barrier   {tt[1] - tt[0]:6d}")
-    prev = tt[1]
-    for l in range(8 if part == 0 else 3):
-        end = tt[9] if l == 7 else tt[2 + l]
-        print(f"  forward layer {l}{' + loss' if l == 7 else '       '}     {end - prev:6d}")
-        prev = end
-    if part == 0:
-        prev = tt[9]                              # forward layer 7 above includes the loss epilogue
-    else:
-        prev = tt[2 + 2]
-    for l in (range(7, 3, -1) if part == 0 else range(3, -1, -1)):
-        a, b = tt[20 + 2 * l], tt[21 + 2 * l]
-        print(f"  backward layer {l}: chain + epilogue {a - prev:6d}   weight-gradient tiles + barrier {b - a:6d}")
-        prev = b
+T = np.array(buf[:], dtype=np.uint64).astype(np.int64).reshape(2, 4, 128)
+
+
+def seg(part, label, ids):
+    """ids: stamp ids in execution order, the first one = the phase's opening barrier; prints per-wave cycles since then"""
+    base = T[part, :, ids[0]]
+    cols = " | ".join(" ".join(f"{T[part, w, i] - base[w]:5d}" for w in range(4)) for i in ids[1:])
+    print(f"  {label:26s} total {T[part, 0, ids[-1]] - base[0]:5d} | {cols}")
+
+
+print("PART 0 (columns: per-wave cycles at [MFMAs done | epilogue issued | (dW done) | barrier passed])")
+print("  iteration total", T[0, 0, 59] - T[0, 0, 0])
+seg(0, "rows -> image 0", [0, 1])
+seg(0, "fwd 0", [1, 40, 41, 2])
+seg(0, "fwd 1", [2, 42, 43, 3])
+seg(0, "fwd 2..5 register chain", [3, 54, 55])
+seg(0, "fwd 6", [55, 52, 53, 8])
+seg(0, "fwd 7 + loss", [8, 9])
+seg(0, "bwd 7", [9, 84, 34, 85, 35])
+seg(0, "bwd 6", [35, 82, 32, 83, 33])
+seg(0, "bwd 5..2 register chain", [33, 56, 57])
+seg(0, "dW 5..2", [57, 58, 59])
+print("PART 1")
+print("  iteration total", T[1, 0, 21] - T[1, 0, 0])
+seg(1, "rows + dZ_1 -> images", [0, 1])
+seg(1, "fwd 0", [1, 40, 41, 2])
+seg(1, "bwd 1", [2, 72, 22, 73, 23])
+seg(1, "bwd 0 (dW only)", [23, 20, 71, 21])

@@ -20,6 +20,8 @@ for k in sorted(d, key=lambda k: -sum(d[k].get("SQ_WAVE_CYCLES", [0]))):
         out.append(f"mfma_busy {c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (1024 * c['GRBM_GUI_ACTIVE'] / 8):.3f}")
     if c.get("SQ_INSTS_MFMA"):
         out.append(f"valu/mfma {(c['SQ_INSTS_VALU'] - c['SQ_INSTS_MFMA']) / c['SQ_INSTS_MFMA']:.2f} mfma {c['SQ_INSTS_MFMA'] / 1e6:.2f}M")
+    if c.get("GRBM_GUI_ACTIVE"):
+        out.append(f"gui_cyc {c['GRBM_GUI_ACTIVE'] / 8 / 1e3:.1f}k wave_cyc {4 * c.get('SQ_WAVE_CYCLES', 0) / 1e6:.1f}M")
     if c.get("SQ_WAVE_CYCLES"):
         out.append(f"wait_any {c.get('SQ_WAIT_ANY', 0) / c['SQ_WAVE_CYCLES']:.3f}")
     if c.get("SQ_LDS_IDX_ACTIVE"):
