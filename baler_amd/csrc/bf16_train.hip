@@ -118,7 +118,7 @@ template <int PART> struct Part {
 // persistent iterations (padding steps load nothing).
 #undef BAMD_BF16_RING
 #ifndef BAMD_BF16_RINGD
-#define BAMD_BF16_RINGD 4
+#define BAMD_BF16_RINGD 3
 #endif
 struct StepInfo { int bwd, l, q, valid, msplit; };
 // steps of a product: N-split = one per k block (<= 4 fragments per wave); M-split = its kb x nt fragments, in MFMA order
@@ -241,11 +241,17 @@ template <int S> __device__ __forceinline__ bf8 tr_operand(lds_p base, int kh) {
 }
 
 __device__ __forceinline__ void lrelu4(v4 &a) {
+#ifdef BAMD_BF16_SCALAR_MUL
+    v4 m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[r] = a[r] * 0.01f; asm("" : "+v"(m[r])); }      // four v_mul_f32 (a packed multiply costs more than two of them in a VALU burst)
+#else
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f k2 = (v2f){0.01f, 0.01f};
     asm("" : "+v"(k2));                       // register pair, vector product: v_pk_mul_f32 (see fused.hip lrelu)
     v4 m = a * (v4){k2[0], k2[1], k2[0], k2[1]};
     asm("" : "+v"(m));
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] = __builtin_amdgcn_fmed3f(a[r], m[r], 3.402823466e38f);
 }
@@ -260,11 +266,17 @@ __device__ __forceinline__ u2 pack4(const v4 &a) {
 // (v_pk_ashrrev_i16) with one v_bfi_b32 per pair: 2.5 VALU instructions per value including the conversion
 // (compare + select on the fp32 values: 3; mask arithmetic on the slope bits: 5.5).
 __device__ __forceinline__ u2 lrelu_bwd_pack4(const v4 &d, u2 y) {
+#ifdef BAMD_BF16_SCALAR_MUL
+    v4 m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[r] = d[r] * 0.01f; asm("" : "+v"(m[r])); }
+#else
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f k2 = (v2f){0.01f, 0.01f};
     asm("" : "+v"(k2));
     v4 m = d * (v4){k2[0], k2[1], k2[0], k2[1]};
     asm("" : "+v"(m));
+#endif
     const u2 p1 = pack4(d), p2 = pack4(m);
     unsigned sh = 0x000F000Fu;      // shift count per half (an inline constant would reach the low half only)
     u2 o;
@@ -288,7 +300,7 @@ template <int NT> struct ChainAcc {
 };
 
 #ifndef BAMD_BF16_BDEPTH
-#define BAMD_BF16_BDEPTH 2
+#define BAMD_BF16_BDEPTH 1
 #endif
 constexpr int kBD = BAMD_BF16_BDEPTH;      // k blocks the B operand reads run ahead of the MFMAs (LDS latency under load: 150-200 cycles)
 // B operands of one k block: [0..3] the four row tiles (N-split slots), [4] this wave's own row tile (M-split tiles)
@@ -422,7 +434,7 @@ __device__ __forceinline__ void acc_visit_pre(ChainAcc<NT> &acc, lds_p img, cons
 // An owned slot that does not exist on this wave (13 tiles over 4 waves) is computed on a clamped address and never flushed:
 // uniform code, and that wave would wait at the barrier anyway.
 #ifndef BAMD_BF16_DWDEPTH
-#define BAMD_BF16_DWDEPTH 3
+#define BAMD_BF16_DWDEPTH 2
 #endif
 constexpr int kDWD = BAMD_BF16_DWDEPTH;
 template <class N, int l> struct DwGeo {
@@ -618,6 +630,16 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     static_assert(kRD >= 2 && kRD <= 6, "ring depth");
     RawX<F> xraw;
     x_issue<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15), n, lane >> 4);
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    constexpr int HB = N::hand_tiles * 32;                   // hand-off bytes per row
+    static_assert(N::iblocks(2) * 64 >= HB, "hand-off row fits the image row");
+    const int hr = threadIdx.x >> 2, hp = threadIdx.x & 3;
+    u4v hand[PART == 1 ? 4 : 1];
+    if constexpr (PART == 1) {
+        const u4v *src = (const u4v *)((const unsigned char *)dz + ((int64_t)blockIdx.x * kRows + hr) * HB) + hp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hand[i] = src[(16 * (hp + 4 * i) < HB) ? 4 * i : 0];
+    }
 
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         // keep the weight loads and the LDS address arithmetic inside the loop (LICM would hoist hundreds of registers)
@@ -651,19 +673,15 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
         x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);       // next iteration's rows, a whole iteration ahead
         if constexpr (PART == 1) {
             // dZ_1 of these rows from the first launch (row-major, 224 B per row) -> region 2: thread (r, p) moves chunks
-            // p, p + 4, p + 8 (and p + 12 for p < 2) of row r to their swizzled places
-            constexpr int HB = N::hand_tiles * 32, S2 = N::istride(2);
-            static_assert(N::iblocks(2) * 64 >= HB, "hand-off row fits the image row");
-            const int r = threadIdx.x >> 2, pp = threadIdx.x & 3;
-            typedef unsigned u4v __attribute__((ext_vector_type(4)));
-            const u4v *src = (const u4v *)((const unsigned char *)dz + (grp * kRows + r) * HB) + pp;
-            const lds_p dst = img + N::zoff(1) + r * S2 + ((pp ^ ((r >> 1) & 3)) << 4);
-            u4v c[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c[i] = src[(16 * (pp + 4 * i) < HB) ? 4 * i : 0];
+            // p, p + 4, p + 8 (and p + 12 for p < 2) of row r to their swizzled places; requested a whole iteration ahead, like the rows
+            const lds_p dst = img + N::zoff(1) + hr * N::istride(2) + ((hp ^ ((hr >> 1) & 3)) << 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (16 * (pp + 4 * i) < HB) *(u4v __attribute__((address_space(3))) *)(dst + 64 * i) = c[i];
+                if (16 * (hp + 4 * i) < HB) *(u4v __attribute__((address_space(3))) *)(dst + 64 * i) = hand[i];
+            const int64_t gn = grp + gridDim.x < ngroups ? grp + gridDim.x : ngroups - 1;
+            const u4v *src = (const u4v *)((const unsigned char *)dz + (gn * kRows + hr) * HB) + hp;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hand[i] = src[(16 * (hp + 4 * i) < HB) ? 4 * i : 0];
         }
         __syncthreads();
         BT(1);
