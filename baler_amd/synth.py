@@ -96,3 +96,50 @@ def cfd_field(n_frames, h=50, w=50, seed=7):
 def wide_rows(n_rows, n_cols, row0=0, seed=512):
     """(n_rows, n_cols) uniform(0,1) float64 rows for the wide tabular config."""
     return uniform01(seed, row0, n_rows, n_cols)
+
+
+def cms_rows_torch(n_rows, row0=0, seed=CMS_SEED, device="cuda", chunk=2_000_000):
+    """The same counter-based generator evaluated on a torch device (int64 arithmetic wraps like uint64; logical
+    shifts by masking), chunk by chunk into one (n_rows, 24) float64 tensor: what bench.py uses for the 12.5 M-row
+    shard of BASELINE configs[2], which would take a minute of numpy per rank.  Same formula as cms_rows; the last
+    bits of exp / log may differ between libraries, so parity tests keep using cms_rows."""
+    import torch
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    def i64(v):
+        v &= 0xFFFFFFFFFFFFFFFF
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    out = torch.empty((n_rows, CMS_NCOLS), dtype=torch.float64, device=device)
+    cols = torch.arange(CMS_NCOLS, dtype=torch.int64, device=device)[None, :]
+    a = torch.tensor([-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                      1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00], dtype=torch.float64)
+    b = [-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01, -1.328068155288572e+01]
+    c = [-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00,
+         4.374664141464968e+00, 2.938163982698783e+00]
+    d = [7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00]
+    a = [float(v) for v in a]
+    is_int = torch.tensor([cc in CMS_INT_COLS for cc in range(CMS_NCOLS)], device=device)[None, :]
+    int_scale = torch.tensor([3.0 + cc % 5 for cc in range(CMS_NCOLS)], dtype=torch.float64, device=device)[None, :]
+    flt_scale = torch.tensor([10.0 ** ((cc % 4) - 1) for cc in range(CMS_NCOLS)], dtype=torch.float64, device=device)[None, :]
+    for lo in range(0, n_rows, chunk):
+        hi = min(n_rows, lo + chunk)
+        rows = torch.arange(row0 + lo, row0 + hi, dtype=torch.int64, device=device)[:, None]
+        z = (rows * CMS_NCOLS + cols) ^ i64(seed)
+        z = z + i64(0x9E3779B97F4A7C15)
+        z = (z ^ lsr(z, 30)) * i64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * i64(0x94D049BB133111EB)
+        z = z ^ lsr(z, 31)
+        u = (lsr(z, 11).to(torch.float64) + 0.5) * (1.0 / 9007199254740992.0)
+        ql = torch.sqrt(-2 * torch.log(u.clamp(max=0.5)))
+        lo_v = (((((c[0] * ql + c[1]) * ql + c[2]) * ql + c[3]) * ql + c[4]) * ql + c[5]) / ((((d[0] * ql + d[1]) * ql + d[2]) * ql + d[3]) * ql + 1)
+        qh = torch.sqrt(-2 * torch.log((1 - u).clamp(max=0.5)))
+        hi_v = -(((((c[0] * qh + c[1]) * qh + c[2]) * qh + c[3]) * qh + c[4]) * qh + c[5]) / ((((d[0] * qh + d[1]) * qh + d[2]) * qh + d[3]) * qh + 1)
+        q = u - 0.5
+        r = q * q
+        mid = (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q / (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1)
+        ppf = torch.where(u < 0.02425, lo_v, torch.where(u > 1 - 0.02425, hi_v, mid))
+        out[lo:hi] = torch.where(is_int, torch.floor(-torch.log(1.0 - u) * int_scale), torch.exp(ppf) * flt_scale)
+    return out

@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip encode/decode/small-batch/bf16/C4/C5 side measurements")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU baseline's epoch (bounded to ~20 s)")
+    ap.add_argument("--c3", action="store_true", help="also run the BASELINE configs[2] leg at --gpus 1 (one 12.5 M-row shard)")
+    ap.add_argument("--c3-rows", type=int, default=0, help="rows per GPU of the configs[2] leg (default 100 M / n_gpus, at most 25 M)")
     return ap.parse_args()
 
 
@@ -214,7 +216,12 @@ def main():
     from baler_amd import native, synth
     from baler_amd.modules import models
 
-    rank, world, local = bdist.init_from_env()
+    try:
+        rank, world, local = bdist.init_from_env()
+    except Exception as e:      # RCCL / rendezvous failure: say so and fail; never re-exec a process that may have touched the GPU
+        print(f"bench.py: torch.distributed initialisation failed on rank {os.environ.get('RANK', '?')}: {type(e).__name__}: {e}",
+              file=sys.stderr, flush=True)
+        sys.exit(3)
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE is {world} (launch with --nproc-per-node {a.gpus}, "
                          f"or run `python bench.py --gpus {a.gpus}` and let it start the ranks)")
@@ -255,6 +262,18 @@ def main():
         train_step()
     torch.cuda.synchronize()
     log("warm-up done")
+    replicas_identical = None
+    if world > 1:
+        # every rank must hold bit-identical parameters after the replicated Adam steps: MAX - MIN of two checksums
+        import torch.distributed as td
+        w = torch.arange(1, flat.numel() + 1, dtype=torch.float64, device=dev)
+        chk = torch.stack([flat.double().sum(), (flat.double() * w).sum()])
+        hi_, lo_ = chk.clone(), chk.clone()
+        td.all_reduce(hi_, op=td.ReduceOp.MAX)
+        td.all_reduce(lo_, op=td.ReduceOp.MIN)
+        replicas_identical = bool(torch.equal(hi_, lo_))
+        if not replicas_identical:
+            raise SystemExit(f"bench.py: parameter replicas diverged after {a.warmup} steps: checksum spread {(hi_ - lo_).tolist()}")
     dt = timed(lambda: train_step(True), a.steps, world, dev)
     rows_total = world * a.rows * a.steps
     value = rows_total / dt
@@ -277,8 +296,18 @@ def main():
         "train_rows_per_s": value, "last_batch_loss": final_loss,
         "rccl_ranks": bdist.rank_world()[1],
         "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
+        "replicas_identical": replicas_identical,
         "source_hash": source_hash(),
     }
+    if world > 1:
+        # the 247 KB [grads | loss] all-reduce alone (latency-bound on xGMI), 200 back-to-back calls
+        for _ in range(10):
+            bdist.allreduce_sum(grads)
+        t_ar = timed(lambda: bdist.allreduce_sum(grads), 200, world, dev)
+        out["allreduce_us"] = 1e6 * t_ar / 200
+        out["allreduce_bytes"] = grads.numel() * grads.element_size()
+        out["allreduce_frac_of_step"] = out["allreduce_us"] * 1e-3 / out["ms_per_step"]
+        log(f"all-reduce of {out['allreduce_bytes']} B: {out['allreduce_us']:.1f} us")
 
     achieved = FLOP_TRAIN_ROW * a.rows / (k_ms * 1e-3) / 1e12
     # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in separate
@@ -394,6 +423,28 @@ def main():
                                  "tflops": FLOP_TRAIN_ROW * world * bs * nb / tb_ / 1e12,
                                  "frac_of_mfma_peak": FLOP_TRAIN_ROW * bs * nb / tb_ / 1e12 / PEAK_TFLOPS[a.mode]}
         out["train_rows_per_s_by_batch"] = by_batch
+        if world > 1:
+            # the numbers above take bs rows PER GPU per step (dp_batch = "per_gpu": global batch = N x bs); the reference's
+            # config means the GLOBAL batch (dist.batch_policy's default): every rank computes bs / N rows of each step
+            out["train_rows_per_s_by_batch_policy"] = "per_gpu"
+            by_global = {}
+            for bs in (512, 4096, 32768):
+                per = bs // world
+                if per < 16 or per * world != bs:
+                    continue
+                nb = max(2, min(400, a.rows // per))
+
+                def gpass():
+                    for i in range(nb):
+                        state["t"] += 1
+                        h.fwd_bwd(x[i * per:(i + 1) * per], grads)
+                        bdist.allreduce_sum(grads)
+                        h.adam_step(flat, grads, m, v, state["t"], 1e-3, loss_accum=loss_acc)
+                gpass()
+                tg_ = timed(gpass, 1, world, dev)
+                by_global[str(bs)] = {"rows_per_s": bs * nb / tg_, "us_per_step": 1e6 * tg_ / nb, "rows_per_gpu_per_step": per,
+                                      "steps_timed": nb}
+            out["train_rows_per_s_by_global_batch"] = by_global
         if "512" in by_batch:
             out["train_bs512_rows_per_s"] = by_batch["512"]["rows_per_s"]
             out["train_bs512_us_per_step"] = by_batch["512"]["us_per_step"]
@@ -409,6 +460,10 @@ def main():
         if rank == 0 and world == 1 and a.mode == "fp32":
             out["other_configs"] = other_configs(dev)
 
+    if world > 1 or a.c3:
+        out["c3"] = c3_leg(a, h, flat, m, v, state, world, dev, rank, loss_acc)
+        out["c3_train_rows_per_s"] = out["c3"]["train_rows_per_s"]
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_rows)
 
@@ -418,6 +473,51 @@ def main():
         import torch.distributed as td
         td.barrier()
         td.destroy_process_group()
+
+
+def c3_leg(a, h, flat, m, v, state, world, dev, rank, loss_acc):
+    """BASELINE configs[2]: the 100 M-row table, data parallel: every rank holds 100 M / N rows resident (12.5 M at N = 8;
+    capped at 25 M rows = 4.8 GB so that N = 2 stays bounded -- `exact_config` says whether the cap applied), one optimizer
+    step per pass over the shards with the RCCL all-reduce between bamd_fwd_bwd and bamd_adam_step.  Rows come from the
+    same counter-based generator, evaluated on the device."""
+    from baler_amd import dist as bdist
+    from baler_amd import native, synth
+    want = 100_000_000 // world if world > 1 else 12_500_000
+    rows = a.c3_rows or min(want, 25_000_000)
+    raw = synth.cms_rows_torch(rows, row0=rank * rows, device=dev)
+    mm = native.col_minmax(raw)      # [min ; max] of this shard; the table's extrema by one MIN and one MAX all-reduce
+    bdist.allreduce_minmax(mm)
+    feats = torch.stack([mm[0], mm[1] - mm[0]])
+    x3 = native.normalize(raw, feats, torch.float64)
+    del raw
+    g3 = torch.zeros_like(flat)
+    ev = []
+
+    def step(record=False):
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        h.fwd_bwd(x3, g3)
+        if record:
+            e1.record()
+            ev.append((e0, e1))
+        if world > 1:
+            bdist.allreduce_sum(g3)
+        state["t"] += 1
+        h.adam_step(flat, g3, m, v, state["t"], 1e-3, loss_accum=loss_acc)
+    step()
+    k = 3
+    dt = timed(lambda: step(True), k, world, dev)
+    k_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    ach = FLOP_TRAIN_ROW * rows / (k_ms * 1e-3) / 1e12
+    res = {"rows_per_gpu": rows, "global_rows": rows * world, "exact_config": bool(world == 8 and rows == 12_500_000),
+           "steps": k, "ms_per_step": 1e3 * dt / k, "train_rows_per_s": world * rows * k / dt,
+           "last_batch_loss": float(g3[-1].item()),
+           "roofline": {"bound": "mfma", "kernel": "bamd_fwd_bwd", "launch_ms": k_ms, "achieved": ach, "peak": PEAK_TFLOPS[a.mode],
+                        "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[a.mode], "traffic": None}}
+    log(f"configs[2] leg: {rows} rows per GPU x {world}: {res['train_rows_per_s']:.4g} rows/s, {res['ms_per_step']:.2f} ms/step")
+    del x3, g3
+    return res
 
 
 def other_configs(dev):

@@ -188,12 +188,19 @@ def test_bench_spawns_two_ranks_one_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--rows", "65536", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+                        "--rows", "65536", "--c3-rows", "131072"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "gloo" and d["value"] > 0
+    # first multi-GPU contact: the all-reduce alone, bit-identical replicas, both batch policies, the configs[2] leg
+    assert d["replicas_identical"] is True and d["allreduce_us"] > 0 and d["allreduce_bytes"] == 4 * 61840
+    assert d["train_rows_per_s_by_batch_policy"] == "per_gpu" and "512" in d["train_rows_per_s_by_batch"]
+    assert d["train_rows_per_s_by_global_batch"]["512"]["rows_per_gpu_per_step"] == 256
+    c3 = d["c3"]
+    assert c3["rows_per_gpu"] == 131072 and c3["global_rows"] == 262144 and c3["train_rows_per_s"] > 0
+    assert 0 < c3["roofline"]["frac"] < 1 and d["c3_train_rows_per_s"] == c3["train_rows_per_s"]
 
 
 _SPLIT_WORKER = r'''
