@@ -149,12 +149,21 @@ constexpr int kRD = BAMD_BF16_RINGD;      // step buffers of the fragment ring (
 // loaded by all four).  NT = 13 -> 3 N-split + tile 12 M-split; 7 -> 2 N-split slots (wave 3's second is empty);
 // 4 -> 1; 2 and 1 -> M-split.
 template <int NT> struct Split {
+#ifndef BAMD_BF16_SPLIT_BALANCED
     static constexpr int R = NT % 4;
     static constexpr int NS = NT < 4 ? 0 : (R == 1 ? NT / 4 : cdiv(NT, 4));
     static constexpr int MS = NT < 4 ? NT : (R == 1 ? 1 : 0);
-    static constexpr int NF = NS + MS;                        // fragments per step and wave
-    static constexpr int m0 = NT < 4 ? 0 : 4 * NS;           // first M-split tile
     static constexpr bool ragged = NT >= 4 && R != 1 && R != 0;   // the last N-split slot does not exist on every wave
+#else
+    // (experiment, measured 14 % SLOWER: 0.889 vs 0.781 ms) NT / 4 N-split slots, the remaining NT % 4 tiles M-split: 7 tiles =
+    // 1 slot + 3 own-row tiles = 7 MFMAs per k block on EVERY wave instead of 8 / 8 / 8 / 4 -- but 16 instead of 7 fragment
+    // loads per k block and workgroup: the kernel is that sensitive to fragment traffic through the 64 B/clk L1 path
+    static constexpr int NS = NT / 4;
+    static constexpr int MS = NT % 4;
+    static constexpr bool ragged = false;
+#endif
+    static constexpr int NF = NS + MS;                        // fragments per step and wave
+    static constexpr int m0 = 4 * NS;                         // first M-split tile
     static_assert(NF <= 4, "ring step buffers hold 4 fragments");
 };
 
@@ -336,6 +345,18 @@ __device__ __forceinline__ void chain_step(ChainAcc<NT> &acc, bf8 (&b)[kBD + 1][
     for (int k = 0; k < SP::MS; ++k) acc.am[k] = mfma(ring.buf[(STEP0 + Q) % kRD][SP::NS + k], bq[4], Q == 0 ? zero : acc.am[k]);
     __builtin_amdgcn_sched_barrier(0);
 }
+#ifndef BAMD_BF16_MONLY_AHEAD
+#define BAMD_BF16_MONLY_AHEAD 1
+#endif
+template <class N, int PART, int STEP0, int KB, int NT, int Q>
+__device__ __forceinline__ void monly_step(ChainAcc<NT> &acc, const bf8 (&b)[KB], Ring &ring, const WStream &ws, int wave) {
+    using SP = Split<NT>;
+    issue<N, PART, STEP0 + Q + kRD - 1>(ring, ws, wave);
+    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < SP::MS; ++k) acc.am[k] = mfma(ring.buf[(STEP0 + Q) % kRD][k], b[Q], Q == 0 ? zero : acc.am[k]);
+    __builtin_amdgcn_sched_barrier(0);
+}
 template <class N, int PART, int STEP0, int KB, int NT, int SIN, int... Q>
 __device__ __forceinline__ void chain_mm_impl(ChainAcc<NT> &acc, lds_p in_row, Ring &ring, const WStream &ws, int wave,
                                               std::integer_sequence<int, Q...>) {
@@ -344,6 +365,15 @@ __device__ __forceinline__ void chain_mm_impl(ChainAcc<NT> &acc, lds_p in_row, R
 #ifdef BAMD_ABLATE_CHAIN
     return;
 #endif
+    if constexpr (SP::NS == 0 && BAMD_BF16_MONLY_AHEAD) {
+        // M-split only (layer 7: two tiles, 7 k blocks of 2 MFMAs): one k block ahead = 32 MFMA cycles, every step waited for
+        // its LDS round trip -- read all k blocks of this wave's row tile first (KB x 4 registers)
+        bf8 ball[KB];
+#pragma unroll
+        for (int q = 0; q < KB; ++q) ball[q] = lds_b128(in_row + 16 * wave * SIN + 64 * q);
+        (monly_step<N, PART, STEP0, KB, NT, Q>(acc, ball, ring, ws, wave), ...);
+        return;
+    }
     bf8 b[kBD + 1][5];
 #pragma unroll
     for (int q = 0; q < kBD && q < KB; ++q) chain_load_b<NT, SIN>(b[q], in_row, wave, q);
