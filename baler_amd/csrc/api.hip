@@ -1,5 +1,7 @@
 // C ABI entry points of libbaler_amd.so (see include/baler_amd.h).  gfx950 only.
+#include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "bamd_internal.hpp"
 #include "fused.hpp"
@@ -114,7 +116,23 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
         if (rc) { bamd_destroy(h); return rc; }
     }
     *out = h;
+    if (bamd_path_of(h) == BAMD_PATH_GENERIC) {
+        const char *q = getenv("BALER_AMD_QUIET");
+        if (!(q && q[0] == '1')) {
+            std::string d;
+            for (int l = 0; l <= n_layers; ++l) d += (l ? "-" : "") + std::to_string(dims[l]);
+            fprintf(stderr, "[baler_amd] model %s (%s) has no fused kernel instantiation: encode / decode / training run layer by layer "
+                            "(generic.hip, activations through HBM)\n", d.c_str(),
+                    mode == BAMD_MODE_F64 ? "fp64" : mode == BAMD_MODE_BF16 ? "bf16" : "fp32");
+        }
+    }
     return BAMD_OK;
+}
+
+int bamd_path_of(const bamd_handle *h) {
+    BAMD_REQUIRE(h, "null handle");
+    if (h->mode == BAMD_MODE_BF16 && h->bf16_state) return BAMD_PATH_BF16;
+    return h->fused_ok ? BAMD_PATH_FUSED : BAMD_PATH_GENERIC;
 }
 
 void bamd_destroy(bamd_handle *h) {

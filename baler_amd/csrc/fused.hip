@@ -3114,32 +3114,35 @@ template <int F, int Z> struct ImplWideBf16 {
     }
 };
 
-// Instantiated shapes: the CMS 24-column model at the usual compression ratios
-// (latent = ceil(24 / ratio): 1.6 -> 15, 2 -> 12, 3 -> 8, 4 -> 6).  Anything else runs on generic.hip.
+// Instantiated shapes.  The CMS 24-column model at the latent sizes its compression-ratio knob produces (latent = ceil(24 / ratio),
+// baler.py:117-123): 1.6 -> 15, 2 -> 12, 2.4 -> 10, 3 -> 8, 4 -> 6, 5 -> 5, 6 -> 4, 8 -> 3, 12 -> 2; the wide-layer models the
+// reference ships configs for: CFD_dense_AE(2500, 25) (CFD_project_animation), CFD_dense_AE(625, 7) (exafel1 / exafel2: 25 x 25
+// blocks at ratio 100, exafel1_config.py:14-15,33) and the 512-column encoder of BASELINE configs[4].  Anything else runs on
+// generic.hip, and bamd_create says so once (bamd_path_of() = BAMD_PATH_GENERIC).
+#define BAMD_AE24(Z_) if (Impl<24, Z_>::matches(h)) return Impl<24, Z_>::ops();
+#define BAMD_AE24_ALL BAMD_AE24(15) BAMD_AE24(12) BAMD_AE24(10) BAMD_AE24(8) BAMD_AE24(6) BAMD_AE24(5) BAMD_AE24(4) BAMD_AE24(3) BAMD_AE24(2)
 static const FusedOps *find_ops(const bamd_handle *h) {
     if (h->mode == BAMD_MODE_BF16) {
         if (ImplWide<2500, 25>::matches(h)) return ImplWideBf16<2500, 25>::ops();
+        if (ImplWide<625, 7>::matches(h)) return ImplWideBf16<625, 7>::ops();
         if (ImplWide<512, 6>::matches(h)) return ImplWideBf16<512, 6>::ops();
         // the 24-column model's bf16 kernels live in bf16.hip / bf16_train.hip; the fp32 kernels here serve its SMALL batches
         // (api.hip: the bf16 training kernels need ~3000 rows to beat the fp32 small-batch step)
-        if (Impl<24, 15>::matches(h)) return Impl<24, 15>::ops();
-        if (Impl<24, 12>::matches(h)) return Impl<24, 12>::ops();
-        if (Impl<24, 8>::matches(h)) return Impl<24, 8>::ops();
-        if (Impl<24, 6>::matches(h)) return Impl<24, 6>::ops();
+        BAMD_AE24(15) BAMD_AE24(12) BAMD_AE24(8) BAMD_AE24(6)
         return nullptr;
     }
     if (h->mode != BAMD_MODE_F32) return nullptr;
-    if (Impl<24, 15>::matches(h)) return Impl<24, 15>::ops();
-    if (Impl<24, 12>::matches(h)) return Impl<24, 12>::ops();
-    if (Impl<24, 8>::matches(h)) return Impl<24, 8>::ops();
-    if (Impl<24, 6>::matches(h)) return Impl<24, 6>::ops();
+    BAMD_AE24_ALL
     if (ImplWide<512, 6>::matches(h)) {   // BALER_AMD_WIDE512=0: the all-in-registers chain (A/B runs)
         const char *e = getenv("BALER_AMD_WIDE512");
         return (e && e[0] == '0') ? ImplInfer<512, 6>::ops() : ImplWide<512, 6>::ops();
     }
     if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();
+    if (ImplWide<625, 7>::matches(h)) return ImplWide<625, 7>::ops();
     return nullptr;
 }
+#undef BAMD_AE24
+#undef BAMD_AE24_ALL
 
 }  // namespace
 

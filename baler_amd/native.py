@@ -23,7 +23,7 @@ SYMBOLS = (
     "bamd_param_count", "bamd_mode_of", "bamd_load_params", "bamd_minmax", "bamd_normalize",
     "bamd_renormalize", "bamd_encode", "bamd_decode", "bamd_forward_loss", "bamd_fwd_bwd",
     "bamd_adam_step", "bamd_train_step", "bamd_emd_rows", "bamd_activation_means",
-    "bamd_error_deltas", "bamd_apply_deltas", "bamd_fwd_bwd_latent", "bamd_swd", "bamd_col_minmax",
+    "bamd_error_deltas", "bamd_apply_deltas", "bamd_fwd_bwd_latent", "bamd_swd", "bamd_col_minmax", "bamd_path_of",
 )
 
 
@@ -64,6 +64,7 @@ def lib():
     L.bamd_load_params.argtypes = [vp, vp, ci, vp]
     L.bamd_minmax.argtypes = [vp, ci, i64, ci, vp, vp]
     L.bamd_col_minmax.argtypes = [vp, ci, i64, ci, vp, vp]
+    L.bamd_path_of.argtypes = [vp]
     L.bamd_normalize.argtypes = [vp, ci, i64, ci, vp, vp, ci, vp]
     L.bamd_renormalize.argtypes = [vp, ci, i64, ci, vp, vp, vp, vp]
     L.bamd_encode.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp]
@@ -272,6 +273,11 @@ class Handle:
     @property
     def z_dim(self):
         return self.dims[(len(self.dims) - 1) // 2]
+
+    @property
+    def path(self):
+        """"fused" | "bf16" | "generic": which kernels serve this shape's throughput calls (bamd_path_of)."""
+        return {0: "generic", 1: "fused", 2: "bf16"}[int(lib().bamd_path_of(self._h))]
 
     def load_params(self, flat):
         flat = _dev_tensor(flat)

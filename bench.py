@@ -555,6 +555,20 @@ def other_configs(dev):
         "bf16_encode_rel_err_vs_fp32": float(torch.linalg.norm(zb.double() - zc.double()) / torch.linalg.norm(zc.double()))})
     hb.close()
     del xc
+    # exafel1 / exafel2: 25 x 25 blocks at compression ratio 100 -> CFD_dense_AE(625, 7) (exafel1_config.py:14-15,33)
+    n = 131072
+    xe = torch.rand((n, 625), dtype=torch.float32, device=dev)
+    me = models.CFD_dense_AE(625, 7, mode="fp32").to(dev)
+    he = me.handle()
+    ge = torch.zeros_like(me.flat)
+    ze = he.encode(xe)
+    ms_e, ms_d, ms_t = event_ms(lambda: he.encode(xe), 3), event_ms(lambda: he.decode(ze), 3), event_ms(lambda: he.fwd_bwd(xe, ge), 3)
+    res["exafel_625_7"] = {
+        "blocks": n, "path": he.path, "encode_rows_per_s": n / ms_e * 1e3, "encode_frac_of_mfma_peak": 300_700 * n / ms_e / 1e9 / PEAK_TFLOPS["fp32"],
+        "decode_rows_per_s": n / ms_d * 1e3, "decode_frac_of_mfma_peak": 300_700 * n / ms_d / 1e9 / PEAK_TFLOPS["fp32"],
+        "train_fwd_bwd_rows_per_s": n / ms_t * 1e3, "train_frac_of_mfma_peak": 1_554_200 * n / ms_t / 1e9 / PEAK_TFLOPS["fp32"]}
+    he.close()
+    del xe, ge, ze
     n = 262144
     xw = torch.as_tensor(synth.wide_rows(n, 512).astype(np.float32)).to(dev)
     mw = models.CFD_dense_AE(512, 6, mode="fp32").to(dev)

@@ -85,6 +85,20 @@ int bamd_device_count(void);
  * except the last encoder layer and the last decoder layer (models.py:141-152). */
 int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle **out);
 void bamd_destroy(bamd_handle *h);
+
+/* Which kernels serve this handle's throughput calls (bamd_encode / bamd_decode / bamd_fwd_bwd at large batches).  The fused
+ * register-chained / wide-layer kernels are template instantiations for the shapes the reference ships configs for: AE(24, z) for
+ * z in {15, 12, 10, 8, 6, 5, 4, 3, 2} (models.py:116-183 at the compression ratios of baler.py:117-123), CFD_dense_AE(2500, 25),
+ * CFD_dense_AE(625, 7) (exafel1_config.py:14-15,33: 25 x 25 blocks) and the 512-column model.  Any other shape -- and every
+ * F64 handle's inference and large-batch training -- runs on the layer-wise kernels (activations through HBM, 2-7x slower):
+ * bamd_create prints one line to stderr for such a handle unless BALER_AMD_QUIET=1.  There is no model object in the
+ * reference to query (models.py builds nn.Linear layers of any width); this call exists so that callers and tests can tell. */
+typedef enum bamd_path {
+    BAMD_PATH_GENERIC = 0,   /* generic.hip: LDS-tiled MFMA GEMM per layer */
+    BAMD_PATH_FUSED = 1,     /* fused.hip: register chain (24-column AE) or streamed wide layers + chain */
+    BAMD_PATH_BF16 = 2       /* bf16.hip / bf16_train.hip (24-column AE, BAMD_MODE_BF16); its small batches use the fused fp32 step */
+} bamd_path;
+int bamd_path_of(const bamd_handle *h);   /* a bamd_path, or BAMD_ERR_INVALID for a null handle */
 int64_t bamd_param_count(const bamd_handle *h);
 int bamd_mode_of(const bamd_handle *h);
 

@@ -369,6 +369,64 @@ def test_cfd_dense_wide_layer_kernels_vs_oracle(n):
     assert np.isclose(dec, want, rtol=1e-4, atol=1e-6).mean() > 0.999        # a truncation may flip where want sits on an integer
 
 
+@pytest.mark.parametrize("n", [1, 17, 100, 1037])
+def test_exafel_625_7_fused_vs_oracle(n):
+    """CFD_dense_AE(625, 7) -- the exafel1 / exafel2 configs' 25 x 25 blocks at compression ratio 100
+    (exafel1_config.py:14-15,33; data_processing.py:26-34) -- runs on the fused wide-layer kernels: encode, decode and
+    forward + loss + backward against the oracle at ragged block counts."""
+    dims = orc.ae_dims(625, 7)
+    flat = orc.formula_params(dims, 23)
+    h, p = make_handle(dims, flat, "fp32")
+    assert h.path == "fused"
+    x = synth.cfd_field(n + 2, 25, 25)[2:].reshape(n, 625) * 20.0
+    z_ref = orc.encode(dims, flat, x)
+    for xin in (dev(x, torch.float32), dev(x)):
+        assert rel(h.encode(xin, out_dtype=torch.float32).cpu().numpy(), z_ref) < TOL32
+    rec_ref = orc.decode(dims, flat, z_ref)
+    assert rel(h.decode(dev(z_ref, torch.float32)).cpu().numpy(), rec_ref) < TOL32
+    grads = torch.zeros_like(p)
+    h.fwd_bwd(dev(x, torch.float32), grads)
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    gh = grads.cpu().numpy().astype(np.float64)
+    assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
+    # the bf16 mode of the same shape (en1 / de4 on the bf16 MFMA): its own 2e-2 bar
+    hb, _ = make_handle(dims, flat, "bf16")
+    assert rel(hb.encode(dev(x, torch.float32), out_dtype=torch.float32).cpu().numpy(), z_ref) < 2e-2
+    assert rel(hb.decode(dev(z_ref, torch.float32)).cpu().numpy(), rec_ref) < 2e-2
+
+
+@pytest.mark.parametrize("z", [10, 5, 4, 3, 2])
+def test_ae24_other_latents_fused(z, monkeypatch):
+    """The 24-column AE at the latent sizes of the other compression ratios (baler.py:117-123: latent = ceil(24 / ratio)) is
+    served by the same fused kernels as latent 15: encode / decode, the small-batch step (512 rows), the throughput pair
+    (4099 rows on a handle whose small-batch limit is lowered: at the default limit of 12288 rows fp32 summation noise alone
+    reaches 1e-5), and bamd_train_step == bamd_fwd_bwd + bamd_adam_step bit for bit."""
+    dims = orc.ae_dims(24, z)
+    flat = orc.formula_params(dims, 100 + z)
+    h, p = make_handle(dims, flat, "fp32")
+    assert h.path == "fused"
+    x = orc.normalize(synth.cms_rows(4099, row0=11))
+    zr = orc.encode(dims, flat, x[:777])
+    assert rel(h.encode(dev(x[:777])).cpu().numpy(), zr) < TOL32
+    assert rel(h.decode(dev(zr)).cpu().numpy(), orc.decode(dims, flat, zr)) < TOL32
+    monkeypatch.setenv("BALER_AMD_LATENCY_ROWS", "1024")
+    hp, pp = make_handle(dims, flat, "fp32")
+    monkeypatch.delenv("BALER_AMD_LATENCY_ROWS")
+    for hh, n in ((h, 512), (hp, 4099)):
+        grads = torch.zeros_like(p)
+        hh.fwd_bwd(dev(x[:n]), grads)
+        lo, go = orc.fwd_bwd(dims, flat, x[:n])
+        gh = grads.cpu().numpy().astype(np.float64)
+        assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo, n
+    h2, p2 = make_handle(dims, flat, "fp32")
+    m1, v1, m2, v2 = (torch.zeros_like(p) for _ in range(4))
+    g2 = torch.zeros_like(p)
+    h.train_step(dev(x[:512]), p, m1, v1, 1, 1e-3)
+    h2.fwd_bwd(dev(x[:512]), g2)
+    h2.adam_step(p2, g2, m2, v2, 1, 1e-3)
+    assert torch.equal(p, p2)
+
+
 def test_wide_512_encoder_vs_oracle():
     dims = orc.ae_dims(512, 6)
     flat = orc.formula_params(dims, 41)
@@ -747,10 +805,11 @@ def test_train_step_empty_batch_and_generic_fallback():
     before = p.clone()
     h.train_step(torch.zeros((0, 24), dtype=torch.float64, device="cuda"), p, m, v, 1, 1e-3)
     assert torch.equal(p, before) and float(m.abs().max()) == 0.0       # zero gradient: Adam moves nothing
-    dims2 = orc.ae_dims(625, 7)
+    dims2 = orc.ae_dims(400, 9)                    # no fused instantiation: the layer-wise kernels
     f2 = orc.formula_params(dims2, 3)
-    x = synth.cfd_field(4).reshape(16, 625)
+    x = synth.cfd_field(4, 40, 40).reshape(16, 400)
     ha, pa = make_handle(dims2, f2, "fp32")
+    assert ha.path == "generic"
     hb, pb = make_handle(dims2, f2, "fp32")
     ma, va, mb_, vb = (torch.zeros_like(pa) for _ in range(4))
     g = torch.zeros_like(pa)

@@ -100,3 +100,24 @@ def test_round2_kernel_floors():
     t_bd = _ms(lambda: hb.decode(zb), 3)
     print(f"bf16 mode, 131072 frames: encode {t_be:.3f} ms, decode {t_bd:.3f} ms")
     assert t_be < 0.60 and t_bd < 1.0, "bf16 wide-layer encode / decode (profiles: 0.40 / 0.73 ms per 131072 frames; fp32 1.34 / 1.22)"
+
+
+def test_round3_kernel_floors():
+    """CFD_dense_AE(625, 7) (exafel1 / exafel2 blocks) on the fused wide-layer kernels: encode >= 55 % of the fp32 MFMA peak at
+    131072 blocks (300,700 FLOP per block; the layer-wise path it used to fall to reaches 33-47 %)."""
+    wd = orc.ae_dims(625, 7)
+    hw = native.Handle(wd, "fp32")
+    assert hw.path == "fused"
+    hw.load_params(torch.from_numpy(np.concatenate([orc.formula_params(wd, 1), [0.0]]).astype(np.float32)).cuda())
+    n = 131072
+    xw = torch.rand((n, 625), dtype=torch.float32, device="cuda")
+    zw = hw.encode(xw)
+    t_e = _ms(lambda: hw.encode(xw), 5)
+    t_d = _ms(lambda: hw.decode(zw), 5)
+    gw = torch.zeros(orc.nparams(wd) + 1, dtype=torch.float32, device="cuda")
+    t_t = _ms(lambda: hw.fwd_bwd(xw, gw), 3)
+    fe, ft = 300_700 * n / 1e9 / 157.3, 1_554_200 * n / 1e9 / 157.3
+    print(f"CFD_dense_AE(625,7), {n} blocks: encode {t_e:.3f} ms = {fe / t_e:.2f} of peak, decode {t_d:.3f} ms = {fe / t_d:.2f}, "
+          f"fwd_bwd {t_t:.3f} ms = {ft / t_t:.2f}")
+    assert fe / t_e > 0.55, "exafel blocks encode fell off the fused wide-layer kernels"
+    assert fe / t_d > 0.45 and ft / t_t > 0.40
