@@ -75,7 +75,17 @@ template <int F, int Z> struct Net {
     __host__ __device__ static constexpr int e_off() { return (bf_off(L) + 63) / 64 * 64; }
     __host__ __device__ static constexpr int ef_off(int l) { return e_off() + wf_off(l); }                       // l = 0..2
     __host__ __device__ static constexpr int eb_off(int l) { int s = e_off() + wf_off(kSplit - 1); for (int j = kSplit - 1; j > l; --j) s += wcount(j); return s; }  // l = kSplit-1..1
-    __host__ __device__ static constexpr int packed_f4() { return eb_off(0) + 16 * 64; }
+    // region L4 (the 4-row small-batch chain, lat4_chain_kernel): per chain GEMM and 64-feature output group, fragments of
+    // 64 output features x 4 contraction indices; then one bias fragment per forward layer and group (L4 below)
+    __host__ __device__ static constexpr int l4_off() { return eb_off(0) + 16 * 64; }
+    __host__ __device__ static constexpr int l4_gemm_k(int g) { return g < 8 ? dim(g) : dim(15 - g + 1); }     // contraction length
+    __host__ __device__ static constexpr int l4_gemm_n(int g) { return g < 8 ? dim(g + 1) : dim(15 - g); }     // outputs
+    __host__ __device__ static constexpr int l4_groups(int g) { return (l4_gemm_n(g) + 63) / 64; }
+    __host__ __device__ static constexpr int l4_ks(int g) { return (l4_gemm_k(g) + 3) / 4; }
+    // offsets in float4 units: GEMM g holds [k / 4][output feature] pieces of 4 contraction indices, features NOT padded
+    __host__ __device__ static constexpr int l4_frag_off(int g) { int s = 0; for (int j = 0; j < g; ++j) s += l4_gemm_n(j) * l4_ks(j); return s; }
+    __host__ __device__ static constexpr int l4_frags() { return F <= 32 ? l4_frag_off(15) : 0; }      // narrow-input models only
+    __host__ __device__ static constexpr int packed_f4() { return l4_off() + l4_frags() + 16 * 64; }
     // weight-gradient tiles of layer l: tiles(N) x tiles(K + 1) (the extra slot carries db)
     __host__ __device__ static constexpr int dw_tiles(int l) { return tiles(dim(l + 1)) * tiles(dim(l) + 1); }
     __host__ __device__ static constexpr int slab_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += dw_tiles(j); return s; }
@@ -2389,6 +2399,280 @@ __global__ void __launch_bounds__(64 * W) lat2_chain_kernel(const v4 *packed, co
     }
 }
 
+// ---- 4-row small-batch chain ---------------------------------------------------------------------------------------------
+// lat2_chain_kernel gives a 16-row block (the smallest 16x16x4 MFMA batch tile) to one CU: the reference's 512-row batch
+// occupies 32 of 256 CUs, and the 15 chain GEMMs of a block are strictly sequential: 634 MFMAs x 32 cycles per wave = 9.7 us
+// whatever the chip size.  v_mfma_f32_4x4x1_16B_f32 computes 16 independent 4 x 4 outer products per instruction at the same
+// 64 FLOP/clk (tools/probe/mfma4_probe.hip: lane 4 b + i holds A_b[i], lane 4 b + j holds B_b[j], lane 4 b + j register i
+// receives D_b[i][j]; 10 cycles per instruction on independent accumulators, 14 on one): with A = 64 output features (lane =
+// feature), B = the 4 batch rows replicated over the 16 blocks and one contraction index per instruction, a workgroup needs
+// only FOUR rows -- 128 CUs carry the 512-row batch and a workgroup's chain is a quarter of the MFMA work.
+//   * what bounds it is the WEIGHT STREAM, not the MFMAs: every workgroup reads all weights once, and one wave takes in at most
+//     ~18 B/clk of vector-memory loads (measured: 58 cycles per 1-KiB fragment and wave whatever the ring depth; the CU's L1
+//     path gives 64 B/clk).  So ALL FOUR waves stream in EVERY GEMM: the 64-feature output groups of a GEMM (200 outputs = 4,
+//     100 = 2, <= 64 = 1) times P = 4 / groups contiguous K ranges; P > 1 costs a reduction through LDS and a second barrier
+//     (the first version gave a group's whole K to one wave: its 1- and 2-group GEMMs ran at 18 / 36 B/clk, chain 11.7 us);
+//   * the fragments are stored [k / 4][feature] WITHOUT padding the features to 64: lanes beyond the last feature (and whole
+//     steps beyond a wave's K range) load through an out-of-range offset -- zeros, no traffic: 482 instead of 634 KB per workgroup;
+//   * activations live in LDS as [4 rows][features] float32 (X_l for the masks of the backward pass, dZ_l); the B operand of
+//     four consecutive contraction steps is ONE ds_read_b128 (all 16 blocks read the same row: a broadcast);
+//   * outputs go to the SAME global images as lat2_chain_kernel's ([16-row block][slot][16 rows]; this workgroup fills rows
+//     4 q .. 4 q + 3 of every slot), so lat2_dw_kernel (weight-gradient tiles + Adam) is unchanged.
+#ifndef BAMD_L4_RING
+#define BAMD_L4_RING 16
+#endif
+template <class N> struct L4 {
+    static constexpr int NG = 15, D = BAMD_L4_RING;                  // chain GEMMs; ring depth (fragments = 4 MFMAs each)
+    __host__ __device__ static constexpr int layer(int g) { return g < 8 ? g : 15 - g; }
+    __host__ __device__ static constexpr int groups(int g) { return N::l4_groups(g); }
+    __host__ __device__ static constexpr int parts(int g) { return 4 / groups(g); }
+    __host__ __device__ static constexpr int ks(int g) { return N::l4_ks(g); }
+    __host__ __device__ static constexpr int ksp(int g) { return (ks(g) + parts(g) - 1) / parts(g); }             // steps per wave
+    __host__ __device__ static constexpr int pos(int g) { int s = 0; for (int j = 0; j < g; ++j) s += ksp(j); return s; }
+    static constexpr int total = pos(NG);
+    __host__ __device__ static constexpr int gemm_at(int S) { int g = 0; for (int j = 0; j < NG; ++j) if (S >= pos(j)) g = j; return g; }
+    // LDS images, float offsets; row strides 64 x groups + 4 (the four rows of a B read then sit in four different bank groups)
+    __host__ __device__ static constexpr int xs(int l) { return (l == 0 ? 32 : 64 * groups(l - 1)) + 4; }          // X_l, l = 0..7
+    __host__ __device__ static constexpr int zs(int l) { return (l == 7 ? 64 : 64 * groups(14 - l)) + 4; }         // dZ_l, l = 0..7
+    __host__ __device__ static constexpr int xo(int l) { int s = 0; for (int j = 0; j < l; ++j) s += 4 * xs(j); return s; }
+    __host__ __device__ static constexpr int zo(int l) { int s = xo(8); for (int j = 0; j < l; ++j) s += 4 * zs(j); return s; }
+    static constexpr int ps = 132;                                   // partial sums: [part][row][<= 128 features + 4]
+    static constexpr int po = zo(8);
+    static constexpr int lds_floats = po + 4 * 4 * ps;
+    static_assert(groups(0) == 4 && groups(1) == 2 && groups(6) == 4 && groups(14) == 4, "K is split only for GEMMs of 1 or 2 groups");
+};
+__device__ __forceinline__ v4 mfma4(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+template <class N, int S>
+__device__ __forceinline__ void l4_issue(v4 (&ring)[L4<N>::D], const WStream &ws, const int (&voff)[15], const int (&k0)[15]) {
+    using T = L4<N>;
+    if constexpr (S < T::total) {
+        constexpr int g = T::gemm_at(S), i = S - T::pos(g);
+        const int k4 = k0[g] + i;                                                   // wave-uniform
+        const int vo = k4 < T::ks(g) ? voff[g] : 0x7F000000;                        // beyond this GEMM's K: a zero fragment
+        ring[S % T::D] = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, vo, (N::l4_frag_off(g) + k4 * N::l4_gemm_n(g)) * 16, 0));
+    }
+}
+template <class N, int... S>
+__device__ __forceinline__ void l4_prologue(v4 (&ring)[L4<N>::D], const WStream &ws, const int (&voff)[15], const int (&k0)[15], std::integer_sequence<int, S...>) {
+    (l4_issue<N, S>(ring, ws, voff, k0), ...);
+    __builtin_amdgcn_sched_barrier(0);
+}
+constexpr int kL4B = 4;        // B operand reads run this many steps (of 4 MFMAs) ahead
+template <class N, int g, int I>
+__device__ __forceinline__ void l4_step(v4 (&acc)[4], v4 (&xb)[kL4B + 1], const float *brow, v4 (&ring)[L4<N>::D], const WStream &ws,
+                                        const int (&voff)[15], const int (&k0)[15]) {
+    using T = L4<N>;
+    constexpr int S0 = T::pos(g), KSP = T::ksp(g);
+    if constexpr (I + kL4B < KSP) xb[(I + kL4B) % (kL4B + 1)] = *(const v4 *)(brow + 4 * (I + kL4B));
+    const v4 a = ring[(S0 + I) % T::D], b = xb[I % (kL4B + 1)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = mfma4(a[r], b[r], acc[r]);     // four accumulators: a dependent 4x4x1 costs 14 cycles, not 10
+    l4_issue<N, S0 + I + T::D>(ring, ws, voff, k0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class N, int g, int... I>
+__device__ __forceinline__ v4 l4_gemm(v4 init, const float *brow /* B row of this lane at this wave's first step */, v4 (&ring)[L4<N>::D],
+                                      const WStream &ws, const int (&voff)[15], const int (&k0)[15], std::integer_sequence<int, I...>) {
+    v4 acc[4] = {init, (v4){0.f, 0.f, 0.f, 0.f}, (v4){0.f, 0.f, 0.f, 0.f}, (v4){0.f, 0.f, 0.f, 0.f}};
+    v4 xb[kL4B + 1];
+#pragma unroll
+    for (int k = 0; k < kL4B && k < L4<N>::ksp(g); ++k) xb[k] = *(const v4 *)(brow + 4 * k);
+    (l4_step<N, g, I>(acc, xb, brow, ring, ws, voff, k0), ...);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+// image slot (x 64 bytes) of feature f of an image of width D, or out of range: full tiles 16 t + i; the partial last tile is
+// r-major (slot_feature): feature index i within the tile sits in slot 4 (i & 3) + (i >> 2)
+template <int D> __device__ __forceinline__ int l4_slot_bytes(int f) {
+    constexpr int T1 = tiles(D) - 1;
+    static_assert(D % 16 != 0, "the last image tile is a partial one (the ones slot lives there)");
+    const int t = f >> 4, i = f & 15;
+    const int s = t < T1 ? f : 16 * t + 4 * (i & 3) + (i >> 2);
+    return t <= T1 ? s * 64 : 0x7F000000;
+}
+// The 64 outputs of one group held in the accumulator layout (lane (b, j): features 64 grp + 4 b .. + 3 of row j) -> LDS image
+// (row stride `rs`) and global image of width D at slot offset `slot0` (ONES: the slot after the last feature holds 1.0: db).
+template <int D, bool ONES>
+__device__ __forceinline__ void l4_publish(v4 val, float *lds_img, int rs, __amdgpu_buffer_rsrc_t irs, int slot0, int rowbytes, int grp, int lane) {
+    const int b = lane >> 2, j = lane & 3, f0 = 64 * grp + 4 * b;
+    if (ONES) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) val[r] = f0 + r == D ? 1.0f : val[r];
+    }
+    *(v4 *)(lds_img + j * rs + f0) = val;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float vr = val[r];      // (bit_cast of the vector element itself stored element 0 four times: hipcc, ROCm 7.2)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vr), irs, l4_slot_bytes<D>(f0 + r) + rowbytes, slot0 * 64, 0);
+    }
+}
+
+template <int F, int Z>
+__global__ void __launch_bounds__(256) lat4_chain_kernel(const v4 *__restrict__ l4, const float *__restrict__ params, const void *__restrict__ xin,
+                                                         int in_f64, int64_t n, const double *__restrict__ feats, float *__restrict__ imgs,
+                                                         double *__restrict__ loss_part) {
+    using N = Net<F, Z>;
+    using T = L4<N>;
+    using LT = Lat<N>;
+    constexpr int kImgFloats = LT::z_off(N::L) * kImgStride;
+    // every feature slot a GEMM reads (4 x steps <= 64 x groups) is written by the producing epilogue: no zero fill needed
+    __shared__ __attribute__((aligned(16))) float lds[T::lds_floats];
+    __shared__ double loss_lds[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    LAT_T(46);
+    const int b = lane >> 2, j = lane & 3;
+    // the four workgroups of a 16-row block share its image lines (16 of the 64 bytes of every slot each): give them workgroup
+    // ids that are equal mod 8, i.e. (as workgroups are dealt to the XCDs round-robin) the same XCD and L2 -- placement only,
+    // nothing depends on it (with ids 4 blk + q the lines were merged in memory and lat2_dw_kernel took 9.2 instead of 7.8 us)
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    int blk = wg >> 2, quad = wg & 3;
+    if (nwg % 32 == 0) { blk = (wg >> 5) * 8 + (wg & 7); quad = (wg >> 3) & 3; }
+    const int64_t row = (int64_t)blk * 16 + 4 * quad + j;
+    const bool valid = row < n;
+    const int rowbytes = (4 * quad + j) * 4;
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void *)(imgs + (int64_t)blk * kImgFloats), 0, kImgFloats * 4, 0x00020000);
+    WStream ws = make_stream(l4, N::l4_frags() * 16, lane);
+    // this wave's group / K part per GEMM
+    int voff[15], k0[15], grp[15], part[15];
+#pragma unroll
+    for (int g = 0; g < 15; ++g) {
+        const int G = T::groups(g);
+        grp[g] = wave & (G - 1);
+        part[g] = wave / G;
+        k0[g] = part[g] * T::ksp(g);
+        const int f = 64 * grp[g] + lane;
+        voff[g] = f < N::l4_gemm_n(g) ? f * 16 : 0x7F000000;
+    }
+    v4 ring[T::D];
+    l4_prologue<N>(ring, ws, voff, k0, std::make_integer_sequence<int, T::D>{});
+    // biases: accumulator layout for the GEMMs without a K split (layers 0 and 6), per finalising thread for the others
+    v4 bias0, bias6;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = 64 * wave + 4 * b + r;
+        bias0[r] = f < N::dim(1) ? params[N::b_off(0) + f] : 0.f;
+        bias6[r] = f < N::dim(7) ? params[N::b_off(6) + f] : 0.f;
+    }
+    const int tf = threadIdx.x >> 2, tj = threadIdx.x & 3;         // finalising thread: feature tf (+ 64), row tj
+    float fb[8][2];
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fb[l][i] = (T::parts(l) > 1 && i < T::groups(l) && tf + 64 * i < N::dim(l + 1)) ? params[N::b_off(l) + tf + 64 * i] : 0.f;
+    double lacc = 0.0;
+    LAT_T(47);
+    if (wave == 0) {
+        // the 4 input rows: lane (b, j), b < F / 4, reads features 4 b .. 4 b + 3 of row j (rows beyond n: row 0, never used)
+        static_assert(F % 4 == 0 && F <= 32, "input rows as 4-feature pieces of one 32-slot row");
+        const int64_t base = (valid ? row : 0) * F + (4 * b < F ? 4 * b : 0);
+        double d[4];
+        if (in_f64) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = ((const double *)xin)[base + r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = (double)((const float *)xin)[base + r];
+        }
+        v4 x0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (feats) d[r] = (d[r] - feats[(4 * b < F ? 4 * b : 0) + r]) / feats[F + (4 * b < F ? 4 * b : 0) + r];
+            x0[r] = 4 * b < F ? (float)d[r] : 0.f;
+        }
+        if (4 * b < 32) l4_publish<F, true>(x0, lds + T::xo(0), T::xs(0), irs, LT::x_off(0), rowbytes, 0, lane);
+    }
+    __syncthreads();
+    LAT_T(48);
+    float *pbuf = lds + T::po;
+    // One chain GEMM.  FWD: layer l = g, input X_l, output X_{l+1} = act(W x + b).  !FWD: layer l = 15 - g, input dZ_l, output
+    // dZ_{l-1} = (W^T dZ_l) . lrelu'(X_l).  `fin(value, feature, i)` finalises one value of a K-split GEMM (thread (tf + 64 i, tj)).
+#define L4_GEMM(g, IN_OFF, IN_RS, DIRECT, FINAL)                                                                             \
+    {                                                                                                                        \
+        const float *brow = lds + (IN_OFF) + j * (IN_RS) + 4 * k0[g];                                                        \
+        v4 init = (v4){0.f, 0.f, 0.f, 0.f};                                                                                  \
+        if ((g) == 0) init = bias0;                                                                                          \
+        if ((g) == 6) init = bias6;                                                                                          \
+        v4 o = l4_gemm<N, g>(init, brow, ring, ws, voff, k0, std::make_integer_sequence<int, T::ksp(g)>{});                  \
+        if constexpr (T::parts(g) == 1) {                                                                                    \
+            DIRECT(o);                                                                                                       \
+        } else {                                                                                                             \
+            *(v4 *)(pbuf + (part[g] * 4 + j) * T::ps + 64 * grp[g] + 4 * b) = o;                                            \
+            __syncthreads();                                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < T::groups(g); ++i) {                                                       \
+                const int f = tf + 64 * i;                                                                                   \
+                float v = 0.f;                                                                                               \
+                _Pragma("unroll") for (int p = 0; p < T::parts(g); ++p) v += pbuf[(p * 4 + tj) * T::ps + f];                 \
+                FINAL(v, f, i);                                                                                              \
+            }                                                                                                                \
+        }                                                                                                                    \
+        __syncthreads();                                                                                                     \
+    }
+    const int trow = (4 * quad + tj) * 4;          // the finalising thread's row offset in an image slot
+    // store one finalised value: LDS image + global image (4 consecutive threads = the 4 rows of a feature = 16 contiguous bytes)
+    auto store1 = [&](auto dtag, bool ones, float v, int f, int ldso, int rs, int slot0) {
+        constexpr int D_ = decltype(dtag)::value;
+        if (ones && f == D_) v = 1.0f;
+        lds[ldso + tj * rs + f] = v;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), irs, l4_slot_bytes<D_>(f) + trow, slot0 * 64, 0);
+    };
+    // ---------------- forward ----------------
+#define L4_FWD(l)                                                                                                            \
+    {                                                                                                                        \
+        auto direct = [&](v4 o) {                                                                                            \
+            if (N::act(l)) { _Pragma("unroll") for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.01f * o[r]; }       \
+            l4_publish<N::dim((l) + 1), true>(o, lds + T::xo((l) + 1), T::xs((l) + 1), irs, LT::x_off((l) + 1), rowbytes, grp[l], lane); \
+        };                                                                                                                   \
+        auto fin = [&](float v, int f, int i) {                                                                              \
+            v += fb[l][i];                                                                                                   \
+            if (N::act(l)) v = v > 0.f ? v : 0.01f * v;                                                                      \
+            store1(std::integral_constant<int, N::dim((l) + 1)>{}, true, v, f, T::xo((l) + 1), T::xs((l) + 1), LT::x_off((l) + 1)); \
+        };                                                                                                                   \
+        L4_GEMM(l, T::xo(l), T::xs(l), direct, fin)                                                                          \
+        LAT_T(49 + (l));                                                                                                     \
+    }
+    L4_FWD(0) L4_FWD(1) L4_FWD(2) L4_FWD(3) L4_FWD(4) L4_FWD(5) L4_FWD(6)
+#undef L4_FWD
+    {   // layer 7 (one group, K split over the four waves) + loss + dL/drecon
+        auto direct = [&](v4) {};
+        auto fin = [&](float v, int f, int i) {
+            v += fb[7][i];
+            const float d = v - lds[T::xo(0) + tj * T::xs(0) + (f < 32 ? f : 0)];
+            const bool live = ((int64_t)blk * 16 + 4 * quad + tj < n) && f < F;
+            if (live) lacc += (double)d * (double)d;
+            v = live ? d * (2.0f / (float)F) : 0.f;
+            store1(std::integral_constant<int, F>{}, false, v, f, T::zo(7), T::zs(7), LT::z_off(7));
+        };
+        L4_GEMM(7, T::xo(7), T::xs(7), direct, fin)
+        LAT_T(56);
+    }
+    // ---------------- backward chain: GEMM 15 - l: dZ_{l-1} = (W_l^T dZ_l) . lrelu'(X_l) ----------------
+#define L4_BWD(l)                                                                                                            \
+    {                                                                                                                        \
+        auto direct = [&](v4 o) {                                                                                            \
+            if (N::act((l) - 1)) {                                                                                           \
+                const v4 y = *(const v4 *)(lds + T::xo(l) + j * T::xs(l) + 64 * grp[15 - (l)] + 4 * b);                      \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) o[r] = y[r] > 0.f ? o[r] : 0.01f * o[r];                       \
+            }                                                                                                                \
+            l4_publish<N::dim(l), false>(o, lds + T::zo((l) - 1), T::zs((l) - 1), irs, LT::z_off((l) - 1), rowbytes, grp[15 - (l)], lane); \
+        };                                                                                                                   \
+        auto fin = [&](float v, int f, int) {                                                                                \
+            if (N::act((l) - 1)) v = lds[T::xo(l) + tj * T::xs(l) + f] > 0.f ? v : 0.01f * v;                                \
+            store1(std::integral_constant<int, N::dim(l)>{}, false, v, f, T::zo((l) - 1), T::zs((l) - 1), LT::z_off((l) - 1)); \
+        };                                                                                                                   \
+        L4_GEMM(15 - (l), T::zo(l), T::zs(l), direct, fin)                                                                   \
+        LAT_T(64 - (l));                                                                                                     \
+    }
+    L4_BWD(7) L4_BWD(6) L4_BWD(5) L4_BWD(4) L4_BWD(3) L4_BWD(2) L4_BWD(1)
+#undef L4_BWD
+#undef L4_GEMM
+    // loss partial of these 4 rows: lanes of a wave, then waves 0..3 (fixed order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lacc += __shfl_down(lacc, off);
+    if (lane == 0) loss_lds[wave] = lacc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_part[4 * blk + quad] = ((loss_lds[0] + loss_lds[1]) + loss_lds[2]) + loss_lds[3];
+}
+
 struct AdamArgs {   // scalars of one Adam step (launch_adam's), and where the state lives
     float *params, *pcopy, *m, *v, *packed;
     const int *sc_off, *sc_idx;
@@ -2403,7 +2687,7 @@ struct AdamArgs {   // scalars of one Adam step (launch_adam's), and where the s
 // requested BEFORE the image loop, so the dependent global round trips overlap instead of queueing up.
 enum { DW_WRITE = 0, DW_ADAM = 1, DW_ACCUM = 2 };   // grads = g | Adam on g (+ grads = g) | grads += g
 template <class N, int MODE>
-__global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ imgs, int nblk, const double *__restrict__ loss_part,
+__global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ imgs, int nblk, const double *__restrict__ loss_part, int nloss,
                                                       const int *__restrict__ inv_map, float *__restrict__ grads, AdamArgs ad) {
     using LT = Lat<N>;
     constexpr int kImgFloats = LT::z_off(N::L) * kImgStride, T = N::slab_off(N::L), np = N::nparams();
@@ -2414,7 +2698,7 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
     if (tile == T) {   // loss: fixed-order sum of the per-block partials, / C
         if (threadIdx.x == 0) {
             double s = 0.0;
-            for (int k = 0; k < nblk; ++k) s += loss_part[k];
+            for (int k = 0; k < nloss; ++k) s += loss_part[k];
             const float gl = (float)(s * (1.0 / N::dim(0)));
             if (grads) grads[np] = MODE == DW_ACCUM ? grads[np] + gl : gl;
             if (MODE == DW_ADAM && ad.loss_accum) *ad.loss_accum += (double)gl;
@@ -2576,6 +2860,10 @@ struct FusedState {
     // <= this many rows: small-batch kernels (BALER_AMD_LATENCY_ROWS overrides).  Measured us/step small-batch vs
     // throughput pair: 1024 rows 27 / 74, 4096 44 / 88, 8192 76 / 101, 16384 133 / 131
     int64_t latency_max_rows = 12288;
+    // <= this many rows the chain runs on 4-row workgroups (lat4_chain_kernel: 128 instead of 32 CUs carry a 512-row batch);
+    // BALER_AMD_LAT4_ROWS overrides, 0 = off.  Measured us per bamd_train_step, 4-row / 16-row chain: 64 rows 15.8 / 20.9,
+    // 256 16.9 / 21.8, 512 21.3 / 23.3, 768 25.9 / 25.6, 1024 30.5 / 26.9 (every workgroup streams all weights: 4x the L2 traffic)
+    int64_t lat4_max_rows = 640;
     DevBuf wb_src[2], wb[2];           // wide models in the bf16 mode: index maps and bf16 fragments of W0 / W7
     int wb_count[2] = {0, 0};
     bool wb_stale = false;             // the bf16 fragments lag the parameters (re-rounded before the next encode / decode)
@@ -2642,6 +2930,22 @@ static int build_maps(bamd_handle *h, FusedState *st) {
         for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::ef_off(l) * 4 + i] = src[(size_t)N::wf_off(l) * 4 + i];
     for (int l = kSplit - 1; l >= 1; --l)
         for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::eb_off(l) * 4 + i] = src[(size_t)N::wb_off(l) * 4 + i];
+    if (TRAIN && N::l4_frags() > 0) {
+        // region L4: GEMM g, step k4, output feature o: component r = W[o][4 k4 + r] (forward: layer g) or its transpose
+        // W_l[4 k4 + r][o] (input-gradient product of layer l = 15 - g)
+        for (int g = 0; g < 15; ++g) {
+            const int l = g < 8 ? g : 15 - g, K = N::dim(l), NN = N::dim(l + 1);
+            const int NO = N::l4_gemm_n(g);
+            for (int k4 = 0; k4 < N::l4_ks(g); ++k4)
+                for (int o = 0; o < NO; ++o)
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 4 * k4 + r;
+                        const size_t at = ((size_t)N::l4_off() + N::l4_frag_off(g) + (size_t)k4 * NO + o) * 4 + r;
+                        if (g < 8) { if (c < K) src[at] = N::w_off(l) + o * K + c; }
+                        else if (c < NN) src[at] = N::w_off(l) + c * K + o;
+                    }
+        }
+    }
     if (TRAIN) {
         for (int v : smap)
             if (v < 0) { set_error("fused: incomplete slab map"); return BAMD_ERR_INVALID; }
@@ -2806,19 +3110,29 @@ template <int F, int Z> struct Impl {
         if (rc) return rc;
         rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk > 1024 ? nblk : 1024));
         if (rc) return rc;
-        // 4 waves per workgroup: a CU has four MFMA units, 8 waves (2 per SIMD) measured no faster (23.4 vs 23.3 us per step)
-        hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 4>), dim3(nblk), dim3(256), 0, s, (const v4 *)h->packed.p, x,
-                           x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
+        rc = h->lossp.ensure(sizeof(double) * (size_t)(4 * nblk > 1024 ? 4 * nblk : 1024));
+        if (rc) return rc;
+        int nloss = nblk;
+        if (n <= st->lat4_max_rows) {
+            // one workgroup per FOUR rows: a 512-row batch on 128 CUs (v_mfma_f32_4x4x1_16B_f32: 64 output features x 4 rows per
+            // instruction); same images, so the weight-gradient kernel below does not change
+            nloss = 4 * nblk;
+            hipLaunchKernelGGL((lat4_chain_kernel<F, Z>), dim3(4 * nblk), dim3(256), 0, s, (const v4 *)h->packed.p + N::l4_off(),
+                               (const float *)h->params.p, x, x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
+        } else
+            // 4 waves per workgroup: a CU has four MFMA units, 8 waves (2 per SIMD) measured no faster (23.4 vs 23.3 us per step)
+            hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 4>), dim3(nblk), dim3(256), 0, s, (const v4 *)h->packed.p, x,
+                               x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
         const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
         if (ad)
             hipLaunchKernelGGL((lat2_dw_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
-                               (const double *)h->lossp.p, (const int *)st->slab_map.p, (float *)grads, *ad);
+                               (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, *ad);
         else if (accumulate)
             hipLaunchKernelGGL((lat2_dw_kernel<N, DW_ACCUM>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
-                               (const double *)h->lossp.p, (const int *)st->slab_map.p, (float *)grads, AdamArgs{});
+                               (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, AdamArgs{});
         else
             hipLaunchKernelGGL((lat2_dw_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
-                               (const double *)h->lossp.p, (const int *)st->slab_map.p, (float *)grads, AdamArgs{});
+                               (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, AdamArgs{});
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
@@ -3146,6 +3460,13 @@ static const FusedOps *find_ops(const bamd_handle *h) {
 
 }  // namespace
 
+// debug aid (not part of the ABI header): copy the small-batch images of the last step to a device buffer
+extern "C" int bamd_debug_copy_imgs(bamd_handle *h, void *dst, size_t bytes) {
+    FusedState *st = (FusedState *)h->fused_state;
+    if (!st || !st->imgs.p) return -1;
+    return (int)hipMemcpy(dst, st->imgs.p, bytes, hipMemcpyDeviceToDevice);
+}
+
 int fused_setup(bamd_handle *h) {
     h->fused_ok = false;
     const FusedOps *ops = find_ops(h);
@@ -3155,6 +3476,7 @@ int fused_setup(bamd_handle *h) {
     FusedState *st = new FusedState();
     st->ops = ops;
     if (const char *lr = getenv("BALER_AMD_LATENCY_ROWS")) st->latency_max_rows = atoll(lr);
+    if (const char *l4 = getenv("BALER_AMD_LAT4_ROWS")) st->lat4_max_rows = atoll(l4);
     if (const char *ts = getenv("BALER_AMD_TAIL_SPLIT")) st->tail_split = ts[0] != '0';
     h->fused_state = st;
     int rc = ops->setup(h, st);

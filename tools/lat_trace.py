@@ -45,3 +45,12 @@ for blk, o in ((0, 32), (150, 40)):
     d = t[o:o + 5]
     print(f"dw block {blk}: start +{d[0] - t[16]} after the chain's last stamp; map/state issued {d[1] - d[0]}, images+mfma {d[2] - d[1]}, "
           f"scatter idx + barrier {d[3] - d[2]}, adam + stores {d[4] - d[3]}")
+
+# 4-row chain (lat4_chain_kernel, batches <= BALER_AMD_LAT4_ROWS): stamps 46..63 of workgroup 0, wave 0
+t4 = t[46:64]
+if t4[0] > 0:
+    names4 = ["zero LDS + bias -> LDS + ring", "ring prologue", "x rows -> X_0", "L0", "L1", "L2", "L3", "L4", "L5", "L6", "L7+loss",
+              "B7", "B6", "B5", "B4", "B3", "B2", "B1"]
+    print("lat4 chain total cycles", t4[17] - t4[0])
+    for i in range(1, 18):
+        print(f"  {names4[i]:16s} {t4[i] - t4[i - 1]:7d} cycles")
