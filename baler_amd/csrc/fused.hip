@@ -2696,10 +2696,19 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
     const int tile = (blockIdx.x & 7) * kPerXcd + (blockIdx.x >> 3);
     if (tile > T) return;
     if (tile == T) {   // loss: fixed-order sum of the per-block partials, / C
+        // 256 strided sums, then a fixed tree (ONE thread adding 32 .. 128 partials one dependent L2 round trip after the other
+        // was the longest workgroup of this kernel: 6.5 us of its 6.5-9 us)
+        double *lred = (double *)red;
+        double s = 0.0;
+        for (int k = threadIdx.x; k < nloss; k += 256) s += loss_part[k];
+        lred[threadIdx.x] = s;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) lred[threadIdx.x] += lred[threadIdx.x + st];
+            __syncthreads();
+        }
         if (threadIdx.x == 0) {
-            double s = 0.0;
-            for (int k = 0; k < nloss; ++k) s += loss_part[k];
-            const float gl = (float)(s * (1.0 / N::dim(0)));
+            const float gl = (float)(lred[0] * (1.0 / N::dim(0)));
             if (grads) grads[np] = MODE == DW_ACCUM ? grads[np] + gl : gl;
             if (MODE == DW_ADAM && ad.loss_accum) *ad.loss_accum += (double)gl;
         }
@@ -2861,9 +2870,10 @@ struct FusedState {
     // throughput pair: 1024 rows 27 / 74, 4096 44 / 88, 8192 76 / 101, 16384 133 / 131
     int64_t latency_max_rows = 12288;
     // <= this many rows the chain runs on 4-row workgroups (lat4_chain_kernel: 128 instead of 32 CUs carry a 512-row batch);
-    // BALER_AMD_LAT4_ROWS overrides, 0 = off.  Measured us per bamd_train_step, 4-row / 16-row chain: 64 rows 15.8 / 20.9,
-    // 256 16.9 / 21.8, 512 21.3 / 23.3, 768 25.9 / 25.6, 1024 30.5 / 26.9 (every workgroup streams all weights: 4x the L2 traffic)
-    int64_t lat4_max_rows = 640;
+    // BALER_AMD_LAT4_ROWS overrides, 0 = off.  Measured us per bamd_train_step, 4-row / 16-row chain: 64 rows 16.1 / 20.9,
+    // 256 16.6 / 21.9, 512 18.0 / 23.4, 1024 21.7 / 27.0, 2048 33.1 / 34.1, 4096 53.6 / 44.1 (every workgroup streams all
+    // weights: 4x the L2 traffic of the 16-row chain)
+    int64_t lat4_max_rows = 2048;
     DevBuf wb_src[2], wb[2];           // wide models in the bf16 mode: index maps and bf16 fragments of W0 / W7
     int wb_count[2] = {0, 0};
     bool wb_stale = false;             // the bf16 fragments lag the parameters (re-rounded before the next encode / decode)
