@@ -23,9 +23,17 @@ import numpy as np
 import torch
 
 CHUNK_BYTES = 64 << 20      # staging buffer size: 2.5 ms of PCIe Gen5 per chunk, launch overheads amortised
-COPY_THREADS = 4            # host threads that fill / drain a staging buffer (numpy releases the GIL inside large copies):
-                            # one thread moves ~15 GB/s from the page cache, PCIe Gen5 x16 takes 50+
+import os
+
+# host threads that fill / drain a staging buffer (numpy releases the GIL inside large copies).  Measured on the MI355X box
+# (2 x EPYC 9575F): the drain of a 64-MB staging buffer WHILE the DMA engine fills the other one moves 31 GB/s with 4 threads,
+# 42 with 8, 49 with 16 (alone: 78 GB/s with 4): the D2H pipeline was bound by these copies, not by PCIe (56 GB/s) and not by
+# page faults (tools/probe/d2h_pipe_probe.py)
+COPY_THREADS = max(4, min(16, (os.cpu_count() or 8) // 2))
 _POOL = None
+
+NP_OF_TORCH = {torch.float32: np.float32, torch.float64: np.float64, torch.float16: np.float16,
+               torch.uint8: np.uint8, torch.int32: np.int32, torch.int64: np.int64}
 
 
 def _pool():
@@ -46,6 +54,37 @@ def _parallel(fn, start, stop, min_rows=4096):
     futs = [_pool().submit(fn, a, min(a + step, stop)) for a in range(start, stop, step)]
     for f in futs:
         f.result()
+
+
+_FAULT_POOL = None
+PREFAULT_THREADS = 8
+
+
+def prefault(arr, span_bytes=32 << 20):
+    """Map the pages of a freshly allocated host array on background threads, AHEAD of the copies that fill it:
+    ctypes.memset per span (the call releases the GIL; a numpy strided store per page did not and serialised everything;
+    madvise(MADV_POPULATE_WRITE) maps 4-KiB pages at 27 GB/s and leaves the array 3x slower to write than pages that
+    came in through transparent huge pages -- memset: 113 GB/s on 8 threads, tools/probe/prefault_probe.py).
+    Measured on the MI355X box: download_rows into a fresh 1.2 GB array 15 GB/s (the drain copies page-fault it in
+    while the DMA engine competes for the memory system) against 49 GB/s into a mapped one.
+    Returns [(end_byte, future)] in address order for wait_prefault(); [] when the array is small."""
+    global _FAULT_POOL
+    nbytes = arr.nbytes
+    if nbytes < (64 << 20):
+        return []
+    import ctypes
+    base = arr.ctypes.data
+    if _FAULT_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _FAULT_POOL = ThreadPoolExecutor(max_workers=PREFAULT_THREADS)
+    return [(min(a + span_bytes, nbytes), _FAULT_POOL.submit(ctypes.memset, base + a, 0, min(span_bytes, nbytes - a)))
+            for a in range(0, nbytes, span_bytes)]
+
+
+def wait_prefault(futs, stop_byte):
+    """Block until the spans that cover bytes below ``stop_byte`` are mapped."""
+    while futs and futs[0][0] - (32 << 20) < stop_byte:
+        futs.pop(0)[1].result()
 
 
 def open_npz_array(path, key="data"):
@@ -230,9 +269,11 @@ def upload_rows(src, plan=None, device=None, chunk_bytes=None):
     return out
 
 
-def _drain(out, stage, pending):
+def _drain(out, stage, pending, faults=None):
     """Move a landed staging buffer into the result array (several host threads)."""
     b, s0, s1, ev = pending
+    if faults:
+        wait_prefault(faults, s1 * (out.nbytes // max(1, out.shape[0])))
     ev.synchronize()
     host = stage[b].numpy()
     _parallel(lambda a, e: np.copyto(out[a:e], host[a - s0:e - s0]), s0, s1)
@@ -245,10 +286,12 @@ def download_rows(dev, out=None, ready=None, block_rows=None, chunk_bytes=None):
     while block k is downloaded); without it the copy stream waits for the current stream once."""
     n = dev.shape[0]
     tail = tuple(dev.shape[1:])
-    np_dtype = {torch.float32: np.float32, torch.float64: np.float64, torch.float16: np.float16,
-                torch.uint8: np.uint8, torch.int32: np.int32, torch.int64: np.int64}[dev.dtype]
+    np_dtype = NP_OF_TORCH[dev.dtype]
+    faults = None
     if out is None:
         out = np.empty((n,) + tail, dtype=np_dtype)
+        if dev.is_cuda:
+            faults = prefault(out)      # pages mapped ahead of the drain copies, in the background
     if n == 0:
         return out
     if not dev.is_cuda:
@@ -274,8 +317,10 @@ def download_rows(dev, out=None, ready=None, block_rows=None, chunk_bytes=None):
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             if pending is not None:
-                _drain(out, stage, pending)
+                _drain(out, stage, pending, faults)
             pending = (k & 1, start, stop, ev)
-        _drain(out, stage, pending)
+        _drain(out, stage, pending, faults)
+        if faults:
+            wait_prefault(faults, out.nbytes + (64 << 20))
     dev.record_stream(copy_stream)
     return out

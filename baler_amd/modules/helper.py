@@ -403,7 +403,7 @@ def _gather_rows(local, n_total, world, ready=None):
         return hostio.download_rows(local, ready=ready)
     full = bdist.gather_rows(local, n_total, dst=0)
     if full is None:
-        return np.empty((0,) + tuple(local.shape[1:]), dtype=hostio.download_rows(local[:0]).dtype)
+        return np.empty((0,) + tuple(local.shape[1:]), dtype=hostio.NP_OF_TORCH[local.dtype])
     return hostio.download_rows(full)
 
 

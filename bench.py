@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip encode/decode/small-batch/bf16/C4/C5 side measurements")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU baseline's epoch (bounded to ~20 s)")
+    ap.add_argument("--pcie-rows", type=int, default=10_000_000, help="rows of the file of the PCIe-inclusive compress / decompress leg")
     ap.add_argument("--c3", action="store_true", help="also run the BASELINE configs[2] leg at --gpus 1 (one 12.5 M-row shard)")
     ap.add_argument("--c3-rows", type=int, default=0, help="rows per GPU of the configs[2] leg (default 100 M / n_gpus, at most 25 M)")
     return ap.parse_args()
@@ -459,6 +460,12 @@ def main():
             + (f", bf16 train {out['bf16_train_rows_per_s']:.4g} rows/s" if "bf16_train_rows_per_s" in out else ""))
         if rank == 0 and world == 1 and a.mode == "fp32":
             out["other_configs"] = other_configs(dev)
+            try:
+                out["pcie"] = pcie_leg(dev, h, a.pcie_rows)
+                out["pcie_compress_rows_per_s"] = out["pcie"]["compress_rows_per_s"]
+                out["pcie_decompress_rows_per_s"] = out["pcie"]["decompress_rows_per_s"]
+            except OSError as e:       # no scratch space for the file: say so, the line stays valid
+                out["pcie"] = {"error": str(e)}
 
     if world > 1 or a.c3:
         out["c3"] = c3_leg(a, h, flat, m, v, state, world, dev, rank, loss_acc)
@@ -518,6 +525,58 @@ def c3_leg(a, h, flat, m, v, state, world, dev, rank, loss_acc):
     log(f"configs[2] leg: {rows} rows per GPU x {world}: {res['train_rows_per_s']:.4g} rows/s, {res['ms_per_step']:.2f} ms/step")
     del x3, g3
     return res
+
+
+def pcie_leg(dev, h, n):
+    """PCIe-INCLUSIVE rates of the compress / decompress data path (never `value`: that is measured with the rows resident):
+    an n-row .npz on local disk (page cache warm) -> memory map -> pinned double-buffered H2D -> column min/max ->
+    bamd_encode per 4 M-row block with the download of block k overlapping the encode of block k + 1 -> host array; and the
+    reverse: latent rows up, bamd_decode (+ un-normalise), decoded table down.  Host clock, second pass (staging pinned)."""
+    import shutil
+    import tempfile
+    from baler_amd import hostio, native, synth
+    tmp = tempfile.mkdtemp(prefix="baler_pcie_")
+    try:
+        path = os.path.join(tmp, "data.npz")
+        raw = synth.cms_rows_torch(n, device=dev)
+        host = hostio.download_rows(raw)
+        del raw
+        np.savez(path, data=host, names=synth.CMS_NAMES)
+        del host
+        res = {}
+        B = 1 << 22
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            src = hostio.open_npz_array(path, "data")
+            x = hostio.upload_rows(src, None, dev)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            feats = native.minmax(x)
+            zdev = torch.empty((n, 15), dtype=torch.float64, device=dev)
+            ready = []
+            for s0 in range(0, n, B):
+                e0 = min(s0 + B, n)
+                h.encode(x[s0:e0], features=feats, out=zdev[s0:e0])
+                ev = torch.cuda.Event(); ev.record(); ready.append((e0, ev))
+            z = hostio.download_rows(zdev, ready=ready)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            del x, zdev
+            zd = hostio.upload_rows(z, None, dev)
+            dec = torch.empty((n, 24), dtype=torch.float64, device=dev)
+            ready = []
+            for s0 in range(0, n, B):
+                e0 = min(s0 + B, n)
+                h.decode(zd[s0:e0], features=feats, out=dec[s0:e0])
+                ev = torch.cuda.Event(); ev.record(); ready.append((e0, ev))
+            back = hostio.download_rows(dec, ready=ready)
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            res = {"rows": n, "file_gb": n * 192 / 1e9, "compress_rows_per_s": n / (t2 - t0), "decompress_rows_per_s": n / (t3 - t2),
+                   "h2d_gbs": n * 192 / 1e9 / (t1 - t0), "encode_plus_d2h_gbs_of_latents": n * 120 / 1e9 / (t2 - t1),
+                   "decompress_gbs_moved": n * (120 + 192) / 1e9 / (t3 - t2), "finite": bool(np.isfinite(back[:1000]).all())}
+            del zd, dec, z, back      # (unmapping a 1.9 GB host array takes ~50 ms: outside the timed regions)
+        log(f"PCIe-inclusive: compress {res['compress_rows_per_s']:.4g} rows/s, decompress {res['decompress_rows_per_s']:.4g} rows/s")
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def other_configs(dev):

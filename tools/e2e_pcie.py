@@ -67,8 +67,7 @@ for rep in range(2):   # second pass: page cache and pinned staging warm
     print(f"pass {rep}: upload {t1 - t0:.3f}s ({gb / (t1 - t0):.1f} GB/s)  minmax {1e3 * (t2 - t1):.1f} ms  encode+download {t3 - t2:.3f}s "
           f"({n * 120 / 1e9 / (t3 - t2):.1f} GB/s D2H)  | compress file->host {n / (t3 - t0) / 1e6:.1f} M rows/s PCIe-inclusive  "
           f"| decompress host->host {n / (t4 - t3) / 1e6:.1f} M rows/s PCIe-inclusive")
-    del x, out, zd, dec
-assert np.isfinite(z).all() and np.isfinite(back).all()
+    del x, out, zd, dec, z, back      # (freeing the host arrays -- ~50 ms per 1.2 GB -- stays outside the next pass's timed regions)
 # the reference's way for comparison: pageable .to(device) of the whole table, .cpu().numpy() of the result
 sync(); t0 = time.perf_counter()
 xt = torch.from_numpy(np.load(path)["data"]).to(dev)
