@@ -758,20 +758,26 @@ static int carve(bamd_handle *h, int64_t n, bool need_grad, Work<T> &wk) {
     chunk = chunk > (1 << 20) ? (1 << 20) : chunk;
     chunk &= ~(int64_t)63;
     if (chunk > n) chunk = n;
-    int rc = h->work.ensure((size_t)(per_row * chunk) * sizeof(T));
+    // every buffer starts on a 16-byte boundary (odd chunk x odd width would leave the next one 4-byte aligned: the kernels'
+    // 16-byte operand loads would then rely on the unaligned-access mode and split their transactions)
+    auto up4 = [](int64_t e) { return (e + 3) & ~(int64_t)3; };
+    int64_t total = 0;
+    for (int l = 0; l <= h->L; ++l) total += up4(chunk * h->dims[l]);
+    for (int l = 0; l < h->L && need_grad; ++l) total += up4(chunk * h->dims[l + 1]);
+    int rc = h->work.ensure((size_t)total * sizeof(T));
     if (rc) return rc;
     T *p = (T *)h->work.p;
     wk.chunk = chunk;
     wk.y.assign(h->L + 1, nullptr);
     for (int l = 0; l <= h->L; ++l) {
         wk.y[l] = p;
-        p += chunk * h->dims[l];
+        p += up4(chunk * h->dims[l]);
     }
     wk.x0 = wk.y[0];
     wk.dz.assign(h->L, nullptr);
     for (int l = 0; l < h->L && need_grad; ++l) {
         wk.dz[l] = p;
-        p += chunk * h->dims[l + 1];
+        p += up4(chunk * h->dims[l + 1]);
     }
     return BAMD_OK;
 }
@@ -917,6 +923,7 @@ static ShortPlan plan_short_dw(const bamd_handle *h, int64_t rows) {
         pl.nsplit[l] = (int)ns;
         pl.rps[l] = rps;
         pl.rp.off[l] = h->w_off[l];
+        base = (base + 3) & ~(int64_t)3;       // 16-byte aligned slabs: dw_wide_k stores float4 (its layers have N K + N = 0 mod 4)
         pl.rp.base[l] = base;
         pl.rp.nsplit[l] = (int)ns;
         base += ns * ((int64_t)N * K + N);

@@ -123,11 +123,14 @@ def gather_rows(local, n_total, dst=0):
     recv = recv.reshape((world * pad,) + tail)
     if n_total == world * pad:
         return recv
-    keep = []
+    # ragged total: shards 0..rem-1 have `pad` rows, the others pad - 1.  Compact IN PLACE (rank r's rows move left by r - rem
+    # rows, through a copy of one shard: source and destination overlap) instead of concatenating trimmed views, which held a
+    # second full copy of the table on rank 0's HBM
     for r in range(world):
         lo, hi = shard_rows(n_total, r, world)
-        keep.append(recv[r * pad:r * pad + (hi - lo)])
-    return torch.cat(keep)
+        if lo != r * pad:
+            recv[lo:hi].copy_(recv[r * pad:r * pad + (hi - lo)].clone())
+    return recv[:n_total]
 
 
 def shard_rows(n_rows, rank=None, world=None):

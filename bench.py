@@ -454,6 +454,35 @@ def main():
                 "launch_us": by_batch["512"]["us_per_step"] / 1.0, "unit": "TFLOP/s",
                 "achieved": by_batch["512"]["tflops"] / world, "peak": PEAK_TFLOPS[a.mode],
                 "frac": by_batch["512"]["frac_of_mfma_peak"]}
+        if world == 1 and a.mode == "fp32":
+            # ---- fp64 mode (the reference's own dtype, models.py:128-136): fused small-batch step, layer-wise inference / large batches ----
+            h64 = native.Handle(model.dims, "fp64")
+            f64 = flat.double().clone()
+            h64.load_params(f64)
+            m64, v64 = torch.zeros_like(f64), torch.zeros_like(f64)
+            g64 = torch.zeros_like(f64)
+            n64 = min(a.rows, 262144)
+            ms = event_ms(lambda: h64.encode(x[:n64]), 3)
+            extra_roof["encode_f64"] = {"bound": "mfma", "kernel": "bamd_encode, BAMD_MODE_F64 (layer-wise v_mfma_f64_16x16x4_f64 GEMMs)", "rows": n64,
+                                        "launch_ms": ms, "unit": "TFLOP/s", "achieved": FLOP_ENCODE_ROW * n64 / ms / 1e9, "peak": PEAK_TFLOPS["fp64"],
+                                        "frac": FLOP_ENCODE_ROW * n64 / ms / 1e9 / PEAK_TFLOPS["fp64"], "rows_per_s": n64 / ms * 1e3}
+            n64t = min(a.rows, 65536)
+            ms = event_ms(lambda: h64.fwd_bwd(x[:n64t], g64), 3)
+            extra_roof["train_f64"] = {"bound": "mfma", "kernel": "bamd_fwd_bwd, BAMD_MODE_F64, layer-wise (batches above 12288 rows)", "rows": n64t,
+                                       "launch_ms": ms, "unit": "TFLOP/s", "achieved": FLOP_TRAIN_ROW * n64t / ms / 1e9, "peak": PEAK_TFLOPS["fp64"],
+                                       "frac": FLOP_TRAIN_ROW * n64t / ms / 1e9 / PEAK_TFLOPS["fp64"], "rows_per_s": n64t / ms * 1e3}
+            t64 = {"t": 0}
+
+            def steps64():
+                for i in range(100):
+                    t64["t"] += 1
+                    h64.train_step(x[i * 512:(i + 1) * 512], f64, m64, v64, t64["t"], 1e-3)
+            steps64()
+            us = 1e6 * timed(steps64, 1, world, dev) / 100
+            extra_roof["train_bs512_f64"] = {"bound": "latency", "kernel": "bamd_train_step at 512 rows, BAMD_MODE_F64 (chain64_kernel + dw64_kernel<adam>)",
+                                             "launch_us": us, "unit": "TFLOP/s", "achieved": FLOP_TRAIN_ROW * 512 / us / 1e6, "peak": PEAK_TFLOPS["fp64"],
+                                             "frac": FLOP_TRAIN_ROW * 512 / us / 1e6 / PEAK_TFLOPS["fp64"], "rows_per_s": 512 / us * 1e6}
+            h64.close()
         out["roofline_extra"] = extra_roof
         log(f"encode {out['encode_rows_per_s']:.4g} rows/s, decode {out['decode_rows_per_s']:.4g} rows/s, "
             + ", ".join(f"bs{k} {v_['us_per_step']:.1f} us" for k, v_ in by_batch.items())

@@ -17,7 +17,9 @@
  *    workspace);
  *  - all work is enqueued asynchronously on the hipStream_t passed as `stream` (void*; NULL =
  *    the default stream); nothing synchronises the host;
- *  - one handle per (model, device); a handle is not thread-safe;
+ *  - one handle per (model, device); a handle is not thread-safe, and it is SINGLE-STREAM: the library re-packs its
+ *    weight fragments lazily, on the stream of the first call that needs them after an optimiser step, so calls on one
+ *    handle must be issued on one stream (or the caller orders its streams with events around every call);
  *  - parameter vectors are FLAT in Baler's state-dict order: for each layer l, W_l[out][in]
  *    row-major then b_l[out] (models.py:128-136; the key order of model.pt);
  *  - rows are independent: multi-GPU = one process and one handle per GPU, rows sharded by the
