@@ -1626,7 +1626,7 @@ __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, c
                                                              const float *__restrict__ y6, const float *__restrict__ y7,
                                                              float *__restrict__ dz0, float *__restrict__ dz1, float *__restrict__ dz2,
                                                              float *__restrict__ dz3, float *__restrict__ dz4, float *__restrict__ dz5,
-                                                             float *__restrict__ dz6) {
+                                                             float *__restrict__ dz6, const float *__restrict__ dz_latent) {
     using N = Net<F, Z>;
     using S = StreamWideMidBwd<N>;
     __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
@@ -1658,6 +1658,12 @@ __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, c
         { v4 a[4]; load_act<50>(a, y5, rrow, g); lrelu_bwd(d4, a); }
         store_rows<50>(d4, dz4, 0, row, valid, lane, nullptr, nullptr);
         bwd_layer<N, S, 4>(d4, d3, ring, ws);                      // the latent layer has no activation
+        if (dz_latent) {      // dL/dz of the caller's regulariser (bamd_fwd_bwd_latent: the sliced-Wasserstein term), added at the bottleneck
+            v4 e[tiles(Z)];
+            load_act<Z>(e, dz_latent, rrow, g);
+#pragma unroll
+            for (int t = 0; t < tiles(Z); ++t) d3[t] += e[t];
+        }
         store_rows<Z>(d3, dz3, 0, row, valid, lane, nullptr, nullptr);
         bwd_layer<N, S, 3>(d3, d2, ring, ws);
         { v4 a[4]; load_act<50>(a, y3, rrow, g); lrelu_bwd(d2, a); }
@@ -3002,7 +3008,7 @@ struct FusedOps {
     int (*train_step)(bamd_handle *, const void *, int, int64_t, const double *, void *, const AdamArgs &, hipStream_t);
     // wide models: the row-local parts of a layer-wise training pass (see wide_train_fwd_kernel / wide_train_bwd_kernel)
     int (*wide_fwd)(bamd_handle *, const float *, int64_t, float *const *, float *, double *, int *, hipStream_t);
-    int (*wide_bwd)(bamd_handle *, int64_t, float *const *, float *const *, hipStream_t);
+    int (*wide_bwd)(bamd_handle *, int64_t, float *const *, float *const *, const float *, hipStream_t);
     int (*pack_extra)(bamd_handle *, FusedState *, hipStream_t);    // further packed copies of the parameters (bf16 fragments)
 };
 
@@ -3309,10 +3315,10 @@ template <int F, int Z> struct ImplWide {
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
-    static int wide_bwd(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, hipStream_t s) {
+    static int wide_bwd(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, const float *dz_latent, hipStream_t s) {
         hipLaunchKernelGGL((wide_train_bwd_kernel<F, Z>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
                            (const float *)dz[7], rows, (const float *)y[1], (const float *)y[2], (const float *)y[3], (const float *)y[5],
-                           (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6]);
+                           (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz_latent);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
@@ -3548,9 +3554,9 @@ int fused_wide_train_forward(bamd_handle *h, const float *x, int64_t rows, float
     if (!fused_wide_train(h)) return BAMD_ERR_UNSUPPORTED;
     return state_of(h)->ops->wide_fwd(h, x, rows, y, dz_last, loss_part, nblk, s);
 }
-int fused_wide_train_backward(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, hipStream_t s) {
+int fused_wide_train_backward(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, const float *dz_latent, hipStream_t s) {
     if (!fused_wide_train(h)) return BAMD_ERR_UNSUPPORTED;
-    return state_of(h)->ops->wide_bwd(h, rows, y, dz, s);
+    return state_of(h)->ops->wide_bwd(h, rows, y, dz, dz_latent, s);
 }
 
 int fused_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,

@@ -994,7 +994,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
             if (rc) return rc;
         }
         // wide models in float32: the row-local work (forward, loss, input-gradient chain) as two fused launches (fused.hip)
-        const bool wide = sizeof(T) == 4 && !latent_grad && fused_wide_train(h);
+        const bool wide = sizeof(T) == 4 && fused_wide_train(h);
         int nblk = 0;
         if (wide) {
             rc = h->lossp.ensure(sizeof(double) * 4096);
@@ -1025,7 +1025,8 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
         hipLaunchKernelGGL(loss_final_k<T>, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk, 1.0 / c,
                            grads + np, chunk_i > 0 ? 1 : 0);
         if (wide) {
-            rc = fused_wide_train_backward(h, rows, (float *const *)wk.y.data(), (float *const *)wk.dz.data(), s);
+            rc = fused_wide_train_backward(h, rows, (float *const *)wk.y.data(), (float *const *)wk.dz.data(),
+                                           latent_grad ? (const float *)latent_grad + r0 * h->dims[h->L / 2] : nullptr, s);
             if (rc) return rc;
         }
         for (int l = h->L - 1; l >= 0; --l) {

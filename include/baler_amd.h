@@ -165,14 +165,16 @@ int bamd_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, con
  * handle's parameter type and is ADDED to the gradient that reaches the encoder output.  Replaces:
  * loss.backward() of training.py:73-92 when config.custom_loss_function == "loss_function_swae" (the
  * loss then has a term that depends on z = model.encode(x) only).  grads[param_count] still receives the
- * reconstruction loss sum((r-x)^2)/n_cols alone.  Runs on the layer-wise kernels. */
+ * reconstruction loss sum((r-x)^2)/n_cols alone.  Wide-layer models (CFD_dense_AE shapes with a fused path) run it on the fused
+ * row-local launches, the latent term added at the bottleneck of the input-gradient chain; other shapes on the layer-wise kernels. */
 int bamd_fwd_bwd_latent(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows,
                         const double *features, const void *latent_grad, void *grads, void *stream);
 /* Replaces: utils.compute_swd (utils.py:58-77) and its backward: for each of n_proj unit vectors
  * proj[s] (n_proj, z_dim) the projections of z and of prior (both (n_rows, z_dim)) are sorted across
  * the batch; *loss_out = reg_weight * mean_{s,k} (sort(z.P_s)_k - sort(prior.P_s)_k)^2 (float64), and
  * dz_out (n_rows, z_dim, `dtype`) = d loss / d z.  The random draws are the caller's (the reference
- * takes them from torch's global generator, utils.py:59,79-91).  2 <= n_rows <= 4096. */
+ * takes them from torch's global generator, utils.py:59,79-91).  2 <= n_rows <= 1048576 (up to 4096 rows one workgroup per
+ * projection sorts in LDS; larger batches, e.g. CFD_project_animation's 6000, take passes through global memory). */
 int bamd_swd(const void *z, const void *prior, const void *proj, int dtype, int64_t n_rows, int z_dim,
              int n_proj, double reg_weight, double *loss_out, void *dz_out, void *stream);
 /* Replaces: torch.optim.Adam.step + zero_grad (training.py:68,95,266) on the flat buffers, and

@@ -22,7 +22,9 @@ def _swd_ref(z, prior, proj, reg_weight):
 
 
 @pytest.mark.parametrize("n,d,s,dtype", [(64, 7, 2000, np.float32), (512, 15, 2000, np.float32), (37, 25, 100, np.float64),
-                                         (4096, 6, 16, np.float32), (2, 3, 5, np.float64)])
+                                         (4096, 6, 16, np.float32), (2, 3, 5, np.float64),
+                                         # above 4096 rows: passes through global memory (CFD_project_animation_config.py:19: batch_size = 6000)
+                                         (6000, 25, 12, np.float32), (4097, 7, 3, np.float64), (20000, 5, 4, np.float32)])
 def test_swd_kernel(n, d, s, dtype):
     rng = np.random.default_rng(n + d)
     z = rng.normal(size=(n, d)).astype(dtype) * 0.3 + 0.1
@@ -38,7 +40,7 @@ def test_swd_kernel(n, d, s, dtype):
     # across such swaps, so the norm-wise tolerance still holds
     assert np.linalg.norm(dz.cpu().numpy() - want_dz) <= 10 * tol * np.linalg.norm(want_dz)
     with pytest.raises(native.NativeError):
-        native.swd(torch.zeros(5000, 3).cuda(), torch.zeros(5000, 3).cuda(), torch.zeros(4, 3).cuda(), 1.0)
+        native.swd(torch.zeros(1, 3).cuda(), torch.zeros(1, 3).cuda(), torch.zeros(4, 3).cuda(), 1.0)
 
 
 def test_swae_step_golden(golden):
