@@ -2694,13 +2694,20 @@ struct AdamArgs {   // scalars of one Adam step (launch_adam's), and where the s
 enum { DW_WRITE = 0, DW_ADAM = 1, DW_ACCUM = 2 };   // grads = g | Adam on g (+ grads = g) | grads += g
 template <class N, int MODE>
 __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ imgs, int nblk, const double *__restrict__ loss_part, int nloss,
-                                                      const int *__restrict__ inv_map, float *__restrict__ grads, AdamArgs ad) {
+                                                      const int *__restrict__ inv_map, float *__restrict__ grads, AdamArgs ad,
+                                                      float *__restrict__ part, int nsplit, int phase) {
+    // phase 0: the whole job in one launch.  From 512 blocks (8192 rows) on a tile's blocks are cut into `nsplit` ranges
+    // (blockIdx.y): phase 1 leaves one partial tile per range in `part`, phase 2 (a second launch, one workgroup per tile again)
+    // adds them in range order and finishes (Adam / store / accumulate).  Measured us per step, split / one launch: 8192 rows
+    // 64.8 / 69.6, 12288 rows 90.5 / 99.8; at 4096 rows 43.8 / 44.2 and below that the second launch costs more than it saves:
+    // there the kernel is bound by the 153 MB the 298 tiles read from the images (each slice is shared by 7-13 tiles), not by latency.
     using LT = Lat<N>;
     constexpr int kImgFloats = LT::z_off(N::L) * kImgStride, T = N::slab_off(N::L), np = N::nparams();
     constexpr int kPerXcd = (T + 1 + 7) / 8;
     __shared__ __attribute__((aligned(16))) v4 red[4 * 64];
     const int tile = (blockIdx.x & 7) * kPerXcd + (blockIdx.x >> 3);
     if (tile > T) return;
+    if (tile == T && phase == 1) return;
     if (tile == T) {   // loss: fixed-order sum of the per-block partials, / C
         // 256 strided sums, then a fixed tree (ONE thread adding 32 .. 128 partials one dependent L2 round trip after the other
         // was the longest workgroup of this kernel: 6.5 us of its 6.5-9 us)
@@ -2743,12 +2750,15 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
     if (MODE == DW_ADAM && p >= 0) { pm = ad.m[p]; pv = ad.v[p]; pp = ad.params[p]; s0 = ad.sc_off[p]; s1 = ad.sc_off[p + 1]; }
     DW_T(1);
     v4 acc = (v4){0.f, 0.f, 0.f, 0.f};
-    for (int b0 = wave; b0 < nblk; b0 += 32) {   // 8 blocks per wave in flight
+    const int per = phase == 1 ? (nblk + nsplit - 1) / nsplit : nblk;
+    const int blo = phase == 1 ? (int)blockIdx.y * per : 0;
+    const int bhi = phase == 2 ? 0 : (blo + per < nblk ? blo + per : nblk);
+    for (int b0 = blo + wave; b0 < bhi; b0 += 32) {   // 8 blocks per wave in flight
         v4 a[8], x[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int b = b0 + 4 * u;
-            const bool ok = b < nblk;
+            const bool ok = b < bhi;
             a[u] = ok ? *(const v4 *)(pz + (int64_t)b * kImgFloats) : (v4){0.f, 0.f, 0.f, 0.f};
             x[u] = ok ? *(const v4 *)(px + (int64_t)b * kImgFloats) : (v4){0.f, 0.f, 0.f, 0.f};
         }
@@ -2768,7 +2778,12 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
     DW_T(3);
     const float *rf = (const float *)red;
     const int e = threadIdx.x;
-    const float gsum = ((rf[e] + rf[256 + e]) + rf[512 + e]) + rf[768 + e];
+    float gsum = ((rf[e] + rf[256 + e]) + rf[512 + e]) + rf[768 + e];
+    if (phase == 1) { part[((int64_t)tile * nsplit + blockIdx.y) * 256 + e] = gsum; return; }
+    if (phase == 2) {
+        gsum = 0.f;
+        for (int k = 0; k < nsplit; ++k) gsum += part[((int64_t)tile * nsplit + k) * 256 + e];
+    }
     if (p < 0) return;
     if (grads) grads[p] = MODE == DW_ACCUM ? grads[p] + gsum : gsum;
     if (MODE == DW_ADAM) {   // elementwise.hip adam_k, on the 256 parameters this tile owns
@@ -2884,6 +2899,7 @@ struct FusedState {
     int wb_count[2] = {0, 0};
     bool wb_stale = false;             // the bf16 fragments lag the parameters (re-rounded before the next encode / decode)
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
+    DevBuf dwpart;                     // partial weight-gradient tiles of the small-batch path when a tile's blocks are split over workgroups
     bool tail_split = true;            // short remainder of the persistent loop on the small-batch kernels (BALER_AMD_TAIL_SPLIT=0: off)
 };
 
@@ -3140,15 +3156,29 @@ template <int F, int Z> struct Impl {
             hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 4>), dim3(nblk), dim3(256), 0, s, (const v4 *)h->packed.p, x,
                                x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
         const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
-        if (ad)
-            hipLaunchKernelGGL((lat2_dw_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
-                               (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, *ad);
-        else if (accumulate)
-            hipLaunchKernelGGL((lat2_dw_kernel<N, DW_ACCUM>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
-                               (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, AdamArgs{});
-        else
-            hipLaunchKernelGGL((lat2_dw_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
-                               (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, AdamArgs{});
+        // tiles x block ranges from 8192 rows on (see lat2_dw_kernel); BALER_AMD_DW_SPLIT=0: always one launch
+        static const bool split_on = !(getenv("BALER_AMD_DW_SPLIT") && getenv("BALER_AMD_DW_SPLIT")[0] == '0');
+        const int nsplit = split_on && nblk >= 512 ? 4 : 1;
+        float *part = nullptr;
+        if (nsplit > 1) {
+            rc = st->dwpart.ensure((size_t)(N::slab_off(N::L) + 1) * nsplit * 256 * sizeof(float));
+            if (rc) return rc;
+            part = (float *)st->dwpart.p;
+        }
+        auto launch = [&](auto mode, const AdamArgs &aa) {
+            constexpr int M = decltype(mode)::value;
+            if (nsplit > 1) {
+                hipLaunchKernelGGL((lat2_dw_kernel<N, M>), dim3(grid.x, nsplit), dim3(256), 0, s, (const float *)st->imgs.p, nblk,
+                                   (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, aa, part, nsplit, 1);
+                hipLaunchKernelGGL((lat2_dw_kernel<N, M>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
+                                   (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, aa, part, nsplit, 2);
+            } else
+                hipLaunchKernelGGL((lat2_dw_kernel<N, M>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
+                                   (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, aa, part, 1, 0);
+        };
+        if (ad) launch(std::integral_constant<int, DW_ADAM>{}, *ad);
+        else if (accumulate) launch(std::integral_constant<int, DW_ACCUM>{}, AdamArgs{});
+        else launch(std::integral_constant<int, DW_WRITE>{}, AdamArgs{});
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
@@ -3508,6 +3538,7 @@ void fused_teardown(bamd_handle *h) {
     st->slab_map.release();
     st->dz.release();
     st->imgs.release();
+    st->dwpart.release();
     for (int k = 0; k < 2; ++k) { st->wb_src[k].release(); st->wb[k].release(); }
     st->sc_off.release();
     st->sc_idx.release();

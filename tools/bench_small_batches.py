@@ -15,7 +15,7 @@ h.load_params(p)
 m, v = torch.zeros_like(p), torch.zeros_like(p)
 x = torch.rand((1 << 20, 24), dtype=torch.float64, device="cuda")
 out = []
-for bs in (64, 128, 256, 512, 768, 1024, 1536, 2048, 4096):
+for bs in (64, 256, 512, 1024, 2048, 4096, 8192, 12288):
     nb = 400
     best = 1e9
     for rep in range(3):
