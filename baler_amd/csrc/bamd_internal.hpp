@@ -107,4 +107,21 @@ int generic_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const
 int generic_activation_means(bamd_handle *h, const void *x, int x_dtype, int64_t n,
                              const double *features, double *out, int max_nodes, hipStream_t s);
 
+
+// Sum of n doubles by ONE 256-thread workgroup in a fixed order (bitwise reproducible): 256 strided partial sums, then a fixed
+// tree through `sh` (256 doubles of LDS).  The result is valid in thread 0.  (A single thread adding the partials one after the
+// other -- what every loss reduction here did first -- is a chain of dependent L2 round trips: 6.5 us for 32 partials.)
+#if defined(__HIPCC__)
+__device__ __forceinline__ double block_sum_fixed(const double *__restrict__ part, int n, double *sh) {
+    double s = 0.0;
+    for (int k = threadIdx.x; k < n; k += 256) s += part[k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    return sh[0];
+}
+#endif
 }  // namespace bamd

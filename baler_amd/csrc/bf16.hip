@@ -461,12 +461,10 @@ __global__ void __launch_bounds__(256) pack_bias_k(const float *__restrict__ par
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) dst[i] = src[i] >= 0 ? params[src[i]] : 0.f;
 }
-__global__ void sum_loss_bf16_k(const double *__restrict__ part, int n, double scale, double *__restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += part[i];
-        *out = s * scale;
-    }
+__global__ void __launch_bounds__(256) sum_loss_bf16_k(const double *__restrict__ part, int n, double scale, double *__restrict__ out) {
+    __shared__ double sh[256];
+    const double s = block_sum_fixed(part, n, sh);
+    if (threadIdx.x == 0) *out = s * scale;
 }
 
 struct Bf16Ops;
@@ -634,7 +632,7 @@ int bf16_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, con
     const int grid = st->ops->run(h, st, true, st->zscratch.p, 0, n, nullptr, recon, recon_dtype == BAMD_F64, nullptr, x,
                                   x_dtype == BAMD_F64, features, (double *)h->lossp.p, s);
     if (grid < 0) return grid;
-    hipLaunchKernelGGL(sum_loss_bf16_k, dim3(1), dim3(64), 0, s, (const double *)h->lossp.p, grid, 1.0 / st->ops->n_features, loss_sum);
+    hipLaunchKernelGGL(sum_loss_bf16_k, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, grid, 1.0 / st->ops->n_features, loss_sum);
     BAMD_HIP(hipGetLastError());
     return BAMD_OK;
 }

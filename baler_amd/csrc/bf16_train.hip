@@ -915,12 +915,8 @@ __global__ void __launch_bounds__(256) reduce_tiles_k(const v4 *__restrict__ sla
     __shared__ v4 part[4][64];
     const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (tile == ntiles) {
-        if (threadIdx.x == 0) {
-            const double *lp = (const double *)(slabs + (int64_t)ntiles * nslab * 64);
-            double l = 0.0;
-            for (int k = 0; k < nslab; ++k) l += lp[k];
-            grads[np] = (float)(l * inv_c);
-        }
+        const double l = block_sum_fixed((const double *)(slabs + (int64_t)ntiles * nslab * 64), nslab, (double *)part);
+        if (threadIdx.x == 0) grads[np] = (float)(l * inv_c);
         return;
     }
     const int q = (nslab + 3) / 4, k0 = wave * q, k1 = k0 + q < nslab ? k0 + q : nslab;

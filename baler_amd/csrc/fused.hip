@@ -2815,12 +2815,8 @@ __global__ void __launch_bounds__(256) reduce_slabs_k(const v4 *__restrict__ sla
     __shared__ v4 part[4][64];
     const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (tile == ntiles) {
-        if (threadIdx.x == 0) {
-            const double *lp = (const double *)(slabs + (int64_t)ntiles * nslab * 64);
-            double l = 0.0;
-            for (int k = 0; k < nslab; ++k) l += lp[k];
-            grads[np] = (T)(l * inv_c);
-        }
+        const double l = block_sum_fixed((const double *)(slabs + (int64_t)ntiles * nslab * 64), nslab, (double *)part);
+        if (threadIdx.x == 0) grads[np] = (T)(l * inv_c);
         return;
     }
     const int q = (nslab + 3) / 4, k0 = wave * q, k1 = k0 + q < nslab ? k0 + q : nslab;
@@ -2855,12 +2851,10 @@ __global__ void __launch_bounds__(256) pack_k(const float *__restrict__ params, 
     }
 }
 
-__global__ void sum_loss_k(const double *__restrict__ part, int n, double scale, double *__restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += part[i];
-        *out = s * scale;
-    }
+__global__ void __launch_bounds__(256) sum_loss_k(const double *__restrict__ part, int n, double scale, double *__restrict__ out) {
+    __shared__ double sh[256];
+    const double s = block_sum_fixed(part, n, sh);
+    if (threadIdx.x == 0) *out = s * scale;
 }
 
 // the same for thousands of partials: 256 strided fixed-order sums, then a fixed tree
@@ -3092,7 +3086,7 @@ template <int F, int Z> struct Impl {
         hipLaunchKernelGGL((infer_kernel<F, Z, K_FORWARD>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x,
                            x_dtype == BAMD_F64, n, features, recon, recon_dtype == BAMD_F64, (const uint8_t *)nullptr,
                            (double *)h->lossp.p);
-        hipLaunchKernelGGL(sum_loss_k, dim3(1), dim3(64), 0, s, (const double *)h->lossp.p, grid, 1.0 / F, loss_sum);
+        hipLaunchKernelGGL(sum_loss_k, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, grid, 1.0 / F, loss_sum);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }

@@ -294,9 +294,8 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     const int tile = (blockIdx.x & 7) * kPerXcd + (blockIdx.x >> 3);       // XCD c takes a contiguous tile range (see fused.hip)
     if (tile > T) return;
     if (tile == T) {   // loss: fixed-order sum of the per-block partials, / C
+        const double s = block_sum_fixed(loss_part, nblk, (double *)red);
         if (threadIdx.x == 0) {
-            double s = 0.0;
-            for (int k = 0; k < nblk; ++k) s += loss_part[k];
             const double gl = s * (1.0 / N::dim(0));
             if (grads) grads[np] = gl;
             if (MODE == DW_ADAM && ad.loss_accum) *ad.loss_accum += gl;

@@ -174,12 +174,10 @@ __global__ void __launch_bounds__(256) swd_dz_k(const T *__restrict__ G, const T
     dz[(int64_t)row * d + k] = acc;
 }
 
-__global__ void swd_loss_k(const double *__restrict__ part, int ns, double scale, double *__restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < ns; ++i) s += part[i];
-        *out = s * scale;
-    }
+__global__ void __launch_bounds__(256) swd_loss_k(const double *__restrict__ part, int ns, double scale, double *__restrict__ out) {
+    __shared__ double sh[256];
+    const double s = block_sum_fixed(part, ns, sh);
+    if (threadIdx.x == 0) *out = s * scale;
 }
 
 template <typename T>
@@ -220,7 +218,7 @@ int swd_T(const void *z, const void *prior, const void *proj, int n, int d, int 
     }
     hipLaunchKernelGGL(swd_dz_k<T>, dim3((unsigned)(((int64_t)n * d + 255) / 256)), dim3(256), 0, s, (const T *)G,
                        (const T *)proj, n, d, ns, (T *)dz_out);
-    hipLaunchKernelGGL(swd_loss_k, dim3(1), dim3(64), 0, s, (const double *)part, ns, scale, loss_out);
+    hipLaunchKernelGGL(swd_loss_k, dim3(1), dim3(256), 0, s, (const double *)part, ns, scale, loss_out);
     BAMD_HIP(hipGetLastError());
     return BAMD_OK;
 }
