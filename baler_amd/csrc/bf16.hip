@@ -567,6 +567,12 @@ const Bf16Ops *find_bf16(const bamd_handle *h) {
     if (BImpl<24, 12>::matches(h)) return BImpl<24, 12>::ops();
     if (BImpl<24, 8>::matches(h)) return BImpl<24, 8>::ops();
     if (BImpl<24, 6>::matches(h)) return BImpl<24, 6>::ops();
+    // the other latent sizes of the compression-ratio knob (see fused.hip find_ops)
+    if (BImpl<24, 10>::matches(h)) return BImpl<24, 10>::ops();
+    if (BImpl<24, 5>::matches(h)) return BImpl<24, 5>::ops();
+    if (BImpl<24, 4>::matches(h)) return BImpl<24, 4>::ops();
+    if (BImpl<24, 3>::matches(h)) return BImpl<24, 3>::ops();
+    if (BImpl<24, 2>::matches(h)) return BImpl<24, 2>::ops();
     return nullptr;
 }
 

@@ -1072,6 +1072,11 @@ const TrainOps *find_train(const bamd_handle *h) {
     if (TImpl<24, 12>::matches(h)) return TImpl<24, 12>::ops();
     if (TImpl<24, 8>::matches(h)) return TImpl<24, 8>::ops();
     if (TImpl<24, 6>::matches(h)) return TImpl<24, 6>::ops();
+    if (TImpl<24, 10>::matches(h)) return TImpl<24, 10>::ops();
+    if (TImpl<24, 5>::matches(h)) return TImpl<24, 5>::ops();
+    if (TImpl<24, 4>::matches(h)) return TImpl<24, 4>::ops();
+    if (TImpl<24, 3>::matches(h)) return TImpl<24, 3>::ops();
+    if (TImpl<24, 2>::matches(h)) return TImpl<24, 2>::ops();
     return nullptr;
 }
 

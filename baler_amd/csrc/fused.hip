@@ -3482,7 +3482,7 @@ static const FusedOps *find_ops(const bamd_handle *h) {
         if (ImplWide<512, 6>::matches(h)) return ImplWideBf16<512, 6>::ops();
         // the 24-column model's bf16 kernels live in bf16.hip / bf16_train.hip; the fp32 kernels here serve its SMALL batches
         // (api.hip: the bf16 training kernels need ~3000 rows to beat the fp32 small-batch step)
-        BAMD_AE24(15) BAMD_AE24(12) BAMD_AE24(8) BAMD_AE24(6)
+        BAMD_AE24_ALL
         return nullptr;
     }
     if (h->mode != BAMD_MODE_F32) return nullptr;

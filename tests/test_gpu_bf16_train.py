@@ -173,3 +173,23 @@ def test_small_batches_of_a_bf16_handle_run_the_fp32_kernels(n, data, monkeypatc
     _, gs = orc.fwd_bwd(DIMS, new, x[:300])
     assert rel(g.cpu().numpy().astype(np.float64)[:-1], gs) < 1e-5
     assert rel(h.encode(big).cpu().numpy(), orc.encode(DIMS, new, x[:8000])) < 6e-3
+
+
+@pytest.mark.parametrize("z", [12, 10, 5, 2])
+def test_other_latents(z, data):
+    """The bf16 kernels (inference and training) at other latent sizes of the compression-ratio knob (latent = ceil(24 / ratio))."""
+    raw, x = data
+    dims = orc.ae_dims(24, z)
+    flat = orc.formula_params(dims, 40 + z)
+    h, p = handle(flat, dims=dims)
+    assert h.path == "bf16"
+    n = 4113
+    xd = torch.as_tensor(x[:n]).cuda()
+    zr = orc.encode(dims, flat, x[:n])
+    assert rel(h.encode(xd).cpu().numpy(), zr) < 2e-2
+    assert rel(h.decode(torch.as_tensor(zr).cuda()).cpu().numpy(), orc.decode(dims, flat, zr)) < 2e-2
+    g = torch.zeros_like(p)
+    h.fwd_bwd(xd, g)
+    loss_ref, g_ref = orc.fwd_bwd(dims, flat, x[:n])
+    gh = g.cpu().numpy().astype(np.float64)
+    assert abs(gh[-1] - loss_ref) < 2e-3 * loss_ref and rel(gh[:-1], g_ref) < 2e-2
