@@ -132,6 +132,7 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
 int bamd_path_of(const bamd_handle *h) {
     BAMD_REQUIRE(h, "null handle");
     if (h->mode == BAMD_MODE_BF16 && h->bf16_state) return BAMD_PATH_BF16;
+    if (h->mode == BAMD_MODE_F64) return h->fused64_state ? BAMD_PATH_FUSED : BAMD_PATH_GENERIC;
     return h->fused_ok ? BAMD_PATH_FUSED : BAMD_PATH_GENERIC;
 }
 
@@ -230,6 +231,10 @@ int bamd_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, cons
     if (int rc = bf16_sync(h, s)) return rc;
     if (h->mode == BAMD_MODE_BF16 && h->bf16_state) return bf16_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
     if (h->fused_ok) return fused_encode(h, x, x_dtype, n_rows, features, z, z_dtype, s);
+    if (h->mode == BAMD_MODE_F64) {
+        const int rc = fused64_infer(h, 0, x, x_dtype, n_rows, features, z, z_dtype, nullptr, nullptr, nullptr, s);
+        if (rc != BAMD_ERR_UNSUPPORTED) return rc;
+    }
     return generic_forward(h, x, x_dtype, n_rows, features, 0, h->L / 2, z, z_dtype, nullptr, nullptr, s);
 }
 
@@ -242,6 +247,10 @@ int bamd_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n_rows, cons
     if (int rc = bf16_sync(h, s)) return rc;
     if (h->mode == BAMD_MODE_BF16 && h->bf16_state) return bf16_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);
     if (h->fused_ok) return fused_decode(h, z, z_dtype, n_rows, features, int_mask, out, out_dtype, s);
+    if (h->mode == BAMD_MODE_F64 && (!features || out_dtype == BAMD_F64)) {      // (un-normalised output is float64, as renormalize_k's)
+        const int rc = fused64_infer(h, 1, z, z_dtype, n_rows, nullptr, out, out_dtype, features, int_mask, nullptr, s);
+        if (rc != BAMD_ERR_UNSUPPORTED) return rc;
+    }
     return generic_forward(h, z, z_dtype, n_rows, nullptr, h->L / 2, h->L, out, out_dtype, features, int_mask, s);
 }
 
@@ -253,6 +262,10 @@ int bamd_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows
     if (int rc = bf16_sync(h, s)) return rc;
     if (h->mode == BAMD_MODE_BF16 && h->bf16_state) return bf16_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
     if (h->fused_ok) return fused_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
+    if (h->mode == BAMD_MODE_F64) {
+        const int rc = fused64_infer(h, 2, x, x_dtype, n_rows, features, recon, recon_dtype, nullptr, nullptr, loss_sum, s);
+        if (rc != BAMD_ERR_UNSUPPORTED) return rc;
+    }
     return generic_forward_loss(h, x, x_dtype, n_rows, features, recon, recon_dtype, loss_sum, s);
 }
 

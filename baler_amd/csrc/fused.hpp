@@ -36,6 +36,9 @@ int fused64_pack(bamd_handle *h, hipStream_t s); // h->params (fp64) -> fragment
 void fused64_scatter(bamd_handle *h, const int **sc_off, const int **sc_idx, void **packed);   // for the fused Adam + pack kernel
 // fwd + loss + bwd (hp == nullptr) or the whole training step (hp != nullptr) of a small batch; BAMD_ERR_UNSUPPORTED when this
 // handle / batch size has no such path (the caller then runs the layer-wise kernels)
+// kind: 0 = encode, 1 = decode, 2 = forward + loss; BAMD_ERR_UNSUPPORTED when the shape has no fp64 fused kernels
+int fused64_infer(bamd_handle *h, int kind, const void *x, int x_dtype, int64_t n, const double *features, void *out, int out_dtype,
+                  const double *renorm, const uint8_t *int_mask, double *loss_sum, hipStream_t s);
 int fused64_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, void *params, void *m,
                  void *v, const bamd_adam *hp, double *loss_accum, hipStream_t s);
 }  // namespace bamd

@@ -8,7 +8,8 @@
 // so register r of an output tile on lane group g holds feature 16 t + 4 r + g, and -- because the B operand of MFMA
 // step r takes k = g from lane group g -- step r of the next layer consumes exactly features 16 q + 4 r .. + 3: the chain
 // closes with NATURAL feature order (slot s = feature s; no g-major / r-major distinction between full and partial tiles).
-// Batches above FusedState64::max_rows and the inference entry points stay on the layer-wise kernels (generic.hip).
+// Batches above FusedState64::max_rows stay on the layer-wise kernels (generic.hip); the inference entry points run on
+// infer64_kernel below (every wave its own 16 rows, register chain, no exchange).
 #include "fused.hpp"
 
 #include <cmath>
@@ -275,6 +276,175 @@ __global__ void __launch_bounds__(64 * W) chain64_kernel(const d4 *packed, const
     }
 }
 
+// ---- fp64 throughput inference: encode / decode / forward + loss at any row count ---------------------------------------------
+// The reference computes in fp64 (models.py:128-136); until round 3 bamd_encode / bamd_decode / bamd_forward_loss of an F64 handle
+// ran layer by layer (activations through HBM, LDS-tiled GEMMs).  Here every WAVE pushes its own 16 rows through the layers with
+// the activations in registers (the transposed register chain above with W = 1: a wave owns every tile of its rows, so there is no
+// exchange and no barrier), 4 waves per workgroup, persistent over row tiles.  A wave streams the half-model's fragments through
+// a ring that wraps across row tiles: 2 KiB per 4 MFMAs of 64 cycles = 8 B/clk per wave, far below the per-wave load rate.
+enum { I_ENCODE = 0, I_DECODE = 1, I_FORWARD = 2 };
+template <class N, int G0, int NGM, int D_> struct ISeq {      // GEMMs G0 .. G0 + NGM - 1 (forward fragments), one wave = all tiles
+    static constexpr int D = D_;
+    __host__ __device__ static constexpr int kd(int g) { return N::dim(G0 + g); }
+    __host__ __device__ static constexpr int nt(int g) { return tiles(N::dim(G0 + g + 1)); }
+    __host__ __device__ static constexpr int base(int g) { return N::wf_off(G0 + g) / 64; }
+    __host__ __device__ static constexpr int nf(int g) { return tiles(kd(g)) * nt(g); }
+    __host__ __device__ static constexpr int start(int g) { int s = 0; for (int j = 0; j < g; ++j) s += nf(j); return s; }
+    static constexpr int real = start(NGM);
+    static constexpr int total = (real + D - 1) / D * D;          // padded so that fragment S always lives in ring slot S % D
+    __host__ __device__ static constexpr int gemm_of(int S) { int g = 0; for (int j = 1; j < NGM; ++j) if (S >= start(j)) g = j; return g; }
+};
+template <class SQ, int S>
+__device__ __forceinline__ void iseq_issue(d4 (&slot)[SQ::D], const WStream &ws) {
+    constexpr int Sm = S % SQ::total;
+    if constexpr (Sm < SQ::real) {
+        constexpr int g = SQ::gemm_of(Sm), f = Sm - SQ::start(g), NT = SQ::nt(g);
+        slot[S % SQ::D] = frag_rt(ws, SQ::base(g) + (f / NT) * NT + f % NT);
+    }
+}
+template <class SQ, int... S>
+__device__ __forceinline__ void iseq_span(d4 (&slot)[SQ::D], const WStream &ws, std::integer_sequence<int, S...>, int) {
+    (iseq_issue<SQ, S>(slot, ws), ...);
+}
+template <class SQ, int S0, int... S>
+__device__ __forceinline__ void iseq_tail(d4 (&slot)[SQ::D], const WStream &ws, std::integer_sequence<int, S...>) {
+    (iseq_issue<SQ, S0 + S + SQ::D>(slot, ws), ...);
+}
+template <class SQ, int g, int f>
+__device__ __forceinline__ void iseq_one(const d4 (&in)[tiles(SQ::kd(g))], d4 (&out)[SQ::nt(g)], d4 (&slot)[SQ::D], const WStream &ws) {
+    constexpr int NT = SQ::nt(g), S0 = SQ::start(g), KD = SQ::kd(g), q = f / NT, i = f % NT, s = (S0 + f) % SQ::D;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (r < tile_steps(KD, q)) out[i] = mfma(slot[s][r], in[q][r], out[i]);
+    iseq_issue<SQ, S0 + f + SQ::D>(slot, ws);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class SQ, int g, int... P>
+__device__ __forceinline__ void iseq_mm_impl(const d4 (&in)[tiles(SQ::kd(g))], d4 (&out)[SQ::nt(g)], d4 (&slot)[SQ::D], const WStream &ws,
+                                             std::integer_sequence<int, P...>) {
+    (iseq_one<SQ, g, P>(in, out, slot, ws), ...);
+}
+// GEMM g: out (initialised with the bias) += W_l in, then the activation
+template <class N, class SQ, int g, int G0>
+__device__ __forceinline__ void ilayer(const d4 (&in)[tiles(SQ::kd(g))], d4 (&out)[SQ::nt(g)], d4 (&slot)[SQ::D], const WStream &ws,
+                                       const d4 *bias_lds, int lg) {
+#pragma unroll
+    for (int t = 0; t < SQ::nt(g); ++t) out[t] = bias_lds[(N::bf_off(G0 + g) - N::bf_off(0)) + t * 4 + lg];
+    iseq_mm_impl<SQ, g>(in, out, slot, ws, std::make_integer_sequence<int, SQ::nf(g)>{});
+    if (N::act(G0 + g)) lrelu(out);
+}
+// rows of width D_ -> register tiles in the f64 accumulator layout (register r of tile t on lane group g = feature 16 t + 4 r + g)
+template <int D_>
+__device__ __forceinline__ void load_rows64(d4 (&a)[tiles(D_)], const void *xin, int in_f64, int64_t row, bool valid, int lg,
+                                            const double *__restrict__ feats) {
+    const int64_t rbase = (valid ? row : 0) * D_;
+#pragma unroll
+    for (int t = 0; t < tiles(D_); ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = creg_feature(D_, t, lg, r);
+            const int fc = f >= 0 ? f : 0;                        // padding slots read feature 0 (finite, meets zero weights)
+            double v = in_f64 ? ((const double *)xin)[rbase + fc] : (double)((const float *)xin)[rbase + fc];
+            if (feats) v = (v - feats[fc]) / feats[D_ + fc];
+            a[t][r] = f >= 0 ? v : 0.0;
+        }
+}
+template <int D_>
+__device__ __forceinline__ void store_rows64(const d4 (&a)[tiles(D_)], void *out, int out_f64, int64_t row, bool valid, int lg,
+                                             const double *__restrict__ renorm, const uint8_t *__restrict__ imask) {
+    if (!valid) return;
+#pragma unroll
+    for (int t = 0; t < tiles(D_); ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = creg_feature(D_, t, lg, r);
+            if (f < 0) continue;
+            double v = a[t][r];
+            if (renorm) {      // norm * range + min with two roundings, then the int-column truncation (elementwise.hip renormalize_k)
+                v = __dadd_rn(__dmul_rn(v, renorm[D_ + f]), renorm[f]);
+                if (imask && imask[f]) v = trunc(v);
+            }
+            if (out_f64) ((double *)out)[row * D_ + f] = v;
+            else ((float *)out)[row * D_ + f] = (float)v;
+        }
+}
+template <int F, int Z, int KIND>
+__global__ void __launch_bounds__(256) infer64_kernel(const d4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
+                                                      const double *__restrict__ feats, void *__restrict__ out, int out_f64,
+                                                      const double *__restrict__ renorm, const uint8_t *__restrict__ imask,
+                                                      double *__restrict__ loss_part) {
+    using N = Net64<F, Z>;
+    constexpr int G0 = KIND == I_DECODE ? 4 : 0, NGM = KIND == I_FORWARD ? 8 : 4;
+    using SQ = ISeq<N, G0, NGM, 8>;
+    constexpr int kNB = N::bf_off(N::L) - N::bf_off(0);
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    d4 *bias_lds = (d4 *)lds_raw;
+    __shared__ double red[256];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lg = lane >> 4;
+    for (int i = threadIdx.x; i < kNB; i += 256) bias_lds[i] = packed[N::bf_off(0) + i];
+    WStream ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)packed, 0, N::packed_d4() * 32, 0x00020000);
+    ws.voff = lane * 32;
+    d4 ring[SQ::D];
+    iseq_span<SQ>(ring, ws, std::make_integer_sequence<int, SQ::D>{}, 0);
+    __syncthreads();
+    double lacc = 0.0;
+    const int64_t ntile = (n + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+        asm volatile("" : "+v"(ws.voff));      // keep the fragment loads inside the loop (LICM would hoist the whole model)
+        const int64_t row = tile * 16 + (lane & 15);
+        const bool valid = row < n;
+        if constexpr (KIND == I_DECODE) {
+            d4 a4[tiles(Z)], s5[4], s6[7], s7[13], o8[tiles(F)];
+            load_rows64<Z>(a4, xin, in_f64, row, valid, lg, feats);
+            ilayer<N, SQ, 0, G0>(a4, s5, ring, ws, bias_lds, lg);
+            ilayer<N, SQ, 1, G0>(s5, s6, ring, ws, bias_lds, lg);
+            ilayer<N, SQ, 2, G0>(s6, s7, ring, ws, bias_lds, lg);
+            ilayer<N, SQ, 3, G0>(s7, o8, ring, ws, bias_lds, lg);
+            store_rows64<F>(o8, out, out_f64, row, valid, lg, renorm, imask);
+        } else {
+            d4 a0[tiles(F)], s1[13], s2[7], s3[4], s4[tiles(Z)];
+            load_rows64<F>(a0, xin, in_f64, row, valid, lg, feats);
+            ilayer<N, SQ, 0, G0>(a0, s1, ring, ws, bias_lds, lg);
+            ilayer<N, SQ, 1, G0>(s1, s2, ring, ws, bias_lds, lg);
+            ilayer<N, SQ, 2, G0>(s2, s3, ring, ws, bias_lds, lg);
+            ilayer<N, SQ, 3, G0>(s3, s4, ring, ws, bias_lds, lg);
+            if constexpr (KIND == I_ENCODE) {
+                store_rows64<Z>(s4, out, out_f64, row, valid, lg, nullptr, nullptr);
+            } else {
+                d4 s5[4], s6[7], s7[13], o8[tiles(F)];
+                ilayer<N, SQ, 4, G0>(s4, s5, ring, ws, bias_lds, lg);
+                ilayer<N, SQ, 5, G0>(s5, s6, ring, ws, bias_lds, lg);
+                ilayer<N, SQ, 6, G0>(s6, s7, ring, ws, bias_lds, lg);
+                ilayer<N, SQ, 7, G0>(s7, o8, ring, ws, bias_lds, lg);
+#pragma unroll
+                for (int t = 0; t < tiles(F); ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double d = o8[t][r] - a0[t][r];
+                        if (valid && creg_feature(F, t, lg, r) >= 0) lacc += d * d;
+                    }
+                if (out) store_rows64<F>(o8, out, out_f64, row, valid, lg, nullptr, nullptr);
+            }
+        }
+        iseq_tail<SQ, SQ::real>(ring, ws, std::make_integer_sequence<int, SQ::total - SQ::real>{});      // step over the padding
+    }
+    if constexpr (KIND == I_FORWARD) {      // per-workgroup loss partial, fixed order
+        red[threadIdx.x] = lacc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) loss_part[blockIdx.x] = red[0];
+    }
+}
+__global__ void __launch_bounds__(256) sum_loss64_k(const double *__restrict__ part, int n, double scale, double *__restrict__ out) {
+    __shared__ double sh[256];
+    const double s = block_sum_fixed(part, n, sh);
+    if (threadIdx.x == 0) *out = s * scale;
+}
+
 struct Adam64 {
     double *params, *pcopy, *m, *v, *packed;
     const int *sc_off, *sc_idx;
@@ -371,6 +541,10 @@ struct State64 {
 struct Ops64 {
     int (*setup)(bamd_handle *, State64 *);
     int (*step)(bamd_handle *, State64 *, const void *, int, int64_t, const double *, double *, const Adam64 *, hipStream_t);
+    // kind (I_ENCODE / I_DECODE / I_FORWARD), input, its dtype, rows, features applied to the input, output (+ dtype),
+    // un-normalisation of the output, int-column mask, loss sum (I_FORWARD)
+    int (*infer)(bamd_handle *, State64 *, int, const void *, int, int64_t, const double *, void *, int, const double *, const uint8_t *,
+                 double *, hipStream_t);
 };
 State64 *st64(bamd_handle *h) { return (State64 *)h->fused64_state; }
 
@@ -471,8 +645,33 @@ template <int F, int Z> struct Impl64 {
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
+    static int infer(bamd_handle *h, State64 *st, int kind, const void *x, int x_dtype, int64_t n, const double *features, void *out,
+                     int out_dtype, const double *renorm, const uint8_t *imask, double *loss_sum, hipStream_t s) {
+        const int64_t ngroup = (n + 63) / 64;
+        static const int cap = getenv("BALER_AMD_F64_INFER_WGS") ? atoi(getenv("BALER_AMD_F64_INFER_WGS")) : 512;
+        const int grid = (int)(ngroup < cap ? ngroup : cap);          // <= 256 registers: two workgroups per CU (two waves per SIMD), persistent
+        constexpr int lds = (N::bf_off(N::L) - N::bf_off(0)) * 32;
+        const int in64 = x_dtype == BAMD_F64, out64 = out_dtype == BAMD_F64;
+        if (kind == I_FORWARD) {
+            int rc = h->lossp.ensure(sizeof(double) * 1024);
+            if (rc) return rc;
+        }
+        if (kind == I_ENCODE)
+            hipLaunchKernelGGL((infer64_kernel<F, Z, I_ENCODE>), dim3(grid), dim3(256), lds, s, (const d4 *)st->packed.p, x, in64, n, features,
+                               out, out64, renorm, imask, (double *)nullptr);
+        else if (kind == I_DECODE)
+            hipLaunchKernelGGL((infer64_kernel<F, Z, I_DECODE>), dim3(grid), dim3(256), lds, s, (const d4 *)st->packed.p, x, in64, n, features,
+                               out, out64, renorm, imask, (double *)nullptr);
+        else {
+            hipLaunchKernelGGL((infer64_kernel<F, Z, I_FORWARD>), dim3(grid), dim3(256), lds, s, (const d4 *)st->packed.p, x, in64, n, features,
+                               out, out64, renorm, imask, (double *)h->lossp.p);
+            hipLaunchKernelGGL(sum_loss64_k, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, grid, 1.0 / F, loss_sum);
+        }
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
     static const Ops64 *ops() {
-        static const Ops64 o = {setup, step};
+        static const Ops64 o = {setup, step, infer};
         return &o;
     }
 };
@@ -483,6 +682,11 @@ const Ops64 *find64(const bamd_handle *h) {
     if (Impl64<24, 12>::matches(h)) return Impl64<24, 12>::ops();
     if (Impl64<24, 8>::matches(h)) return Impl64<24, 8>::ops();
     if (Impl64<24, 6>::matches(h)) return Impl64<24, 6>::ops();
+    if (Impl64<24, 10>::matches(h)) return Impl64<24, 10>::ops();
+    if (Impl64<24, 5>::matches(h)) return Impl64<24, 5>::ops();
+    if (Impl64<24, 4>::matches(h)) return Impl64<24, 4>::ops();
+    if (Impl64<24, 3>::matches(h)) return Impl64<24, 3>::ops();
+    if (Impl64<24, 2>::matches(h)) return Impl64<24, 2>::ops();
     return nullptr;
 }
 
@@ -541,6 +745,17 @@ int fused64_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const do
     ad.step_size = hp->lr / (1.0 - pow(hp->beta1, (double)hp->step));
     ad.bc2_sqrt = sqrt(1.0 - pow(hp->beta2, (double)hp->step));
     return st->ops->step(h, st, x, x_dtype, n, features, (double *)grads, &ad, s);
+}
+
+
+// encode / decode / forward + loss of an F64 handle on the register-chained kernel (BAMD_ERR_UNSUPPORTED: no fp64 fused path for this
+// shape -> the caller falls back to the layer-wise kernels)
+int fused64_infer(bamd_handle *h, int kind, const void *x, int x_dtype, int64_t n, const double *features, void *out, int out_dtype,
+                  const double *renorm, const uint8_t *int_mask, double *loss_sum, hipStream_t s) {
+    State64 *st = st64(h);
+    static const bool on = !(getenv("BALER_AMD_F64_INFER") && getenv("BALER_AMD_F64_INFER")[0] == '0');
+    if (!st || !on || n <= 0) return BAMD_ERR_UNSUPPORTED;
+    return st->ops->infer(h, st, kind, x, x_dtype, n, features, out, out_dtype, renorm, int_mask, loss_sum, s);
 }
 
 }  // namespace bamd

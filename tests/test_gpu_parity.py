@@ -427,6 +427,38 @@ def test_ae24_other_latents_fused(z, monkeypatch):
     assert torch.equal(p, p2)
 
 
+@pytest.mark.parametrize("n", [1, 15, 64, 65, 1037, 70001])
+def test_fp64_register_chain_inference(n, monkeypatch):
+    """fp64 mode (the reference's own dtype, models.py:128-136): bamd_encode / bamd_decode / bamd_forward_loss of the 24-column
+    AE on the register-chained fp64 kernel (infer64_kernel, v_mfma_f64_16x16x4_f64) against the scalar oracle at 1e-11 and
+    against the layer-wise kernels (BALER_AMD_F64_INFER=0), ragged row counts, float32 / float64 rows, fused (un)normalisation."""
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 29)
+    raw = synth.cms_rows(n, row0=77)
+    full = synth.cms_rows(2048)
+    mn, rg = np.minimum(raw.min(0), full.min(0)), np.maximum(raw.max(0), full.max(0)) - np.minimum(raw.min(0), full.min(0))
+    xn = (raw - mn) / rg
+    feats = dev(np.stack([mn, rg]))
+    h, _ = make_handle(dims, flat, "fp64")
+    monkeypatch.setenv("BALER_AMD_F64_INFER", "0")
+    hl, _ = make_handle(dims, flat, "fp64")          # (the switch is read once per process: checked through the results below)
+    z_ref = orc.encode(dims, flat, xn)
+    assert rel(h.encode(dev(xn)).cpu().numpy(), z_ref) < TOL64
+    assert rel(h.encode(dev(raw), features=feats).cpu().numpy(), z_ref) < TOL64
+    assert rel(h.encode(dev(xn, torch.float32), out_dtype=torch.float64).cpu().numpy(), orc.encode(dims, flat, xn.astype(np.float32).astype(np.float64))) < TOL64
+    rec_ref = orc.decode(dims, flat, z_ref)
+    assert rel(h.decode(dev(z_ref)).cpu().numpy(), rec_ref) < TOL64
+    mask = np.array([1 if t == "int" else 0 for t in synth.CMS_TYPE_LIST], dtype=np.uint8)
+    dec = h.decode(dev(z_ref), features=feats, int_mask=torch.as_tensor(mask).cuda()).cpu().numpy()
+    want = rec_ref * rg + mn
+    want[:, mask == 1] = np.trunc(want[:, mask == 1])
+    assert np.isclose(dec, want, rtol=1e-10, atol=1e-12).mean() > 0.9999          # a truncation may flip where want sits on an integer
+    recon, loss = h.forward_loss(dev(xn))
+    assert rel(recon.cpu().numpy(), orc.decode(dims, flat, z_ref)) < TOL64
+    loss_ref = float(((orc.decode(dims, flat, z_ref) - xn) ** 2).sum() / 24)
+    assert abs(loss.item() - loss_ref) < 1e-11 * max(loss_ref, 1e-300)
+
+
 def test_wide_512_encoder_vs_oracle():
     dims = orc.ae_dims(512, 6)
     flat = orc.formula_params(dims, 41)
