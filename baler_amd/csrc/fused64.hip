@@ -536,7 +536,10 @@ struct State64 {
     const Ops64 *ops = nullptr;
     DevBuf pack_src, inv_map, sc_off, sc_idx, packed, imgs;
     int packed_doubles = 0;
-    int64_t max_rows = 12288;   // larger batches: layer-wise kernels (BALER_AMD_LATENCY_ROWS overrides, as for fp32)
+    // larger batches: layer-wise kernels (BALER_AMD_LATENCY_ROWS overrides, as for fp32).  The fused pair stays ahead of them at every
+    // size measured (us per step, fused / layer-wise: 16384 rows 347 / 847, 65536 rows 1324 / 2666); the limit is the images' memory
+    // (13 KB per row: 3.5 GB at 262144 rows)
+    int64_t max_rows = 262144;
 };
 struct Ops64 {
     int (*setup)(bamd_handle *, State64 *);

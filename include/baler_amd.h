@@ -92,7 +92,7 @@ void bamd_destroy(bamd_handle *h);
  * register-chained / wide-layer kernels are template instantiations for the shapes the reference ships configs for: AE(24, z) for
  * z in {15, 12, 10, 8, 6, 5, 4, 3, 2} (models.py:116-183 at the compression ratios of baler.py:117-123), CFD_dense_AE(2500, 25),
  * CFD_dense_AE(625, 7) (exafel1_config.py:14-15,33: 25 x 25 blocks) and the 512-column model; an F64 handle of the 24-column AE
- * has fused fp64 kernels for inference and for training steps of up to 12288 rows (larger fp64 batches run layer by layer).
+ * has fused fp64 kernels for inference and for training steps of up to 262144 rows (larger fp64 batches run layer by layer).
  * Any other shape runs on the layer-wise kernels (activations through HBM, 2-7x slower):
  * bamd_create prints one line to stderr for such a handle unless BALER_AMD_QUIET=1.  There is no model object in the
  * reference to query (models.py builds nn.Linear layers of any width); this call exists so that callers and tests can tell. */
