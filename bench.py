@@ -378,7 +378,7 @@ def main():
                 bf16_step()
             t_bt = timed(bf16_step, max(5, a.steps // 2), world, dev)
             out["bf16_train_rows_per_s"] = world * a.rows * max(5, a.steps // 2) / t_bt
-            ms = event_ms(lambda: hb.fwd_bwd(x, gb), 5)
+            ms = event_ms(lambda: hb.fwd_bwd(x, gb), 20)
             extra_roof["train_bf16"] = {
                 "bound": "mfma", "kernel": "bamd_fwd_bwd, BAMD_MODE_BF16 = bf16_train_kernel<PART 0> + <PART 1> + reduce_tiles_k",
                 "launch_ms": ms, "unit": "TFLOP/s", "achieved": FLOP_TRAIN_ROW * a.rows / ms / 1e9, "peak": PEAK_TFLOPS["bf16"],
