@@ -453,6 +453,53 @@ __device__ __forceinline__ void acc_visit_pre(ChainAcc<NT> &acc, lds_p img, cons
     }
 }
 
+// The backward epilogue again, cut into per-tile UNITS (unit U < 4 NS: N-split slot U / 4, row tile U % 4; then the M-split tiles)
+// that dw_phase spreads between the MFMAs of the layer's weight-gradient tiles: those MFMAs read dZ_l and X_l, the epilogue
+// writes dZ_{l-1} into a third region, so the two are independent -- and run one after the other the epilogue's ~94 cycles per
+// tile (LDS round trips more than its 10 VALU instructions) and the MFMAs' 16 each simply added up.  A slot the wave does not
+// own (ragged split) runs on whatever its registers hold and stores into a per-wave scratch row: uniform code, no branch.
+// MEASURED AND REJECTED (default off): epilogue + weight-gradient tiles take exactly as long dealt together as one after the
+// other (bwd 6: 1,884 vs 744 + 1,228 cycles; bwd 1: 2,496 vs 2,496) and the kernel pair gets 6.6 % slower (0.823 vs 0.769 ms):
+// neither part is bound by its VALU or MFMA issue but by LDS round trips in the wave's one in-order LDS queue, which the
+// mixture does not shorten.
+#ifndef BAMD_BF16_EPIMIX
+#define BAMD_BF16_EPIMIX 0
+#endif
+template <int NT> struct EpiGeo {
+    using SP = Split<NT>;
+    static constexpr int E = 4 * SP::NS + SP::MS;
+};
+template <int NT, int SOUT, int U> __device__ __forceinline__ lds_p epi_addr(lds_p img, const Lay &lay, int wave) {
+    using SP = Split<NT>;
+    if constexpr (U < 4 * SP::NS) {
+        constexpr int k = U / 4, m = U % 4;
+        const bool own = !(SP::ragged && k == SP::NS - 1) || wave + 4 * k < NT;
+        return img + lay.wr(wave & 1) + 32 * (wave & ~1) + (own ? 128 * k : 0) + 16 * m * SOUT;
+    } else {
+        constexpr int t = SP::m0 + (U - 4 * SP::NS);
+        return img + 16 * wave * SOUT + lay.wr(t & 1) + 32 * (t & ~1);
+    }
+}
+template <int NT, int U> __device__ __forceinline__ bool epi_owned(int wave) {
+    using SP = Split<NT>;
+    return !(SP::ragged && U < 4 * SP::NS && U / 4 == SP::NS - 1) || wave + 4 * (U / 4) < NT;
+}
+template <int NT, int U> __device__ __forceinline__ v4 &epi_acc(ChainAcc<NT> &acc) {
+    using SP = Split<NT>;
+    if constexpr (U < 4 * SP::NS) return acc.an[U / 4][U % 4];
+    else return acc.am[U - 4 * SP::NS];
+}
+template <int NT, int SOUT, int... U>
+__device__ __forceinline__ void epi_pre(u2 (&y)[EpiGeo<NT>::E], lds_p img, const Lay &lay, int wave, std::integer_sequence<int, U...>) {
+    ((y[U] = lds_b64(epi_addr<NT, SOUT, U>(img, lay, wave))), ...);
+}
+template <int U0, int U1, class Fn> __device__ __forceinline__ void epi_units(Fn &fn) {
+    if constexpr (U0 < U1) {
+        fn(std::integral_constant<int, U0>{});
+        epi_units<U0 + 1, U1>(fn);
+    }
+}
+
 // ---- weight-gradient tiles of layer l --------------------------------------------------------------------------------
 // A operand: dZ_l^T (image ZI, stride SZ), B operand: [X_l | 1] (image XI, stride SX), both by transposed reads;
 // contraction over the 64 rows = 2 MFMAs per tile.  Tiles owned by this wave: see TNet::by_nt.
@@ -474,9 +521,10 @@ template <class N, int l> struct DwGeo {
     static constexpr int OWN = BYN ? NT : KT;                       // tiles on the owned side
     static constexpr int NS = BYN ? KT : NT;                        // streamed tiles
 };
-template <class N, int l, int SZ, int SX, int S>
+struct NoEpi { template <class U> __device__ __forceinline__ void operator()(U) {} };
+template <class N, int l, int SZ, int SX, int E, int S, class Epi>
 __device__ __forceinline__ void dw_step(v4 (&acc)[N::dwn(l)], const bf8 (&own)[DwGeo<N, l>::NO][2], bf8 (&ring)[kDWD + 1][2], lds_p sbase0,
-                                        lds_p sbase1) {
+                                        lds_p sbase1, Epi &epi) {
     using G = DwGeo<N, l>;
     constexpr int SS = G::BYN ? SX : SZ;          // stride of the streamed image
     if constexpr (S + kDWD < G::NS) {
@@ -494,10 +542,21 @@ __device__ __forceinline__ void dw_step(v4 (&acc)[N::dwn(l)], const bf8 (&own)[D
             v4 &c = acc[i * G::NS + S];
             c = G::BYN ? mfma(own[i][h], st[h], c) : mfma(st[h], own[i][h], c);      // A = dZ^T tile, B = [X | 1] tile
         }
+    // this step's share of the E epilogue units, dealt between its 2 NO MFMAs (10 VALU instructions per unit)
+    constexpr int u0 = S * E / G::NS, u1 = (S + 1) * E / G::NS;
+    if constexpr (u1 > u0) {
+        epi_units<u0, u1>(epi);
+        constexpr int per = cdiv(10 * (u1 - u0), 2 * G::NO);
+#pragma unroll
+        for (int i = 0; i < 2 * G::NO; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
-template <class N, int l, int SZ, int SX, int... S>
-__device__ __forceinline__ void dw_phase_impl(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave,
+template <class N, int l, int SZ, int SX, int E, class Epi, int... S>
+__device__ __forceinline__ void dw_phase_impl(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave, Epi &epi,
                                               std::integer_sequence<int, S...>) {
     using G = DwGeo<N, l>;
     constexpr int SO = G::BYN ? SZ : SX, SS = G::BYN ? SX : SZ;
@@ -519,15 +578,21 @@ __device__ __forceinline__ void dw_phase_impl(v4 (&acc)[N::dwn(l)], lds_p zimg, 
         ring[t][0] = tr_operand<SS>(sb, 0);
         ring[t][1] = tr_operand<SS>(sb, 1);
     }
-    (dw_step<N, l, SZ, SX, S>(acc, own, ring, sb0, sb1), ...);
+    (dw_step<N, l, SZ, SX, E, S>(acc, own, ring, sb0, sb1, epi), ...);
+}
+// E epilogue units (epi(integral_constant<int, U>)) are spread over the steps; E = 0: none
+template <class N, int l, int SZ, int SX, int E, class Epi>
+__device__ __forceinline__ void dw_phase_epi(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave, Epi &epi) {
+    static_assert(N::dwn(l) == DwGeo<N, l>::NO * DwGeo<N, l>::NS, "accumulator count");
+    dw_phase_impl<N, l, SZ, SX, E>(acc, zimg, ximg, lz, lx, wave, epi, std::make_integer_sequence<int, DwGeo<N, l>::NS>{});
 }
 template <class N, int l, int SZ, int SX>
 __device__ __forceinline__ void dw_phase(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave) {
 #ifdef BAMD_ABLATE_DW
     return;
 #endif
-    static_assert(N::dwn(l) == DwGeo<N, l>::NO * DwGeo<N, l>::NS, "accumulator count");
-    dw_phase_impl<N, l, SZ, SX>(acc, zimg, ximg, lz, lx, wave, std::make_integer_sequence<int, DwGeo<N, l>::NS>{});
+    NoEpi none;
+    dw_phase_epi<N, l, SZ, SX, 0>(acc, zimg, ximg, lz, lx, wave, none);
 }
 
 template <class N, int l>
@@ -631,8 +696,9 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     const lds_p img = (lds_p)lds_raw;
     float *xf = (float *)(lds_raw + N::img_bytes());          // fp32 copy of the normalised input rows: [64][32]
     double *fl = (double *)(xf + kRows * 32);                 // [0..31] min, [32..63] range
+    const lds_p scratch = img + (N::img_bytes() + kRows * 32 * 4 + 64 * 8) + 8 * (int)threadIdx.x;   // 512 B per wave: where the epilogue of a slot the wave does not own lands
 #ifdef BAMD_BF16_TRACE
-    unsigned long long *bt_lds = (unsigned long long *)(fl + 64);
+    unsigned long long *bt_lds = (unsigned long long *)(fl + 64 + 256);
 #endif
     for (int i = threadIdx.x; i < N::img_bytes() / 16; i += 256) ((uint4 *)lds_raw)[i] = make_uint4(0, 0, 0, 0);   // finite padding slots
     if (threadIdx.x < 64) {
@@ -796,20 +862,40 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
             constexpr int SZ = N::istride((l) + 1);   /* dZ_l has the shape of X_{l+1} */                                    \
             const lds_p zimg = img + N::zoff(l);                                                                             \
             if constexpr ((l) >= 1) {                                                                                        \
-                ChainAcc<N::ntb(l)> acc;                                                                                     \
-                chain_mm<N, PART, SC::bstep(l), N::kbb(l), N::ntb(l), SZ>(acc, zimg + lay_of<SZ>(ls).row, ring, ws, wave);   \
+                constexpr int NTB = N::ntb(l), SO = N::istride(l);                                                           \
+                ChainAcc<NTB> acc;                                                                                           \
+                chain_mm<N, PART, SC::bstep(l), N::kbb(l), NTB, SZ>(acc, zimg + lay_of<SZ>(ls).row, ring, ws, wave);         \
                 BT(70 + 2 * (l));                                                                                            \
                 constexpr int DELTA = N::zoff((l) - 1) - N::ioff(l);   /* same stride, same lane offsets: a constant shift */ \
-                if constexpr (N::act((l) - 1))                                                                               \
-                    acc_visit_pre<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,          \
-                                                            [&](lds_p src) { return lds_b64(src); },                         \
-                                                            [&](v4 &a, lds_p src, u2 y) { lds_w64(src + DELTA, lrelu_bwd_pack4(a, y)); }); \
-                else                                                                                                         \
-                    acc_visit<N::ntb(l), N::istride(l)>(acc, img + N::ioff(l), lay_of<N::istride(l)>(ls), wave,              \
-                                                        [&](v4 &a, lds_p src) { lds_w64(src + DELTA, pack4(a)); });          \
+                if constexpr (N::act((l) - 1) && BAMD_BF16_EPIMIX) {                                                         \
+                    constexpr int E = EpiGeo<NTB>::E;                                                                        \
+                    const lds_p ximg = img + N::ioff(l);                                                                     \
+                    const Lay &lo = lay_of<SO>(ls);                                                                          \
+                    u2 y[E];                                                                                                 \
+                    epi_pre<NTB, SO>(y, ximg, lo, wave, std::make_integer_sequence<int, E>{});                               \
+                    auto epi = [&](auto U) {                                                                                 \
+                        constexpr int u = decltype(U)::value;                                                                \
+                        const lds_p a = epi_addr<NTB, SO, u>(ximg, lo, wave);                                                \
+                        const lds_p dst = epi_owned<NTB, u>(wave) ? a + DELTA : scratch;                                     \
+                        lds_w64(dst, lrelu_bwd_pack4(epi_acc<NTB, u>(acc), y[u]));                                           \
+                    };                                                                                                       \
+                    BT(20 + 2 * (l));                                                                                        \
+                    dw_phase_epi<N, l, SZ, SO, E>(G, zimg, ximg, lay_of<SZ>(ls), lo, wave, epi);                             \
+                } else {                                                                                                     \
+                    if constexpr (N::act((l) - 1))                                                                           \
+                        acc_visit_pre<NTB, SO>(acc, img + N::ioff(l), lay_of<SO>(ls), wave,                                  \
+                                               [&](lds_p src) { return lds_b64(src); },                                      \
+                                               [&](v4 &a, lds_p src, u2 y) { lds_w64(src + DELTA, lrelu_bwd_pack4(a, y)); }); \
+                    else                                                                                                     \
+                        acc_visit<NTB, SO>(acc, img + N::ioff(l), lay_of<SO>(ls), wave,                                      \
+                                           [&](v4 &a, lds_p src) { lds_w64(src + DELTA, pack4(a)); });                       \
+                    BT(20 + 2 * (l));                                                                                        \
+                    dw_phase<N, l, SZ, SO>(G, zimg, img + N::ioff(l), lay_of<SZ>(ls), lay_of<SO>(ls), wave);                 \
+                }                                                                                                            \
+            } else {                                                                                                         \
+                BT(20 + 2 * (l));                                                                                            \
+                dw_phase<N, l, SZ, N::istride(l)>(G, zimg, img + N::ioff(l), lay_of<SZ>(ls), lay_of<N::istride(l)>(ls), wave); \
             }                                                                                                                \
-            BT(20 + 2 * (l));                                                                                                \
-            dw_phase<N, l, SZ, N::istride(l)>(G, zimg, img + N::ioff(l), lay_of<SZ>(ls), lay_of<N::istride(l)>(ls), wave);   \
             BT(71 + 2 * (l));                                                                                                \
             __syncthreads();                                                                                                 \
             BT(21 + 2 * (l));                                                                                                \
@@ -967,9 +1053,9 @@ TrainState *tstate(bamd_handle *h) { return (TrainState *)h->bf16_train_state; }
 template <int F, int Z> struct TImpl {
     using N = TNet<F, Z>;
 #ifdef BAMD_BF16_TRACE
-    static constexpr size_t lds_bytes() { return (size_t)N::img_bytes() + kRows * 32 * 4 + 64 * 8 + 4096; }
+    static constexpr size_t lds_bytes() { return (size_t)N::img_bytes() + kRows * 32 * 4 + 64 * 8 + 2048 + 4096; }
 #else
-    static constexpr size_t lds_bytes() { return (size_t)N::img_bytes() + kRows * 32 * 4 + 64 * 8; }
+    static constexpr size_t lds_bytes() { return (size_t)N::img_bytes() + kRows * 32 * 4 + 64 * 8 + 2048; }
 #endif
     static_assert(lds_bytes() <= 160 * 1024, "LDS images exceed one CU");
     static bool matches(const bamd_handle *h) {

@@ -4,7 +4,7 @@
       hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 \
             -DBAMD_LAT_TRACE -c fused.hip -o /tmp/fused_trace.o && \
       hipcc --offload-arch=gfx950 -shared -fPIC -o ../../.abl/trace.so api.o elementwise.o generic.o swd.o bf16.o /tmp/fused_trace.o
-    BALER_AMD_LIB=$PWD/.abl/trace.so python tools/lat_trace.py          (on the GPU box)
+    BALER_AMD_LIB=$PWD/.abl/trace.so python tools/lat_trace.py [ROWS]   (on the GPU box)
 """
 import ctypes
 import os
@@ -18,7 +18,8 @@ from baler_amd import native, synth                               # noqa: E402
 from baler_amd.modules import models                              # noqa: E402
 
 dev = torch.device("cuda", 0)
-x = torch.from_numpy(synth.cms_rows(512 * 50)).to(dev)
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 512          # rows per step
+x = torch.from_numpy(synth.cms_rows(R * 50)).to(dev)
 x = native.normalize(x, native.minmax(x))
 model = models.AE(24, 15).to(dev)
 h = model.handle()
@@ -27,7 +28,7 @@ grads = torch.zeros(n + 1, dtype=torch.float32, device=dev)
 m = torch.zeros(n, dtype=torch.float32, device=dev)
 v = torch.zeros(n, dtype=torch.float32, device=dev)
 for i in range(50):
-    h.train_step(x[i * 512:(i + 1) * 512], model.flat, m, v, i + 1, 1e-3)
+    h.train_step(x[i * R:(i + 1) * R], model.flat, m, v, i + 1, 1e-3)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 64)()
 L = native.lib()
