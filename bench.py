@@ -450,7 +450,7 @@ def main():
             out["train_bs512_rows_per_s"] = by_batch["512"]["rows_per_s"]
             out["train_bs512_us_per_step"] = by_batch["512"]["us_per_step"]
             extra_roof["train_bs512_" + DTYPE_NAME[a.mode]] = {
-                "bound": "latency", "kernel": "bamd_train_step at 512 rows (lat2_chain_kernel + lat2_dw_kernel<adam>)",
+                "bound": "latency", "kernel": "bamd_train_step at 512 rows (lat4_chain_kernel + lat2_dw_kernel<adam>)",
                 "launch_us": by_batch["512"]["us_per_step"] / 1.0, "unit": "TFLOP/s",
                 "achieved": by_batch["512"]["tflops"] / world, "peak": PEAK_TFLOPS[a.mode],
                 "frac": by_batch["512"]["frac_of_mfma_peak"]}
@@ -463,12 +463,12 @@ def main():
             g64 = torch.zeros_like(f64)
             n64 = min(a.rows, 262144)
             ms = event_ms(lambda: h64.encode(x[:n64]), 3)
-            extra_roof["encode_f64"] = {"bound": "mfma", "kernel": "bamd_encode, BAMD_MODE_F64 (layer-wise v_mfma_f64_16x16x4_f64 GEMMs)", "rows": n64,
+            extra_roof["encode_f64"] = {"bound": "mfma", "kernel": "bamd_encode, BAMD_MODE_F64 (infer64_kernel: register chain on v_mfma_f64_16x16x4_f64)", "rows": n64,
                                         "launch_ms": ms, "unit": "TFLOP/s", "achieved": FLOP_ENCODE_ROW * n64 / ms / 1e9, "peak": PEAK_TFLOPS["fp64"],
                                         "frac": FLOP_ENCODE_ROW * n64 / ms / 1e9 / PEAK_TFLOPS["fp64"], "rows_per_s": n64 / ms * 1e3}
             n64t = min(a.rows, 65536)
             ms = event_ms(lambda: h64.fwd_bwd(x[:n64t], g64), 3)
-            extra_roof["train_f64"] = {"bound": "mfma", "kernel": "bamd_fwd_bwd, BAMD_MODE_F64, layer-wise (batches above 12288 rows)", "rows": n64t,
+            extra_roof["train_f64"] = {"bound": "mfma", "kernel": "bamd_fwd_bwd, BAMD_MODE_F64 (chain64_kernel + dw64_kernel, the fused pair up to 262144 rows)", "rows": n64t,
                                        "launch_ms": ms, "unit": "TFLOP/s", "achieved": FLOP_TRAIN_ROW * n64t / ms / 1e9, "peak": PEAK_TFLOPS["fp64"],
                                        "frac": FLOP_TRAIN_ROW * n64t / ms / 1e9 / PEAK_TFLOPS["fp64"], "rows_per_s": n64t / ms * 1e3}
             t64 = {"t": 0}
