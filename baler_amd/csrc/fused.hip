@@ -1677,6 +1677,329 @@ __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, c
     }
 }
 
+// ---- bf16 training of the wide models (BAMD_MODE_BF16): the two wide products of the forward pass (en1, de4) and de4's input-gradient
+// product on v_mfma_f32_16x16x32_bf16, everything else -- the six narrow layers, the loss, the masks, and all weight-gradient products
+// (which read the float32 activations / gradients these kernels store) -- in float32 as in wide_train_fwd/bwd_kernel.  95 % of the
+// model's forward and input-gradient work is in those three products; at fp32 MFMA rates they made the row-local launches MFMA-bound
+// (75 % busy), at bf16 rates the launches are bound by their 10-KB-per-frame row traffic.
+//
+// acc0 / acc1[13 tiles of the 200-feature side] += sum over the wide dimension of frag(chunk c, tile t) . x^T[chunk c] for the wave's two
+// 16-row tiles: the streamed product of wide_bf16_encode_kernel as a function (fragments [32-feature chunk][tile], shared by the four waves
+// through the double-buffered LDS stage `wst`, every load three chunks ahead; see that kernel).  Contains workgroup barriers.
+template <int F>
+__device__ __forceinline__ void wide_in_product_bf16(v4 (&a1)[13], v4 (&b1)[13], v4 (&wst)[2][13][64], const WStream &ww,
+                                                     __amdgpu_buffer_rsrc_t xrs, int xo0, int xo1, int wave, int lane, int g) {
+    constexpr int KB = F / 32;
+    bf8 wq[2][4];
+    XPair x0r[3], x1r[3];
+    auto wload = [&](bf8 (&w)[4], int c) {
+        c = c < KB ? c : KB - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = wave + 4 * k;
+            w[k] = frag_bf(ww, c * 13 + (t < 13 ? t : 12));
+        }
+    };
+    auto wstore = [&](const bf8 (&w)[4], int slot) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = wave + 4 * k;
+            if (t < 13) wst[slot][t][lane] = __builtin_bit_cast(v4, w[k]);
+        }
+    };
+    auto lx0 = [&](int c) { return wide_x_chunk32_buf<F, true>(xrs, xo0, 0, c < KB ? c : 0, g); };
+    auto lx1 = [&](int c) { return wide_x_chunk32_buf<F, true>(xrs, xo1, 0, c < KB ? c : 0, g); };
+    wload(wq[0], 0);
+    wload(wq[1], 1);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { x0r[u] = lx0(u); x1r[u] = lx1(u); }
+    __syncthreads();              // the previous user of the stage has read its last chunk
+    wstore(wq[0], 0);
+    wload(wq[0], 2);
+    auto iter = [&](int c, auto wsl, auto xsl) {
+        constexpr int WS = decltype(wsl)::value, XS = decltype(xsl)::value;      // c % 2, c % 3
+        __syncthreads();
+        wstore(wq[WS ^ 1], WS ^ 1);
+        const bf8 q0 = to_bf8(x0r[XS].lo, x0r[XS].hi), q1 = to_bf8(x1r[XS].lo, x1r[XS].hi);
+        wload(wq[WS ^ 1], c + 3);
+        x0r[XS] = lx0(c + 3);
+        x1r[XS] = lx1(c + 3);
+        bf8 wl[2][4];
+        auto rd = [&](bf8 (&w)[4], int t0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = __builtin_bit_cast(bf8, wst[WS][t0 + k < 13 ? t0 + k : 12][lane]);
+        };
+        auto mm = [&](const bf8 (&w)[4], int t0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t0 + k < 13) { a1[t0 + k] = mfma_bf(w[k], q0, a1[t0 + k]); b1[t0 + k] = mfma_bf(w[k], q1, b1[t0 + k]); }
+        };
+        rd(wl[0], 0);
+        rd(wl[1], 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wl[0], 0);
+        rd(wl[0], 8);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wl[1], 4);
+        rd(wl[1], 12);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wl[0], 8);
+        mm(wl[1], 12);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    int c = 0;
+    for (; c + 6 <= KB; c += 6) {
+        iter(c, I0(), I0()); iter(c + 1, I1(), I1()); iter(c + 2, I0(), I2());
+        iter(c + 3, I1(), I0()); iter(c + 4, I0(), I1()); iter(c + 5, I1(), I2());
+    }
+    if (c < KB) iter(c, I0(), I0());
+    if (c + 1 < KB) iter(c + 1, I1(), I1());
+    if (c + 2 < KB) iter(c + 2, I0(), I2());
+    if (c + 3 < KB) iter(c + 3, I1(), I0());
+    if (c + 4 < KB) iter(c + 4, I0(), I1());
+    if (F % 32 != 0) {            // the remaining F % 32 features: one partial chunk, fragments straight from L2
+        const XPair p0 = wide_x_chunk32_buf<F>(xrs, xo0, 0, KB, g), p1 = wide_x_chunk32_buf<F>(xrs, xo1, 0, KB, g);
+        const bf8 q0 = to_bf8(p0.lo, p0.hi), q1 = to_bf8(p1.lo, p1.hi);
+#pragma unroll
+        for (int t = 0; t < 13; ++t) {
+            const bf8 w = frag_bf(ww, KB * 13 + t);
+            a1[t] = mfma_bf(w, q0, a1[t]);
+            b1[t] = mfma_bf(w, q1, b1[t]);
+        }
+    }
+}
+
+// forward + loss + dL/drecon of 2 x 16 rows per wave (128 rows per workgroup pass): interface and results as wide_train_fwd_kernel<TRAIN = true>
+// (y1..y7, dz8 = 2 (recon - x) / F in float32, per-workgroup loss partials), en1 and de4 on the bf16 MFMA.
+template <int F, int Z>
+__global__ void __launch_bounds__(256) wide_bf16_train_fwd_kernel(const v4 *packed, const v4 *w0b, const v4 *w7b, const float *__restrict__ x,
+                                                                  int64_t n, float *__restrict__ y1, float *__restrict__ y2,
+                                                                  float *__restrict__ y3, float *__restrict__ y4, float *__restrict__ y5,
+                                                                  float *__restrict__ y6, float *__restrict__ y7, float *__restrict__ dz8,
+                                                                  double *__restrict__ loss_part) {
+    using N = Net<F, Z>;
+    using S = StreamWideMid<N>;
+    constexpr int KBT = (F + 31) / 32, KT = tiles(F), KTF = F / 16;
+    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
+    __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
+    constexpr int kTG = 4, kTS = 16 * kTG + 4;
+    __shared__ __attribute__((aligned(16))) float tstage[4][32][kTS];     // transposing stage of the dz8 stores (wide_bf16_decode_kernel)
+    __shared__ double sh[256];
+    stage_bias<N>(bias_lds, packed);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 127) / 128;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
+    WStream w0 = make_stream(w0b, KBT * 13 * 1024, lane);
+    WStream w7 = make_stream(w7b, KT * 7 * 1024, lane);
+    const v4 *bias7 = bias_lds + (N::bf_off(7) - N::bf_off(0));
+    const float gscale = 2.0f / F;
+    double lacc = 0.0;
+    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+        const int64_t r0 = (grp * 4 + wave) * 32 + (lane & 15), r1 = r0 + 16;
+        const bool v0 = r0 < n, v1 = r1 < n;
+        const int64_t rr0 = v0 ? r0 : 0, rr1 = v1 ? r1 : 0;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)x + (size_t)(grp * 128) * F * 4), 0,
+                                                                             0x7fffffff, 0x00020000);
+        const int lr0 = wave * 32 + (lane & 15);
+        const int xo0 = ((v0 ? lr0 : 0) * F + 8 * g) * 4, xo1 = ((v1 ? lr0 + 16 : 0) * F + 8 * g) * 4;
+        asm volatile("" : "+v"(ws.voff), "+v"(w0.voff), "+v"(w7.voff));
+        bf8 qa[7], qb[7];
+        {
+            v4 a1[13], b1[13];
+            init_bias(a1, bias_lds, lane);
+#pragma unroll
+            for (int t = 0; t < 13; ++t) b1[t] = a1[t];
+            wide_in_product_bf16<F>(a1, b1, wst, w0, xrs, xo0, xo1, wave, lane, g);
+            lrelu(a1);
+            lrelu(b1);
+            store_rows<200>(a1, y1, 0, r0, v0, lane, nullptr, nullptr);
+            store_rows<200>(b1, y1, 0, r1, v1, lane, nullptr, nullptr);
+            const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+            auto narrow = [&](const v4 (&in)[13], bf8 (&q)[7], int64_t row, bool valid) {
+                Ring ring;
+                ring_prime<S::total>(ring, ws);
+                v4 a2[7], a3[4], a4[tiles(Z)], a5[4], a6[7], a7[13];
+                fwd_layer<N, S, 1>(in, a2, ring, ws, bias_lds, lane);
+                store_rows<100>(a2, y2, 0, row, valid, lane, nullptr, nullptr);
+                fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
+                store_rows<50>(a3, y3, 0, row, valid, lane, nullptr, nullptr);
+                fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
+                store_rows<Z>(a4, y4, 0, row, valid, lane, nullptr, nullptr);
+                fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
+                store_rows<50>(a5, y5, 0, row, valid, lane, nullptr, nullptr);
+                fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
+                store_rows<100>(a6, y6, 0, row, valid, lane, nullptr, nullptr);
+                fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
+                store_rows<200>(a7, y7, 0, row, valid, lane, nullptr, nullptr);
+#pragma unroll
+                for (int c = 0; c < 7; ++c) q[c] = to_bf8(a7[2 * c], 2 * c + 1 < 13 ? a7[2 * c + 1 < 13 ? 2 * c + 1 : 12] : zero);
+            };
+            narrow(a1, qa, r0, v0);
+            narrow(b1, qb, r1, v1);
+        }
+        // de4 tile by tile against the x tile it reconstructs; fragments and x tiles three output tiles ahead in four rotating buffers
+        bf8 wr[4][7];
+        v4 xa[4], xb[4];
+        // (the loop covers the KTF full tiles; a partial last tile is an epilogue: a "full tile?" test in front of the x loads would put
+        // every load of the loop behind a branch, see wide_x_chunk)
+        auto load_w = [&](bf8 (&w)[7], v4 &x0t, v4 &x1t, int t) {
+            t = t < KTF ? t : KTF - 1;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) w[c] = frag_bf(w7, t * 7 + c);
+            x0t = wide_x_chunk<F, true>(x, 0, rr0, t, g);
+            x1t = wide_x_chunk<F, true>(x, 0, rr1, t, g);
+        };
+        auto tile_out = [&](const bf8 (&w)[7], const v4 &x0t, const v4 &x1t, int t, auto jj) {
+            constexpr int J = decltype(jj)::value % kTG;
+            if (t >= KTF) return;
+            v4 o0 = bias7[t * 4 + g], o1 = o0;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) { o0 = mfma_bf(w[c], qa[c], o0); o1 = mfma_bf(w[c], qb[c], o1); }
+            const v4 d0 = o0 - x0t, d1 = o1 - x1t;
+            if (v0) lacc += (double)(d0[0] * d0[0] + d0[1] * d0[1]) + (double)(d0[2] * d0[2] + d0[3] * d0[3]);
+            if (v1) lacc += (double)(d1[0] * d1[0] + d1[1] * d1[1]) + (double)(d1[2] * d1[2] + d1[3] * d1[3]);
+            const v4 e0 = d0 * gscale, e1 = d1 * gscale;
+            if (t + (kTG - 1 - J) < KTF) {               // the whole group is made of full tiles: 4 rows x 256 contiguous bytes per store
+                *(v4 *)&tstage[wave][lane & 15][16 * J + 4 * g] = e0;
+                *(v4 *)&tstage[wave][16 + (lane & 15)][16 * J + 4 * g] = e1;
+                if (J == kTG - 1) {
+                    const int64_t rb = (grp * 4 + wave) * 32;
+                    constexpr int LR = 4 * kTG;
+#pragma unroll
+                    for (int k = 0; k < 32 * LR / 64; ++k) {
+                        const int rl = (64 / LR) * k + lane / LR;
+                        const v4 v = *(const v4 *)&tstage[wave][rl][4 * (lane % LR)];
+                        if (rb + rl < n) *(v4 *)(dz8 + (rb + rl) * F + 16 * (t - (kTG - 1)) + 4 * (lane % LR)) = v;
+                    }
+                }
+            } else {
+                if (v0) wide_store_tile<F, true>(e0, dz8, 0, r0, t, g);
+                if (v1) wide_store_tile<F, true>(e1, dz8, 0, r1, t, g);
+            }
+        };
+        load_w(wr[0], xa[0], xb[0], 0);
+        load_w(wr[1], xa[1], xb[1], 1);
+        load_w(wr[2], xa[2], xb[2], 2);
+        for (int t0 = 0; t0 < KTF; t0 += 8) {
+            load_w(wr[3], xa[3], xb[3], t0 + 3);
+            tile_out(wr[0], xa[0], xb[0], t0, std::integral_constant<int, 0>());
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wr[0], xa[0], xb[0], t0 + 4);
+            tile_out(wr[1], xa[1], xb[1], t0 + 1, std::integral_constant<int, 1>());
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wr[1], xa[1], xb[1], t0 + 5);
+            tile_out(wr[2], xa[2], xb[2], t0 + 2, std::integral_constant<int, 2>());
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wr[2], xa[2], xb[2], t0 + 6);
+            tile_out(wr[3], xa[3], xb[3], t0 + 3, std::integral_constant<int, 3>());
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wr[3], xa[3], xb[3], t0 + 7);
+            tile_out(wr[0], xa[0], xb[0], t0 + 4, std::integral_constant<int, 4>());
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wr[0], xa[0], xb[0], t0 + 8);
+            tile_out(wr[1], xa[1], xb[1], t0 + 5, std::integral_constant<int, 5>());
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wr[1], xa[1], xb[1], t0 + 9);
+            tile_out(wr[2], xa[2], xb[2], t0 + 6, std::integral_constant<int, 6>());
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wr[2], xa[2], xb[2], t0 + 10);
+            tile_out(wr[3], xa[3], xb[3], t0 + 7, std::integral_constant<int, 7>());
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (F % 16 != 0) {      // the partial last tile (r-major slots; padding slots: zero weights and bias against a zero x)
+            constexpr int t = KT - 1;
+            v4 o0 = bias7[t * 4 + g], o1 = o0;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                const bf8 w = frag_bf(w7, t * 7 + c);
+                o0 = mfma_bf(w, qa[c], o0);
+                o1 = mfma_bf(w, qb[c], o1);
+            }
+            const v4 d0 = o0 - wide_x_chunk<F>(x, 0, rr0, t, g), d1 = o1 - wide_x_chunk<F>(x, 0, rr1, t, g);
+            if (v0) { lacc += (double)(d0[0] * d0[0] + d0[1] * d0[1]) + (double)(d0[2] * d0[2] + d0[3] * d0[3]); wide_store_tile<F>(d0 * gscale, dz8, 0, r0, t, g); }
+            if (v1) { lacc += (double)(d1[0] * d1[0] + d1[1] * d1[1]) + (double)(d1[2] * d1[2] + d1[3] * d1[3]); wide_store_tile<F>(d1 * gscale, dz8, 0, r1, t, g); }
+        }
+    }
+    sh[threadIdx.x] = lacc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = sh[0];
+}
+
+// the input-gradient chain of 2 x 16 rows per wave: dZ_6 = (dZ_7 W_7) * lrelu'(y7) with the wide product on the bf16 MFMA (fragments of
+// W_7^T in en1's [chunk][tile] order), then layers 6..1 in float32 as in wide_train_bwd_kernel, one row tile after the other.
+template <int F, int Z>
+__global__ void __launch_bounds__(256) wide_bf16_train_bwd_kernel(const v4 *packed, const v4 *w7tb, const float *__restrict__ dz7, int64_t n,
+                                                                  const float *__restrict__ y1, const float *__restrict__ y2,
+                                                                  const float *__restrict__ y3, const float *__restrict__ y5,
+                                                                  const float *__restrict__ y6, const float *__restrict__ y7,
+                                                                  float *__restrict__ dz0, float *__restrict__ dz1, float *__restrict__ dz2,
+                                                                  float *__restrict__ dz3, float *__restrict__ dz4, float *__restrict__ dz5,
+                                                                  float *__restrict__ dz6, const float *__restrict__ dz_latent) {
+    using N = Net<F, Z>;
+    using S = StreamWideMidBwd<N>;
+    constexpr int KBT = (F + 31) / 32;
+    __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 127) / 128;
+    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
+    WStream w7 = make_stream(w7tb, KBT * 13 * 1024, lane);
+    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+        const int64_t r0 = (grp * 4 + wave) * 32 + (lane & 15), r1 = r0 + 16;
+        const bool v0 = r0 < n, v1 = r1 < n;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)dz7 + (size_t)(grp * 128) * F * 4), 0,
+                                                                             0x7fffffff, 0x00020000);
+        const int lr0 = wave * 32 + (lane & 15);
+        const int xo0 = ((v0 ? lr0 : 0) * F + 8 * g) * 4, xo1 = ((v1 ? lr0 + 16 : 0) * F + 8 * g) * 4;
+        asm volatile("" : "+v"(ws.voff), "+v"(w7.voff));
+        v4 d6a[13], d6b[13];
+        zero_tiles(d6a);
+        zero_tiles(d6b);
+        wide_in_product_bf16<F>(d6a, d6b, wst, w7, xrs, xo0, xo1, wave, lane, g);
+        auto narrow = [&](v4 (&d6)[13], int64_t row, bool valid) {
+            const int64_t rrow = valid ? row : 0;
+            Ring ring;
+            ring_prime<S::total>(ring, ws);
+            {
+                v4 a[13];
+                load_act<200>(a, y7, rrow, g);
+                lrelu_bwd(d6, a);
+            }
+            store_rows<200>(d6, dz6, 0, row, valid, lane, nullptr, nullptr);
+            v4 d5[7], d4[4], d3[tiles(Z)], d2[4], d1[7], d0[13];
+            bwd_layer<N, S, 6>(d6, d5, ring, ws);
+            { v4 a[7]; load_act<100>(a, y6, rrow, g); lrelu_bwd(d5, a); }
+            store_rows<100>(d5, dz5, 0, row, valid, lane, nullptr, nullptr);
+            bwd_layer<N, S, 5>(d5, d4, ring, ws);
+            { v4 a[4]; load_act<50>(a, y5, rrow, g); lrelu_bwd(d4, a); }
+            store_rows<50>(d4, dz4, 0, row, valid, lane, nullptr, nullptr);
+            bwd_layer<N, S, 4>(d4, d3, ring, ws);
+            if (dz_latent) {
+                v4 e[tiles(Z)];
+                load_act<Z>(e, dz_latent, rrow, g);
+#pragma unroll
+                for (int t = 0; t < tiles(Z); ++t) d3[t] += e[t];
+            }
+            store_rows<Z>(d3, dz3, 0, row, valid, lane, nullptr, nullptr);
+            bwd_layer<N, S, 3>(d3, d2, ring, ws);
+            { v4 a[4]; load_act<50>(a, y3, rrow, g); lrelu_bwd(d2, a); }
+            store_rows<50>(d2, dz2, 0, row, valid, lane, nullptr, nullptr);
+            bwd_layer<N, S, 2>(d2, d1, ring, ws);
+            { v4 a[7]; load_act<100>(a, y2, rrow, g); lrelu_bwd(d1, a); }
+            store_rows<100>(d1, dz1, 0, row, valid, lane, nullptr, nullptr);
+            bwd_layer<N, S, 1>(d1, d0, ring, ws);
+            { v4 a[13]; load_act<200>(a, y1, rrow, g); lrelu_bwd(d0, a); }
+            store_rows<200>(d0, dz0, 0, row, valid, lane, nullptr, nullptr);
+        };
+        narrow(d6a, r0, v0);
+        narrow(d6b, r1, v1);
+    }
+}
+
 // ---- training kernels ---------------------------------------------------------------------------------
 // Activations + weight-gradient accumulators of the whole model do not fit one CU (register file 512 KB + LDS
 // 160 KB), so training runs as TWO launches over the same rows, cut at layer kSplit.  The first
@@ -2889,8 +3212,8 @@ struct FusedState {
     // 256 16.6 / 21.9, 512 18.0 / 23.4, 1024 21.7 / 27.0, 2048 33.1 / 34.1, 4096 53.6 / 44.1 (every workgroup streams all
     // weights: 4x the L2 traffic of the 16-row chain)
     int64_t lat4_max_rows = 2048;
-    DevBuf wb_src[2], wb[2];           // wide models in the bf16 mode: index maps and bf16 fragments of W0 / W7
-    int wb_count[2] = {0, 0};
+    DevBuf wb_src[3], wb[3];           // wide models in the bf16 mode: index maps and bf16 fragments of W0 / W7 / W7^T (training)
+    int wb_count[3] = {0, 0, 0};
     bool wb_stale = false;             // the bf16 fragments lag the parameters (re-rounded before the next encode / decode)
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
     DevBuf dwpart;                     // partial weight-gradient tiles of the small-batch path when a tile's blocks are split over workgroups
@@ -3378,8 +3701,18 @@ template <int F, int Z> struct ImplWideBf16 {
                         const int nf = slot_feature(F, t, i / 4, i % 4), kf = q < 13 ? slot_feature(200, q, g, j % 4) : -1;
                         if (nf >= 0 && kf >= 0) s7[(((size_t)t * 7 + c) * 64 + lane) * 8 + j] = N::w_off(7) + nf * 200 + kf;
                     }
-        const std::vector<int> *srcs[2] = {&s0, &s7};
-        for (int k = 0; k < 2; ++k) {
+        // W7^T for the input-gradient product of training, in en1's [chunk of 32 wide features][tile of the 200 side] order
+        std::vector<int> s7t((size_t)KB * 13 * 64 * 8, -1);
+        for (int c = 0; c < KB; ++c)
+            for (int t = 0; t < 13; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = lane & 15, g = lane >> 4;
+                        const int nf = slot_feature(200, t, i / 4, i % 4), kf = 32 * c + 8 * g + j;
+                        if (nf >= 0 && kf < F) s7t[(((size_t)c * 13 + t) * 64 + lane) * 8 + j] = N::w_off(7) + kf * 200 + nf;
+                    }
+        const std::vector<int> *srcs[3] = {&s0, &s7, &s7t};
+        for (int k = 0; k < 3; ++k) {
             st->wb_count[k] = (int)srcs[k]->size();
             rc = st->wb_src[k].ensure(srcs[k]->size() * sizeof(int));
             if (rc) return rc;
@@ -3390,7 +3723,7 @@ template <int F, int Z> struct ImplWideBf16 {
         return BAMD_OK;
     }
     static int pack_extra(bamd_handle *h, FusedState *st, hipStream_t s) {
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 3; ++k)
             hipLaunchKernelGGL(pack_wide_bf16_k, dim3((st->wb_count[k] + 255) / 256), dim3(256), 0, s, (const float *)h->params.p,
                                (const int *)st->wb_src[k].p, st->wb_count[k], (__bf16 *)st->wb[k].p);
         st->wb_stale = false;
@@ -3462,8 +3795,37 @@ template <int F, int Z> struct ImplWideBf16 {
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
+    // training: the row-local launches with en1 / de4 / de4's input-gradient product on the bf16 MFMA (BALER_AMD_BF16_WIDE_TRAIN=0: the
+    // float32 launches, as before round 3); the weight-gradient products stay in float32 on what these launches store
+    static bool bf16_train_on() {      // read per call (tests flip it)
+        const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
+        return !(e && e[0] == '0');
+    }
+    static int wide_fwd(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
+                        hipStream_t s) {
+        if (!bf16_train_on()) return W::wide_fwd(h, x, rows, y, dz_last, loss_part, nblk, s);
+        FusedState *st = state_of(h);
+        if (st->wb_stale) { int rc = pack_extra(h, st, s); if (rc) return rc; }
+        const int grid = grid_for(rows);
+        hipLaunchKernelGGL((wide_bf16_train_fwd_kernel<F, Z>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const v4 *)st->wb[0].p,
+                           (const v4 *)st->wb[1].p, x, rows, y[1], y[2], y[3], y[4], y[5], y[6], y[7], dz_last, loss_part);
+        *nblk = grid;
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int wide_bwd(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, const float *dz_latent, hipStream_t s) {
+        if (!bf16_train_on()) return W::wide_bwd(h, rows, y, dz, dz_latent, s);
+        FusedState *st = state_of(h);
+        if (st->wb_stale) { int rc = pack_extra(h, st, s); if (rc) return rc; }
+        hipLaunchKernelGGL((wide_bf16_train_bwd_kernel<F, Z>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                           (const v4 *)st->wb[2].p, (const float *)dz[7], rows, (const float *)y[1], (const float *)y[2], (const float *)y[3],
+                           (const float *)y[5], (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6],
+                           dz_latent);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
     static const FusedOps *ops() {
-        static const FusedOps o = {setup, encode, decode, W::forward_loss, nullptr, nullptr, W::wide_fwd, W::wide_bwd, pack_extra};
+        static const FusedOps o = {setup, encode, decode, W::forward_loss, nullptr, nullptr, wide_fwd, wide_bwd, pack_extra};
         return &o;
     }
 };
@@ -3533,7 +3895,7 @@ void fused_teardown(bamd_handle *h) {
     st->dz.release();
     st->imgs.release();
     st->dwpart.release();
-    for (int k = 0; k < 2; ++k) { st->wb_src[k].release(); st->wb[k].release(); }
+    for (int k = 0; k < 3; ++k) { st->wb_src[k].release(); st->wb[k].release(); }
     st->sc_off.release();
     st->sc_idx.release();
     delete st;

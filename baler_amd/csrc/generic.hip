@@ -710,6 +710,161 @@ __global__ void __launch_bounds__(256) dw_wide_k(const float *__restrict__ dzm, 
     }
 }
 
+// The same two products on v_mfma_f32_16x16x32_bf16, for BAMD_MODE_BF16 handles: operands rounded to bfloat16 from the float32 rows on
+// load, float32 accumulation, float32 partial gradients.  The contraction index of that MFMA holds EIGHT consecutive batch rows per
+// lane: lane (g, i) loads columns 4 i .. 4 i + 3 of rows 8 g + e (e = 0..7) of a 32-row block -- 16-byte loads, 4 rows x 256 contiguous
+// bytes per instruction -- and register j of the eight loads, packed by four v_cvt_pk_bf16_f32, is the operand of strided tile j.
+// Column-to-lane maps, accumulators and epilogue are dw_wide_k's.  52 MFMAs (832 cycles) per 40 KiB loaded: the kernel is bound by the
+// rows it streams (the float32 launch: MFMA busy 73-75 %).
+template <bool P_IS_N>
+__global__ void __launch_bounds__(256) dw_wide_bf16_k(const float *__restrict__ dzm, const float *__restrict__ xm, int N, int K, int64_t rows,
+                                                      int64_t rps, float *__restrict__ slab, int64_t slab_size) {
+    using v4 = MF<float>::v4;
+    typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const float *__restrict__ pm = P_IS_N ? dzm : xm;
+    const float *__restrict__ qm = P_IS_N ? xm : dzm;
+    const int DP = P_IS_N ? N : K, DQ = P_IS_N ? K : N;
+    const int CQ = P_IS_N ? K + 1 : N;
+    const int gq = (int)blockIdx.x * 4 + wave;
+    if (64 * gq >= CQ) return;
+    const int64_t r_begin = (int64_t)blockIdx.y * rps;
+    const int64_t r_end = r_begin + rps < rows ? r_begin + rps : rows;
+    if (r_begin >= r_end) return;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(pm + r_begin * DP), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(qm + r_begin * DQ), 0, 0x7fffffff, 0x00020000);
+    const int cq = 64 * gq + 4 * i;
+    const int offq = (8 * g * DQ + (cq + 4 <= DQ ? cq : DQ - 4)) * 4;
+    const int offpg = (8 * g * DP + 4 * i) * 4;
+    const int offpl = (8 * g * DP + (192 + i < DP ? 192 + i : DP - 1)) * 4;
+    const bool q_one = P_IS_N && cq == K;
+    const bool p_one = !P_IS_N && 192 + i == K;
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t &r, int voff, int soff) {
+        return __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    v4 acc[4][13];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 13; ++t) acc[u][t] = (v4){0.f, 0.f, 0.f, 0.f};
+    struct Raw { v4 pg[3][8]; float pl[8]; v4 q[8]; };             // [group][row e], plain tile [row e], [row e]
+    struct Pk { bf8 p[13]; bf8 q[4]; };
+    const int64_t nr = r_end - r_begin;
+    auto load = [&](Raw &f, int64_t rb, bool tail) {
+        const int sp = (int)rb * DP * 4, sq = (int)rb * DQ * 4;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int back_p = 0, back_q = 0;
+            bool ok = true;
+            if (tail) {                                            // rows beyond the range read its last row, dZ zeroed
+                ok = rb + 8 * g + e < nr;
+                const int back = ok ? 0 : (int)(rb + 8 * g + e - (nr - 1));
+                back_p = back * DP * 4;
+                back_q = back * DQ * 4;
+            }
+            f.q[e] = ld4(rq, offq - back_q, sq + e * 4 * DQ);
+#pragma unroll
+            for (int G = 0; G < 3; ++G) f.pg[G][e] = ld4(rp, offpg + 256 * G - back_p, sp + e * 4 * DP);
+            f.pl[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, offpl - back_p, sp + e * 4 * DP, 0));
+            if (tail && !ok) {
+                if (P_IS_N) {
+#pragma unroll
+                    for (int G = 0; G < 3; ++G) f.pg[G][e] = (v4){0.f, 0.f, 0.f, 0.f};
+                    f.pl[e] = 0.f;
+                } else {
+                    f.q[e] = (v4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    };
+    auto pack8 = [&](float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+        const bf2 p0 = {(__bf16)a0, (__bf16)a1}, p1 = {(__bf16)a2, (__bf16)a3}, p2 = {(__bf16)a4, (__bf16)a5}, p3 = {(__bf16)a6, (__bf16)a7};
+        const u4 w = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1), __builtin_bit_cast(unsigned, p2),
+                      __builtin_bit_cast(unsigned, p3)};
+        return __builtin_bit_cast(bf8, w);
+    };
+    auto pack = [&](Pk &k, Raw &f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (P_IS_N) f.q[e][0] = q_one ? 1.0f : f.q[e][0];
+            else f.pl[e] = p_one ? 1.0f : f.pl[e];
+        }
+#pragma unroll
+        for (int G = 0; G < 3; ++G)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                k.p[4 * G + j] = pack8(f.pg[G][0][j], f.pg[G][1][j], f.pg[G][2][j], f.pg[G][3][j], f.pg[G][4][j], f.pg[G][5][j], f.pg[G][6][j],
+                                       f.pg[G][7][j]);
+        k.p[12] = pack8(f.pl[0], f.pl[1], f.pl[2], f.pl[3], f.pl[4], f.pl[5], f.pl[6], f.pl[7]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k.q[u] = pack8(f.q[0][u], f.q[1][u], f.q[2][u], f.q[3][u], f.q[4][u], f.q[5][u], f.q[6][u], f.q[7][u]);
+    };
+    auto mma = [&](const Pk &k) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 13; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k.q[u], k.p[t], acc[u][t], 0, 0, 0);
+    };
+    Raw ra;
+    Pk pk;
+    const int64_t nfull = nr >> 5;
+    if (nfull > 0) {
+        load(ra, 0, false);
+        for (int64_t b = 0; b < nfull; ++b) {
+            pack(pk, ra);
+            __builtin_amdgcn_sched_barrier(0);
+            if (b + 1 < nfull) load(ra, 32 * (b + 1), false);      // the next block's rows stream in behind this block's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            mma(pk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (nr & 31) {
+        load(ra, 32 * nfull, true);
+        pack(pk, ra);
+        mma(pk);
+    }
+    // C map: as dw_wide_k (register r of lane (g, i) in accumulator (u, t): Q column 64 gq + 16 g + 4 r + u; P column 64 G + 4 i + j for
+    // the strided tile t = 4 G + j, 192 + i for the plain tile t = 12)
+    float *out = slab + (int64_t)blockIdx.y * slab_size;
+    if (P_IS_N) {
+#pragma unroll
+        for (int t = 0; t < 13; ++t) {
+            const int n = t < 12 ? 64 * (t >> 2) + 4 * i + (t & 3) : 192 + i;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k0 = 64 * gq + 16 * g + 4 * r;
+                if (k0 + 3 < K) {
+                    *(v4 *)(out + (int64_t)n * K + k0) = (v4){acc[0][t][r], acc[1][t][r], acc[2][t][r], acc[3][t][r]};
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (k0 + u < K) out[(int64_t)n * K + k0 + u] = acc[u][t][r];
+                        else if (k0 + u == K) out[(int64_t)N * K + n] = acc[u][t][r];
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 64 * gq + 16 * g + 4 * r + u;
+                if (n >= N) continue;
+#pragma unroll
+                for (int G = 0; G < 3; ++G)
+                    *(v4 *)(out + (int64_t)n * K + 64 * G + 4 * i) = (v4){acc[u][4 * G][r], acc[u][4 * G + 1][r], acc[u][4 * G + 2][r], acc[u][4 * G + 3][r]};
+                const int k = 192 + i;
+                if (k < K) out[(int64_t)n * K + k] = acc[u][12][r];
+                else if (k == K) out[(int64_t)N * K + n] = acc[u][12][r];
+            }
+    }
+}
+
 // grads[off + j] (+)= sum over the layer's splits of slab_l[split][j], splits in fixed order
 struct ReducePlan {
     int64_t off[9];        // parameter offsets of the layers (off[L] = parameter count); at most 8 layers
@@ -941,11 +1096,17 @@ static void launch_dw_short(bool p_is_n, const float *dz, const float *xm, int N
     if (p_is_n) hipLaunchKernelGGL((dw_short_k<PT, 2, true>), grid, dim3(256), 0, s, dz, xm, N, K, rows, rps, slab, size);
     else hipLaunchKernelGGL((dw_short_k<PT, 2, false>), grid, dim3(256), 0, s, dz, xm, N, K, rows, rps, slab, size);
 }
-static void run_dw_short(const ShortPlan &pl, int l, const float *dz, const float *xm, int N, int K, int64_t rows, float *slabs, hipStream_t s) {
+static void run_dw_short(const ShortPlan &pl, int l, const float *dz, const float *xm, int N, int K, int64_t rows, float *slabs, bool bf16,
+                         hipStream_t s) {
     const dim3 grid((unsigned)pl.ncol[l], (unsigned)pl.nsplit[l]);
     float *slab = slabs + pl.rp.base[l];
     if (pl.wide[l]) {
         const int64_t size = (int64_t)N * K + N;
+        if (bf16) {      // BAMD_MODE_BF16 handles: the two wide weight gradients on the bf16 MFMA (BALER_AMD_BF16_WIDE_TRAIN=0: float32)
+            if (pl.p_is_n[l]) hipLaunchKernelGGL((dw_wide_bf16_k<true>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
+            else hipLaunchKernelGGL((dw_wide_bf16_k<false>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
+            return;
+        }
         if (pl.p_is_n[l]) hipLaunchKernelGGL((dw_wide_k<true>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
         else hipLaunchKernelGGL((dw_wide_k<false>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
         return;
@@ -1034,7 +1195,11 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
             const T *dz = wk.dz[l];
             // [dW | db] = dZ^T [X | 1], reduced over this chunk's rows in nsplit fixed slabs
             if (sp.ok) {
-                if constexpr (sizeof(T) == 4) run_dw_short(sp, l, dz, l == 0 ? x0 : wk.y[l], N, K, rows, slabs, s);
+                if constexpr (sizeof(T) == 4) {
+                    const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
+                    const bool bf16 = wide && h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0');
+                    run_dw_short(sp, l, dz, l == 0 ? x0 : wk.y[l], N, K, rows, slabs, bf16, s);
+                }
             } else {
                 Opnd<T> A{dz, 1, N, N, -1};
                 Opnd<T> B{l == 0 ? x0 : wk.y[l], 1, K, K, K};

@@ -637,7 +637,10 @@ def other_configs(dev):
     zb = hb.encode(xc, out_dtype=torch.float32)
     ms_be = event_ms(lambda: hb.encode(xc, out_dtype=torch.float32), 3)
     ms_bd = event_ms(lambda: hb.decode(zb), 3)
+    gb = torch.zeros_like(mc.flat)
+    ms_bt = event_ms(lambda: hb.fwd_bwd(xc, gb), 3)      # en1 / de4 / de4's input-gradient product and the two wide weight gradients on the bf16 MFMA
     res["c4_cfd_dense_2500_25"].update({
+        "bf16_train_fwd_bwd_rows_per_s": n / ms_bt * 1e3, "bf16_train_vs_fp32": ms_t / ms_bt,
         "bf16_encode_rows_per_s": n / ms_be * 1e3, "bf16_encode_frac_of_hbm": 10100 * n / ms_be / 1e6 / PEAK_HBM_GBS,
         "bf16_decode_rows_per_s": n / ms_bd * 1e3, "bf16_decode_frac_of_hbm": 10100 * n / ms_bd / 1e6 / PEAK_HBM_GBS,
         "bf16_encode_rel_err_vs_fp32": float(torch.linalg.norm(zb.double() - zc.double()) / torch.linalg.norm(zc.double()))})

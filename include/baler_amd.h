@@ -60,11 +60,13 @@ typedef enum bamd_dtype { BAMD_F32 = 0, BAMD_F64 = 1 } bamd_dtype;
  * activations and gradients through the chain, fp32 accumulation and fp32 partial gradients; params / m / v / grads stay
  * FLOAT (the caller's fp32 master copy and Adam state); bamd_adam_step re-rounds the bf16 fragments.  3.3x the F32 training
  * rate; one-step gradients within ~5e-3 rel-L2 of the fp64 reference; batches of <= 3072 rows run on the F32 small-batch
- * kernels instead (exact fp32, and faster there: 23 vs 34 us per 512-row step).  Available for the 24-column AE (latent 15/12/8/6)
- * and, for bamd_encode / bamd_decode, for the wide models CFD_dense_AE(2500, 25) and the 512-column model (their two wide
- * layers on the bf16 MFMA, HBM-bound; the narrow layers, training and validation of such a handle run in fp32);
- * other shapes of a BF16 handle are rejected by bamd_create.  bamd_fwd_bwd_latent and bamd_activation_means of a BF16
- * handle run on the fp32 layer-wise kernels. */
+ * kernels instead (exact fp32, and faster there: 18 vs 34 us per 512-row step).  Available for the 24-column AE (every fused latent
+ * size) and for the wide models CFD_dense_AE(2500, 25), CFD_dense_AE(625, 7) and the 512-column model: their two wide layers on
+ * the bf16 MFMA in bamd_encode / bamd_decode (HBM-bound) and in the training pass (forward of en1 / de4 and de4's input-gradient
+ * product; the six narrow layers, the loss, the masks and every weight-gradient product in fp32 on the fp32 activations the pass
+ * stores: one-step gradients within ~1e-3 rel-L2; BALER_AMD_BF16_WIDE_TRAIN=0: the F32 launches); validation of such a handle runs
+ * in fp32; other shapes of a BF16 handle are rejected by bamd_create.  bamd_activation_means of a BF16 handle runs on the fp32
+ * layer-wise kernels. */
 typedef enum bamd_mode { BAMD_MODE_F32 = 0, BAMD_MODE_F64 = 1, BAMD_MODE_BF16 = 2 } bamd_mode;
 
 /* Adam hyper-parameters of one step (torch.optim.Adam defaults are beta1=.9 beta2=.999 eps=1e-8). */

@@ -857,12 +857,13 @@ def test_bf16_mode_unsupported_shape():
         native.Handle(orc.ae_dims(100, 10), "bf16")
 
 
-@pytest.mark.parametrize("shape,n", [((2500, 25), 1), ((2500, 25), 33), ((2500, 25), 1000), ((512, 6), 17), ((512, 6), 4100)])
-def test_bf16_mode_wide_models(shape, n):
+@pytest.mark.parametrize("shape,n", [((2500, 25), 1), ((2500, 25), 33), ((2500, 25), 1000), ((625, 7), 129), ((512, 6), 17), ((512, 6), 4100)])
+def test_bf16_mode_wide_models(shape, n, monkeypatch):
     """BAMD_MODE_BF16 on the wide models: en1 / de4 on the bf16 MFMA (HBM-bound kernels), the narrow layers on the fp32 chain;
     bf16-level agreement with the oracle (inputs and the two wide weight matrices are rounded to bf16), ragged pair counts,
-    float32 / float64 rows, fused (un)normalisation; training calls of such a handle run the fp32 wide-layer kernels (exact) and
-    re-round the bf16 fragments before the next encode."""
+    float32 / float64 rows, fused (un)normalisation; training calls of such a handle run en1 / de4 / de4's input-gradient product on
+    the bf16 MFMA too (bf16 bar 2e-2; BALER_AMD_BF16_WIDE_TRAIN=0: the fp32 launches, exact) and re-round the bf16 fragments before
+    the next encode."""
     dims = orc.ae_dims(*shape)
     flat = orc.formula_params(dims, 41)
     h, p = make_handle(dims, flat, "bf16")
@@ -879,10 +880,19 @@ def test_bf16_mode_wide_models(shape, n):
     assert rel(h.encode(dev(x), features=feats, out_dtype=torch.float32).cpu().numpy(), zn) < 6e-3
     dec = h.decode(dev(zn, torch.float32), features=feats, out_dtype=torch.float64).cpu().numpy()
     assert rel(dec, orc.decode(dims, flat, zn) * rg + mn) < 6e-3
-    # training pass in fp32 (exact), then an optimiser step: the next encode must see the new weights
+    # training pass: bf16 wide products (bf16 bar), the fp32 launches behind the switch (exact), then an optimiser step: the next
+    # encode must see the new weights
     grads = torch.zeros_like(p)
-    h.fwd_bwd(dev(x, torch.float32), grads)
     lo, go = orc.fwd_bwd(dims, flat, x)
+    for xin in (dev(x, torch.float32), dev(x)):
+        grads.fill_(7.0)
+        h.fwd_bwd(xin, grads)
+        gh = grads.cpu().numpy().astype(np.float64)
+        # (a single row: one hidden unit whose pre-activation changes sign under bf16 rounding moves whole gradient rows -- LeakyReLU kink)
+        assert rel(gh[:-1], go) < (5e-3 if n >= 33 else 1e-1) and abs(gh[-1] - lo) < 1e-3 * lo, xin.dtype
+    monkeypatch.setenv("BALER_AMD_BF16_WIDE_TRAIN", "0")
+    h.fwd_bwd(dev(x, torch.float32), grads)
+    monkeypatch.delenv("BALER_AMD_BF16_WIDE_TRAIN")
     gh = grads.cpu().numpy().astype(np.float64)
     assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
     m, v = torch.zeros_like(p), torch.zeros_like(p)
