@@ -28,6 +28,12 @@ $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/cstats -o run -- $
 $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cpmc_f -o run -- $C > $O/cpmc_f.log 2>&1
 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cpmc_w -o run -- $C > $O/cpmc_w.log 2>&1
 $T rocprofv3 --kernel-trace --pmc $PM --output-format csv -d $O/cpmc_m -o run -- $C > $O/cpmc_m.log 2>&1
+# the same model on a BAMD_MODE_BF16 handle: training passes with the wide products on the bf16 MFMA
+CB="python3 $R/tools/prof_wide_bf16_train.py"
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/cbstats -o run -- $CB > $O/cbstats.log 2>&1
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cbpmc_f -o run -- $CB > $O/cbpmc_f.log 2>&1
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cbpmc_w -o run -- $CB > $O/cbpmc_w.log 2>&1
+$T rocprofv3 --kernel-trace --pmc $PM --output-format csv -d $O/cbpmc_m -o run -- $CB > $O/cbpmc_m.log 2>&1
 # the reference's own regime: 512-row optimiser steps (lat4_chain_kernel + lat2_dw_kernel), and 4096-row steps (lat2_chain_kernel)
 S="python3 $R/tools/bench_one_batch.py 512 400"
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/sstats -o run -- $S > $O/sstats.log 2>&1
@@ -43,5 +49,5 @@ $T rocprofv3 --kernel-trace --pmc $PM --output-format csv -d $O/fpmc_m -o run --
 # bf16 inference
 I="python3 $R/tools/bench_bf16_infer.py"
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/istats -o run -- $I > $O/istats.log 2>&1
-for d in stats bstats cstats sstats mstats fstats istats; do echo "== $d"; python3 $R/tools/kstats.py $O/$d 8; done
+for d in stats bstats cstats cbstats sstats mstats fstats istats; do echo "== $d"; python3 $R/tools/kstats.py $O/$d 8; done
 tail -1 $O/bench.json | cut -c1-400

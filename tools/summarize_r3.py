@@ -22,6 +22,8 @@ KEYS = (("train_dec_kernel", "train_dec"), ("train_enc_kernel", "train_enc"), ("
         ("reduce_tiles_k", "reduce_tiles_k"),
         ("wide_encode_lds_kernel", "wide_encode_lds_kernel<2500, 25"), ("wide_infer_kernel<DECODE>", "wide_infer_kernel<2500, 25, 1"), ("wide_decode_lds_kernel", "wide_decode_lds_kernel<2500, 25"),
         ("wide_train_fwd_kernel", "wide_train_fwd_kernel<2500, 25, true>"), ("wide_train_bwd_kernel", "wide_train_bwd_kernel<2500, 25>"),
+        ("wide_bf16_train_fwd_kernel", "wide_bf16_train_fwd_kernel<2500, 25"), ("wide_bf16_train_bwd_kernel", "wide_bf16_train_bwd_kernel<2500, 25"),
+        ("dw_wide_bf16_k<P = dZ>", "dw_wide_bf16_k<true>"), ("dw_wide_bf16_k<P = [X|1]>", "dw_wide_bf16_k<false>"),
         ("dw_wide_k<P = dZ>", "dw_wide_k<true>"), ("dw_wide_k<P = [X|1]>", "dw_wide_k<false>"), ("reduce_layers_k", "reduce_layers_k"))
 
 
@@ -57,6 +59,7 @@ import bench  # noqa: E402  (source_hash)
 fp32 = merge("")
 bf16 = merge("b")
 c4 = merge("c")
+c4b = merge("cb")
 small = merge("s")
 f64 = {k: v for k, v in load(f"{R}/fpmc_m/**/*counter_collection.csv").items()}
 for k, e in f64.items():
@@ -78,6 +81,7 @@ out = {
             "coalesced read, MI355X_MICROARCH.md; checked on minmax_partial: 96 MB reported for a 192 MB read)",
     "source_hash": bench.source_hash(), "rows": 1000000, "kernels": fp32, "bf16_kernels": bf16,
     "c4_note": "CFD_dense_AE(2500, 25), 32768 frames per launch, `python3 tools/bench_c4.py 32768`", "c4_kernels": c4,
+    "c4_bf16_note": "the same model on a BAMD_MODE_BF16 handle, training passes, `python3 tools/prof_wide_bf16_train.py`", "c4_bf16_kernels": c4b,
     "bs512_note": "512-row bamd_train_step, `python3 tools/bench_one_batch.py 512 400`", "bs512_kernels": small,
     "fp64_note": "fp64 handle, 262,144 rows per launch (512 rows for chain64 / dw64), SQ counters only, `python3 tools/prof_fp64.py`", "fp64_kernels": f64,
     "fwd_bwd_hbm_bytes_per_launch": sum(fp32[k]["hbm_bytes"] for k in ("train_dec_kernel", "train_enc_kernel", "reduce_slabs_k") if k in fp32),
@@ -85,6 +89,7 @@ out = {
 }
 json.dump(out, open(os.path.join(REPO, "profiles", "pmc_summary.json"), "w"), indent=1)
 STATS = (("stats", "r3_kernel_stats.csv"), ("bstats", "r3_bf16_kernel_stats.csv"), ("cstats", "r3_c4_kernel_stats.csv"),
+         ("cbstats", "r3_c4_bf16_train_kernel_stats.csv"),
          ("sstats", "r3_bs512_kernel_stats.csv"), ("mstats", "r3_bs4096_kernel_stats.csv"), ("fstats", "r3_fp64_kernel_stats.csv"),
          ("istats", "r3_bf16_infer_kernel_stats.csv"))
 for d, name in STATS:
@@ -95,7 +100,7 @@ d = json.loads(open(f"{R}/bench.json").read().strip().splitlines()[-1])
 if d.get("source_hash") == out["source_hash"]:
     d["roofline"]["traffic"] = out["fwd_bwd_hbm_bytes_per_launch"]
 json.dump(d, open(os.path.join(REPO, "profiles", "r3_bench.json"), "w"), indent=1)
-for name, tab in (("fp32", fp32), ("bf16", bf16), ("c4", c4), ("bs512", small), ("fp64", f64)):
+for name, tab in (("fp32", fp32), ("bf16", bf16), ("c4", c4), ("c4 bf16", c4b), ("bs512", small), ("fp64", f64)):
     for k, v in tab.items():
         print(f"{name} {k:28s} busy {100 * v.get('mfma_busy', 0):5.1f}%  valu/mfma {v.get('valu_per_mfma', 0):.2f}  wait_any {v.get('wait_any_frac', 0):.3f}  "
               f"hbm {v.get('hbm_bytes', 0) / 1e6:7.1f} MB  mfma {v.get('SQ_INSTS_MFMA', 0) / 1e6:.1f} M  lds_conflict {v.get('lds_conflict_frac', 0):.2f}")
