@@ -865,6 +865,144 @@ __global__ void __launch_bounds__(256) dw_wide_bf16_k(const float *__restrict__ 
     }
 }
 
+// dw_short_k's plain tiles on the bf16 MFMA, for the wide weight gradients of a BAMD_MODE_BF16 handle whose rows are not 16-byte
+// aligned (the exafel blocks' 625 columns): lane (g, i) loads column 16 t + i of rows 8 g + e (e = 0..7) of a 32-row block with dword
+// loads and packs the eight values of a tile into the MFMA's k slots.  120 loads per 26 MFMAs: issue-bound on the vector-memory
+// pipe (~63 us at 131,072 blocks), still well under the float32 kernel's MFMA time (364-390 us).
+template <int PT, int TQ, bool P_IS_N>
+__global__ void __launch_bounds__(256) dw_short_bf16_k(const float *__restrict__ dzm, const float *__restrict__ xm, int N, int K, int64_t rows,
+                                                       int64_t rps, float *__restrict__ slab, int64_t slab_size) {
+    using v4 = MF<float>::v4;
+    typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const float *__restrict__ pm = P_IS_N ? dzm : xm;
+    const float *__restrict__ qm = P_IS_N ? xm : dzm;
+    const int DP = P_IS_N ? N : K, DQ = P_IS_N ? K : N;
+    const int CQ = P_IS_N ? K + 1 : N;
+    const int qt0 = ((int)blockIdx.x * 4 + wave) * TQ;
+    if (qt0 * 16 >= CQ) return;
+    const int64_t r_begin = (int64_t)blockIdx.y * rps;
+    const int64_t r_end = r_begin + rps < rows ? r_begin + rps : rows;
+    if (r_begin >= r_end) return;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(pm + r_begin * DP), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(qm + r_begin * DQ), 0, 0x7fffffff, 0x00020000);
+    int offq[TQ];
+    const int offp0 = (8 * g * DP + i) * 4;
+    const int offpl = (8 * g * DP + (16 * (PT - 1) + i < DP ? 16 * (PT - 1) + i : DP - 1)) * 4;
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) { const int c = 16 * (qt0 + u) + i; offq[u] = (8 * g * DQ + (c < DQ ? c : DQ - 1)) * 4; }
+    auto ldp = [&](int voff, int soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, voff, soff, 0)); };
+    auto ldq = [&](int voff, int soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, voff, soff, 0)); };
+    const bool p_one = !P_IS_N && 16 * (PT - 1) + i == K;
+    bool q_one[TQ];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) q_one[u] = P_IS_N && 16 * (qt0 + u) + i == K;
+    v4 acc[TQ][PT];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[u][t] = (v4){0.f, 0.f, 0.f, 0.f};
+    struct Raw { float p[PT][8]; float q[TQ][8]; };
+    struct Pk { bf8 p[PT]; bf8 q[TQ]; };
+    const int64_t nr = r_end - r_begin;
+    auto load = [&](Raw &f, int64_t rb, bool tail) {
+        const int sp = (int)rb * DP * 4, sq = (int)rb * DQ * 4;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bool ok = true;
+            int back = 0;
+            if (tail) {                                            // rows beyond the range read its last row, dZ zeroed
+                ok = rb + 8 * g + e < nr;
+                back = ok ? 0 : (int)(rb + 8 * g + e - (nr - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < TQ; ++u) {
+                const float v = ldq(offq[u] - back * DQ * 4, sq + e * 4 * DQ);
+                f.q[u][e] = (tail && !P_IS_N && !ok) ? 0.f : v;
+            }
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                const float v = ldp((t == PT - 1 ? offpl : offp0 + 64 * t) - back * DP * 4, sp + e * 4 * DP);
+                f.p[t][e] = (tail && P_IS_N && !ok) ? 0.f : v;
+            }
+        }
+    };
+    auto pack8 = [&](const float (&a)[8]) {
+        const bf2 p0 = {(__bf16)a[0], (__bf16)a[1]}, p1 = {(__bf16)a[2], (__bf16)a[3]}, p2 = {(__bf16)a[4], (__bf16)a[5]}, p3 = {(__bf16)a[6], (__bf16)a[7]};
+        const u4 w = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1), __builtin_bit_cast(unsigned, p2),
+                      __builtin_bit_cast(unsigned, p3)};
+        return __builtin_bit_cast(bf8, w);
+    };
+    auto pack = [&](Pk &k, Raw &f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (!P_IS_N) f.p[PT - 1][e] = p_one ? 1.0f : f.p[PT - 1][e];
+            else {
+#pragma unroll
+                for (int u = 0; u < TQ; ++u) f.q[u][e] = q_one[u] ? 1.0f : f.q[u][e];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) k.p[t] = pack8(f.p[t]);
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) k.q[u] = pack8(f.q[u]);
+    };
+    auto mma = [&](const Pk &k) {
+#pragma unroll
+        for (int u = 0; u < TQ; ++u)
+#pragma unroll
+            for (int t = 0; t < PT; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k.q[u], k.p[t], acc[u][t], 0, 0, 0);
+    };
+    Raw ra;
+    Pk pk;
+    const int64_t nfull = nr >> 5;
+    if (nfull > 0) {
+        load(ra, 0, false);
+        for (int64_t b = 0; b < nfull; ++b) {
+            pack(pk, ra);
+            __builtin_amdgcn_sched_barrier(0);
+            if (b + 1 < nfull) load(ra, 32 * (b + 1), false);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(pk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (nr & 31) {
+        load(ra, 32 * nfull, true);
+        pack(pk, ra);
+        mma(pk);
+    }
+    // C map: register r of lane (g, i) = (q column 4 g + r of the tile, p column i), as dw_short_k
+    float *out = slab + (int64_t)blockIdx.y * slab_size;
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const int q0 = 16 * (qt0 + u) + 4 * g;
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int pc = 16 * t + i;
+            if (P_IS_N) {
+                if (pc < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (q0 + r < K) out[(int64_t)pc * K + q0 + r] = acc[u][t][r];
+                        else if (q0 + r == K) out[(int64_t)N * K + pc] = acc[u][t][r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (q0 + r < N) {
+                        if (pc < K) out[(int64_t)(q0 + r) * K + pc] = acc[u][t][r];
+                        else if (pc == K) out[(int64_t)N * K + q0 + r] = acc[u][t][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // grads[off + j] (+)= sum over the layer's splits of slab_l[split][j], splits in fixed order
 struct ReducePlan {
     int64_t off[9];        // parameter offsets of the layers (off[L] = parameter count); at most 8 layers
@@ -1109,6 +1247,12 @@ static void run_dw_short(const ShortPlan &pl, int l, const float *dz, const floa
         }
         if (pl.p_is_n[l]) hipLaunchKernelGGL((dw_wide_k<true>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
         else hipLaunchKernelGGL((dw_wide_k<false>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
+        return;
+    }
+    if (bf16 && pl.pt[l] == 13) {      // a wide layer whose rows are not 16-byte aligned (625 columns), BAMD_MODE_BF16 handle
+        const int64_t size = (int64_t)N * K + N;
+        if (pl.p_is_n[l]) hipLaunchKernelGGL((dw_short_bf16_k<13, 2, true>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
+        else hipLaunchKernelGGL((dw_short_bf16_k<13, 2, false>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
         return;
     }
     switch (pl.pt[l]) {

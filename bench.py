@@ -658,6 +658,11 @@ def other_configs(dev):
         "blocks": n, "path": he.path, "encode_rows_per_s": n / ms_e * 1e3, "encode_frac_of_mfma_peak": 300_700 * n / ms_e / 1e9 / PEAK_TFLOPS["fp32"],
         "decode_rows_per_s": n / ms_d * 1e3, "decode_frac_of_mfma_peak": 300_700 * n / ms_d / 1e9 / PEAK_TFLOPS["fp32"],
         "train_fwd_bwd_rows_per_s": n / ms_t * 1e3, "train_frac_of_mfma_peak": 1_554_200 * n / ms_t / 1e9 / PEAK_TFLOPS["fp32"]}
+    heb = native.Handle([625, 200, 100, 50, 7, 50, 100, 200, 625], "bf16")
+    heb.load_params(me.flat)
+    ms_bt = event_ms(lambda: heb.fwd_bwd(xe, ge), 3)
+    res["exafel_625_7"].update({"bf16_train_fwd_bwd_rows_per_s": n / ms_bt * 1e3, "bf16_train_vs_fp32": ms_t / ms_bt})
+    heb.close()
     he.close()
     del xe, ge, ze
     n = 262144
