@@ -255,3 +255,25 @@ def test_wide_model_full_size_and_rate():
     assert abs(gb[-1] - gf[-1]) < 1e-3 * gf[-1] and rel(gb[:-1], gf[:-1]) < 5e-3
     assert np.isfinite(gb).all()
     assert tb < tf / 1.5
+
+
+@pytest.mark.parametrize("shape,n", [((512, 6), 300001), ((625, 7), 270000)])
+def test_wide_model_large_batches(shape, n):
+    """More 128-row groups than workgroups (the persistent loops of the bf16 launches take several passes; the shared fragment stage is
+    reused across them) and, for 625 columns, the weight gradients of rows that are not 16-byte aligned (dw_short_bf16_k): bf16 pass
+    against the fp32 pass of an F32 handle with the same parameters, and bitwise reproducibility."""
+    dims = orc.ae_dims(*shape)
+    flat = orc.formula_params(dims, 3)
+    x = torch.rand((n, shape[0]), dtype=torch.float32, device="cuda")
+    res = {}
+    for mode in ("fp32", "bf16"):
+        h, p = handle(flat, mode, dims)
+        g, g2 = torch.zeros_like(p), torch.zeros_like(p)
+        h.fwd_bwd(x, g)
+        h.fwd_bwd(x, g2)
+        assert torch.equal(g, g2)
+        res[mode] = g.cpu().numpy().astype(np.float64)
+        h.close()
+    a, b = res["bf16"], res["fp32"]
+    assert np.isfinite(a).all()
+    assert abs(a[-1] - b[-1]) < 1e-4 * b[-1] and rel(a[:-1], b[:-1]) < 5e-3
