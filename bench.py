@@ -131,7 +131,8 @@ def timed(fn, steps, world, dev):
 
 def warm(fn, ms=40.0):
     """Run fn back to back for ~`ms` of GPU time before a measurement: the first ~20-30 ms of a new kernel mix run 10-13 % slower than
-    its steady state (measured: bf16 fwd_bwd 0.87 ms for the first 20 launches, 0.77 after), whatever ran before."""
+    its steady state (measured: bf16 fwd_bwd 0.87 ms for the first 20 launches, 0.77 after), whatever ran before.  The number of calls
+    depends on the clock: ONLY for functions without collectives (ranks would run different counts); use a fixed count otherwise."""
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -390,7 +391,8 @@ def main():
                     bdist.allreduce_sum(gb)
                 tb["t"] += 1
                 hb.adam_step(fb, gb, mb, vb, tb["t"], 1e-3)
-            warm(bf16_step)
+            for _ in range(50):      # ~40 ms to the steady state; a fixed count: the step holds a collective when world > 1
+                bf16_step()
             t_bt = timed(bf16_step, max(5, a.steps // 2), world, dev)
             out["bf16_train_rows_per_s"] = world * a.rows * max(5, a.steps // 2) / t_bt
             ms = event_ms(lambda: hb.fwd_bwd(x, gb), 20)
@@ -433,7 +435,8 @@ def main():
                     h.fwd_bwd(xb, grads)
                     bdist.allreduce_sum(grads)
                     h.adam_step(flat, grads, m, v, state["t"], 1e-3, loss_accum=loss_acc)
-            batch_pass()
+            for _ in range(4 if bs <= 4096 else 1):      # to the steady state (fixed count: collectives inside when world > 1)
+                batch_pass()
             tb_ = timed(batch_pass, 1, world, dev)
             by_batch[str(bs)] = {"rows_per_s": world * bs * nb / tb_, "us_per_step": 1e6 * tb_ / nb, "steps_timed": nb,
                                  "tflops": FLOP_TRAIN_ROW * world * bs * nb / tb_ / 1e12,

@@ -151,7 +151,7 @@ bdist.barrier()
 def test_sharding_collectives_world3_gloo(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, REPO=REPO, OMP_NUM_THREADS="1")
+    env = dict(os.environ, REPO=REPO, OMP_NUM_THREADS="1", BALER_AMD_FORCE_DEVICE="0")      # (on a one-GPU box all three ranks share device 0)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr",
                           "127.0.0.1", "--master-port", str(free_port()), str(script)],
                          env=env, capture_output=True, text=True, timeout=600)
