@@ -143,15 +143,20 @@ def warm(fn, ms=40.0):
 
 
 def event_ms(fn, reps):
-    """Average duration of fn on the launch stream by HIP events (fn must only enqueue work)."""
-    warm(fn)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    """Duration of fn on the launch stream by HIP events (fn must only enqueue work): after warm(), the MEDIAN of five samples of `reps`
+    back-to-back launches each -- single samples of a few launches scatter by +-15 % with the clock state (boost after an idle gap,
+    power cap under sustained MFMA load)."""
+    warm(fn, 25.0)
+    samples = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        samples.append(e0.elapsed_time(e1) / reps)
+    return sorted(samples)[2]
 
 
 def cpu_model():
