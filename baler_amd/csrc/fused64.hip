@@ -457,7 +457,10 @@ struct Adam64 {
 enum { DW_WRITE = 0, DW_ADAM = 1 };
 template <class N, int MODE>
 __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ imgs, int nblk, const double *__restrict__ loss_part,
-                                                   const int *__restrict__ inv_map, double *__restrict__ grads, Adam64 ad) {
+                                                   const int *__restrict__ inv_map, double *__restrict__ grads, Adam64 ad,
+                                                   const double *__restrict__ part, int nsplit) {
+    // nsplit == 0: the whole job.  nsplit > 0: the tiles' partial sums over `nsplit` block ranges are in `part` (dw64m_kernel); this
+    // launch adds them in range order and finishes (store / Adam).
     constexpr int T = N::slab_off(N::L), np = N::nparams();
     constexpr int kPerXcd = (T + 1 + 7) / 8;
     __shared__ __attribute__((aligned(32))) d4 red[4 * 64];
@@ -489,7 +492,7 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     int s0 = 0, s1 = 0;
     if (MODE == DW_ADAM && p >= 0) { pm = ad.m[p]; pv = ad.v[p]; pp = ad.params[p]; s0 = ad.sc_off[p]; s1 = ad.sc_off[p + 1]; }
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int b0 = wave; b0 < nblk; b0 += 16) {   // 4 blocks per wave in flight
+    for (int b0 = wave; b0 < (nsplit > 0 ? 0 : nblk); b0 += 16) {   // 4 blocks per wave in flight
         d4 a[4], x[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -508,7 +511,11 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     // thread e = 4 lane' + r' owns D[n slot = g' + 4 r'][k slot = lane' & 15]  (f64 C/D map)
     const double *rf = (const double *)red;
     const int e = threadIdx.x;
-    const double gsum = ((rf[e] + rf[256 + e]) + rf[512 + e]) + rf[768 + e];
+    double gsum = ((rf[e] + rf[256 + e]) + rf[512 + e]) + rf[768 + e];
+    if (nsplit > 0) {
+        gsum = 0.0;
+        for (int k = 0; k < nsplit; ++k) gsum += part[((int64_t)tile * nsplit + k) * 256 + e];
+    }
     if (p < 0) return;
     if (grads) grads[p] = gsum;
     if (MODE == DW_ADAM) {   // elementwise.hip adam_k, on the parameters this tile owns
@@ -525,6 +532,96 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     }
 }
 
+// Weight-gradient tiles in 2 x 4 BLOCKS for large fp64 batches.  dw64_kernel's one-tile workgroups each read their two image slices of
+// every 16-row block: at 262,144 rows that is 19.5 GB through L2 / fabric (3.6 of the step's 3.9 ms, MFMA busy 14 %).  Here a workgroup
+// owns 2 output tiles x 4 input tiles of one layer: 6 slices per block feed 8 tiles (0.49x the reads), over `nsplit` block ranges
+// (blockIdx.y); partial tiles go to `part`, dw64_kernel(nsplit) finishes.  Tiles beyond a layer's edge run on a clamped slice and are not
+// stored: uniform code.  (The fp32 twin of this kernel gained 1-5 % at <= 12,288 rows, where unique image bytes bound the step:
+// fused.hip history / DESIGN.md section 4.1; fp64 batches run this decomposition up to 262,144 rows, where the re-reads dominate.)
+template <class N, int MN, int MK> struct Dwm64 {
+    __host__ __device__ static constexpr int mn(int l) { return (tiles(N::dim(l + 1)) + MN - 1) / MN; }
+    __host__ __device__ static constexpr int mk(int l) { return (tiles(N::dim(l) + 1) + MK - 1) / MK; }
+    __host__ __device__ static constexpr int off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += mn(j) * mk(j); return s; }
+    static constexpr int total = off(N::L);
+    static constexpr int per_xcd = (total + 7) / 8;
+};
+template <class N, int MN, int MK>
+__global__ void __launch_bounds__(256) dw64m_kernel(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit) {
+    using D = Dwm64<N, MN, MK>;
+    constexpr int NA = MN * MK, U = 2, HALF = NA / 2;
+    static_assert(NA % 2 == 0, "the reduction runs in two halves");
+    __shared__ __attribute__((aligned(32))) d4 red[HALF * 4 * 64];       // 32 KB
+    const int mac = (blockIdx.x & 7) * D::per_xcd + (blockIdx.x >> 3);
+    if (mac >= D::total) return;
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < N::L; ++j) if (mac >= D::off(j)) l = j;
+    int ntc = tiles(N::dim(1)), ktc = tiles(N::dim(0) + 1), mnc = D::mn(0), moff = 0, soff = 0, xo = N::x_off(0), zo = N::z_off(0);
+#pragma unroll
+    for (int j = 1; j < N::L; ++j)
+        if (l == j) { ntc = tiles(N::dim(j + 1)); ktc = tiles(N::dim(j) + 1); mnc = D::mn(j); moff = D::off(j); soff = N::slab_off(j);
+                      xo = N::x_off(j); zo = N::z_off(j); }
+    const int idx = mac - moff, mkt = idx / mnc, mnt = idx - mkt * mnc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    const double *pz[MN], *px[MK];
+    int nt[MN], kt[MK];
+#pragma unroll
+    for (int a = 0; a < MN; ++a) {
+        nt[a] = MN * mnt + a;
+        const int c = nt[a] < ntc ? nt[a] : ntc - 1;
+        pz[a] = imgs + ((zo + 16 * c + i) * 16 + 4 * g);
+    }
+#pragma unroll
+    for (int b = 0; b < MK; ++b) {
+        kt[b] = MK * mkt + b;
+        const int c = kt[b] < ktc ? kt[b] : ktc - 1;
+        px[b] = imgs + ((xo + 16 * c + i) * 16 + 4 * g);
+    }
+    d4 acc[NA];
+#pragma unroll
+    for (int t = 0; t < NA; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int per = (nblk + nsplit - 1) / nsplit, blo = (int)blockIdx.y * per, bhi = blo + per < nblk ? blo + per : nblk;
+    for (int b0 = blo + wave; b0 < bhi; b0 += 4 * U) {
+        d4 za[U][MN], xa[U][MK];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + 4 * u;
+            const bool ok = b < bhi;
+            const int64_t o = (int64_t)(ok ? b : blo) * N::img_doubles;
+#pragma unroll
+            for (int a = 0; a < MN; ++a) { za[u][a] = *(const d4 *)(pz[a] + o); if (!ok) za[u][a] = (d4){0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+            for (int c = 0; c < MK; ++c) xa[u][c] = *(const d4 *)(px[c] + o);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < MK; ++c)
+#pragma unroll
+                    for (int a = 0; a < MN; ++a) acc[c * MN + a] = mfma(za[u][a][r], xa[u][c][r], acc[c * MN + a]);
+    }
+    const double *rf = (const double *)red;
+    const int e = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < HALF; ++t) red[(t * 4 + wave) * 64 + lane] = acc[h * HALF + t];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < HALF; ++t) {
+            const int ta = h * HALF + t, c = ta / MN, a = ta % MN;
+            if (nt[a] >= ntc || kt[c] >= ktc) continue;
+            const double *q = rf + t * 1024;
+            const double gsum = ((q[e] + q[256 + e]) + q[512 + e]) + q[768 + e];
+            const int tile = soff + kt[c] * ntc + nt[a];
+            part[((int64_t)tile * nsplit + blockIdx.y) * 256 + e] = gsum;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) pack64_k(const double *__restrict__ params, const int *__restrict__ src, int count,
                                                 double *__restrict__ packed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -534,10 +631,10 @@ __global__ void __launch_bounds__(256) pack64_k(const double *__restrict__ param
 struct Ops64;
 struct State64 {
     const Ops64 *ops = nullptr;
-    DevBuf pack_src, inv_map, sc_off, sc_idx, packed, imgs;
+    DevBuf pack_src, inv_map, sc_off, sc_idx, packed, imgs, dwpart;
     int packed_doubles = 0;
     // larger batches: layer-wise kernels (BALER_AMD_LATENCY_ROWS overrides, as for fp32).  The fused pair stays ahead of them at every
-    // size measured (us per step, fused / layer-wise: 16384 rows 347 / 847, 65536 rows 1324 / 2666); the limit is the images' memory
+    // size measured (us per step, fused / layer-wise: 16384 rows 227 / 847, 65536 rows 850 / 2666); the limit is the images' memory
     // (13 KB per row: 3.5 GB at 262144 rows)
     int64_t max_rows = 262144;
 };
@@ -639,12 +736,27 @@ template <int F, int Z> struct Impl64 {
         hipLaunchKernelGGL((chain64_kernel<F, Z, 4>), dim3(nblk), dim3(256), kLds, s, (const d4 *)st->packed.p, x, x_dtype == BAMD_F64, n,
                            features, (double *)st->imgs.p, (double *)h->lossp.p);
         const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
+        // from 64 blocks (1,024 rows) on: 2 x 4 tile blocks over block ranges + the finishing launch (BALER_AMD_DW64_MACRO_BLKS, 0 = off).
+        // Measured ms per bamd_fwd_bwd, blocks / one tile per workgroup: 512 rows 0.045 / 0.040, 1,024: 0.046 / 0.049, 2,048: 0.054 / 0.064,
+        // 4,096: 0.068 / 0.094, 16,384: 0.227 / 0.341, 65,536: 0.85 / 1.32, 262,144: 3.22 / 5.51 (0.37 / 0.22 of the fp64 MFMA peak)
+        static const int macro_blks = getenv("BALER_AMD_DW64_MACRO_BLKS") ? atoi(getenv("BALER_AMD_DW64_MACRO_BLKS")) : 64;
+        int nsplit = 0;
+        const double *part = nullptr;
+        if (macro_blks > 0 && nblk >= macro_blks) {
+            using D = Dwm64<N, 2, 4>;
+            nsplit = nblk >= 4096 ? 16 : 8;
+            rc = st->dwpart.ensure((size_t)(N::slab_off(N::L) + 1) * nsplit * 256 * sizeof(double));
+            if (rc) return rc;
+            part = (const double *)st->dwpart.p;
+            hipLaunchKernelGGL((dw64m_kernel<N, 2, 4>), dim3(8 * D::per_xcd, nsplit), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
+                               (double *)st->dwpart.p, nsplit);
+        }
         if (ad)
             hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk, (const double *)h->lossp.p,
-                               (const int *)st->inv_map.p, grads, *ad);
+                               (const int *)st->inv_map.p, grads, *ad, part, nsplit);
         else
             hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk, (const double *)h->lossp.p,
-                               (const int *)st->inv_map.p, grads, Adam64{});
+                               (const int *)st->inv_map.p, grads, Adam64{}, part, nsplit);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
@@ -710,7 +822,7 @@ int fused64_setup(bamd_handle *h) {
 void fused64_teardown(bamd_handle *h) {
     State64 *st = st64(h);
     if (!st) return;
-    st->pack_src.release(); st->inv_map.release(); st->sc_off.release(); st->sc_idx.release(); st->packed.release(); st->imgs.release();
+    st->pack_src.release(); st->inv_map.release(); st->sc_off.release(); st->sc_idx.release(); st->packed.release(); st->imgs.release(); st->dwpart.release();
     delete st;
     h->fused64_state = nullptr;
 }

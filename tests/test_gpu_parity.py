@@ -216,11 +216,11 @@ def test_gradients_ragged(n, path, data10k, monkeypatch):
     assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
 
 
-@pytest.mark.parametrize("n", [1, 7, 16, 17, 272, 513, 4099, 12288, 12289])
+@pytest.mark.parametrize("n", [1, 7, 16, 17, 272, 513, 1009, 1040, 4099, 12288, 12289, 70001])
 def test_fp64_fused_step_ragged(n, data10k):
-    """fp64 mode: batches up to 12288 rows run on the fused fp64 step (chain + weight-gradient tiles on v_mfma_f64_16x16x4_f64,
-    fused64.hip), larger ones on the layer-wise kernels; both within 1e-11 of the scalar fp64 oracle, and
-    bamd_train_step == bamd_fwd_bwd + bamd_adam_step bit for bit."""
+    """fp64 mode: batches up to 262144 rows run on the fused fp64 step (chain + weight-gradient tiles on v_mfma_f64_16x16x4_f64,
+    fused64.hip; from 1024 rows on the tiles in 2 x 4 blocks over 8 or 16 block ranges + a finishing launch), larger ones on the
+    layer-wise kernels; within 1e-11 of the scalar fp64 oracle, and bamd_train_step == bamd_fwd_bwd + bamd_adam_step bit for bit."""
     dims = orc.ae_dims(24, 15)
     flat = orc.formula_params(dims, 23)
     x = data10k[:n] if n <= 10000 else orc.normalize(synth.cms_rows(n, row0=11))
