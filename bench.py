@@ -491,7 +491,7 @@ def main():
                                         "frac": FLOP_ENCODE_ROW * n64 / ms / 1e9 / PEAK_TFLOPS["fp64"], "rows_per_s": n64 / ms * 1e3}
             n64t = min(a.rows, 65536)
             ms = event_ms(lambda: h64.fwd_bwd(x[:n64t], g64), 3)
-            extra_roof["train_f64"] = {"bound": "mfma", "kernel": "bamd_fwd_bwd, BAMD_MODE_F64 (chain64_kernel + dw64_kernel, the fused pair up to 262144 rows)", "rows": n64t,
+            extra_roof["train_f64"] = {"bound": "mfma", "kernel": "bamd_fwd_bwd, BAMD_MODE_F64 (chain64_kernel + dw64m_kernel + dw64_kernel: the fused pair, weight-gradient tiles in 2 x 4 blocks)", "rows": n64t,
                                        "launch_ms": ms, "unit": "TFLOP/s", "achieved": FLOP_TRAIN_ROW * n64t / ms / 1e9, "peak": PEAK_TFLOPS["fp64"],
                                        "frac": FLOP_TRAIN_ROW * n64t / ms / 1e9 / PEAK_TFLOPS["fp64"], "rows_per_s": n64t / ms * 1e3}
             t64 = {"t": 0}
