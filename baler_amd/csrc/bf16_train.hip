@@ -105,8 +105,21 @@ template <int F, int Z> struct TNet {
 
 // Which layers a launch covers.  PART 0: forward 0..7, loss, backward 7..2 (input-gradient chain down to dZ_1).
 // PART 1: forward 0, backward 1..0.
+// BAMD_BF16_HANDX = 1: PART 0 also hands X_0 (the bf16 input image) and X_1 (layer 0's output) over, so PART 1 neither reads the rows
+// nor recomputes layer 0 (its rows phase + layer 0 were 2.7k of its 7.5k cycles per iteration); the hand-off record is TILE-major per
+// 64-row group -- [slot][64 rows][32 B], slots = 7 tiles of dZ_1, 13 of X_1, 2 halves of X_0 = 704 B per row -- so that PART 0's
+// 8-byte tile stores and PART 1's 32-byte row-slot loads are both contiguous per instruction.  0 (default): PART 1 reads the rows and
+// recomputes layer 0; dZ_1 only is handed over, row-major, 224 B per row.
+// MEASURED AND REJECTED: identical results, 0.811 vs 0.774 ms per 1M rows -- PART 0 610 -> 641 us (14 more tile stores per lane and
+// iteration), PART 1 243 -> 247 us: it moves 704 instead of 416 B per row (2.9 TB/s with its slabs) one iteration ahead and is bound
+// by that, not by the layer-0 work it no longer does.  The fp32 pair showed the same (fused.hip, "hand en1's output").
+#ifndef BAMD_BF16_HANDX
+#define BAMD_BF16_HANDX 0
+#endif
+constexpr bool kHandX = BAMD_BF16_HANDX;
+constexpr int kHandSlots = 7 + 13 + 2, kHandGroupBytes = kHandSlots * 2048;
 template <int PART> struct Part {
-    static constexpr int fwd_end = PART == 1 ? 1 : 8;        // forward layers [0, fwd_end)
+    static constexpr int fwd_end = PART == 1 ? (kHandX ? 0 : 1) : 8;        // forward layers [0, fwd_end)
     static constexpr int bwd_hi = PART == 1 ? 1 : 7;         // backward layers bwd_hi .. bwd_lo
     static constexpr int bwd_lo = PART == 0 ? 2 : 0;
     __host__ __device__ static constexpr bool has(int l) { return l <= bwd_hi && l >= bwd_lo; }
@@ -406,6 +419,25 @@ __device__ __forceinline__ void acc_visit(ChainAcc<NT> &acc, lds_p img, const La
     for (int k = 0; k < SP::MS; ++k) {
         const int t = SP::m0 + k;                 // compile-time after unrolling
         fn(acc.am[k], wm0 + lay.wr(t & 1) + 32 * (t & ~1));
+    }
+}
+
+// the same, `fn(tile, address, output tile index, row tile index)`
+template <int NT, int SOUT, class Fn>
+__device__ __forceinline__ void acc_visit_idx(ChainAcc<NT> &acc, lds_p img, const Lay &lay, int wave, Fn fn) {
+    using SP = Split<NT>;
+    const lds_p wn = img + lay.wr(wave & 1) + 32 * (wave & ~1);
+#pragma unroll
+    for (int k = 0; k < SP::NS; ++k) {
+        if (SP::ragged && k == SP::NS - 1 && wave + 4 * k >= NT) continue;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fn(acc.an[k][m], wn + 128 * k + 16 * m * SOUT, wave + 4 * k, m);
+    }
+    const lds_p wm0 = img + 16 * wave * SOUT;
+#pragma unroll
+    for (int k = 0; k < SP::MS; ++k) {
+        const int t = SP::m0 + k;
+        fn(acc.am[k], wm0 + lay.wr(t & 1) + 32 * (t & ~1), t, wave);
     }
 }
 
@@ -724,18 +756,32 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     if constexpr (kRD > 4) issue<N, PART, 3>(ring, ws, wave);
     if constexpr (kRD > 5) issue<N, PART, 4>(ring, ws, wave);
     static_assert(kRD >= 2 && kRD <= 6, "ring depth");
+    constexpr bool kRowsIn = PART == 0 || !kHandX;           // this launch reads the input rows
     RawX<F> xraw;
-    x_issue<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15), n, lane >> 4);
+    if constexpr (kRowsIn) x_issue<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15), n, lane >> 4);
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    constexpr int HB = N::hand_tiles * 32;                   // hand-off bytes per row
+    constexpr int HB = N::hand_tiles * 32;                   // hand-off bytes per row (kHandX = 0)
     static_assert(N::iblocks(2) * 64 >= HB, "hand-off row fits the image row");
+    static_assert(!kHandX || (N::hand_tiles == 7 && N::nt(0) == 13 && N::istride(0) == 64), "hand-off slots");
     const int hr = threadIdx.x >> 2, hp = threadIdx.x & 3;
-    u4v hand[PART == 1 ? 4 : 1];
-    if constexpr (PART == 1) {
-        const u4v *src = (const u4v *)((const unsigned char *)dz + ((int64_t)blockIdx.x * kRows + hr) * HB) + hp;
+    u4v hand[PART == 1 ? (kHandX ? 12 : 4) : 1];
+    // kHandX: thread (row = lane, wave q) moves the row's 32 bytes of slots q, q + 4, .., q + 20 (< 22): two 16-byte chunks each
+    auto hand_load = [&](int64_t g_) {
+        if constexpr (PART == 1 && kHandX) {
+            const u4v *src = (const u4v *)((const unsigned char *)dz + g_ * kHandGroupBytes + lane * 32);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hand[i] = src[(16 * (hp + 4 * i) < HB) ? 4 * i : 0];
-    }
+            for (int i = 0; i < 6; ++i) {
+                const int sl = wave + 4 * i < kHandSlots ? wave + 4 * i : 0;
+                hand[2 * i] = src[sl * 128];
+                hand[2 * i + 1] = src[sl * 128 + 1];
+            }
+        } else if constexpr (PART == 1) {
+            const u4v *src = (const u4v *)((const unsigned char *)dz + (g_ * kRows + hr) * HB) + hp;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hand[i] = src[(16 * (hp + 4 * i) < HB) ? 4 * i : 0];
+        }
+    };
+    hand_load(blockIdx.x);
 
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         // keep the weight loads and the LDS address arithmetic inside the loop (LICM would hoist hundreds of registers)
@@ -747,7 +793,8 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
         const int64_t row = grp * kRows + 16 * wave + j;
         const bool valid = row < n;
         // ---- input rows -> image 0 (bf16, with the ones slot) and the fp32 copy the loss uses -------------------------
-        {
+        u2 *const hgrp = dz + grp * (kHandGroupBytes / 8);       // this group's hand-off record (kHandX), in 8-byte units
+        if constexpr (kRowsIn) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -764,20 +811,36 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                 float *xr = xf + (16 * wave + j) * 32 + 8 * g;
                 *(float4 *)xr = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4 *)(xr + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                if constexpr (kHandX)      // X_0 for the second launch: slots 20 / 21 = features 0..15 / 16..31 of the row
+                    *(bf8 *)((unsigned char *)hgrp + (20 + (g >> 1)) * 2048 + (16 * wave + j) * 32 + 16 * (g & 1)) = o;
             }
+            x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);       // next iteration's rows, a whole iteration ahead
         }
-        x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);       // next iteration's rows, a whole iteration ahead
-        if constexpr (PART == 1) {
+        if constexpr (PART == 1 && kHandX) {
+            // dZ_1, X_1, X_0 of these rows from the first launch -> regions 2, 1, 0, at their swizzled places; requested a whole
+            // iteration ahead, like the rows of the first launch
+            const int sg = (lane >> 1) & 3;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int sl = wave + 4 * i;              // wave-uniform
+                if (sl < kHandSlots) {
+                    const int off = sl < 7 ? N::zoff(1) : (sl < 20 ? N::ioff(1) : N::ioff(0));
+                    const int st = sl < 7 ? N::istride(2) : (sl < 20 ? N::istride(1) : N::istride(0));
+                    const int t = sl < 7 ? sl : (sl < 20 ? sl - 7 : sl - 20);
+                    const int o0 = off + lane * st + (((2 * t) ^ sg) << 4);      // chunks 2 t, 2 t + 1 of the row: the second = bit 4 flipped
+                    *(u4v __attribute__((address_space(3))) *)(img + o0) = hand[2 * i];
+                    *(u4v __attribute__((address_space(3))) *)(img + (o0 ^ 16)) = hand[2 * i + 1];
+                }
+            }
+            hand_load(grp + gridDim.x < ngroups ? grp + gridDim.x : ngroups - 1);
+        } else if constexpr (PART == 1) {
             // dZ_1 of these rows from the first launch (row-major, 224 B per row) -> region 2: thread (r, p) moves chunks
             // p, p + 4, p + 8 (and p + 12 for p < 2) of row r to their swizzled places; requested a whole iteration ahead, like the rows
             const lds_p dst = img + N::zoff(1) + hr * N::istride(2) + ((hp ^ ((hr >> 1) & 3)) << 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (16 * (hp + 4 * i) < HB) *(u4v __attribute__((address_space(3))) *)(dst + 64 * i) = hand[i];
-            const int64_t gn = grp + gridDim.x < ngroups ? grp + gridDim.x : ngroups - 1;
-            const u4v *src = (const u4v *)((const unsigned char *)dz + (gn * kRows + hr) * HB) + hp;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hand[i] = src[(16 * (hp + 4 * i) < HB) ? 4 * i : 0];
+            hand_load(grp + gridDim.x < ngroups ? grp + gridDim.x : ngroups - 1);
         }
         __syncthreads();
         BT(1);
@@ -809,7 +872,25 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                 lds_w64(ob + lo.wr(t & 1) + 32 * (t & ~1), pk[t]);                                                           \
             }                                                                                                                \
         }
-        BAMD_FWD(0)
+        if constexpr (P::fwd_end >= 1) {
+            if constexpr (PART == 0 && kHandX) {      // layer 0 with its output tiles also handed to the second launch (slots 7 + t)
+                ChainAcc<N::nt(0)> acc;
+                chain_mm<N, PART, SC::fstep(0), N::kb(0), N::nt(0), N::istride(0)>(acc, img + N::ioff(0) + lay_of<N::istride(0)>(ls).row, ring, ws, wave);
+                BT(40);
+                acc_visit_idx<N::nt(0), N::istride(1)>(acc, img + N::ioff(1), lay_of<N::istride(1)>(ls), wave,
+                                                       [&](v4 &a, lds_p dst, int t, int m) {
+                                                           lrelu4(a);
+                                                           const u2 pk = pack4(a);
+                                                           lds_w64(dst, pk);
+                                                           hgrp[(7 + t) * 256 + (16 * m + j) * 4 + g] = pk;
+                                                       });
+                BT(41);
+                __syncthreads();
+                BT(2);
+            } else {
+                BAMD_FWD(0)
+            }
+        }
         if constexpr (P::fwd_end == 8) {
             BAMD_FWD(1)
             {
@@ -939,7 +1020,10 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
             // carry zeros (their dL/drecon is zero)
             static_assert(N::ntb(2) == N::hand_tiles, "hand-off width");
 #pragma unroll
-            for (int t = 0; t < N::ntb(2); ++t) dz[row * (4 * N::hand_tiles) + 4 * t + g] = q1[t];
+            for (int t = 0; t < N::ntb(2); ++t) {
+                if constexpr (kHandX) hgrp[t * 256 + (16 * wave + j) * 4 + g] = q1[t];      // slot t, tile-major
+                else dz[row * (4 * N::hand_tiles) + 4 * t + g] = q1[t];
+            }
             BT(56);
             __syncthreads();
             BT(57);
@@ -1138,7 +1222,8 @@ template <int F, int Z> struct TImpl {
         // tiles + one double per workgroup for the loss
         int rc = h->slabs.ensure(((size_t)st->ntiles * 1024 + 16) * (size_t)grid);
         if (rc) return rc;
-        rc = st->dz.ensure((size_t)ngroups * kRows * N::hand_tiles * 32);          // dZ_1 hand-off: 112 bf16 per row, whole row groups
+        rc = st->dz.ensure(kHandX ? (size_t)ngroups * kHandGroupBytes              // dZ_1 + X_1 + X_0: 704 B per row, whole row groups
+                                  : (size_t)ngroups * kRows * N::hand_tiles * 32);
         if (rc) return rc;
         hipLaunchKernelGGL((bf16_train_kernel<F, Z, 0>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
         hipLaunchKernelGGL((bf16_train_kernel<F, Z, 1>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
