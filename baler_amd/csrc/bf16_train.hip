@@ -117,6 +117,14 @@ template <int F, int Z> struct TNet {
 #define BAMD_BF16_HANDX 0
 #endif
 constexpr bool kHandX = BAMD_BF16_HANDX;
+// PART 1 requests the NEXT iteration's rows and hand-off records right after the last fragment wait of its input-gradient product
+// (layer 1) instead of at the top of the iteration.  Loads of a wave retire in order: requested at the top, these HBM fetches (~2 us)
+// stood in front of every fragment requested after them, and the product's third k block -- 3,000 cycles later -- waited for them.
+// From the new place the next wait on a younger load is a whole epilogue + two weight-gradient phases + the rows phase away.
+#ifndef BAMD_BF16_LATE_PF
+#define BAMD_BF16_LATE_PF 1
+#endif
+constexpr bool kLatePf = BAMD_BF16_LATE_PF;
 constexpr int kHandSlots = 7 + 13 + 2, kHandGroupBytes = kHandSlots * 2048;
 template <int PART> struct Part {
     static constexpr int fwd_end = PART == 1 ? (kHandX ? 0 : 1) : 8;        // forward layers [0, fwd_end)
@@ -814,7 +822,8 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                 if constexpr (kHandX)      // X_0 for the second launch: slots 20 / 21 = features 0..15 / 16..31 of the row
                     *(bf8 *)((unsigned char *)hgrp + (20 + (g >> 1)) * 2048 + (16 * wave + j) * 32 + 16 * (g & 1)) = o;
             }
-            x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);       // next iteration's rows, a whole iteration ahead
+            if constexpr (!(PART == 1 && kLatePf))
+                x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);       // next iteration's rows, a whole iteration ahead
         }
         if constexpr (PART == 1 && kHandX) {
             // dZ_1, X_1, X_0 of these rows from the first launch -> regions 2, 1, 0, at their swizzled places; requested a whole
@@ -840,7 +849,7 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (16 * (hp + 4 * i) < HB) *(u4v __attribute__((address_space(3))) *)(dst + 64 * i) = hand[i];
-            hand_load(grp + gridDim.x < ngroups ? grp + gridDim.x : ngroups - 1);
+            if constexpr (!kLatePf) hand_load(grp + gridDim.x < ngroups ? grp + gridDim.x : ngroups - 1);
         }
         __syncthreads();
         BT(1);
@@ -947,6 +956,10 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                 ChainAcc<NTB> acc;                                                                                           \
                 chain_mm<N, PART, SC::bstep(l), N::kbb(l), NTB, SZ>(acc, zimg + lay_of<SZ>(ls).row, ring, ws, wave);         \
                 BT(70 + 2 * (l));                                                                                            \
+                if constexpr (PART == 1 && (l) == 1 && kLatePf && !kHandX) {                                                 \
+                    x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);                                   \
+                    hand_load(grp + gridDim.x < ngroups ? grp + gridDim.x : ngroups - 1);                                    \
+                }                                                                                                            \
                 constexpr int DELTA = N::zoff((l) - 1) - N::ioff(l);   /* same stride, same lane offsets: a constant shift */ \
                 if constexpr (N::act((l) - 1) && BAMD_BF16_EPIMIX) {                                                         \
                     constexpr int E = EpiGeo<NTB>::E;                                                                        \
