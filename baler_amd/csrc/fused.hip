@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
 
 // Encode / decode with TWO 16-row tiles per wave (see chain_gemm2): same results, half the fragment loads per MFMA.
 template <int F, int Z, int KIND>
-__global__ void __launch_bounds__(256) infer2_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) infer2_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
                                                      const double *__restrict__ feats, void *__restrict__ out, int out_f64,
                                                      const uint8_t *__restrict__ imask) {
     using N = Net<F, Z>;
@@ -565,25 +565,60 @@ __global__ void __launch_bounds__(256) infer2_kernel(const v4 *packed, const voi
     WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, threadIdx.x & 63);
     Ring ring;
     ring_prime<S::total>(ring, ws);
+    // The NEXT pass's rows are requested in front of this pass's last long layer (behind the register peak) and converted at
+    // the top of the next pass: requested at the top of their own pass, the wave sat out one HBM round trip (~1.4 us of a 14-us pass)
+    // behind the previous pass's stores before its first MFMA (BALER_AMD_INFER_PREFETCH=0 at build time: BAMD_INFER_NOPF).
+    constexpr int DIN = KIND == K_ENCODE ? F : Z;
+    RawRows<DIN> ra, rb;
+    {
+        const int64_t p0 = (int64_t)blockIdx.x * 4 + wave;
+        const int64_t q0 = p0 * 32 + (lane & 15), q1 = q0 + 16;
+        load_rows_issue<DIN>(ra, xin, in_f64, q0, q0 < n, lane);
+        load_rows_issue<DIN>(rb, xin, in_f64, q1, q1 < n, lane);
+    }
     for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < npair; pr += (int64_t)gridDim.x * 4) {
         const int64_t r0 = pr * 32 + (lane & 15), r1 = r0 + 16;
         const bool v0 = r0 < n, v1 = r1 < n;
+        const int64_t pn = pr + (int64_t)gridDim.x * 4;
+        const int64_t n0 = pn * 32 + (lane & 15), n1 = n0 + 16;
         asm volatile("" : "+v"(ws.voff));   // keep the weight loads inside the loop (see infer_kernel)
-        if (KIND == K_ENCODE) {
+        if constexpr (KIND == K_ENCODE) {
             v4 a0[tiles(F)], b0[tiles(F)], a1[13], b1[13], a2[7], b2[7], a3[4], b3[4], a4[tiles(Z)], b4[tiles(Z)];
+#ifdef BAMD_INFER_NOPF
             load_rows<F>(a0, xin, in_f64, r0, v0, lane, feats);
             load_rows<F>(b0, xin, in_f64, r1, v1, lane, feats);
+#else
+            load_rows_finish<F>(a0, ra, v0, lane, feats);
+            load_rows_finish<F>(b0, rb, v1, lane, feats);
+#endif
             fwd_layer2<N, S, 0>(a0, b0, a1, b1, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 1>(a1, b1, a2, b2, ring, ws, bias_lds, lane);
+#ifndef BAMD_INFER_NOPF
+            __builtin_amdgcn_sched_barrier(0);
+            load_rows_issue<F>(ra, xin, in_f64, n0, n0 < n, lane);      // (behind the widest layer: the raw rows do not add to the register peak)
+            load_rows_issue<F>(rb, xin, in_f64, n1, n1 < n, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             fwd_layer2<N, S, 2>(a2, b2, a3, b3, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 3>(a3, b3, a4, b4, ring, ws, bias_lds, lane);
             store_rows<Z>(a4, out, out_f64, r0, v0, lane, nullptr, nullptr);
             store_rows<Z>(b4, out, out_f64, r1, v1, lane, nullptr, nullptr);
         } else {
             v4 a4[tiles(Z)], b4[tiles(Z)], a5[4], b5[4], a6[7], b6[7], a7[13], b7[13], a8[tiles(F)], b8[tiles(F)];
+#ifdef BAMD_INFER_NOPF
             load_rows<Z>(a4, xin, in_f64, r0, v0, lane, nullptr);
             load_rows<Z>(b4, xin, in_f64, r1, v1, lane, nullptr);
+#else
+            load_rows_finish<Z>(a4, ra, v0, lane, nullptr);
+            load_rows_finish<Z>(b4, rb, v1, lane, nullptr);
+#endif
             fwd_layer2<N, S, 4>(a4, b4, a5, b5, ring, ws, bias_lds, lane);
+#ifndef BAMD_INFER_NOPF
+            __builtin_amdgcn_sched_barrier(0);
+            load_rows_issue<Z>(ra, xin, in_f64, n0, n0 < n, lane);
+            load_rows_issue<Z>(rb, xin, in_f64, n1, n1 < n, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             fwd_layer2<N, S, 5>(a5, b5, a6, b6, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 6>(a6, b6, a7, b7, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 7>(a7, b7, a8, b8, ring, ws, bias_lds, lane);
