@@ -1721,12 +1721,32 @@ __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, c
 // acc0 / acc1[13 tiles of the 200-feature side] += sum over the wide dimension of frag(chunk c, tile t) . x^T[chunk c] for the wave's two
 // 16-row tiles: the streamed product of wide_bf16_encode_kernel as a function (fragments [32-feature chunk][tile], shared by the four waves
 // through the double-buffered LDS stage `wst`, every load three chunks ahead; see that kernel).  Contains workgroup barriers.
-template <int F>
+// SRC16: the rows are stored as bfloat16 (the dz8 of a BF16 handle's training pass, F % 4 == 0): 16 bytes per lane and chunk as two
+// 8-byte loads (a row is F x 2 bytes: 8-byte aligned), no conversion; xo0 / xo1 are then byte offsets of bfloat16 elements.
+template <int F, bool SRC16 = false>
 __device__ __forceinline__ void wide_in_product_bf16(v4 (&a1)[13], v4 (&b1)[13], v4 (&wst)[2][13][64], const WStream &ww,
                                                      __amdgpu_buffer_rsrc_t xrs, int xo0, int xo1, int wave, int lane, int g) {
     constexpr int KB = F / 32;
     bf8 wq[2][4];
-    XPair x0r[3], x1r[3];
+    struct XR { XPair p; bf8 h; };
+    XR x0r[3], x1r[3];
+    auto ldx = [&](int xo, int c) {
+        XR r;
+        if constexpr (SRC16) {
+            typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+            typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+            const u2_ lo = __builtin_bit_cast(u2_, __builtin_amdgcn_raw_buffer_load_b64(xrs, xo, c * 64, 0));
+            const u2_ hi = __builtin_bit_cast(u2_, __builtin_amdgcn_raw_buffer_load_b64(xrs, xo + 8, c * 64, 0));
+            r.h = __builtin_bit_cast(bf8, (u4_){lo[0], lo[1], hi[0], hi[1]});
+        } else {
+            r.p = wide_x_chunk32_buf<F, true>(xrs, xo, 0, c, g);
+        }
+        return r;
+    };
+    auto cvx = [&](const XR &r) {
+        if constexpr (SRC16) return r.h;
+        else return to_bf8(r.p.lo, r.p.hi);
+    };
     auto wload = [&](bf8 (&w)[4], int c) {
         c = c < KB ? c : KB - 1;
 #pragma unroll
@@ -1742,8 +1762,8 @@ __device__ __forceinline__ void wide_in_product_bf16(v4 (&a1)[13], v4 (&b1)[13],
             if (t < 13) wst[slot][t][lane] = __builtin_bit_cast(v4, w[k]);
         }
     };
-    auto lx0 = [&](int c) { return wide_x_chunk32_buf<F, true>(xrs, xo0, 0, c < KB ? c : 0, g); };
-    auto lx1 = [&](int c) { return wide_x_chunk32_buf<F, true>(xrs, xo1, 0, c < KB ? c : 0, g); };
+    auto lx0 = [&](int c) { return ldx(xo0, c < KB ? c : 0); };
+    auto lx1 = [&](int c) { return ldx(xo1, c < KB ? c : 0); };
     wload(wq[0], 0);
     wload(wq[1], 1);
 #pragma unroll
@@ -1755,7 +1775,7 @@ __device__ __forceinline__ void wide_in_product_bf16(v4 (&a1)[13], v4 (&b1)[13],
         constexpr int WS = decltype(wsl)::value, XS = decltype(xsl)::value;      // c % 2, c % 3
         __syncthreads();
         wstore(wq[WS ^ 1], WS ^ 1);
-        const bf8 q0 = to_bf8(x0r[XS].lo, x0r[XS].hi), q1 = to_bf8(x1r[XS].lo, x1r[XS].hi);
+        const bf8 q0 = cvx(x0r[XS]), q1 = cvx(x1r[XS]);
         wload(wq[WS ^ 1], c + 3);
         x0r[XS] = lx0(c + 3);
         x1r[XS] = lx1(c + 3);
@@ -1794,8 +1814,23 @@ __device__ __forceinline__ void wide_in_product_bf16(v4 (&a1)[13], v4 (&b1)[13],
     if (c + 3 < KB) iter(c + 3, I1(), I0());
     if (c + 4 < KB) iter(c + 4, I0(), I1());
     if (F % 32 != 0) {            // the remaining F % 32 features: one partial chunk, fragments straight from L2
-        const XPair p0 = wide_x_chunk32_buf<F>(xrs, xo0, 0, KB, g), p1 = wide_x_chunk32_buf<F>(xrs, xo1, 0, KB, g);
-        const bf8 q0 = to_bf8(p0.lo, p0.hi), q1 = to_bf8(p1.lo, p1.hi);
+        bf8 q0, q1;
+        if constexpr (SRC16) {      // pairs of elements (F is even: a pair never straddles the end of the row), zero beyond the row
+            typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+            u4_ w0 = {0u, 0u, 0u, 0u}, w1 = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp)
+                if (32 * KB + 8 * g + 2 * jp < F) {
+                    w0[jp] = __builtin_bit_cast(unsigned, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo0 + 4 * jp, KB * 64, 0));
+                    w1[jp] = __builtin_bit_cast(unsigned, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo1 + 4 * jp, KB * 64, 0));
+                }
+            q0 = __builtin_bit_cast(bf8, w0);
+            q1 = __builtin_bit_cast(bf8, w1);
+        } else {
+            const XPair p0 = wide_x_chunk32_buf<F>(xrs, xo0, 0, KB, g), p1 = wide_x_chunk32_buf<F>(xrs, xo1, 0, KB, g);
+            q0 = to_bf8(p0.lo, p0.hi);
+            q1 = to_bf8(p1.lo, p1.hi);
+        }
 #pragma unroll
         for (int t = 0; t < 13; ++t) {
             const bf8 w = frag_bf(ww, KB * 13 + t);
@@ -1807,12 +1842,33 @@ __device__ __forceinline__ void wide_in_product_bf16(v4 (&a1)[13], v4 (&b1)[13],
 
 // forward + loss + dL/drecon of 2 x 16 rows per wave (128 rows per workgroup pass): interface and results as wide_train_fwd_kernel<TRAIN = true>
 // (y1..y7, dz8 = 2 (recon - x) / F in float32, per-workgroup loss partials), en1 and de4 on the bf16 MFMA.
-template <int F, int Z>
+// four values of a wide row as bfloat16 (DZ16: dz8 is stored as bfloat16 -- both of its readers, the input-gradient product and de4's
+// weight gradient, round it to bfloat16 on load anyway: same numbers, half the bytes of its one write and two reads)
+__device__ __forceinline__ unsigned long long pack4_bf16(const v4 &o) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 lo = {(__bf16)o[0], (__bf16)o[1]}, hi = {(__bf16)o[2], (__bf16)o[3]};
+    return (unsigned long long)__builtin_bit_cast(unsigned, lo) | ((unsigned long long)__builtin_bit_cast(unsigned, hi) << 32);
+}
+template <int F, bool FULL = false>
+__device__ __forceinline__ void wide_store_tile_bf16(const v4 &o, __bf16 *out, int64_t row, int t, int g) {
+    if (FULL || 16 * t + 16 <= F) {
+        *(unsigned long long *)(out + row * F + 16 * t + 4 * g) = pack4_bf16(o);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = slot_feature(F, t, g, r);
+            if (f >= 0) out[row * F + f] = (__bf16)o[r];
+        }
+    }
+}
+template <int F, int Z, bool DZ16>
 __global__ void __launch_bounds__(256) wide_bf16_train_fwd_kernel(const v4 *packed, const v4 *w0b, const v4 *w7b, const float *__restrict__ x,
                                                                   int64_t n, float *__restrict__ y1, float *__restrict__ y2,
                                                                   float *__restrict__ y3, float *__restrict__ y4, float *__restrict__ y5,
-                                                                  float *__restrict__ y6, float *__restrict__ y7, float *__restrict__ dz8,
+                                                                  float *__restrict__ y6, float *__restrict__ y7, void *__restrict__ dz8v,
                                                                   double *__restrict__ loss_part) {
+    float *const dz8 = (float *)dz8v;
+    __bf16 *const dz8h = (__bf16 *)dz8v;
     using N = Net<F, Z>;
     using S = StreamWideMid<N>;
     constexpr int KBT = (F + 31) / 32, KT = tiles(F), KTF = F / 16;
@@ -1905,9 +1961,15 @@ __global__ void __launch_bounds__(256) wide_bf16_train_fwd_kernel(const v4 *pack
                     for (int k = 0; k < 32 * LR / 64; ++k) {
                         const int rl = (64 / LR) * k + lane / LR;
                         const v4 v = *(const v4 *)&tstage[wave][rl][4 * (lane % LR)];
-                        if (rb + rl < n) *(v4 *)(dz8 + (rb + rl) * F + 16 * (t - (kTG - 1)) + 4 * (lane % LR)) = v;
+                        if (rb + rl < n) {
+                            if constexpr (DZ16) *(unsigned long long *)(dz8h + (rb + rl) * F + 16 * (t - (kTG - 1)) + 4 * (lane % LR)) = pack4_bf16(v);
+                            else *(v4 *)(dz8 + (rb + rl) * F + 16 * (t - (kTG - 1)) + 4 * (lane % LR)) = v;
+                        }
                     }
                 }
+            } else if constexpr (DZ16) {
+                if (v0) wide_store_tile_bf16<F, true>(e0, dz8h, r0, t, g);
+                if (v1) wide_store_tile_bf16<F, true>(e1, dz8h, r1, t, g);
             } else {
                 if (v0) wide_store_tile<F, true>(e0, dz8, 0, r0, t, g);
                 if (v1) wide_store_tile<F, true>(e1, dz8, 0, r1, t, g);
@@ -1952,8 +2014,14 @@ __global__ void __launch_bounds__(256) wide_bf16_train_fwd_kernel(const v4 *pack
                 o1 = mfma_bf(w, qb[c], o1);
             }
             const v4 d0 = o0 - wide_x_chunk<F>(x, 0, rr0, t, g), d1 = o1 - wide_x_chunk<F>(x, 0, rr1, t, g);
-            if (v0) { lacc += (double)(d0[0] * d0[0] + d0[1] * d0[1]) + (double)(d0[2] * d0[2] + d0[3] * d0[3]); wide_store_tile<F>(d0 * gscale, dz8, 0, r0, t, g); }
-            if (v1) { lacc += (double)(d1[0] * d1[0] + d1[1] * d1[1]) + (double)(d1[2] * d1[2] + d1[3] * d1[3]); wide_store_tile<F>(d1 * gscale, dz8, 0, r1, t, g); }
+            if (v0) {
+                lacc += (double)(d0[0] * d0[0] + d0[1] * d0[1]) + (double)(d0[2] * d0[2] + d0[3] * d0[3]);
+                if constexpr (DZ16) wide_store_tile_bf16<F>(d0 * gscale, dz8h, r0, t, g); else wide_store_tile<F>(d0 * gscale, dz8, 0, r0, t, g);
+            }
+            if (v1) {
+                lacc += (double)(d1[0] * d1[0] + d1[1] * d1[1]) + (double)(d1[2] * d1[2] + d1[3] * d1[3]);
+                if constexpr (DZ16) wide_store_tile_bf16<F>(d1 * gscale, dz8h, r1, t, g); else wide_store_tile<F>(d1 * gscale, dz8, 0, r1, t, g);
+            }
         }
     }
     sh[threadIdx.x] = lacc;
@@ -1967,8 +2035,8 @@ __global__ void __launch_bounds__(256) wide_bf16_train_fwd_kernel(const v4 *pack
 
 // the input-gradient chain of 2 x 16 rows per wave: dZ_6 = (dZ_7 W_7) * lrelu'(y7) with the wide product on the bf16 MFMA (fragments of
 // W_7^T in en1's [chunk][tile] order), then layers 6..1 in float32 as in wide_train_bwd_kernel, one row tile after the other.
-template <int F, int Z>
-__global__ void __launch_bounds__(256) wide_bf16_train_bwd_kernel(const v4 *packed, const v4 *w7tb, const float *__restrict__ dz7, int64_t n,
+template <int F, int Z, bool DZ16>
+__global__ void __launch_bounds__(256) wide_bf16_train_bwd_kernel(const v4 *packed, const v4 *w7tb, const void *__restrict__ dz7, int64_t n,
                                                                   const float *__restrict__ y1, const float *__restrict__ y2,
                                                                   const float *__restrict__ y3, const float *__restrict__ y5,
                                                                   const float *__restrict__ y6, const float *__restrict__ y7,
@@ -1986,15 +2054,16 @@ __global__ void __launch_bounds__(256) wide_bf16_train_bwd_kernel(const v4 *pack
     for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
         const int64_t r0 = (grp * 4 + wave) * 32 + (lane & 15), r1 = r0 + 16;
         const bool v0 = r0 < n, v1 = r1 < n;
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)dz7 + (size_t)(grp * 128) * F * 4), 0,
+        constexpr int es = DZ16 ? 2 : 4;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)dz7 + (size_t)(grp * 128) * F * es), 0,
                                                                              0x7fffffff, 0x00020000);
         const int lr0 = wave * 32 + (lane & 15);
-        const int xo0 = ((v0 ? lr0 : 0) * F + 8 * g) * 4, xo1 = ((v1 ? lr0 + 16 : 0) * F + 8 * g) * 4;
+        const int xo0 = ((v0 ? lr0 : 0) * F + 8 * g) * es, xo1 = ((v1 ? lr0 + 16 : 0) * F + 8 * g) * es;
         asm volatile("" : "+v"(ws.voff), "+v"(w7.voff));
         v4 d6a[13], d6b[13];
         zero_tiles(d6a);
         zero_tiles(d6b);
-        wide_in_product_bf16<F>(d6a, d6b, wst, w7, xrs, xo0, xo1, wave, lane, g);
+        wide_in_product_bf16<F, DZ16>(d6a, d6b, wst, w7, xrs, xo0, xo1, wave, lane, g);
         auto narrow = [&](v4 (&d6)[13], int64_t row, bool valid) {
             const int64_t rrow = valid ? row : 0;
             Ring ring;
@@ -3250,6 +3319,7 @@ struct FusedState {
     DevBuf wb_src[3], wb[3];           // wide models in the bf16 mode: index maps and bf16 fragments of W0 / W7 / W7^T (training)
     int wb_count[3] = {0, 0, 0};
     bool wb_stale = false;             // the bf16 fragments lag the parameters (re-rounded before the next encode / decode)
+    bool dz16 = false;                 // this pass stores dL/drecon as bfloat16 (set per pass by the layer-wise driver: fused_wide_set_dz16)
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
     DevBuf dwpart;                     // partial weight-gradient tiles of the small-batch path when a tile's blocks are split over workgroups
     bool tail_split = true;            // short remainder of the persistent loop on the small-batch kernels (BALER_AMD_TAIL_SPLIT=0: off)
@@ -3842,8 +3912,18 @@ template <int F, int Z> struct ImplWideBf16 {
         FusedState *st = state_of(h);
         if (st->wb_stale) { int rc = pack_extra(h, st, s); if (rc) return rc; }
         const int grid = grid_for(rows);
-        hipLaunchKernelGGL((wide_bf16_train_fwd_kernel<F, Z>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const v4 *)st->wb[0].p,
-                           (const v4 *)st->wb[1].p, x, rows, y[1], y[2], y[3], y[4], y[5], y[6], y[7], dz_last, loss_part);
+        if constexpr (F % 4 == 0) {
+            if (st->dz16) {
+                hipLaunchKernelGGL((wide_bf16_train_fwd_kernel<F, Z, true>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p,
+                                   (const v4 *)st->wb[0].p, (const v4 *)st->wb[1].p, x, rows, y[1], y[2], y[3], y[4], y[5], y[6], y[7],
+                                   (void *)dz_last, loss_part);
+                *nblk = grid;
+                BAMD_HIP(hipGetLastError());
+                return BAMD_OK;
+            }
+        }
+        hipLaunchKernelGGL((wide_bf16_train_fwd_kernel<F, Z, false>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const v4 *)st->wb[0].p,
+                           (const v4 *)st->wb[1].p, x, rows, y[1], y[2], y[3], y[4], y[5], y[6], y[7], (void *)dz_last, loss_part);
         *nblk = grid;
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
@@ -3852,8 +3932,18 @@ template <int F, int Z> struct ImplWideBf16 {
         if (!bf16_train_on()) return W::wide_bwd(h, rows, y, dz, dz_latent, s);
         FusedState *st = state_of(h);
         if (st->wb_stale) { int rc = pack_extra(h, st, s); if (rc) return rc; }
-        hipLaunchKernelGGL((wide_bf16_train_bwd_kernel<F, Z>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
-                           (const v4 *)st->wb[2].p, (const float *)dz[7], rows, (const float *)y[1], (const float *)y[2], (const float *)y[3],
+        if constexpr (F % 4 == 0) {
+            if (st->dz16) {
+                hipLaunchKernelGGL((wide_bf16_train_bwd_kernel<F, Z, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                                   (const v4 *)st->wb[2].p, (const void *)dz[7], rows, (const float *)y[1], (const float *)y[2],
+                                   (const float *)y[3], (const float *)y[5], (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2],
+                                   dz[3], dz[4], dz[5], dz[6], dz_latent);
+                BAMD_HIP(hipGetLastError());
+                return BAMD_OK;
+            }
+        }
+        hipLaunchKernelGGL((wide_bf16_train_bwd_kernel<F, Z, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                           (const v4 *)st->wb[2].p, (const void *)dz[7], rows, (const float *)y[1], (const float *)y[2], (const float *)y[3],
                            (const float *)y[5], (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6],
                            dz_latent);
         BAMD_HIP(hipGetLastError());
@@ -3975,6 +4065,11 @@ int fused_wide_train_forward(bamd_handle *h, const float *x, int64_t rows, float
                              hipStream_t s) {
     if (!fused_wide_train(h)) return BAMD_ERR_UNSUPPORTED;
     return state_of(h)->ops->wide_fwd(h, x, rows, y, dz_last, loss_part, nblk, s);
+}
+// BF16 handles of a wide model whose last layer's weight gradient runs on dw_wide_bf16_k: dL/drecon (the largest array of the pass)
+// is stored as bfloat16 by the forward launch and read as such by the backward launch and that kernel
+void fused_wide_set_dz16(bamd_handle *h, bool on) {
+    if (h->fused_ok && h->fused_state) ((FusedState *)h->fused_state)->dz16 = on;
 }
 int fused_wide_train_backward(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, const float *dz_latent, hipStream_t s) {
     if (!fused_wide_train(h)) return BAMD_ERR_UNSUPPORTED;

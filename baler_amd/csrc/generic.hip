@@ -716,13 +716,18 @@ __global__ void __launch_bounds__(256) dw_wide_k(const float *__restrict__ dzm, 
 // bytes per instruction -- and register j of the eight loads, packed by four v_cvt_pk_bf16_f32, is the operand of strided tile j.
 // Column-to-lane maps, accumulators and epilogue are dw_wide_k's.  52 MFMAs (832 cycles) per 40 KiB loaded: the kernel is bound by the
 // rows it streams (the float32 launch: MFMA busy 73-75 %).
-template <bool P_IS_N>
+// Q16: the Q side (dZ of the last layer, P_IS_N = false) is stored as bfloat16: 8-byte loads of the lane's four columns, the k slots
+// assembled with v_perm_b32 instead of conversions.
+template <bool P_IS_N, bool Q16 = false>
 __global__ void __launch_bounds__(256) dw_wide_bf16_k(const float *__restrict__ dzm, const float *__restrict__ xm, int N, int K, int64_t rows,
                                                       int64_t rps, float *__restrict__ slab, int64_t slab_size) {
+    static_assert(!(Q16 && P_IS_N), "the bfloat16 operand is dZ on the Q side");
     using v4 = MF<float>::v4;
     typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    constexpr int qes = Q16 ? 2 : 4;                               // bytes per stored element of Q
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const float *__restrict__ pm = P_IS_N ? dzm : xm;
     const float *__restrict__ qm = P_IS_N ? xm : dzm;
@@ -734,9 +739,9 @@ __global__ void __launch_bounds__(256) dw_wide_bf16_k(const float *__restrict__ 
     const int64_t r_end = r_begin + rps < rows ? r_begin + rps : rows;
     if (r_begin >= r_end) return;
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(pm + r_begin * DP), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(qm + r_begin * DQ), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)qm + r_begin * DQ * qes), 0, 0x7fffffff, 0x00020000);
     const int cq = 64 * gq + 4 * i;
-    const int offq = (8 * g * DQ + (cq + 4 <= DQ ? cq : DQ - 4)) * 4;
+    const int offq = (8 * g * DQ + (cq + 4 <= DQ ? cq : DQ - 4)) * qes;
     const int offpg = (8 * g * DP + 4 * i) * 4;
     const int offpl = (8 * g * DP + (192 + i < DP ? 192 + i : DP - 1)) * 4;
     const bool q_one = P_IS_N && cq == K;
@@ -749,11 +754,11 @@ __global__ void __launch_bounds__(256) dw_wide_bf16_k(const float *__restrict__ 
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int t = 0; t < 13; ++t) acc[u][t] = (v4){0.f, 0.f, 0.f, 0.f};
-    struct Raw { v4 pg[3][8]; float pl[8]; v4 q[8]; };             // [group][row e], plain tile [row e], [row e]
+    struct Raw { v4 pg[3][8]; float pl[8]; v4 q[8]; u2 q16[8]; };  // [group][row e], plain tile [row e], [row e] (q16: Q16)
     struct Pk { bf8 p[13]; bf8 q[4]; };
     const int64_t nr = r_end - r_begin;
     auto load = [&](Raw &f, int64_t rb, bool tail) {
-        const int sp = (int)rb * DP * 4, sq = (int)rb * DQ * 4;
+        const int sp = (int)rb * DP * 4, sq = (int)rb * DQ * qes;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int back_p = 0, back_q = 0;
@@ -762,9 +767,10 @@ __global__ void __launch_bounds__(256) dw_wide_bf16_k(const float *__restrict__ 
                 ok = rb + 8 * g + e < nr;
                 const int back = ok ? 0 : (int)(rb + 8 * g + e - (nr - 1));
                 back_p = back * DP * 4;
-                back_q = back * DQ * 4;
+                back_q = back * DQ * qes;
             }
-            f.q[e] = ld4(rq, offq - back_q, sq + e * 4 * DQ);
+            if constexpr (Q16) f.q16[e] = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(rq, offq - back_q, sq + e * qes * DQ, 0));
+            else f.q[e] = ld4(rq, offq - back_q, sq + e * 4 * DQ);
 #pragma unroll
             for (int G = 0; G < 3; ++G) f.pg[G][e] = ld4(rp, offpg + 256 * G - back_p, sp + e * 4 * DP);
             f.pl[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, offpl - back_p, sp + e * 4 * DP, 0));
@@ -775,6 +781,7 @@ __global__ void __launch_bounds__(256) dw_wide_bf16_k(const float *__restrict__ 
                     f.pl[e] = 0.f;
                 } else {
                     f.q[e] = (v4){0.f, 0.f, 0.f, 0.f};
+                    f.q16[e] = (u2){0u, 0u};
                 }
             }
         }
@@ -799,7 +806,17 @@ __global__ void __launch_bounds__(256) dw_wide_bf16_k(const float *__restrict__ 
                                        f.pg[G][7][j]);
         k.p[12] = pack8(f.pl[0], f.pl[1], f.pl[2], f.pl[3], f.pl[4], f.pl[5], f.pl[6], f.pl[7]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) k.q[u] = pack8(f.q[0][u], f.q[1][u], f.q[2][u], f.q[3][u], f.q[4][u], f.q[5][u], f.q[6][u], f.q[7][u]);
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (Q16) {      // column u of rows e = 2 d, 2 d + 1 -> dword d of the operand: halves picked by v_perm_b32
+                u4 w;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    w[d] = __builtin_amdgcn_perm(f.q16[2 * d + 1][u >> 1], f.q16[2 * d][u >> 1], (u & 1) ? 0x07060302u : 0x05040100u);
+                k.q[u] = __builtin_bit_cast(bf8, w);
+            } else {
+                k.q[u] = pack8(f.q[0][u], f.q[1][u], f.q[2][u], f.q[3][u], f.q[4][u], f.q[5][u], f.q[6][u], f.q[7][u]);
+            }
+        }
     };
     auto mma = [&](const Pk &k) {
 #pragma unroll
@@ -1235,13 +1252,14 @@ static void launch_dw_short(bool p_is_n, const float *dz, const float *xm, int N
     else hipLaunchKernelGGL((dw_short_k<PT, 2, false>), grid, dim3(256), 0, s, dz, xm, N, K, rows, rps, slab, size);
 }
 static void run_dw_short(const ShortPlan &pl, int l, const float *dz, const float *xm, int N, int K, int64_t rows, float *slabs, bool bf16,
-                         hipStream_t s) {
+                         bool dz16, hipStream_t s) {
     const dim3 grid((unsigned)pl.ncol[l], (unsigned)pl.nsplit[l]);
     float *slab = slabs + pl.rp.base[l];
     if (pl.wide[l]) {
         const int64_t size = (int64_t)N * K + N;
         if (bf16) {      // BAMD_MODE_BF16 handles: the two wide weight gradients on the bf16 MFMA (BALER_AMD_BF16_WIDE_TRAIN=0: float32)
             if (pl.p_is_n[l]) hipLaunchKernelGGL((dw_wide_bf16_k<true>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
+            else if (dz16) hipLaunchKernelGGL((dw_wide_bf16_k<false, true>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
             else hipLaunchKernelGGL((dw_wide_bf16_k<false>), grid, dim3(256), 0, s, dz, xm, N, K, rows, pl.rps[l], slab, size);
             return;
         }
@@ -1300,6 +1318,15 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
         }
         // wide models in float32: the row-local work (forward, loss, input-gradient chain) as two fused launches (fused.hip)
         const bool wide = sizeof(T) == 4 && fused_wide_train(h);
+        // BF16 handles: dL/drecon stored as bfloat16 when its two readers take it that way (BALER_AMD_BF16_DZ16=0: float32)
+        bool dz16 = false;
+        if constexpr (sizeof(T) == 4) {
+            const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN"), *e16 = getenv("BALER_AMD_BF16_DZ16");
+            const int ll = h->L - 1;
+            dz16 = wide && h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0') && !(e16 && e16[0] == '0') && sp.ok && sp.wide[ll] &&
+                   !sp.p_is_n[ll] && h->dims[ll + 1] % 4 == 0;
+            if (wide) fused_wide_set_dz16(h, dz16);
+        }
         int nblk = 0;
         if (wide) {
             rc = h->lossp.ensure(sizeof(double) * 4096);
@@ -1342,7 +1369,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 if constexpr (sizeof(T) == 4) {
                     const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
                     const bool bf16 = wide && h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0');
-                    run_dw_short(sp, l, dz, l == 0 ? x0 : wk.y[l], N, K, rows, slabs, bf16, s);
+                    run_dw_short(sp, l, dz, l == 0 ? x0 : wk.y[l], N, K, rows, slabs, bf16, dz16 && l == h->L - 1, s);
                 }
             } else {
                 Opnd<T> A{dz, 1, N, N, -1};

@@ -252,6 +252,18 @@ def test_wide_model_full_size_and_rate():
         h.close()
     (gf, tf), (gb, tb) = res["fp32"], res["bf16"]
     print(f"CFD_dense_AE(2500,25) fwd_bwd at {n} frames: fp32 {tf:.3f} ms, bf16 {tb:.3f} ms")
+    # dL/drecon stored as bfloat16 (default) or float32 between the launches: both readers round it to bfloat16, so the SAME gradient
+    import os
+    h, p = handle(flat, "bf16", dims)
+    g1, g2 = torch.zeros_like(p), torch.zeros_like(p)
+    h.fwd_bwd(x[:4100], g1)
+    os.environ["BALER_AMD_BF16_DZ16"] = "0"
+    try:
+        h.fwd_bwd(x[:4100], g2)
+    finally:
+        del os.environ["BALER_AMD_BF16_DZ16"]
+    assert torch.equal(g1, g2)
+    h.close()
     assert abs(gb[-1] - gf[-1]) < 1e-3 * gf[-1] and rel(gb[:-1], gf[:-1]) < 5e-3
     assert np.isfinite(gb).all()
     assert tb < tf / 1.5
