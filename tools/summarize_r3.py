@@ -23,7 +23,7 @@ KEYS = (("train_dec_kernel", "train_dec"), ("train_enc_kernel", "train_enc"), ("
         ("wide_encode_lds_kernel", "wide_encode_lds_kernel<2500, 25"), ("wide_infer_kernel<DECODE>", "wide_infer_kernel<2500, 25, 1"), ("wide_decode_lds_kernel", "wide_decode_lds_kernel<2500, 25"),
         ("wide_train_fwd_kernel", "wide_train_fwd_kernel<2500, 25, true>"), ("wide_train_bwd_kernel", "wide_train_bwd_kernel<2500, 25>"),
         ("wide_bf16_train_fwd_kernel", "wide_bf16_train_fwd_kernel<2500, 25"), ("wide_bf16_train_bwd_kernel", "wide_bf16_train_bwd_kernel<2500, 25"),
-        ("dw_wide_bf16_k<P = dZ>", "dw_wide_bf16_k<true>"), ("dw_wide_bf16_k<P = [X|1]>", "dw_wide_bf16_k<false>"),
+        ("dw_wide_bf16_k<P = dZ>", "dw_wide_bf16_k<true"), ("dw_wide_bf16_k<P = [X|1]>", "dw_wide_bf16_k<false"),
         ("dw_wide_k<P = dZ>", "dw_wide_k<true>"), ("dw_wide_k<P = [X|1]>", "dw_wide_k<false>"), ("reduce_layers_k", "reduce_layers_k"))
 
 
