@@ -17,6 +17,14 @@ __device__ __forceinline__ double ld(const void *p, int64_t i) {
 // data_processing.find_minmax (data_processing.py:113-130).  Rows are contiguous, so a workgroup
 // reads R = 256/tcols whole rows per pass (one coalesced segment) and every thread keeps the running
 // min/max of ONE column.  Algorithmic traffic: n*c*sizeof(T) bytes read once.
+// np.min / np.max PROPAGATE a NaN (data_processing.py:124-125 calls them per column): a column with a NaN cell has min = max =
+// range = NaN in the reference, while `v < mn ? v : mn` would silently skip it.  The streaming loop keeps a per-thread "saw a
+// NaN" flag (one unordered compare per element) and poisons its running pair at the end; the combines below use the sticky form.
+__device__ __forceinline__ void mm_merge(double a, double b, double &mn, double &mx) {
+    mn = (a < mn || a != a) ? a : mn;      // once mn is a NaN no comparison is true: it stays
+    mx = (b > mx || b != b) ? b : mx;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) minmax_partial(const T *__restrict__ x, int64_t n, int c,
                                                       int tcols, double *__restrict__ part) {
@@ -24,6 +32,7 @@ __global__ void __launch_bounds__(256) minmax_partial(const T *__restrict__ x, i
     const int lc = threadIdx.x % tcols, lr = threadIdx.x / tcols;
     const int col = blockIdx.y * tcols + lc;
     double mn = INFINITY, mx = -INFINITY;
+    bool nan = false;
     if (lr < R && col < c) {
         const int64_t step = (int64_t)gridDim.x * R;
         int64_t r = (int64_t)blockIdx.x * R + lr;
@@ -32,46 +41,42 @@ __global__ void __launch_bounds__(256) minmax_partial(const T *__restrict__ x, i
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = (double)x[(r + u * step) * c + col];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+            for (int u = 0; u < 8; ++u) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; nan |= v[u] != v[u]; }
         }
         for (; r < n; r += step) {
             double v = (double)x[r * c + col];
             mn = v < mn ? v : mn;
             mx = v > mx ? v : mx;
+            nan |= v != v;
         }
     }
+    if (nan) mn = mx = __builtin_nan("");
     __shared__ double smn[256], smx[256];
     smn[threadIdx.x] = mn;
     smx[threadIdx.x] = mx;
     __syncthreads();
     if (lr == 0 && col < c) {
-        for (int k = 1; k < R; ++k) {
-            double a = smn[k * tcols + lc], b = smx[k * tcols + lc];
-            mn = a < mn ? a : mn;
-            mx = b > mx ? b : mx;
-        }
+        for (int k = 1; k < R; ++k) mm_merge(smn[k * tcols + lc], smx[k * tcols + lc], mn, mx);
         part[((int64_t)blockIdx.x * 2 + 0) * c + col] = mn;
         part[((int64_t)blockIdx.x * 2 + 1) * c + col] = mx;
     }
 }
 
-// one workgroup per column: 256 threads stride over the block partials, LDS tree (min / max are exact in any order)
+// one workgroup per column: 256 threads stride over the block partials, LDS tree (min / max are exact in any order; a NaN
+// partial wins every merge)
 __global__ void __launch_bounds__(256) minmax_final(const double *__restrict__ part, int nblk, int c,
                                                     double *__restrict__ features, int raw) {
     __shared__ double smn[256], smx[256];
     const int col = blockIdx.x;
     double mn = INFINITY, mx = -INFINITY;
-    for (int b = threadIdx.x; b < nblk; b += 256) {
-        const double a = part[((int64_t)b * 2 + 0) * c + col], d = part[((int64_t)b * 2 + 1) * c + col];
-        mn = a < mn ? a : mn;
-        mx = d > mx ? d : mx;
-    }
+    for (int b = threadIdx.x; b < nblk; b += 256) mm_merge(part[((int64_t)b * 2 + 0) * c + col], part[((int64_t)b * 2 + 1) * c + col], mn, mx);
     smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
         if ((int)threadIdx.x < st) {
-            smn[threadIdx.x] = smn[threadIdx.x + st] < smn[threadIdx.x] ? smn[threadIdx.x + st] : smn[threadIdx.x];
-            smx[threadIdx.x] = smx[threadIdx.x + st] > smx[threadIdx.x] ? smx[threadIdx.x + st] : smx[threadIdx.x];
+            double a = smn[threadIdx.x], b = smx[threadIdx.x];
+            mm_merge(smn[threadIdx.x + st], smx[threadIdx.x + st], a, b);
+            smn[threadIdx.x] = a; smx[threadIdx.x] = b;
         }
         __syncthreads();
     }

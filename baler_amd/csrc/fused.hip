@@ -3987,12 +3987,20 @@ static const FusedOps *find_ops(const bamd_handle *h) {
 
 }  // namespace
 
-// debug aid (not part of the ABI header): copy the small-batch images of the last step to a device buffer
+#ifdef BAMD_DEBUG
+// debug builds only (make HIPFLAGS+=-DBAMD_DEBUG; tools/check_lat4_imgs.py): copy the small-batch images of the last step to a
+// device buffer.  Not part of the ABI: the shipped library does not export it.
 extern "C" int bamd_debug_copy_imgs(bamd_handle *h, void *dst, size_t bytes) {
+    if (!h || !dst) return BAMD_ERR_INVALID;
     FusedState *st = (FusedState *)h->fused_state;
-    if (!st || !st->imgs.p) return -1;
-    return (int)hipMemcpy(dst, st->imgs.p, bytes, hipMemcpyDeviceToDevice);
+    if (!st || !st->imgs.p || bytes > st->imgs.bytes) return BAMD_ERR_INVALID;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(h->device) != hipSuccess) return BAMD_ERR_HIP;
+    const int rc = (int)hipMemcpy(dst, st->imgs.p, bytes, hipMemcpyDeviceToDevice);
+    (void)hipSetDevice(prev);
+    return rc;
 }
+#endif
 
 int fused_setup(bamd_handle *h) {
     h->fused_ok = false;

@@ -768,7 +768,7 @@ template <int F, int Z> struct Impl64 {
         constexpr int lds = (N::bf_off(N::L) - N::bf_off(0)) * 32;
         const int in64 = x_dtype == BAMD_F64, out64 = out_dtype == BAMD_F64;
         if (kind == I_FORWARD) {
-            int rc = h->lossp.ensure(sizeof(double) * 1024);
+            int rc = h->lossp.ensure(sizeof(double) * (size_t)(grid > 1024 ? grid : 1024));     // one partial per workgroup (BALER_AMD_F64_INFER_WGS may exceed 1024)
             if (rc) return rc;
         }
         if (kind == I_ENCODE)

@@ -93,10 +93,18 @@ def global_batch(config, world=None):
 
 def allreduce_minmax(mm):
     """mm = [min ; max] (2, C) float64 of this rank's rows -> the extrema over all ranks, in place: one MIN and one
-    MAX all-reduce of C doubles (exact in any order)."""
+    MAX all-reduce of C doubles (exact in any order).  np.min / np.max propagate a NaN (a column with a NaN cell has
+    min = max = NaN in data_processing.find_minmax); what a collective's MIN / MAX makes of one is not specified, so
+    the NaN columns travel as a third, tiny MAX all-reduce of a 0/1 flag and are poisoned again afterwards."""
     if is_dist() and td.get_world_size() > 1:
+        nan = torch.isnan(mm).any(dim=0)
+        flag = nan.to(mm.dtype)
+        mm[0].masked_fill_(nan, float("inf"))
+        mm[1].masked_fill_(nan, float("-inf"))
         td.all_reduce(mm[0], op=td.ReduceOp.MIN)
         td.all_reduce(mm[1], op=td.ReduceOp.MAX)
+        td.all_reduce(flag, op=td.ReduceOp.MAX)
+        mm[:, flag > 0] = float("nan")
     return mm
 
 

@@ -60,14 +60,18 @@ _FAULT_POOL = None
 PREFAULT_THREADS = 8
 
 
-def prefault(arr, span_bytes=32 << 20):
+PREFAULT_SPAN = 32 << 20
+
+
+def prefault(arr):
     """Map the pages of a freshly allocated host array on background threads, AHEAD of the copies that fill it:
     ctypes.memset per span (the call releases the GIL; a numpy strided store per page did not and serialised everything;
     madvise(MADV_POPULATE_WRITE) maps 4-KiB pages at 27 GB/s and leaves the array 3x slower to write than pages that
     came in through transparent huge pages -- memset: 113 GB/s on 8 threads, tools/probe/prefault_probe.py).
     Measured on the MI355X box: download_rows into a fresh 1.2 GB array 15 GB/s (the drain copies page-fault it in
     while the DMA engine competes for the memory system) against 49 GB/s into a mapped one.
-    Returns [(end_byte, future)] in address order for wait_prefault(); [] when the array is small."""
+    Returns [(start_byte, end_byte, future)] in address order for wait_prefault(); [] when the array is small.
+    Every job holds a reference to ``arr``: the memory cannot be freed under a running memset, whatever the caller does."""
     global _FAULT_POOL
     nbytes = arr.nbytes
     if nbytes < (64 << 20):
@@ -77,14 +81,19 @@ def prefault(arr, span_bytes=32 << 20):
     if _FAULT_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
         _FAULT_POOL = ThreadPoolExecutor(max_workers=PREFAULT_THREADS)
-    return [(min(a + span_bytes, nbytes), _FAULT_POOL.submit(ctypes.memset, base + a, 0, min(span_bytes, nbytes - a)))
-            for a in range(0, nbytes, span_bytes)]
+
+    def job(keep, addr, count):
+        ctypes.memset(addr, 0, count)
+        return keep is not None
+
+    return [(a, min(a + PREFAULT_SPAN, nbytes), _FAULT_POOL.submit(job, arr, base + a, min(PREFAULT_SPAN, nbytes - a)))
+            for a in range(0, nbytes, PREFAULT_SPAN)]
 
 
-def wait_prefault(futs, stop_byte):
-    """Block until the spans that cover bytes below ``stop_byte`` are mapped."""
-    while futs and futs[0][0] - (32 << 20) < stop_byte:
-        futs.pop(0)[1].result()
+def wait_prefault(futs, stop_byte=None):
+    """Block until the spans that START below ``stop_byte`` are mapped (``None``: all of them)."""
+    while futs and (stop_byte is None or futs[0][0] < stop_byte):
+        futs.pop(0)[2].result()
 
 
 def open_npz_array(path, key="data"):
@@ -306,21 +315,25 @@ def download_rows(dev, out=None, ready=None, block_rows=None, chunk_bytes=None):
         copy_stream.wait_stream(torch.cuda.current_stream(dev.device))
     pending = None                               # (buffer index, start, stop, event)
     ri = 0
-    with torch.cuda.device(dev.device):
-        for k, start in enumerate(range(0, n, chunk_rows)):
-            stop = min(start + chunk_rows, n)
-            while ri < len(ready) and (ri == 0 or ready[ri - 1][0] < stop):
-                copy_stream.wait_event(ready[ri][1])      # every producer event up to the one covering `stop`
-                ri += 1
-            with torch.cuda.stream(copy_stream):
-                stage[k & 1][:stop - start].copy_(dev[start:stop], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(copy_stream)
-            if pending is not None:
-                _drain(out, stage, pending, faults)
-            pending = (k & 1, start, stop, ev)
-        _drain(out, stage, pending, faults)
+    try:
+        with torch.cuda.device(dev.device):
+            for k, start in enumerate(range(0, n, chunk_rows)):
+                stop = min(start + chunk_rows, n)
+                while ri < len(ready) and (ri == 0 or ready[ri - 1][0] < stop):
+                    copy_stream.wait_event(ready[ri][1])      # every producer event up to the one covering `stop`
+                    ri += 1
+                with torch.cuda.stream(copy_stream):
+                    stage[k & 1][:stop - start].copy_(dev[start:stop], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                if pending is not None:
+                    _drain(out, stage, pending, faults)
+                pending = (k & 1, start, stop, ev)
+            _drain(out, stage, pending, faults)
+    finally:
+        # no memset may outlive this call: a HIP error or KeyboardInterrupt above would otherwise leave up to
+        # PREFAULT_THREADS jobs zeroing spans of an array the caller has already had copied into (or dropped)
         if faults:
-            wait_prefault(faults, out.nbytes + (64 << 20))
+            wait_prefault(faults)
     dev.record_stream(copy_stream)
     return out

@@ -83,26 +83,33 @@ def emd_rows(true_data, reconstructed_data):
 
 
 class EarlyStopping:
+    """Stops a run whose epoch loss has stopped improving (reference: utils.py:240-282; behaviour pinned by fixture g13).
+
+    The state is the best loss seen and a strike counter.  Per epoch the GAIN over the best loss decides: a gain above
+    ``min_delta`` is a new best and clears the strikes; a gain below it is a strike, and ``patience`` strikes set
+    ``early_stop``.  A gain of exactly ``min_delta`` (or a NaN loss) is neither -- the reference tests both sides strictly.
+    Attribute names and the two progress lines are the reference's (callers and logs read them)."""
+
     def __init__(self, patience: int, min_delta: float):
-        self.patience = patience
-        self.min_delta = min_delta
-        self.counter = 0
-        self.best_loss = None
-        self.early_stop = False
+        self.patience, self.min_delta = patience, min_delta
+        self.counter, self.best_loss, self.early_stop = 0, None, False
+
+    def _strike(self):
+        self.counter += 1
+        print(f"Early stopping counter {self.counter} of {self.patience}")
+        if self.counter >= self.patience:
+            print("Early Stopping")
+            self.early_stop = True
 
     def __call__(self, train_loss):
-        if self.best_loss is None:
+        if self.best_loss is None:              # first epoch: nothing to compare with
             self.best_loss = train_loss
-        elif self.best_loss - train_loss > self.min_delta:
-            self.best_loss = train_loss
-            self.counter = 0
-        elif self.best_loss - train_loss < self.min_delta:
-            # equality (best - loss == min_delta) changes nothing, exactly like the reference
-            self.counter += 1
-            print(f"Early stopping counter {self.counter} of {self.patience}")
-            if self.counter >= self.patience:
-                print("Early Stopping")
-                self.early_stop = True
+            return
+        gain = self.best_loss - train_loss
+        if gain > self.min_delta:
+            self.best_loss, self.counter = train_loss, 0
+        elif gain < self.min_delta:
+            self._strike()
 
 
 class LRScheduler:

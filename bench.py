@@ -98,6 +98,25 @@ def log(msg):
 T0 = time.perf_counter()
 
 
+def rank_diag(stage, local=None):
+    """One stderr line per rank and stage, BEFORE the first collective: which device, how many XCDs / CUs, the IPC mode RCCL
+    depends on on this driver (HSA_ENABLE_IPC_MODE_LEGACY=0 = dmabuf), visibility masks and the rendezvous -- so that a failed
+    multi-GPU run is diagnosable from its tail.  Counting devices does not initialise the GPU; the device properties are only
+    read once the process group is up (local is not None)."""
+    env = os.environ
+    msg = (f"rank {env.get('RANK', '0')}/{env.get('WORLD_SIZE', '1')} local {env.get('LOCAL_RANK', '0')} pid {os.getpid()} {stage}: "
+           f"visible_devices={torch.cuda.device_count()} HSA_ENABLE_IPC_MODE_LEGACY={env.get('HSA_ENABLE_IPC_MODE_LEGACY', '<unset>')} "
+           f"HIP_VISIBLE_DEVICES={env.get('HIP_VISIBLE_DEVICES', '<unset>')} ROCR_VISIBLE_DEVICES={env.get('ROCR_VISIBLE_DEVICES', '<unset>')} "
+           f"master={env.get('MASTER_ADDR', '<unset>')}:{env.get('MASTER_PORT', '<unset>')} "
+           f"backend={env.get('BALER_AMD_DIST_BACKEND', 'nccl(RCCL)')} force_device={env.get('BALER_AMD_FORCE_DEVICE', '<unset>')}")
+    if local is not None and torch.cuda.is_available():
+        p = torch.cuda.get_device_properties(local)
+        cus = p.multi_processor_count
+        msg += (f" | device {local}: {p.name} arch={getattr(p, 'gcnArchName', '?')} CUs={cus} XCDs={cus // 32 if cus % 32 == 0 else '?'} "
+                f"HBM={p.total_memory / 2**30:.0f}GiB")
+    log(msg)
+
+
 def source_hash():
     """Hash of the kernel sources the running library was built from: a committed PMC summary is only quoted when it
     was taken on the same sources."""
@@ -234,12 +253,27 @@ def main():
     from baler_amd import native, synth
     from baler_amd.modules import models
 
+    rank_diag("start")
     try:
         rank, world, local = bdist.init_from_env()
     except Exception as e:      # RCCL / rendezvous failure: say so and fail; never re-exec a process that may have touched the GPU
         print(f"bench.py: torch.distributed initialisation failed on rank {os.environ.get('RANK', '?')}: {type(e).__name__}: {e}",
               file=sys.stderr, flush=True)
         sys.exit(3)
+    rank_diag("process group up", local)
+    if world > 1:
+        # the FIRST collective of the run, on its own, so that a hang or an IPC failure is attributable from the log tail
+        import torch.distributed as td
+        try:
+            probe = torch.ones(1, device=torch.device("cuda", local) if torch.cuda.is_available() else "cpu")
+            td.all_reduce(probe)
+            ok = float(probe.item()) == world
+        except Exception as e:
+            print(f"bench.py: first all-reduce failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            sys.exit(3)
+        rank_diag(f"first all-reduce {'OK' if ok else 'WRONG SUM'}", local)
+        if not ok:
+            sys.exit(3)
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE is {world} (launch with --nproc-per-node {a.gpus}, "
                          f"or run `python bench.py --gpus {a.gpus}` and let it start the ranks)")

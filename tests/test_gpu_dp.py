@@ -87,6 +87,42 @@ def test_bench_two_ranks_one_gpu(tmp_path):
     assert d["value"] > 0 and "cpu_baseline" not in d and d["roofline"]["frac"] > 0
 
 
+def test_bench_scale_record_two_ranks_driver_launch():
+    """The round-end SCALE run, rehearsed: the driver's own launch line (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`, default extras) with two
+    ranks on the one GPU, BALER_AMD_DP_BATCH=per_gpu in the environment as a per-GPU-batch run would have it.  Asserts what the
+    SCALE record is computed from -- ONE JSON line from rank 0 with `value`, `rccl_ranks`, `allreduce_us`, both batch policies at
+    batch_size 512, bit-identical replicas, the configs[2] leg -- and that every rank wrote its diagnostic lines (device, XCD
+    count, IPC mode) BEFORE the first collective, so that a failed multi-GPU run can be read from its stderr tail."""
+    env = dict(os.environ, BALER_AMD_FORCE_DEVICE="0", BALER_AMD_DIST_BACKEND="gloo", BALER_AMD_DP_BATCH="per_gpu",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = _torchrun(2, [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "65536",
+                      "--c3-rows", "65536", "--pcie-rows", "200000", "--cpu-rows", "20000"], env, free_port())
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "rccl_ranks", "allreduce_us", "allreduce_bytes", "allreduce_frac_of_step",
+                "train_rows_per_s_by_batch_policy", "train_rows_per_s_by_batch", "train_rows_per_s_by_global_batch",
+                "replicas_identical", "c3", "c3_train_rows_per_s"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["replicas_identical"] is True
+    assert d["allreduce_us"] > 0 and d["train_rows_per_s_by_batch_policy"] == "per_gpu"
+    assert d["train_rows_per_s_by_batch"]["512"]["rows_per_s"] > 0          # 512 rows PER GPU per step (global batch 1024)
+    assert d["train_rows_per_s_by_global_batch"]["512"]["rows_per_gpu_per_step"] == 256
+    assert d["c3"]["global_rows"] == 131072 and d["c3"]["train_rows_per_s"] > 0
+    for rank in (0, 1):
+        tag = f"rank {rank}/2"
+        mine = [l for l in r.stderr.splitlines() if tag in l]
+        assert any("start" in l and "HSA_ENABLE_IPC_MODE_LEGACY=0" in l for l in mine), r.stderr[-3000:]
+        assert any("process group up" in l and "XCDs=8" in l and "CUs=256" in l for l in mine), r.stderr[-3000:]
+        assert any("first all-reduce OK" in l for l in mine), r.stderr[-3000:]
+    # the diagnostics come before the first collective of the run
+    err = r.stderr
+    assert err.index("process group up") < err.index("first all-reduce OK") < err.index("data resident")
+
+
 _CLI_WORKER = r'''
 import os, sys, shutil
 sys.path.insert(0, os.environ["REPO"])

@@ -19,10 +19,24 @@ TOL32 = 1e-5
 TOL64 = 1e-11
 
 
-def rel(a, b):
+def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def rel(a, b):
+    """THE error measure of the fp32 / fp64 parity assertions below: the larger of the rel-L2 error and the max-norm error
+    max|a - b| / max|b| of the tensor pair.  A single element off by 1e-3 in a million-element tensor passes a 1e-5 rel-L2 bar;
+    it does not pass this one.  (The bf16 throughput mode is held to rel-L2 only, `rel_l2`: its bar is a statistical one.)"""
+    return max(rel_l2(a, b), maxerr(a, b))
+
+
+def maxerr(a, b):
+    """max |a - b| / max |b|: a single outlier of 1e-3 in a million-element tensor passes a 1e-5 rel-L2 bar; this one sees it."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300) if b.size else 0.0
 
 
 def dev(a, dtype=None):
@@ -333,11 +347,17 @@ def test_cfd_dense_golden(golden):
     grads = torch.zeros_like(p)
     h.fwd_bwd(x, grads)
     gh = grads.cpu().numpy().astype(np.float64)
-    assert abs(gh[-1] - g["loss"]) < 1e-4 * abs(g["loss"])  # the reference itself is fp32 here
+    # The reference computes CFD_dense_AE in float32 (models.py:186-209 builds it without dtype=float64), so ITS loss and per-tensor
+    # gradient norms -- all the fixture can hold of a 1,037,575-element gradient -- carry float32 rounding of their own: 1e-4 against
+    # those; the gradient ITSELF is held to the 1e-5 bar, per tensor, L2 and max-norm, against the fp64 oracle on the same frames.
+    assert abs(gh[-1] - g["loss"]) < 1e-4 * abs(g["loss"])
+    lo, go = orc.fwd_bwd(dims, flat, x.cpu().numpy().astype(np.float64))
+    assert abs(gh[-1] - lo) < TOL32 * lo
     norms, off = [], 0
     for l in range(8):
         for n in (dims[l + 1] * dims[l], dims[l + 1]):
             norms.append(np.linalg.norm(gh[off:off + n]))
+            assert rel(gh[off:off + n], go[off:off + n]) < TOL32, (l, n)
             off += n
     assert rel(norms, g["grad_tensor_l2"]) < 1e-4
 
@@ -355,18 +375,28 @@ def test_cfd_dense_wide_layer_kernels_vs_oracle(n):
     xn = (raw - mn) / rg
     z_ref = orc.encode(dims, flat, xn)
     feats = dev(np.stack([mn, rg]))
-    for xin, f in ((dev(xn, torch.float32), None), (dev(xn), None), (dev(raw), feats), (dev(raw, torch.float32), feats)):
+    # float32 RAW rows: the rounding of the raw value to float32 happens before the normalisation and is part of the input, not of
+    # the kernel -- the oracle gets the same rounded rows, and the bar stays 1e-5 (it was 2e-4 against the unrounded rows)
+    raw32 = raw.astype(np.float32).astype(np.float64)
+    z_ref32 = orc.encode(dims, flat, (raw32 - mn) / rg)
+    for xin, f, want in ((dev(xn, torch.float32), None, z_ref), (dev(xn), None, z_ref), (dev(raw), feats, z_ref),
+                         (dev(raw, torch.float32), feats, z_ref32)):
         z = h.encode(xin, features=f, out_dtype=torch.float32)
-        assert rel(z.cpu().numpy(), z_ref) < (TOL32 if f is None or xin.dtype == torch.float64 else 2e-4), (xin.dtype, f is None)
+        assert rel(z.cpu().numpy(), want) < TOL32, (xin.dtype, f is None)
     rec_ref = orc.decode(dims, flat, z_ref)
     for zin in (dev(z_ref, torch.float32), dev(z_ref)):
         assert rel(h.decode(zin).cpu().numpy(), rec_ref) < TOL32
     mask = np.zeros(2500, dtype=np.uint8)
     mask[::7] = 1
     dec = h.decode(dev(z_ref, torch.float32), features=feats, int_mask=torch.as_tensor(mask).cuda(), out_dtype=torch.float64).cpu().numpy()
-    want = rec_ref * rg + mn
-    want[:, mask == 1] = np.trunc(want[:, mask == 1])
-    assert np.isclose(dec, want, rtol=1e-4, atol=1e-6).mean() > 0.999        # a truncation may flip where want sits on an integer
+    pre = rec_ref * rg + mn
+    m1 = mask == 1
+    assert rel(dec[:, ~m1], pre[:, ~m1]) < TOL32
+    # int columns: trunc() of a float32-accurate value equals trunc() of the exact one unless the value sits within its own
+    # rounding error of an integer; those cells (a handful) may flip by one, every other cell must match exactly
+    edge = np.abs(pre[:, m1] - np.round(pre[:, m1])) < 1e-4 * np.maximum(1.0, np.abs(pre[:, m1]))
+    got_i, want_i = dec[:, m1], np.trunc(pre[:, m1])
+    assert np.array_equal(got_i[~edge], want_i[~edge]) and np.all(np.abs(got_i[edge] - want_i[edge]) <= 1.0) and edge.mean() < 0.01
 
 
 @pytest.mark.parametrize("n", [1, 17, 100, 1037])
@@ -391,8 +421,8 @@ def test_exafel_625_7_fused_vs_oracle(n):
     assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
     # the bf16 mode of the same shape (en1 / de4 on the bf16 MFMA): its own 2e-2 bar
     hb, _ = make_handle(dims, flat, "bf16")
-    assert rel(hb.encode(dev(x, torch.float32), out_dtype=torch.float32).cpu().numpy(), z_ref) < 2e-2
-    assert rel(hb.decode(dev(z_ref, torch.float32)).cpu().numpy(), rec_ref) < 2e-2
+    assert rel_l2(hb.encode(dev(x, torch.float32), out_dtype=torch.float32).cpu().numpy(), z_ref) < 2e-2
+    assert rel_l2(hb.decode(dev(z_ref, torch.float32)).cpu().numpy(), rec_ref) < 2e-2
 
 
 @pytest.mark.parametrize("z", [10, 5, 4, 3, 2])
@@ -505,6 +535,74 @@ def test_full_size_properties():
     assert rel(h.decode(h.encode(x[:4096])).cpu().numpy(), recon.cpu().numpy()) < 1e-6
 
 
+def _wide_full_size(shape, n, seed):
+    """Size-independent properties of a wide model at SURVEY 8(d)'s full per-GPU size: row offsets beyond 2^32 bytes in the
+    wide-layer kernels, sampled rows (first / last tile, either side of every 2^32-byte boundary) against the oracle, whole ==
+    concatenation of parts (bit for bit: parts are cut on 128-row boundaries and stay on the same kernels), determinism, loss and
+    gradient additive over row shards, forward loss == the loss slot of fwd_bwd."""
+    F, Z = shape
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, seed)
+    h, p = make_handle(dims, flat, "fp32")
+    assert h.path == "fused"
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.rand((n, F), dtype=torch.float32, device="cuda", generator=gen)
+    row_bytes = F * 4
+    idx = {0, 1, 15, 16, n - 17, n - 16, n - 1, n // 2 + 7}
+    for k in range(1, int(n * row_bytes >> 32) + 1):          # the rows either side of each 4-GiB boundary
+        r = (k << 32) // row_bytes
+        idx.update({r - 1, r, r + 1})
+    idx = torch.as_tensor(sorted(i for i in idx if 0 <= i < n), device="cuda")
+    xs = x[idx].cpu().numpy().astype(np.float64)
+    # encode
+    z = h.encode(x)
+    assert rel(z[idx].cpu().numpy(), orc.encode(dims, flat, xs)) < TOL32
+    assert torch.equal(z, h.encode(x))
+    cut = (n // 3) & ~127
+    assert cut >= 65536
+    assert torch.equal(z, torch.cat([h.encode(x[:cut]), h.encode(x[cut:])]))
+    assert torch.equal(z[idx], h.encode(x[idx].contiguous())) or rel(z[idx].cpu().numpy(), h.encode(x[idx].contiguous()).cpu().numpy()) < 2e-6
+    # decode (the output is the n x F array: its store offsets pass 2^32 as well)
+    d = h.decode(z)
+    assert rel(d[idx].cpu().numpy(), orc.decode(dims, flat, z[idx].cpu().numpy().astype(np.float64))) < TOL32
+    assert torch.equal(d[cut:], h.decode(z[cut:].contiguous()))
+    assert bool(torch.isfinite(d).all())
+    # forward + loss, and the training pass
+    rec, loss = h.forward_loss(x)
+    assert rel(rec[idx].cpu().numpy(), orc.forward(dims, flat, xs)) < TOL32
+    del rec, d
+    torch.cuda.empty_cache()
+    g_full, g_a, g_b = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+    h.fwd_bwd(x, g_full)
+    assert abs(loss.item() - float(g_full[-1])) < 1e-5 * loss.item()
+    h.fwd_bwd(x[:cut], g_a)
+    h.fwd_bwd(x[cut:], g_b)
+    assert rel((g_a.double() + g_b.double()).cpu().numpy(), g_full.cpu().numpy()) < 1e-5
+    g2 = torch.zeros_like(p)
+    h.fwd_bwd(x, g2)
+    assert torch.equal(g2, g_full)                      # fixed-order reductions: bitwise reproducible
+    # a small slice against the oracle: the same kernels, so the full-size sums above are sums of THESE per-row terms
+    lo, go = orc.fwd_bwd(dims, flat, xs)
+    gs = torch.zeros_like(p)
+    h.fwd_bwd(x[idx].contiguous(), gs)
+    gh = gs.cpu().numpy().astype(np.float64)
+    assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
+    h.close()
+    del x, z
+    torch.cuda.empty_cache()
+
+
+def test_c4_full_size_properties():
+    """BASELINE configs[3] at SURVEY 8(d)'s throughput size: CFD_dense_AE(2500, 25), 262,144 frames = 2.6 GB of float32."""
+    _wide_full_size((2500, 25), 262_144, 61)
+
+
+def test_c5_full_size_properties():
+    """BASELINE configs[4] at ONE GPU's share: the 512-column model, 4,194,304 rows x 512 float32 = 8.6 GB -- row offsets cross
+    2^32 bytes twice in the wide kernels' loads (encode, training) and stores (decode, forward)."""
+    _wide_full_size((512, 6), 4_194_304, 62)
+
+
 def test_c3_shard_size_properties():
     """BASELINE configs[2] (100 M rows over 8 GPUs) at ONE rank's size: 12.5 M rows = 2.4 GB of float64 resident on one GPU
     (the 8-GPU run itself needs an 8-GPU node).  Size-independent properties: training and encode over the shard equal the
@@ -533,7 +631,7 @@ def test_c3_shard_size_properties():
     hb, pb = make_handle(dims, flat, "bf16")
     gb = torch.zeros_like(pb)
     hb.fwd_bwd(x, gb)
-    assert rel(gb.cpu().numpy()[:-1], g_full.cpu().numpy()[:-1]) < 2e-2
+    assert rel_l2(gb.cpu().numpy()[:-1], g_full.cpu().numpy()[:-1]) < 2e-2
     assert abs(float(gb[-1]) - float(g_full[-1])) < 2e-3 * float(g_full[-1])
 
 
@@ -767,26 +865,26 @@ def test_bf16_mode_encode_decode_forward(z_dim, data10k):
         z = h.encode(dev(x, dt))
         assert z.dtype == dt and rel(z.cpu().numpy(), zo) < BF16_TOL
         d = h.decode(dev(zo, dt))
-        assert rel(d.cpu().numpy(), orc.decode(dims, flat, zo)) < BF16_TOL
+        assert rel_l2(d.cpu().numpy(), orc.decode(dims, flat, zo)) < BF16_TOL
     recon, loss = h.forward_loss(dev(x))
     ro = orc.decode(dims, flat, zo)
-    assert rel(recon.cpu().numpy(), ro) < BF16_TOL
+    assert rel_l2(recon.cpu().numpy(), ro) < BF16_TOL
     assert abs(loss.item() - ((ro - x) ** 2).sum() / 24) < BF16_TOL * ((ro - x) ** 2).sum() / 24
     _, loss2 = h.forward_loss(dev(x), want_recon=False)
     assert loss2.item() == loss.item()                                  # reproducible, with or without the recon store
     for n in (1, 15, 16, 17, 63, 64, 65, 511, 513):
-        assert rel(h.encode(dev(x[:n])).cpu().numpy(), zo[:n]) < BF16_TOL
+        assert rel_l2(h.encode(dev(x[:n])).cpu().numpy(), zo[:n]) < BF16_TOL
     assert h.encode(dev(x[:0])).shape == (0, z_dim)
     # fused normalisation on load, un-normalisation + int truncation on store
     raw = synth.cms_rows(3001)
     feats = orc.find_minmax(raw)
     zn = h.encode(dev(raw), features=dev(feats))
-    assert rel(zn.cpu().numpy(), orc.encode(dims, flat, orc.normalize(raw))) < BF16_TOL
+    assert rel_l2(zn.cpu().numpy(), orc.encode(dims, flat, orc.normalize(raw))) < BF16_TOL
     mask = np.array([t == "int" for t in synth.CMS_TYPE_LIST], dtype=np.uint8)
     out = h.decode(dev(zo), features=dev(feats), int_mask=torch.from_numpy(mask).cuda()).cpu().numpy()
     want = orc.renormalize(orc.decode(dims, flat, zo), feats[0], feats[1])
     fl = mask == 0
-    assert rel(out[:, fl], want[:, fl]) < BF16_TOL
+    assert rel_l2(out[:, fl], want[:, fl]) < BF16_TOL
     assert np.array_equal(out[:, ~fl], np.trunc(out[:, ~fl]))
 
 
@@ -804,13 +902,13 @@ def test_bf16_mode_training_calls(data10k, kernels, monkeypatch):
     grads = torch.zeros_like(p)
     h.fwd_bwd(dev(x, torch.float64), grads)
     lo, go = orc.fwd_bwd(dims, flat, x)
-    assert rel(grads.cpu().numpy()[:-1], go) < (BF16_TOL if kernels == "bf16" else TOL32)
+    assert (rel_l2(grads.cpu().numpy()[:-1], go) < BF16_TOL) if kernels == "bf16" else (rel(grads.cpu().numpy()[:-1], go) < TOL32)
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     z0 = h.encode(dev(x))
     h.adam_step(p, grads, m, v, 1, 1e-2)
     z1 = h.encode(dev(x))
     assert not torch.equal(z0, z1)                                       # the step reached the packed bf16 weights
-    assert rel(z1.cpu().numpy(), orc.encode(dims, p.cpu().numpy().astype(np.float64)[:-1], x)) < BF16_TOL
+    assert rel_l2(z1.cpu().numpy(), orc.encode(dims, p.cpu().numpy().astype(np.float64)[:-1], x)) < BF16_TOL
 
 
 @pytest.mark.parametrize("n", [12288, 12289])
@@ -870,16 +968,16 @@ def test_bf16_mode_wide_models(shape, n, monkeypatch):
     x = np.random.default_rng(n).random((n, shape[0]))
     z_ref = orc.encode(dims, flat, x)
     for xin in (dev(x, torch.float32), dev(x)):
-        assert rel(h.encode(xin, out_dtype=torch.float32).cpu().numpy(), z_ref) < 6e-3
+        assert rel_l2(h.encode(xin, out_dtype=torch.float32).cpu().numpy(), z_ref) < 6e-3
     rec_ref = orc.decode(dims, flat, z_ref)
     for zin in (dev(z_ref, torch.float32), dev(z_ref)):
-        assert rel(h.decode(zin).cpu().numpy(), rec_ref) < 6e-3
+        assert rel_l2(h.decode(zin).cpu().numpy(), rec_ref) < 6e-3
     mn, rg = x.min(0) - 0.5, x.max(0) - x.min(0) + 1.0
     feats = dev(np.stack([mn, rg]))
     zn = orc.encode(dims, flat, (x - mn) / rg)
-    assert rel(h.encode(dev(x), features=feats, out_dtype=torch.float32).cpu().numpy(), zn) < 6e-3
+    assert rel_l2(h.encode(dev(x), features=feats, out_dtype=torch.float32).cpu().numpy(), zn) < 6e-3
     dec = h.decode(dev(zn, torch.float32), features=feats, out_dtype=torch.float64).cpu().numpy()
-    assert rel(dec, orc.decode(dims, flat, zn) * rg + mn) < 6e-3
+    assert rel_l2(dec, orc.decode(dims, flat, zn) * rg + mn) < 6e-3
     # training pass: bf16 wide products (bf16 bar), the fp32 launches behind the switch (exact), then an optimiser step: the next
     # encode must see the new weights
     grads = torch.zeros_like(p)
@@ -889,7 +987,7 @@ def test_bf16_mode_wide_models(shape, n, monkeypatch):
         h.fwd_bwd(xin, grads)
         gh = grads.cpu().numpy().astype(np.float64)
         # (a single row: one hidden unit whose pre-activation changes sign under bf16 rounding moves whole gradient rows -- LeakyReLU kink)
-        assert rel(gh[:-1], go) < (5e-3 if n >= 33 else 1e-1) and abs(gh[-1] - lo) < 1e-3 * lo, xin.dtype
+        assert rel_l2(gh[:-1], go) < (5e-3 if n >= 33 else 1e-1) and abs(gh[-1] - lo) < 1e-3 * lo, xin.dtype
     monkeypatch.setenv("BALER_AMD_BF16_WIDE_TRAIN", "0")
     h.fwd_bwd(dev(x, torch.float32), grads)
     monkeypatch.delenv("BALER_AMD_BF16_WIDE_TRAIN")
@@ -898,8 +996,8 @@ def test_bf16_mode_wide_models(shape, n, monkeypatch):
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     h.adam_step(p, grads, m, v, 1, 1e-2)
     z_new = orc.encode(dims, p.cpu().numpy().astype(np.float64)[:-1], x)
-    assert rel(h.encode(dev(x), out_dtype=torch.float32).cpu().numpy(), z_new) < 6e-3
-    assert rel(z_new, z_ref) > 2e-2          # the step moved the latents by far more than the bf16 tolerance
+    assert rel_l2(h.encode(dev(x), out_dtype=torch.float32).cpu().numpy(), z_new) < 6e-3
+    assert rel_l2(z_new, z_ref) > 2e-2          # the step moved the latents by far more than the bf16 tolerance
 
 
 def test_two_handles_two_streams(data10k):

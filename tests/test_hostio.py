@@ -135,6 +135,14 @@ mine = torch.from_numpy(table[lo:hi])
 mm = torch.stack([mine.min(0).values, mine.max(0).values])
 bdist.allreduce_minmax(mm)
 assert np.array_equal(mm[0].numpy(), table.min(0)) and np.array_equal(mm[1].numpy(), table.max(0))
+# a NaN cell on ONE rank poisons its column on every rank (np.min / np.max propagate it), the other columns stay exact
+t2 = table.copy(); t2[700, 4] = np.nan
+mine = torch.from_numpy(t2[lo:hi])
+has = torch.isnan(mine).any(0)
+mm = torch.stack([mine.min(0).values, mine.max(0).values]); mm[:, has] = float("nan")
+bdist.allreduce_minmax(mm)
+ok = [c for c in range(6) if c != 4]
+assert torch.isnan(mm[:, 4]).all() and np.array_equal(mm[0].numpy()[ok], table.min(0)[ok]) and np.array_equal(mm[1].numpy()[ok], table.max(0)[ok])
 # a rank keeps only its slice of every global batch, and the slices tile the table
 plan = hostio.RowPlan.cyclic(n, 128, rank, world)
 local = hostio.upload_rows(table, plan, "cpu")
@@ -173,3 +181,24 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert r.returncode != 0
     assert "no MI355X" in r.stderr and "nproc" not in r.stdout
     assert r.stderr.count("NativeError") >= 2 or "local_rank: 1" in r.stderr or "rank: 1" in r.stderr
+
+
+def test_prefault_jobs_hold_the_array_and_wait_by_span_start():
+    """hostio.prefault: every background memset keeps its array alive, and wait_prefault(stop) waits for every span that
+    STARTS below `stop` (a span overlapping the rows about to be drained must be mapped before they are copied in)."""
+    import gc
+    import weakref
+    n = (3 * hostio.PREFAULT_SPAN + 12345) // 8
+    arr = np.empty(n, dtype=np.float64)
+    ref = weakref.ref(arr)
+    futs = hostio.prefault(arr)
+    assert [(a, e) for a, e, _ in futs] == [(a, min(a + hostio.PREFAULT_SPAN, arr.nbytes))
+                                            for a in range(0, arr.nbytes, hostio.PREFAULT_SPAN)]
+    del arr
+    gc.collect()
+    assert ref() is not None                      # the pending / finished jobs still reference it
+    hostio.wait_prefault(futs, hostio.PREFAULT_SPAN + 1)
+    assert len(futs) == 2                         # spans starting at 0 and at PREFAULT_SPAN are done and popped
+    hostio.wait_prefault(futs)
+    assert futs == []
+    assert hostio.prefault(np.empty(1024)) == []  # small arrays are not worth a thread hop

@@ -1,3 +1,4 @@
+# needs a debug build of the library: make -C baler_amd/csrc clean all HIPFLAGS+=-DBAMD_DEBUG (bamd_debug_copy_imgs)
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, "/root/repo")
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np, torch
 from baler_amd import native
 from oracle import c_oracle as orc
