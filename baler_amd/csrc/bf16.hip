@@ -66,7 +66,7 @@ __device__ __forceinline__ void lrelu4(v4 &a) {
     v4 m = a * (v4){k2[0], k2[1], k2[0], k2[1]};
     asm("" : "+v"(m));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = __builtin_amdgcn_fmed3f(a[r], m[r], 3.402823466e38f);
+    for (int r = 0; r < 4; ++r) a[r] = __builtin_elementwise_maximum(a[r], m[r]);
 }
 __device__ __forceinline__ bf8 pack8(const v4 &lo, const v4 &hi) {
     bf8 o;

@@ -283,7 +283,7 @@ __device__ __forceinline__ void lrelu4(v4 &a) {
     asm("" : "+v"(m));
 #endif
 #pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = __builtin_amdgcn_fmed3f(a[r], m[r], 3.402823466e38f);
+    for (int r = 0; r < 4; ++r) a[r] = __builtin_elementwise_maximum(a[r], m[r]);
 }
 // two v_cvt_pk_bf16_f32 (built pair by pair: a 4-element bf16 vector makes hipcc convert elements 2, 3 one by one + v_perm)
 __device__ __forceinline__ u2 pack4(const v4 &a) {

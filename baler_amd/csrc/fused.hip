@@ -222,13 +222,15 @@ template <int NT> __device__ __forceinline__ void lrelu(v4 (&a)[NT]) {
     const v4 kk = (v4){k2[0], k2[1], k2[0], k2[1]};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        // x > 0 ? x : 0.01 x == max(x, 0.01 x) == med3(x, 0.01 x, +inf).  The products of a tile are one vector
-        // multiply (two v_pk_mul_f32 instead of four v_mul_f32: every VALU instruction costs MFMA issue slots), then
-        // v_med3 per register (FLT_MAX, not inf: hipcc folds med3(x,y,inf) back into canonicalise + v_max)
+        // x > 0 ? x : 0.01 x == max(x, 0.01 x).  The products of a tile are one vector multiply (two v_pk_mul_f32 instead of
+        // four v_mul_f32: every VALU instruction costs MFMA issue slots), then ONE v_maximum3_f32 per register (gfx950's IEEE-2019
+        // maximum: a NaN stays a NaN, as in torch's leaky_relu).  fmaxf() costs a canonicalising v_max in front of the v_max; the
+        // med3(x, 0.01 x, FLT_MAX) of rounds 1-3 was one instruction too but turned a NaN into FLT_MAX (v_med3 falls back to
+        // min3 on a NaN input) -- found by tests/test_gpu_edge.py
         v4 m = a[t] * kk;
         asm("" : "+v"(m));            // keep the product a vector: extract-of-fmul would be scalarised again
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[t][r] = __builtin_amdgcn_fmed3f(a[t][r], m[r], 3.402823466e38f);
+        for (int r = 0; r < 4; ++r) a[t][r] = __builtin_elementwise_maximum(a[t][r], m[r]);
     }
 }
 // dZ = dY * lrelu'(pre) ; sign(pre) == sign(post-activation y)
@@ -1118,8 +1120,269 @@ __global__ void __launch_bounds__(256) wide_bf16_encode_kernel(const v4 *packed,
     }
 }
 
+// ---- the NARROW layers of a wide model on the bf16 MFMA, two row tiles at once ----------------------------------------------------
+// In the bf16 encode / decode of the wide models the six narrow layers were left on the float32 chain "because they are 4 % of the
+// work" -- but a float32 MFMA is 16x slower: per 32 rows 2 x 508 v_mfma_f32_16x16x4 = 32.5k cycles, 13.5 us in which a wave does not
+// touch its rows (measured with timing-only builds of the encode kernel below: 4.18 -> 5.28 TB/s of rows without that tail).  Here a
+// layer is NT output tiles x KBK k blocks of 32 inputs: a C-tile pair (2 c, 2 c + 1) of the previous layer is k block c of this one
+// after v_cvt_pk_bf16_f32 (no lane movement, the trick of bf16.hip), the fragments (ImplWideBf16::setup: k slot (g, j) <-> the feature
+// of slot (tile 2 c + j / 4, g, j % 4)) come straight from L2, one k block ahead, and feed both row tiles; accumulation and bias in
+// float32.  69 / 70 MFMAs of 16 cycles per tile instead of 508 of 32.
+template <int KD, int NT>
+__device__ __forceinline__ void chain_bf16_pair(const v4 (&in0)[tiles(KD)], const v4 (&in1)[tiles(KD)], v4 (&out0)[NT], v4 (&out1)[NT],
+                                                const WStream &wc, int base) {
+    constexpr int KT = tiles(KD), KBK = (KT + 1) / 2;
+    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+    bf8 w[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[0][t] = frag_bf(wc, base + t);
+    // all B operands first: the float32 input tiles are dead from here on (the wide layer's 2 x 13 tiles would not fit next to the
+    // fragment buffers otherwise)
+    bf8 q0[KBK], q1[KBK];
+#pragma unroll
+    for (int c = 0; c < KBK; ++c) {
+        q0[c] = to_bf8(in0[2 * c], 2 * c + 1 < KT ? in0[2 * c + 1 < KT ? 2 * c + 1 : 0] : zero);
+        q1[c] = to_bf8(in1[2 * c], 2 * c + 1 < KT ? in1[2 * c + 1 < KT ? 2 * c + 1 : 0] : zero);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < KBK; ++c) {
+        if (c + 1 < KBK) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w[(c + 1) & 1][t] = frag_bf(wc, base + (c + 1) * NT + t);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { out0[t] = mfma_bf(w[c & 1][t], q0[c], out0[t]); out1[t] = mfma_bf(w[c & 1][t], q1[c], out1[t]); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// one narrow layer l of the pair: bias (float32, from LDS) -> bf16 product -> LeakyReLU;  CB = first layer of the chain buffer `wc`
+template <class N, int l, int CB>
+__device__ __forceinline__ void fwd_layer_bf16_pair(const v4 (&in0)[tiles(N::dim(l))], const v4 (&in1)[tiles(N::dim(l))],
+                                                    v4 (&out0)[tiles(N::dim(l + 1))], v4 (&out1)[tiles(N::dim(l + 1))], const WStream &wc,
+                                                    const v4 *bias_l, int lane) {
+    constexpr int base = [] { int b = 0; for (int j = CB; j < l; ++j) b += ((tiles(N::dim(j)) + 1) / 2) * tiles(N::dim(j + 1)); return b; }();
+    init_bias(out0, bias_l, lane);
+#pragma unroll
+    for (int t = 0; t < tiles(N::dim(l + 1)); ++t) out1[t] = out0[t];
+    chain_bf16_pair<N::dim(l), tiles(N::dim(l + 1))>(in0, in1, out0, out1, wc, base);
+    if (N::act(l)) { lrelu(out0); lrelu(out1); }
+}
+template <class N, int CB> constexpr int chain_bf16_frags() {
+    int b = 0;
+    for (int j = CB; j < CB + 3; ++j) b += ((tiles(N::dim(j)) + 1) / 2) * tiles(N::dim(j + 1));
+    return b;
+}
+
+// ---- bf16 encode of the wide models with the ROW STREAM DECOUPLED from the compute waves (float32 rows whose length is a multiple
+// of 16 bytes: C4's 2500 and C5's 512 columns) -------------------------------------------------------------------------------------
+// The kernel above is HBM-bound on paper (10 KB of float32 per C4 frame against 26 bf16 MFMAs per 4 KB) and ran at 0.40 of the HBM
+// roof: its rows travel through REGISTERS, three chunks (12 KB) ahead per wave at 300 registers and one wave per SIMD, i.e. 48 KB in
+// flight per CU -- under Little's law for 8 TB/s x 2-3 us.  Here two LOADER waves (waves 4, 5; 384-thread workgroups) do nothing but
+// stream the workgroup's 128 rows into an 8-slot LDS ring with direct-to-LDS buffer loads (buffer_load_dwordx4 ... lds: no VGPRs,
+// 7 chunks = 112 KB in flight per CU; one wave can have at most 63 loads outstanding, hence two loaders with 56 each), and their
+// vector-memory queue holds NOTHING ELSE, so the lead is the ring depth (loads of a wave retire in order: in the compute waves every
+// fragment wait also waited for the rows requested before it).  The compute waves keep the fragment stage of the kernel above
+// (plain loads, counted by hipcc; the DMA is inline asm in the loader branch only) and take their B operands from the ring.
+//   * ring slot = [compute wave][row tile][half][64 lanes x 16 B]: a 1-KiB block is one DMA instruction, whose lane (i, g) fetches
+//     bytes 64 h + 16 g .. + 15 of the chunk of row i -- 64 contiguous bytes per row and instruction -- and it is read back with one
+//     linear, conflict-free ds_read_b128 by the same lane of the compute wave: that lane then holds k slots (g, j) <-> features
+//     16 (j >> 2) + 4 g + (j & 3) of the chunk, the order the fragments `w0p` are packed in (ImplWideBf16::setup);
+//   * per chunk ONE workgroup barrier (it already existed for the fragment stage): a loader waits (counted vmcnt, asm) until its
+//     share of chunk c has landed, joins barrier c, then refills the slot of chunk c - 1, which every compute wave finished
+//     reading before it joined barrier c.  The loaders run ahead across row groups: no bubble at a group's start.
+constexpr int kDmaRing = 8;             // ring slots: 8 x 16 KiB (+ 26 KiB fragment stage + biases = 156 KiB of the 160)
+constexpr int kDmaChunk = 16384;        // 128 rows x 32 float32 features
+__device__ __forceinline__ void lds_dma_b128(unsigned lds_addr, int voff, __amdgpu_buffer_rsrc_t rs, int soff) {
+    unsigned keep;      // M0 (the LDS base of a direct-to-LDS load) is not preserved by hipcc around asm: set and restore it here
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+template <int F, int Z>
+__global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *packed, const v4 *w0p, const v4 *wce, const float *__restrict__ xin, int64_t n,
+                                                                   void *__restrict__ out, int out_f64) {
+    using N = Net<F, Z>;
+    using S = StreamWideEnc<N>;
+    constexpr int KB = F / 32, KBT = (F + 31) / 32;
+    static_assert((F * 4) % 16 == 0 && KB >= kDmaRing, "16-byte pieces of float32 rows; a row group fills the ring");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char dma_lds[];
+    unsigned char *const ring_b = dma_lds;
+    v4 (*const wst)[13][64] = (v4 (*)[13][64])(dma_lds + kDmaRing * kDmaChunk);
+    v4 *const bias_lds = (v4 *)(dma_lds + kDmaRing * kDmaChunk + 2 * 13 * 1024);
+    constexpr int nb = N::bf_off(4) - N::bf_off(0);                      // biases of layers 0..3
+    for (int i = threadIdx.x; i < nb; i += 384) bias_lds[i] = packed[N::bf_off(0) + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 127) / 128;
+    if (wave >= 4) {
+        // ---- loader: rows 64 L .. 64 L + 63 of every group of this workgroup, chunk after chunk, group after group ------------
+        const int L = wave - 4;
+        const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring_b + (unsigned)L * 8192u;
+        int64_t gi = blockIdx.x;            // issue cursor: group, chunk, ring slot
+        int ci = 0, pi = 0;
+        auto issue = [&]() {
+            const int64_t gg = gi < ngroup ? gi : ngroup - 1;            // past the end: harmless re-reads keep the DMA count uniform
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xin + (size_t)gg * 128 * F), 0, 0x7fffffff, 0x00020000);
+            const int soff = ci * 128;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // (compute wave 2 L + (q >> 1), row tile q & 1)
+                const int rl = 64 * L + 16 * q + (lane & 15);
+                const int voff = (gg * 128 + rl < n ? rl : 0) * (F * 4) + 16 * g;       // rows beyond n read the group's first row
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ring0 + (unsigned)pi * kDmaChunk + (unsigned)q * 2048u);
+                lds_dma_b128(dst, voff, rs, soff);
+                lds_dma_b128(dst + 1024u, voff, rs, soff + 64);
+            }
+            if (++ci == KB) { ci = 0; gi += gridDim.x; }
+            pi = (pi + 1) & (kDmaRing - 1);
+        };
+#ifndef BAMD_DMA_LEAD
+#define BAMD_DMA_LEAD (kDmaRing - 1)
+#endif
+        for (int k = 0; k < BAMD_DMA_LEAD; ++k) issue();
+        for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+#ifndef BAMD_DMA_NOBAR
+            __builtin_amdgcn_s_barrier();                                // the compute waves' barrier at the top of a group
+#endif
+            for (int c = 0; c < KB; ++c) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 * (BAMD_DMA_LEAD - 1)) : "memory");        // all but the 6 youngest chunks (8 loads each): chunk c is in LDS
+#ifndef BAMD_DMA_NOBAR
+                __builtin_amdgcn_s_barrier();                            // barrier c
+#endif
+                issue();                                                 // chunk c + 7 into the slot of chunk c - 1
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // nothing may land in LDS after the workgroup has gone
+        return;
+    }
+    // ---- compute waves: wave w owns rows 32 w .. 32 w + 31 of the group (two 16-row tiles) -------------------------------------
+    WStream ww = make_stream(w0p, KBT * 13 * 1024, lane);
+    WStream wc = make_stream(wce, chain_bf16_frags<N, 1>() * 1024, lane);
+    int slot = 0;
+    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+        const int64_t r0 = (grp * 4 + wave) * 32 + (lane & 15), r1 = r0 + 16;
+        const bool v0 = r0 < n, v1 = r1 < n;
+        asm volatile("" : "+v"(wc.voff), "+v"(ww.voff));
+        v4 a1[13], b1[13];
+        init_bias(a1, bias_lds, lane);
+#pragma unroll
+        for (int t = 0; t < 13; ++t) b1[t] = a1[t];
+        {
+            bf8 wq[2][4];                 // this wave's share (tiles wave, wave + 4, wave + 8, 12 for wave 0) of two chunks in flight
+            auto wload = [&](bf8 (&w)[4], int c) {
+                c = c < KB ? c : KB - 1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = wave + 4 * k;
+                    if (t < 13) w[k] = frag_bf(ww, c * 13 + t);      // 13 loads per chunk and workgroup, not 16: every fragment byte through the
+                }                                                    // CU's vector-memory path costs the row stream ~0.45 bytes (hbm_stream_mix_probe)
+            };
+            auto wstore = [&](const bf8 (&w)[4], int sl) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = wave + 4 * k;
+                    if (t < 13) wst[sl][t][lane] = __builtin_bit_cast(v4, w[k]);
+                }
+            };
+            wload(wq[0], 0);
+            wload(wq[1], 1);
+#ifndef BAMD_DMA_NOBAR
+            __syncthreads();              // the previous group's last chunk has been read
+#endif
+            wstore(wq[0], 0);
+            wload(wq[0], 2);
+            auto iter = [&](int c, auto wsl) {
+                constexpr int WS = decltype(wsl)::value;                                 // c % 2
+#ifndef BAMD_DMA_NOBAR
+                __syncthreads();          // barrier c: fragments of chunk c in stage slot WS, its rows in ring slot `slot`; stage slot WS ^ 1 free
+#endif
+#if defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 1      // timing-only build: the loaders alone (compute waves only keep the barriers)
+                slot = (slot + 1) & (kDmaRing - 1);
+                return;
+#endif
+#if !(defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 3)  // 3: no fragment stage (MFMAs on whatever the registers hold)
+                wstore(wq[WS ^ 1], WS ^ 1);                                              // chunk c + 1 (fetched two chunks ago)
+#endif
+                const v4 *xs = (const v4 *)(ring_b + slot * kDmaChunk + wave * 4096) + lane;
+                const v4 l0 = xs[0], h0 = xs[64], l1 = xs[128], h1 = xs[192];
+                slot = (slot + 1) & (kDmaRing - 1);
+#if !(defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 3)
+                wload(wq[WS ^ 1], c + 3);
+#endif
+                const bf8 q0 = to_bf8(l0, h0), q1 = to_bf8(l1, h1);
+#if defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 4      // 4: rows read and converted, nothing else
+                asm volatile("" :: "v"(q0), "v"(q1));
+                return;
+#endif
+                bf8 wl[2][4];
+                auto rd = [&](bf8 (&w)[4], int t0) {
+#if defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 3
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) asm volatile("" : "=v"(w[k]));
+#else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w[k] = __builtin_bit_cast(bf8, wst[WS][t0 + k < 13 ? t0 + k : 12][lane]);
+#endif
+                };
+                auto mm = [&](const bf8 (&w)[4], int t0) {
+#if defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 2      // 2: no MFMAs (operands kept alive)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) asm volatile("" :: "v"(w[k]), "v"(q0), "v"(q1));
+#else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (t0 + k < 13) { a1[t0 + k] = mfma_bf(w[k], q0, a1[t0 + k]); b1[t0 + k] = mfma_bf(w[k], q1, b1[t0 + k]); }
+#endif
+                };
+                rd(wl[0], 0);
+                rd(wl[1], 4);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wl[0], 0);
+                rd(wl[0], 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wl[1], 4);
+                rd(wl[1], 12);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wl[0], 8);
+                mm(wl[1], 12);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            int c = 0;
+            for (; c + 2 <= KB; c += 2) { iter(c, I0()); iter(c + 1, I1()); }
+            if (c < KB) iter(c, I0());
+            if (F % 32 != 0) {            // the remaining F % 32 features: one partial chunk, rows and fragments straight from L2 (natural k order)
+                const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(xin + (size_t)(grp * 128) * F), 0, 0x7fffffff, 0x00020000);
+                const int lr0 = wave * 32 + (lane & 15);
+                const int xo0 = ((v0 ? lr0 : 0) * F + 8 * g) * 4, xo1 = ((v1 ? lr0 + 16 : 0) * F + 8 * g) * 4;
+                const XPair p0 = wide_x_chunk32_buf<F>(xrs, xo0, 0, KB, g), p1 = wide_x_chunk32_buf<F>(xrs, xo1, 0, KB, g);
+                const bf8 q0 = to_bf8(p0.lo, p0.hi), q1 = to_bf8(p1.lo, p1.hi);
+#pragma unroll
+                for (int t = 0; t < 13; ++t) {
+                    const bf8 w = frag_bf(ww, KB * 13 + t);
+                    a1[t] = mfma_bf(w, q0, a1[t]);
+                    b1[t] = mfma_bf(w, q1, b1[t]);
+                }
+            }
+        }
+#ifdef BAMD_DMA_NOTAIL      // timing-only build: no narrow layers, no stores
+        asm volatile("" :: "v"(a1[0]), "v"(b1[12]));
+        continue;
+#endif
+        lrelu(a1);
+        lrelu(b1);
+        {   // the narrow layers on the bf16 MFMA, both row tiles at once (chain_bf16_pair)
+            v4 a2[7], b2[7], a3[4], b3[4], a4[tiles(Z)], b4[tiles(Z)];
+            fwd_layer_bf16_pair<N, 1, 1>(a1, b1, a2, b2, wc, bias_lds + (N::bf_off(1) - N::bf_off(0)), lane);
+            fwd_layer_bf16_pair<N, 2, 1>(a2, b2, a3, b3, wc, bias_lds + (N::bf_off(2) - N::bf_off(0)), lane);
+            fwd_layer_bf16_pair<N, 3, 1>(a3, b3, a4, b4, wc, bias_lds + (N::bf_off(3) - N::bf_off(0)), lane);
+            store_rows<Z>(a4, out, out_f64, r0, v0, lane, nullptr, nullptr);
+            store_rows<Z>(b4, out, out_f64, r1, v1, lane, nullptr, nullptr);
+        }
+    }
+}
+
 template <int F, int Z, bool OUT64>
-__global__ void __launch_bounds__(256) wide_bf16_decode_kernel(const v4 *packed, const v4 *w7b, const void *__restrict__ zin, int in_f64,
+__global__ void __launch_bounds__(256) wide_bf16_decode_kernel(const v4 *packed, const v4 *w7b, const v4 *wcd, const void *__restrict__ zin, int in_f64,
                                                                int64_t n, void *__restrict__ out) {
     constexpr int out_f64 = OUT64 ? 1 : 0;
     using N = Net<F, Z>;
@@ -1133,23 +1396,21 @@ __global__ void __launch_bounds__(256) wide_bf16_decode_kernel(const v4 *packed,
     stage_bias<N>(bias_lds, packed);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const int64_t npair = (n + 31) / 32;
-    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
+    WStream wc = make_stream(wcd, chain_bf16_frags<N, 4>() * 1024, lane);
     WStream ww = make_stream(w7b, KT * 7 * 1024, lane);
     const v4 *bias7 = bias_lds + (N::bf_off(7) - N::bf_off(0));
     for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < npair; pr += (int64_t)gridDim.x * 4) {
         const int64_t r0 = pr * 32 + (lane & 15), r1 = r0 + 16;
         const bool v0 = r0 < n, v1 = r1 < n;
-        asm volatile("" : "+v"(ws.voff), "+v"(ww.voff));
+        asm volatile("" : "+v"(wc.voff), "+v"(ww.voff));
         bf8 qa[7], qb[7];                          // a7 of both row tiles as bf16 B operands (k chunk c = tiles 2 c, 2 c + 1)
-        {
-            Ring ring;
-            ring_prime<S::total>(ring, ws);
+        {   // the narrow layers on the bf16 MFMA (chain_bf16_pair: 70 MFMAs of 16 cycles per tile instead of 508 of 32 on the float32 chain)
             v4 a4[tiles(Z)], b4[tiles(Z)], a5[4], b5[4], a6[7], b6[7], a7[13], b7[13];
             load_rows<Z>(a4, zin, in_f64, r0, v0, lane, nullptr);
             load_rows<Z>(b4, zin, in_f64, r1, v1, lane, nullptr);
-            fwd_layer2<N, S, 4>(a4, b4, a5, b5, ring, ws, bias_lds, lane);
-            fwd_layer2<N, S, 5>(a5, b5, a6, b6, ring, ws, bias_lds, lane);
-            fwd_layer2<N, S, 6>(a6, b6, a7, b7, ring, ws, bias_lds, lane);
+            fwd_layer_bf16_pair<N, 4, 4>(a4, b4, a5, b5, wc, bias_lds + (N::bf_off(4) - N::bf_off(0)), lane);
+            fwd_layer_bf16_pair<N, 5, 4>(a5, b5, a6, b6, wc, bias_lds + (N::bf_off(5) - N::bf_off(0)), lane);
+            fwd_layer_bf16_pair<N, 6, 4>(a6, b6, a7, b7, wc, bias_lds + (N::bf_off(6) - N::bf_off(0)), lane);
             const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 7; ++c) {
@@ -3316,8 +3577,9 @@ struct FusedState {
     // 256 16.6 / 21.9, 512 18.0 / 23.4, 1024 21.7 / 27.0, 2048 33.1 / 34.1, 4096 53.6 / 44.1 (every workgroup streams all
     // weights: 4x the L2 traffic of the 16-row chain)
     int64_t lat4_max_rows = 2048;
-    DevBuf wb_src[3], wb[3];           // wide models in the bf16 mode: index maps and bf16 fragments of W0 / W7 / W7^T (training)
-    int wb_count[3] = {0, 0, 0};
+    DevBuf wb_src[6], wb[6];           // wide models in the bf16 mode: index maps and bf16 fragments of W0 / W7 / W7^T (training) / W0 in the DMA encode's
+                                       // k order / the narrow encoder layers 1..3 / the narrow decoder layers 4..6 (chain_bf16_pair)
+    int wb_count[6] = {0, 0, 0, 0, 0, 0};
     bool wb_stale = false;             // the bf16 fragments lag the parameters (re-rounded before the next encode / decode)
     bool dz16 = false;                 // this pass stores dL/drecon as bfloat16 (set per pass by the layer-wise driver: fused_wide_set_dz16)
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
@@ -3786,6 +4048,9 @@ template <int F, int Z> struct ImplWideBf16 {
     using N = Net<F, Z>;
     using W = ImplWide<F, Z>;
     static constexpr int KB = (F + 31) / 32, KT = tiles(F);
+    // float32 rows of a multiple of 16 bytes take the encode kernel with the decoupled row stream (wide_bf16_encode_dma_kernel)
+    static constexpr bool kDma = (F * 4) % 16 == 0 && F / 32 >= kDmaRing;
+    static constexpr size_t dma_lds_bytes() { return (size_t)kDmaRing * kDmaChunk + 2 * 13 * 1024 + (size_t)(N::bf_off(4) - N::bf_off(0)) * 16; }
     static int setup(bamd_handle *h, FusedState *st) {
         int rc = build_maps<F, Z, false>(h, st);
         if (rc) return rc;
@@ -3816,8 +4081,42 @@ template <int F, int Z> struct ImplWideBf16 {
                         const int nf = slot_feature(200, t, i / 4, i % 4), kf = 32 * c + 8 * g + j;
                         if (nf >= 0 && kf < F) s7t[(((size_t)c * 13 + t) * 64 + lane) * 8 + j] = N::w_off(7) + kf * 200 + nf;
                     }
-        const std::vector<int> *srcs[3] = {&s0, &s7, &s7t};
-        for (int k = 0; k < 3; ++k) {
+        // W0 once more for the DMA encode kernel: full chunks in ITS k order -- k slot (g, j) <-> feature 16 (j >> 2) + 4 g + (j & 3) of the
+        // chunk, what a lane holds after reading bytes 16 g .. + 15 of each 64-byte half of the row's chunk; a partial last chunk natural
+        std::vector<int> s0p((size_t)KB * 13 * 64 * 8, -1);
+        for (int c = 0; c < KB; ++c)
+            for (int t = 0; t < 13; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = lane & 15, g = lane >> 4;
+                        const int nf = slot_feature(200, t, i / 4, i % 4);
+                        const int kf = 32 * c + (c < F / 32 ? 16 * (j >> 2) + 4 * g + (j & 3) : 8 * g + j);
+                        if (nf >= 0 && kf < F) s0p[(((size_t)c * 13 + t) * 64 + lane) * 8 + j] = N::w_off(0) + nf * F + kf;
+                    }
+        // the narrow layers for chain_bf16_pair: layer l as [k block c][output tile t] fragments, lane (i, g) element j =
+        // W_l[slot (t, i / 4, i % 4) of the outputs][slot (tile 2 c + j / 4, g, j % 4) of the inputs]
+        auto chain_map = [](int l0) {
+            std::vector<int> m;
+            for (int l = l0; l < l0 + 3; ++l) {
+                const int K = N::dim(l), NN = N::dim(l + 1), kbk = (tiles(K) + 1) / 2, nt = tiles(NN);
+                const size_t off = m.size();
+                m.resize(off + (size_t)kbk * nt * 64 * 8, -1);
+                for (int c = 0; c < kbk; ++c)
+                    for (int t = 0; t < nt; ++t)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int i = lane & 15, g = lane >> 4, q = 2 * c + j / 4;
+                                const int nf = slot_feature(NN, t, i / 4, i % 4), kf = q < tiles(K) ? slot_feature(K, q, g, j % 4) : -1;
+                                if (nf >= 0 && kf >= 0) m[off + (((size_t)c * nt + t) * 64 + lane) * 8 + j] = N::w_off(l) + nf * K + kf;
+                            }
+            }
+            return m;
+        };
+        const std::vector<int> sce = chain_map(1), scd = chain_map(4);
+        const std::vector<int> *srcs[6] = {&s0, &s7, &s7t, &s0p, &sce, &scd};
+        if constexpr (kDma)
+            BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_encode_dma_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes()));
+        for (int k = 0; k < 6; ++k) {
             st->wb_count[k] = (int)srcs[k]->size();
             rc = st->wb_src[k].ensure(srcs[k]->size() * sizeof(int));
             if (rc) return rc;
@@ -3828,7 +4127,7 @@ template <int F, int Z> struct ImplWideBf16 {
         return BAMD_OK;
     }
     static int pack_extra(bamd_handle *h, FusedState *st, hipStream_t s) {
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 6; ++k)
             hipLaunchKernelGGL(pack_wide_bf16_k, dim3((st->wb_count[k] + 255) / 256), dim3(256), 0, s, (const float *)h->params.p,
                                (const int *)st->wb_src[k].p, st->wb_count[k], (__bf16 *)st->wb[k].p);
         st->wb_stale = false;
@@ -3859,6 +4158,16 @@ template <int F, int Z> struct ImplWideBf16 {
             const int64_t ngroup = (rows + 127) / 128;
             const dim3 grid((unsigned)(ngroup > 2048 ? 2048 : ngroup));
             void *zo = (void *)((char *)z + (size_t)r0 * Z * zes);
+            const char *dma_env = getenv("BALER_AMD_WIDE_DMA");        // =0: the register-streamed kernel (A/B runs, tools/ab_c4_bf16.py)
+            const bool dma_on = !(dma_env && dma_env[0] == '0');
+            if constexpr (kDma) {
+                if (!src_f64 && dma_on) {      // persistent: one workgroup (4 compute + 2 loader waves, 156 KiB of LDS) per CU
+                    hipLaunchKernelGGL((wide_bf16_encode_dma_kernel<F, Z>), dim3((unsigned)(ngroup > st->nwg_max ? st->nwg_max : ngroup)), dim3(384),
+                                       dma_lds_bytes(), s, (const v4 *)h->packed.p, (const v4 *)st->wb[3].p, (const v4 *)st->wb[4].p, (const float *)src, rows, zo,
+                                       z_dtype == BAMD_F64);
+                    continue;
+                }
+            }
             if (src_f64)
                 hipLaunchKernelGGL((wide_bf16_encode_kernel<F, Z, true>), grid, dim3(256), 0, s, (const v4 *)h->packed.p,
                                    (const v4 *)st->wb[0].p, src, rows, zo, z_dtype == BAMD_F64);
@@ -3888,10 +4197,10 @@ template <int F, int Z> struct ImplWideBf16 {
             }
             if (kout_f64)
                 hipLaunchKernelGGL((wide_bf16_decode_kernel<F, Z, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
-                                   (const v4 *)st->wb[1].p, (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout);
+                                   (const v4 *)st->wb[1].p, (const v4 *)st->wb[5].p, (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout);
             else
                 hipLaunchKernelGGL((wide_bf16_decode_kernel<F, Z, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
-                                   (const v4 *)st->wb[1].p, (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout);
+                                   (const v4 *)st->wb[1].p, (const v4 *)st->wb[5].p, (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout);
             if (features) {
                 int rc = launch_renormalize(kout, BAMD_F32, rows, F, features, int_mask, (double *)dst, s);
                 if (rc) return rc;
@@ -4028,7 +4337,7 @@ void fused_teardown(bamd_handle *h) {
     st->dz.release();
     st->imgs.release();
     st->dwpart.release();
-    for (int k = 0; k < 3; ++k) { st->wb_src[k].release(); st->wb[k].release(); }
+    for (int k = 0; k < 6; ++k) { st->wb_src[k].release(); st->wb[k].release(); }
     st->sc_off.release();
     st->sc_idx.release();
     delete st;

@@ -69,7 +69,8 @@ def test_minmax_nan_and_inf_anywhere(n, where, dtype):
         assert same_with_nans(got, want)
         mm = native.col_minmax(dev(x, dtype)).cpu().numpy()
         assert same_with_nans(mm, np.array([x.min(0), x.max(0)]))
-    assert np.isnan(got[:, 2]).all() and np.isposinf(got[1, 7]) and np.isneginf(got[0, 11])
+    assert np.isnan(got[:, 2]).all() and np.isneginf(got[0, 11])
+    assert np.isposinf(got[1, 7]) if n > 1 else np.isnan(got[1, 7])      # one row: range = inf - inf
 
 
 def test_renormalize_int_mask_edge():
