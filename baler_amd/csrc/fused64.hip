@@ -12,7 +12,9 @@
 // infer64_kernel below (every wave its own 16 rows, register chain, no exchange).
 #include "fused.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <utility>
 
@@ -546,7 +548,11 @@ template <class N, int MN, int MK> struct Dwm64 {
     static constexpr int per_xcd = (total + 7) / 8;
 };
 template <class N, int MN, int MK>
-__global__ void __launch_bounds__(256) dw64m_kernel(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit) {
+__global__ void __launch_bounds__(256) dw64m_kernel(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total,
+                                                    int split0) {
+    // this launch covers block ranges split0 .. split0 + gridDim.y - 1 of the nsplit_total ranges the finishing launch adds up (a batch
+    // beyond State64::chunk_rows runs chunk after chunk over the same image buffer: one launch of this kernel per chunk)
+    const int nsplit = (int)gridDim.y;
     using D = Dwm64<N, MN, MK>;
     constexpr int NA = MN * MK, U = 2, HALF = NA / 2;
     static_assert(NA % 2 == 0, "the reduction runs in two halves");
@@ -617,7 +623,7 @@ __global__ void __launch_bounds__(256) dw64m_kernel(const double *__restrict__ i
             const double *q = rf + t * 1024;
             const double gsum = ((q[e] + q[256 + e]) + q[512 + e]) + q[768 + e];
             const int tile = soff + kt[c] * ntc + nt[a];
-            part[((int64_t)tile * nsplit + blockIdx.y) * 256 + e] = gsum;
+            part[((int64_t)tile * nsplit_total + split0 + blockIdx.y) * 256 + e] = gsum;
         }
     }
 }
@@ -633,10 +639,13 @@ struct State64 {
     const Ops64 *ops = nullptr;
     DevBuf pack_src, inv_map, sc_off, sc_idx, packed, imgs, dwpart;
     int packed_doubles = 0;
-    // larger batches: layer-wise kernels (BALER_AMD_LATENCY_ROWS overrides, as for fp32).  The fused pair stays ahead of them at every
-    // size measured (us per step, fused / layer-wise: 16384 rows 227 / 847, 65536 rows 850 / 2666); the limit is the images' memory
-    // (13 KB per row: 3.5 GB at 262144 rows)
-    int64_t max_rows = 262144;
+    // The fused pair stays ahead of the layer-wise kernels at every size measured (us per step, fused / layer-wise: 16384 rows 227 / 847,
+    // 65536 rows 850 / 2666).  Its images take 13 KB per row (3.5 GB at 262144 rows), so a larger batch runs CHUNK AFTER CHUNK over the
+    // same image buffer: chain + tile blocks per chunk, the partial tiles of all chunks' block ranges added in order by ONE finishing
+    // launch (round 4; before, batches above 262144 rows fell to the layer-wise kernels at ~0.20 of the fp64 peak).
+    // BALER_AMD_LATENCY_ROWS (as for fp32) caps the rows the fused pair takes at all: larger batches then run layer by layer.
+    int64_t chunk_rows = 262144;
+    int64_t max_rows = INT64_MAX;
 };
 struct Ops64 {
     int (*setup)(bamd_handle *, State64 *);
@@ -728,34 +737,54 @@ template <int F, int Z> struct Impl64 {
     }
     static int step(bamd_handle *h, State64 *st, const void *x, int x_dtype, int64_t n, const double *features, double *grads,
                     const Adam64 *ad, hipStream_t s) {
-        const int nblk = (int)((n + 15) / 16);
-        int rc = st->imgs.ensure((size_t)N::img_doubles * sizeof(double) * (size_t)nblk);
+        const int64_t nblk_all = (n + 15) / 16;
+        if (nblk_all > (int64_t)1 << 30) { set_error("fp64 fused step: batch too large"); return BAMD_ERR_INVALID; }
+        const int64_t chunk = st->chunk_rows & ~(int64_t)15;
+        const int nchunk = (int)((n + chunk - 1) / chunk);
+        const int nblk_max = (int)((std::min(n, chunk) + 15) / 16);
+        int rc = st->imgs.ensure((size_t)N::img_doubles * sizeof(double) * (size_t)nblk_max);
         if (rc) return rc;
-        rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk > 1024 ? nblk : 1024));
+        rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk_all > 1024 ? nblk_all : 1024));
         if (rc) return rc;
-        hipLaunchKernelGGL((chain64_kernel<F, Z, 4>), dim3(nblk), dim3(256), kLds, s, (const d4 *)st->packed.p, x, x_dtype == BAMD_F64, n,
-                           features, (double *)st->imgs.p, (double *)h->lossp.p);
         const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
         // from 64 blocks (1,024 rows) on: 2 x 4 tile blocks over block ranges + the finishing launch (BALER_AMD_DW64_MACRO_BLKS, 0 = off).
         // Measured ms per bamd_fwd_bwd, blocks / one tile per workgroup: 512 rows 0.045 / 0.040, 1,024: 0.046 / 0.049, 2,048: 0.054 / 0.064,
         // 4,096: 0.068 / 0.094, 16,384: 0.227 / 0.341, 65,536: 0.85 / 1.32, 262,144: 3.22 / 5.51 (0.37 / 0.22 of the fp64 MFMA peak)
         static const int macro_blks = getenv("BALER_AMD_DW64_MACRO_BLKS") ? atoi(getenv("BALER_AMD_DW64_MACRO_BLKS")) : 64;
+        const bool macro = nchunk > 1 || (macro_blks > 0 && nblk_all >= macro_blks);
+        // block ranges per chunk: 16 from 4,096 blocks on, else 8; every chunk but the last is a full one
+        auto splits_of = [](int64_t blks) { return blks >= 4096 ? 16 : 8; };
         int nsplit = 0;
-        const double *part = nullptr;
-        if (macro_blks > 0 && nblk >= macro_blks) {
-            using D = Dwm64<N, 2, 4>;
-            nsplit = nblk >= 4096 ? 16 : 8;
+        if (macro) {
+            for (int k = 0; k < nchunk; ++k) nsplit += splits_of((std::min(n - k * chunk, chunk) + 15) / 16);
             rc = st->dwpart.ensure((size_t)(N::slab_off(N::L) + 1) * nsplit * 256 * sizeof(double));
             if (rc) return rc;
-            part = (const double *)st->dwpart.p;
-            hipLaunchKernelGGL((dw64m_kernel<N, 2, 4>), dim3(8 * D::per_xcd, nsplit), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
-                               (double *)st->dwpart.p, nsplit);
         }
+        const size_t xes = x_dtype == BAMD_F64 ? 8 : 4;
+        int split0 = 0;
+        for (int k = 0; k < nchunk; ++k) {
+            const int64_t r0 = k * chunk, rows = std::min(n - r0, chunk);
+            const int nblk = (int)((rows + 15) / 16);
+            hipLaunchKernelGGL((chain64_kernel<F, Z, 4>), dim3(nblk), dim3(256), kLds, s, (const d4 *)st->packed.p,
+                               (const void *)((const char *)x + (size_t)r0 * F * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
+                               (double *)h->lossp.p + r0 / 16);
+            if (macro) {
+                using D = Dwm64<N, 2, 4>;
+                const int ns = splits_of(nblk);
+                hipLaunchKernelGGL((dw64m_kernel<N, 2, 4>), dim3(8 * D::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
+                                   (double *)st->dwpart.p, nsplit, split0);
+                split0 += ns;
+            }
+        }
+        const double *part = macro ? (const double *)st->dwpart.p : nullptr;
+        // the finishing launch: the loss partials of ALL blocks; with `part` the sum over all chunks' block ranges in order, else
+        // (one small chunk) the tiles themselves over the images
+        const int nblk_fin = (int)nblk_all;
         if (ad)
-            hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk, (const double *)h->lossp.p,
+            hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
                                (const int *)st->inv_map.p, grads, *ad, part, nsplit);
         else
-            hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk, (const double *)h->lossp.p,
+            hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
                                (const int *)st->inv_map.p, grads, Adam64{}, part, nsplit);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
@@ -815,6 +844,7 @@ int fused64_setup(bamd_handle *h) {
     State64 *st = new State64();
     st->ops = ops;
     if (const char *lr = getenv("BALER_AMD_LATENCY_ROWS")) st->max_rows = atoll(lr);
+    if (const char *cr = getenv("BALER_AMD_F64_CHUNK_ROWS")) st->chunk_rows = std::max<int64_t>(16, atoll(cr));      // tests: several chunks at small sizes
     h->fused64_state = st;
     return ops->setup(h, st);
 }

@@ -232,9 +232,10 @@ def test_gradients_ragged(n, path, data10k, monkeypatch):
 
 @pytest.mark.parametrize("n", [1, 7, 16, 17, 272, 513, 1009, 1040, 4099, 12288, 12289, 70001])
 def test_fp64_fused_step_ragged(n, data10k):
-    """fp64 mode: batches up to 262144 rows run on the fused fp64 step (chain + weight-gradient tiles on v_mfma_f64_16x16x4_f64,
-    fused64.hip; from 1024 rows on the tiles in 2 x 4 blocks over 8 or 16 block ranges + a finishing launch), larger ones on the
-    layer-wise kernels; within 1e-11 of the scalar fp64 oracle, and bamd_train_step == bamd_fwd_bwd + bamd_adam_step bit for bit."""
+    """fp64 mode: every batch runs on the fused fp64 step (chain + weight-gradient tiles on v_mfma_f64_16x16x4_f64, fused64.hip; from
+    1024 rows on the tiles in 2 x 4 blocks over 8 or 16 block ranges + a finishing launch; beyond 262144 rows chunk after chunk:
+    test_fp64_fused_step_beyond_one_chunk); within 1e-11 of the scalar fp64 oracle, and bamd_train_step == bamd_fwd_bwd + bamd_adam_step
+    bit for bit."""
     dims = orc.ae_dims(24, 15)
     flat = orc.formula_params(dims, 23)
     x = data10k[:n] if n <= 10000 else orc.normalize(synth.cms_rows(n, row0=11))
@@ -262,6 +263,41 @@ def test_fp64_fused_step_ragged(n, data10k):
     assert torch.equal(g3, g4)
     _, go2 = orc.fwd_bwd(dims, p2.cpu().numpy()[:-1], x)
     assert rel(g4.cpu().numpy()[:-1], go2) < TOL64
+
+
+@pytest.mark.parametrize("n,chunk", [(70001, 4096), (20000, 16), (300_001, None), (1_000_003, None)])
+def test_fp64_fused_step_beyond_one_chunk(n, chunk, monkeypatch):
+    """fp64 batches beyond 262,144 rows (the images of the fused pair take 13 KB per row) run chunk after chunk over the same image
+    buffer, the partial weight-gradient tiles of all chunks added in order by one finishing launch: 300,001 and 1,000,003 rows (the
+    headline workload in the reference's own dtype) against the scalar fp64 oracle at 1e-11, the one-call step == fwd_bwd + adam_step bit
+    for bit, bitwise reproducible; small chunks (BALER_AMD_F64_CHUNK_ROWS) force many chunks incl. a ragged last one."""
+    if chunk:
+        monkeypatch.setenv("BALER_AMD_F64_CHUNK_ROWS", str(chunk))
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 29)
+    x = orc.normalize(synth.cms_rows(n, row0=5))
+    h, p = make_handle(dims, flat, "fp64")
+    assert h.path == "fused"
+    xd = dev(x)
+    grads, g2 = torch.zeros_like(p), torch.zeros_like(p)
+    h.fwd_bwd(xd, grads)
+    h.fwd_bwd(xd, g2)
+    assert torch.equal(grads, g2)
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    gh = grads.cpu().numpy()
+    assert rel(gh[:-1], go) < TOL64 and abs(gh[-1] - lo) < TOL64 * lo
+    m1, v1, m2, v2 = (torch.zeros_like(p) for _ in range(4))
+    p1, p2 = p.clone(), p.clone()
+    h1, _ = make_handle(dims, flat, "fp64")
+    h1.train_step(xd, p1, m1, v1, 1, 1e-3)
+    h.adam_step(p2, grads, m2, v2, 1, 1e-3)
+    assert torch.equal(p1[:-1], p2[:-1]) and torch.equal(m1[:-1], m2[:-1]) and torch.equal(v1[:-1], v2[:-1])
+    if chunk:      # the same batch in one chunk: another summation order, same numbers to 1e-13
+        monkeypatch.delenv("BALER_AMD_F64_CHUNK_ROWS")
+        h2, _ = make_handle(dims, flat, "fp64")
+        g3 = torch.zeros_like(p)
+        h2.fwd_bwd(xd, g3)
+        assert rel(g3.cpu().numpy(), gh) < 1e-13
 
 
 def test_empty_shard_gives_zero_grad():
