@@ -318,8 +318,13 @@ template <class N> struct StreamWideDec {   // wide models: forward fragments of
 // long MFMA phase and convert them after it (the HBM latency of the first touch of a row is ~2 us).
 template <int D> struct RawRows { double v[tiles(D) * 4]; };
 
-template <int D>
-__device__ __forceinline__ void load_rows_issue(RawRows<D> &raw, const void *x, int is_f64, int64_t row, bool valid, int lane) {
+// RT = "run-time width": the kernel is instantiated for a CLASS of narrow tables -- D is the class width (16 T - 1: T tiles, the last
+// one partial so that the ones slot of the weight-gradient images has a place), `dr` <= D the table's real column count, a kernel
+// argument.  Slots map to features exactly as for a D-column table (slot_feature); a slot whose feature is >= dr reads feature 0 and
+// is ZEROED, so that padding meets the zero weights / biases the pack map gives it with a zero on the data side too: the loss, dL/drecon
+// and every weight-gradient product see exact zeros there, and nothing else in a kernel needs to know the real width.
+template <int D, bool RT = false>
+__device__ __forceinline__ void load_rows_issue(RawRows<D> &raw, const void *x, int is_f64, int64_t row, bool valid, int lane, int dr = D) {
     // Branch-free: lanes beyond the last row read row 0 and padding slots read feature 0 (always inside the table), so no
     // lane needs an exec-masked branch or a zero fill.  Their values are never used: padding slots meet zero weights and
     // unmapped gradient slots, rows beyond n get a zero loss gradient / are not stored.
@@ -330,16 +335,21 @@ __device__ __forceinline__ void load_rows_issue(RawRows<D> &raw, const void *x, 
     for (int s = 0; s < NS; ++s) raw.v[s] = 0.0;
     return;
 #endif
-    const int64_t base = (valid ? row : 0) * D;
+    const int64_t base = (valid ? row : 0) * (RT ? dr : D);
     // slot (t, r) holds a feature on SOME lane group iff the tile is full or 4r < its valid count (r-major partial tiles)
     auto used = [](int s) { return D - 16 * (s >> 2) >= 16 || 4 * (s & 3) < D - 16 * (s >> 2); };
     // ... and on EVERY lane group iff the tile is full or 4r + 3 < count: then its index needs no select
     auto every = [](int s) { return D - 16 * (s >> 2) >= 16 || 4 * (s & 3) + 3 < D - 16 * (s >> 2); };
     auto feat = [&](int s) {
         const int t = s >> 2, r = s & 3;
-        if (D - 16 * t >= 16) return 16 * t + 4 * g + r;
-        const int f = 16 * t + 4 * r + g;                 // r-major partial tile (slot_feature)
-        return every(s) ? f : (4 * r + g < D - 16 * t ? f : 0);
+        int f;
+        if (D - 16 * t >= 16) f = 16 * t + 4 * g + r;
+        else {
+            f = 16 * t + 4 * r + g;                       // r-major partial tile (slot_feature)
+            f = every(s) ? f : (4 * r + g < D - 16 * t ? f : 0);
+        }
+        if (RT) f = f < dr ? f : 0;
+        return f;
     };
     if (is_f64) {
 #pragma unroll
@@ -353,9 +363,9 @@ __device__ __forceinline__ void load_rows_issue(RawRows<D> &raw, const void *x, 
     }
 }
 
-template <int D>
+template <int D, bool RT = false>
 __device__ __forceinline__ void load_rows_finish(v4 (&a)[tiles(D)], RawRows<D> &raw, bool valid, int lane,
-                                                 const double *__restrict__ feats) {
+                                                 const double *__restrict__ feats, int dr = D) {
     constexpr int NS = tiles(D) * 4;
     const int g = lane >> 4;
     if (feats) {
@@ -366,22 +376,30 @@ __device__ __forceinline__ void load_rows_finish(v4 (&a)[tiles(D)], RawRows<D> &
             int f = left >= 16 ? 16 * t + 4 * g + r : 16 * t + 4 * r + g;
             if (!(left >= 16 || 4 * r + 3 < left)) f = (4 * r + g < left) ? f : 0;     // padding on some lane group: clamp
             if (!(left >= 16 || 4 * r < left)) f = 0;                                  // padding everywhere
+            if (RT) f = f < dr ? f : 0;
             mn[s] = feats[f];
-            rg[s] = feats[D + f];
+            rg[s] = feats[(RT ? dr : D) + f];
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) raw.v[s] = (raw.v[s] - mn[s]) / rg[s];   // (x - min)/(max - min) in float64
+    }
+    if (RT) {      // the class's slots beyond the table's width: exact zeros
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int f = slot_feature(D, s >> 2, g, s & 3);
+            if (!(f >= 0 && f < dr)) raw.v[s] = 0.0;
+        }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) a[s >> 2][s & 3] = (float)raw.v[s];
 }
 
-template <int D>
+template <int D, bool RT = false>
 __device__ __forceinline__ void load_rows(v4 (&a)[tiles(D)], const void *x, int is_f64, int64_t row, bool valid,
-                                          int lane, const double *__restrict__ feats) {
+                                          int lane, const double *__restrict__ feats, int dr = D) {
     RawRows<D> raw;
-    load_rows_issue<D>(raw, x, is_f64, row, valid, lane);
-    load_rows_finish<D>(a, raw, valid, lane, feats);
+    load_rows_issue<D, RT>(raw, x, is_f64, row, valid, lane, dr);
+    load_rows_finish<D, RT>(a, raw, valid, lane, feats, dr);
 }
 
 // Wide rows (D > 64, e.g. the 512-column table): tile by tile, 16/32-byte vector loads for full tiles
@@ -423,9 +441,9 @@ __device__ __forceinline__ void load_rows_wide(v4 (&a)[tiles(D)], const void *x,
     }
 }
 
-template <int D>
+template <int D, bool RT = false>
 __device__ __forceinline__ void store_rows(const v4 (&a)[tiles(D)], void *out, int is_f64, int64_t row, bool valid,
-                                           int lane, const double *__restrict__ renorm, const uint8_t *__restrict__ imask) {
+                                           int lane, const double *__restrict__ renorm, const uint8_t *__restrict__ imask, int dr = D) {
     // ONE lane mask (valid row) around everything and the uniform dtype / renorm tests outside the element loops; a slot
     // needs its own lane test only if it is padding on SOME lane group (the last register of a partial r-major tile).
     const int g = lane >> 4;
@@ -437,12 +455,25 @@ __device__ __forceinline__ void store_rows(const v4 (&a)[tiles(D)], void *out, i
         for (int r = 0; r < 4; ++r) {
             v[t][r] = (double)a[t][r];
             const int f = slot_feature(D, t, g, r);
-            if (renorm && f >= 0) {
+            if (renorm && f >= 0 && (!RT || f < dr)) {
                 // norm*range + min with two roundings (numpy), then trunc for "int" columns (baler.py:420-435)
-                v[t][r] = __dadd_rn(__dmul_rn(v[t][r], renorm[D + f]), renorm[f]);
+                v[t][r] = __dadd_rn(__dmul_rn(v[t][r], renorm[(RT ? dr : D) + f]), renorm[f]);
                 if (imask && imask[f]) v[t][r] = trunc(v[t][r]);
             }
         }
+    if (RT) {      // run-time width (a class instantiation): element by element, rows of dr values
+#pragma unroll
+        for (int t = 0; t < tiles(D); ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = slot_feature(D, t, g, r);
+                if (f >= 0 && f < dr) {
+                    const int64_t i = row * dr + f;
+                    if (is_f64) ((double *)out)[i] = v[t][r]; else ((float *)out)[i] = (float)v[t][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < tiles(D); ++t) {
         const int left = D - 16 * t;                       // features from this tile on
@@ -479,11 +510,11 @@ __device__ __forceinline__ void stage_bias(v4 *bias_lds, const v4 *packed) {
     __syncthreads();
 }
 
-template <int F, int Z, int KIND>
+template <int F, int Z, int KIND, bool RT = false>
 __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64,
                                                     int64_t n, const double *__restrict__ feats, void *__restrict__ out,
                                                     int out_f64, const uint8_t *__restrict__ imask,
-                                                    double *__restrict__ loss_part) {
+                                                    double *__restrict__ loss_part, int fr, int zr) {
     using N = Net<F, Z>;
     using S = typename std::conditional<KIND == K_ENCODE, StreamEncode<N>,
                                         typename std::conditional<KIND == K_DECODE, StreamDecode<N>, StreamForward<N>>::type>::type;
@@ -505,20 +536,20 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
         if (KIND == K_ENCODE || KIND == K_FORWARD) {
             v4 a0[tiles(F)], a1[13], a2[7], a3[4], a4[tiles(Z)];
             if (F > 64) load_rows_wide<F>(a0, xin, in_f64, row, valid, lane, feats);
-            else load_rows<F>(a0, xin, in_f64, row, valid, lane, feats);
+            else load_rows<F, RT>(a0, xin, in_f64, row, valid, lane, feats, fr);
             fwd_layer<N, S, 0>(a0, a1, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
             if (KIND == K_ENCODE) {
-                store_rows<Z>(a4, out, out_f64, row, valid, lane, nullptr, nullptr);
+                store_rows<Z, RT>(a4, out, out_f64, row, valid, lane, nullptr, nullptr, zr);
             } else {
                 v4 a5[4], a6[7], a7[13], a8[tiles(F)];
                 fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
                 fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
                 fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
                 fwd_layer<N, S, 7>(a7, a8, ring, ws, bias_lds, lane);
-                if (out) store_rows<F>(a8, out, out_f64, row, valid, lane, nullptr, nullptr);
+                if (out) store_rows<F, RT>(a8, out, out_f64, row, valid, lane, nullptr, nullptr, fr);
                 if (valid) {
 #pragma unroll
                     for (int t = 0; t < tiles(F); ++t)
@@ -532,12 +563,12 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
             }
         } else {
             v4 a4[tiles(Z)], a5[4], a6[7], a7[13], a8[tiles(F)];
-            load_rows<Z>(a4, xin, in_f64, row, valid, lane, nullptr);
+            load_rows<Z, RT>(a4, xin, in_f64, row, valid, lane, nullptr, zr);
             fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 7>(a7, a8, ring, ws, bias_lds, lane);
-            store_rows<F>(a8, out, out_f64, row, valid, lane, feats, imask);
+            store_rows<F, RT>(a8, out, out_f64, row, valid, lane, feats, imask, fr);
         }
         ring_tail<S::total>(ring, ws);
     }
@@ -553,10 +584,10 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
 }
 
 // Encode / decode with TWO 16-row tiles per wave (see chain_gemm2): same results, half the fragment loads per MFMA.
-template <int F, int Z, int KIND>
+template <int F, int Z, int KIND, bool RT = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) infer2_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
                                                      const double *__restrict__ feats, void *__restrict__ out, int out_f64,
-                                                     const uint8_t *__restrict__ imask) {
+                                                     const uint8_t *__restrict__ imask, int fr, int zr) {
     using N = Net<F, Z>;
     using S = typename std::conditional<KIND == K_ENCODE, StreamEncode<N>, StreamDecode<N>>::type;
     static_assert(KIND == K_ENCODE || KIND == K_DECODE, "pair kernel: encode or decode");
@@ -575,8 +606,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     {
         const int64_t p0 = (int64_t)blockIdx.x * 4 + wave;
         const int64_t q0 = p0 * 32 + (lane & 15), q1 = q0 + 16;
-        load_rows_issue<DIN>(ra, xin, in_f64, q0, q0 < n, lane);
-        load_rows_issue<DIN>(rb, xin, in_f64, q1, q1 < n, lane);
+        load_rows_issue<DIN, RT>(ra, xin, in_f64, q0, q0 < n, lane, (KIND == K_ENCODE ? fr : zr));
+        load_rows_issue<DIN, RT>(rb, xin, in_f64, q1, q1 < n, lane, (KIND == K_ENCODE ? fr : zr));
     }
     for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < npair; pr += (int64_t)gridDim.x * 4) {
         const int64_t r0 = pr * 32 + (lane & 15), r1 = r0 + 16;
@@ -587,45 +618,45 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if constexpr (KIND == K_ENCODE) {
             v4 a0[tiles(F)], b0[tiles(F)], a1[13], b1[13], a2[7], b2[7], a3[4], b3[4], a4[tiles(Z)], b4[tiles(Z)];
 #ifdef BAMD_INFER_NOPF
-            load_rows<F>(a0, xin, in_f64, r0, v0, lane, feats);
-            load_rows<F>(b0, xin, in_f64, r1, v1, lane, feats);
+            load_rows<F, RT>(a0, xin, in_f64, r0, v0, lane, feats, fr);
+            load_rows<F, RT>(b0, xin, in_f64, r1, v1, lane, feats, fr);
 #else
-            load_rows_finish<F>(a0, ra, v0, lane, feats);
-            load_rows_finish<F>(b0, rb, v1, lane, feats);
+            load_rows_finish<F, RT>(a0, ra, v0, lane, feats, fr);
+            load_rows_finish<F, RT>(b0, rb, v1, lane, feats, fr);
 #endif
             fwd_layer2<N, S, 0>(a0, b0, a1, b1, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 1>(a1, b1, a2, b2, ring, ws, bias_lds, lane);
 #ifndef BAMD_INFER_NOPF
             __builtin_amdgcn_sched_barrier(0);
-            load_rows_issue<F>(ra, xin, in_f64, n0, n0 < n, lane);      // (behind the widest layer: the raw rows do not add to the register peak)
-            load_rows_issue<F>(rb, xin, in_f64, n1, n1 < n, lane);
+            load_rows_issue<F, RT>(ra, xin, in_f64, n0, n0 < n, lane, fr);      // (behind the widest layer: the raw rows do not add to the register peak)
+            load_rows_issue<F, RT>(rb, xin, in_f64, n1, n1 < n, lane, fr);
             __builtin_amdgcn_sched_barrier(0);
 #endif
             fwd_layer2<N, S, 2>(a2, b2, a3, b3, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 3>(a3, b3, a4, b4, ring, ws, bias_lds, lane);
-            store_rows<Z>(a4, out, out_f64, r0, v0, lane, nullptr, nullptr);
-            store_rows<Z>(b4, out, out_f64, r1, v1, lane, nullptr, nullptr);
+            store_rows<Z, RT>(a4, out, out_f64, r0, v0, lane, nullptr, nullptr, zr);
+            store_rows<Z, RT>(b4, out, out_f64, r1, v1, lane, nullptr, nullptr, zr);
         } else {
             v4 a4[tiles(Z)], b4[tiles(Z)], a5[4], b5[4], a6[7], b6[7], a7[13], b7[13], a8[tiles(F)], b8[tiles(F)];
 #ifdef BAMD_INFER_NOPF
-            load_rows<Z>(a4, xin, in_f64, r0, v0, lane, nullptr);
-            load_rows<Z>(b4, xin, in_f64, r1, v1, lane, nullptr);
+            load_rows<Z, RT>(a4, xin, in_f64, r0, v0, lane, nullptr, zr);
+            load_rows<Z, RT>(b4, xin, in_f64, r1, v1, lane, nullptr, zr);
 #else
-            load_rows_finish<Z>(a4, ra, v0, lane, nullptr);
-            load_rows_finish<Z>(b4, rb, v1, lane, nullptr);
+            load_rows_finish<Z, RT>(a4, ra, v0, lane, nullptr, zr);
+            load_rows_finish<Z, RT>(b4, rb, v1, lane, nullptr, zr);
 #endif
             fwd_layer2<N, S, 4>(a4, b4, a5, b5, ring, ws, bias_lds, lane);
 #ifndef BAMD_INFER_NOPF
             __builtin_amdgcn_sched_barrier(0);
-            load_rows_issue<Z>(ra, xin, in_f64, n0, n0 < n, lane);
-            load_rows_issue<Z>(rb, xin, in_f64, n1, n1 < n, lane);
+            load_rows_issue<Z, RT>(ra, xin, in_f64, n0, n0 < n, lane, zr);
+            load_rows_issue<Z, RT>(rb, xin, in_f64, n1, n1 < n, lane, zr);
             __builtin_amdgcn_sched_barrier(0);
 #endif
             fwd_layer2<N, S, 5>(a5, b5, a6, b6, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 6>(a6, b6, a7, b7, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 7>(a7, b7, a8, b8, ring, ws, bias_lds, lane);
-            store_rows<F>(a8, out, out_f64, r0, v0, lane, feats, imask);
-            store_rows<F>(b8, out, out_f64, r1, v1, lane, feats, imask);
+            store_rows<F, RT>(a8, out, out_f64, r0, v0, lane, feats, imask, fr);
+            store_rows<F, RT>(b8, out, out_f64, r1, v1, lane, feats, imask, fr);
         }
         ring_tail<S::total>(ring, ws);
     }
@@ -2503,10 +2534,10 @@ __device__ __forceinline__ void dw_flush(v4 *__restrict__ slab, const v4 (&acc)[
 // layer's image writes never touch what a slower wave is still reading: ONE barrier per layer.
 constexpr int kImgA = 240, kImgB = 320;
 
-template <int F, int Z>
+template <int F, int Z, bool RT = false>
 __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64,
                                                         int64_t n, const double *__restrict__ feats, v4 *__restrict__ slabs,
-                                                        v4 *__restrict__ dz_out) {
+                                                        v4 *__restrict__ dz_out, int fr, int zr) {
     using N = Net<F, Z>;
     using S = StreamTrainDec<N>;
     static_assert(DW<N, 7>::rows_x + DW<N, 7>::rows_dz <= kImgA && DW<N, 6>::rows_x + DW<N, 6>::rows_dz <= kImgB &&
@@ -2531,7 +2562,7 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
     v4 a0n[tiles(F)];   // next row group's input, loaded one iteration ahead (software pipeline)
     {
         const int64_t row0 = (int64_t)blockIdx.x * kRowsPerWG + 16 * wave + (lane & 15);
-        load_rows<F>(a0n, xin, in_f64, row0, row0 < n, lane, feats);
+        load_rows<F, RT>(a0n, xin, in_f64, row0, row0 < n, lane, feats, fr);
     }
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         // keep the weight loads AND the per-tile LDS address arithmetic inside the loop: both are loop
@@ -2570,7 +2601,7 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
                     float d = d8[t][r] - a0[t][r];
                     const bool live = valid && slot_feature(F, t, lane >> 4, r) >= 0;
                     if (live) lacc += (double)d * (double)d;
-                    d8[t][r] = live ? d * (2.0f / (float)F) : 0.f;
+                    d8[t][r] = live ? d * (2.0f / (float)(RT ? fr : F)) : 0.f;
                 }
         }
         // decoder backward: per layer, image writes -> dX chain (registers only) -> barrier -> dW tiles
@@ -2583,9 +2614,9 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
         q_write_x<100>(imgB, a6, lane, wave); q_write(imgB + DW<N, 6>::rows_x * kQS, d7, lane, wave);
         bwd_layer<N, S, 6>(d7, d6, ring, ws); lrelu_bwd(d6, a6);
         __syncthreads();
-        load_rows_issue<F>(xraw, xin, in_f64, row_next, valid_next, lane);   // lands during the longest dW phase
+        load_rows_issue<F, RT>(xraw, xin, in_f64, row_next, valid_next, lane, fr);   // lands during the longest dW phase
         dw_phase<N, 6>(imgB + DW<N, 6>::rows_x * kQS, imgB, g6, lane, wave);
-        load_rows_finish<F>(a0n, xraw, valid_next, lane, feats);
+        load_rows_finish<F, RT>(a0n, xraw, valid_next, lane, feats, fr);
 
         q_write_x<50>(imgA, a5, lane, wave); q_write(imgA + DW<N, 5>::rows_x * kQS, d6, lane, wave);
         bwd_layer<N, S, 5>(d6, d5, ring, ws); lrelu_bwd(d5, a5);
@@ -2636,10 +2667,10 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
 
 #if BAMD_SPLIT == 2
 // Encoder-gradient kernel, cut after en2: recomputes only en1's forward, receives dZ_1 (7 tiles per row).
-template <int F, int Z>
+template <int F, int Z, bool RT = false>
 __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64,
                                                         int64_t n, const double *__restrict__ feats, v4 *__restrict__ slabs,
-                                                        const v4 *__restrict__ dz_in) {
+                                                        const v4 *__restrict__ dz_in, int fr, int zr) {
     using N = Net<F, Z>;
     using S = StreamTrainEnc<N>;
     static_assert(DW<N, 1>::rows_x + DW<N, 1>::rows_dz <= kImgB && DW<N, 0>::rows_x + DW<N, 0>::rows_dz <= kImgA, "image buffers");
@@ -2658,7 +2689,7 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
     v4 a0n[tiles(F)], d2n[7];   // next row group's inputs, loaded one iteration ahead (software pipeline)
     {
         const int64_t row0 = (int64_t)blockIdx.x * kRowsPerWG + 16 * wave + (lane & 15);
-        load_rows<F>(a0n, xin, in_f64, row0, row0 < n, lane, feats);
+        load_rows<F, RT>(a0n, xin, in_f64, row0, row0 < n, lane, feats, fr);
 #pragma unroll
         for (int t = 0; t < 7; ++t) d2n[t] = dz_in[((row0 >> 4) * 7 + t) * 64 + lane];
     }
@@ -2678,11 +2709,11 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
         q_write_x<200>(imgB, a1, lane, wave); q_write(imgB + DW<N, 1>::rows_x * kQS, d2, lane, wave);
         bwd_layer<N, S, 1>(d2, d1, ring, ws); lrelu_bwd(d1, a1);
         __syncthreads();
-        load_rows_issue<F>(xraw, xin, in_f64, row_next, valid_next, lane);   // lands during the long dW phase
+        load_rows_issue<F, RT>(xraw, xin, in_f64, row_next, valid_next, lane, fr);   // lands during the long dW phase
 #pragma unroll
         for (int t = 0; t < 7; ++t) d2n[t] = dz_in[((row_next >> 4) * 7 + t) * 64 + lane];   // one round past the end stays inside the buffer
         dw_phase<N, 1>(imgB + DW<N, 1>::rows_x * kQS, imgB, g1, lane, wave);
-        load_rows_finish<F>(a0n, xraw, valid_next, lane, feats);
+        load_rows_finish<F, RT>(a0n, xraw, valid_next, lane, feats, fr);
 
         q_write_x<F>(imgA, a0, lane, wave); q_write(imgA + DW<N, 0>::rows_x * kQS, d1, lane, wave);
         __syncthreads();
@@ -2692,10 +2723,10 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
     dw_flush<N, 1>(slab, g1, lane, wave); dw_flush<N, 0>(slab, g0, lane, wave);
 }
 #else
-template <int F, int Z>
+template <int F, int Z, bool RT = false>
 __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64,
                                                         int64_t n, const double *__restrict__ feats, v4 *__restrict__ slabs,
-                                                        const v4 *__restrict__ dz_in) {
+                                                        const v4 *__restrict__ dz_in, int fr, int zr) {
     using N = Net<F, Z>;
     using S = StreamTrainEnc<N>;
     static_assert(Z <= 16, "dL/dz hand-off is one tile per row");
@@ -2716,7 +2747,7 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
     v4 a0n[tiles(F)], d4n;   // next row group's inputs, loaded one iteration ahead (software pipeline)
     {
         const int64_t row0 = (int64_t)blockIdx.x * kRowsPerWG + 16 * wave + (lane & 15);
-        load_rows<F>(a0n, xin, in_f64, row0, row0 < n, lane, feats);
+        load_rows<F, RT>(a0n, xin, in_f64, row0, row0 < n, lane, feats, fr);
         d4n = row0 < n ? dz_in[row0 * 4 + (lane >> 4)] : (v4){0.f, 0.f, 0.f, 0.f};
     }
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -2747,10 +2778,10 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
         q_write_x<200>(imgB, a1, lane, wave); q_write(imgB + DW<N, 1>::rows_x * kQS, d2, lane, wave);
         bwd_layer<N, S, 1>(d2, d1, ring, ws); lrelu_bwd(d1, a1);
         __syncthreads();
-        load_rows_issue<F>(xraw, xin, in_f64, row_next, valid_next, lane);   // lands during the longest dW phase
+        load_rows_issue<F, RT>(xraw, xin, in_f64, row_next, valid_next, lane, fr);   // lands during the longest dW phase
         v4 dzraw = valid_next ? dz_in[row_next * 4 + (lane >> 4)] : (v4){0.f, 0.f, 0.f, 0.f};
         dw_phase<N, 1>(imgB + DW<N, 1>::rows_x * kQS, imgB, g1, lane, wave);
-        load_rows_finish<F>(a0n, xraw, valid_next, lane, feats);
+        load_rows_finish<F, RT>(a0n, xraw, valid_next, lane, feats, fr);
         d4n = dzraw;
 
         q_write_x<F>(imgA, a0, lane, wave); q_write(imgA + DW<N, 0>::rows_x * kQS, d1, lane, wave);
@@ -2888,10 +2919,10 @@ __device__ __forceinline__ void lat2_publish(v4 *xch, __amdgpu_buffer_rsrc_t irs
     }
 }
 
-template <int F, int Z, int W>
+template <int F, int Z, int W, bool RT = false>
 __global__ void __launch_bounds__(64 * W) lat2_chain_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
                                                             const double *__restrict__ feats, float *__restrict__ imgs,
-                                                            double *__restrict__ loss_part) {
+                                                            double *__restrict__ loss_part, int fr, int zr) {
     using N = Net<F, Z>;
     using LT = Lat<N>;
     constexpr int kImgFloats = LT::z_off(N::L) * kImgStride;
@@ -2907,7 +2938,7 @@ __global__ void __launch_bounds__(64 * W) lat2_chain_kernel(const v4 *packed, co
     const int64_t row = (int64_t)blockIdx.x * 16 + (lane & 15);
     const bool valid = row < n;
     RawRows<F> xraw;
-    load_rows_issue<F>(xraw, xin, in_f64, row, valid, lane);
+    load_rows_issue<F, RT>(xraw, xin, in_f64, row, valid, lane, fr);
     using SQ = LatSeq<N, W, (W == 4 ? 32 : 24)>;
     v4 ring[SQ::D];
     constexpr int kNB = N::bf_off(N::L) - N::bf_off(0), kBV = (kNB + 64 * W - 1) / (64 * W);
@@ -2919,7 +2950,7 @@ __global__ void __launch_bounds__(64 * W) lat2_chain_kernel(const v4 *packed, co
     }
     seq_prologue<SQ>(ring, ws, wave, std::make_integer_sequence<int, SQ::D>{});
     v4 a0[TF];
-    load_rows_finish<F>(a0, xraw, valid, lane, feats);
+    load_rows_finish<F, RT>(a0, xraw, valid, lane, feats, fr);
 #pragma unroll
     for (int k = 0; k < kBV; ++k) {
         const int idx = (int)threadIdx.x + k * 64 * W;
@@ -3004,7 +3035,7 @@ __global__ void __launch_bounds__(64 * W) lat2_chain_kernel(const v4 *packed, co
             float d = o8[0][r] - x0[r];
             const bool live = valid && t < TF && slot_feature(F, t < TF ? t : TF - 1, g, r) >= 0;
             if (live) lacc += (double)d * (double)d;
-            o8[0][r] = live ? d * (2.0f / (float)F) : 0.f;
+            o8[0][r] = live ? d * (2.0f / (float)(RT ? fr : F)) : 0.f;
         }
     }
     // ---------------- backward chain (input gradients), publishing dZ images ----------------
@@ -3201,10 +3232,10 @@ __device__ __forceinline__ void l4_publish(v4 val, float *lds_img, int rs, __amd
     }
 }
 
-template <int F, int Z>
+template <int F, int Z, bool RT = false>
 __global__ void __launch_bounds__(256) lat4_chain_kernel(const v4 *__restrict__ l4, const float *__restrict__ params, const void *__restrict__ xin,
                                                          int in_f64, int64_t n, const double *__restrict__ feats, float *__restrict__ imgs,
-                                                         double *__restrict__ loss_part) {
+                                                         double *__restrict__ loss_part, int fr, int zr) {
     using N = Net<F, Z>;
     using T = L4<N>;
     using LT = Lat<N>;
@@ -3333,7 +3364,7 @@ __global__ void __launch_bounds__(256) lat4_chain_kernel(const v4 *__restrict__ 
             const float d = v - lds[T::xo(0) + tj * T::xs(0) + (f < 32 ? f : 0)];
             const bool live = ((int64_t)blk * 16 + 4 * quad + tj < n) && f < F;
             if (live) lacc += (double)d * (double)d;
-            v = live ? d * (2.0f / (float)F) : 0.f;
+            v = live ? d * (2.0f / (float)(RT ? fr : F)) : 0.f;
             store1(std::integral_constant<int, F>{}, false, v, f, T::zo(7), T::zs(7), LT::z_off(7));
         };
         L4_GEMM(7, T::xo(7), T::xs(7), direct, fin)
@@ -3383,14 +3414,16 @@ enum { DW_WRITE = 0, DW_ADAM = 1, DW_ACCUM = 2 };   // grads = g | Adam on g (+ 
 template <class N, int MODE>
 __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ imgs, int nblk, const double *__restrict__ loss_part, int nloss,
                                                       const int *__restrict__ inv_map, float *__restrict__ grads, AdamArgs ad,
-                                                      float *__restrict__ part, int nsplit, int phase) {
+                                                      float *__restrict__ part, int nsplit, int phase, int np, double inv_c) {
+    // (np = index of the loss slot = the model's parameter count, inv_c = 1 / columns: arguments, since an instantiation for a CLASS of
+    // narrow tables serves models of different real widths)
     // phase 0: the whole job in one launch.  From 512 blocks (8192 rows) on a tile's blocks are cut into `nsplit` ranges
     // (blockIdx.y): phase 1 leaves one partial tile per range in `part`, phase 2 (a second launch, one workgroup per tile again)
     // adds them in range order and finishes (Adam / store / accumulate).  Measured us per step, split / one launch: 8192 rows
     // 64.8 / 69.6, 12288 rows 90.5 / 99.8; at 4096 rows 43.8 / 44.2 and below that the second launch costs more than it saves:
     // there the kernel is bound by the 153 MB the 298 tiles read from the images (each slice is shared by 7-13 tiles), not by latency.
     using LT = Lat<N>;
-    constexpr int kImgFloats = LT::z_off(N::L) * kImgStride, T = N::slab_off(N::L), np = N::nparams();
+    constexpr int kImgFloats = LT::z_off(N::L) * kImgStride, T = N::slab_off(N::L);
     constexpr int kPerXcd = (T + 1 + 7) / 8;
     __shared__ __attribute__((aligned(16))) v4 red[4 * 64];
     const int tile = (blockIdx.x & 7) * kPerXcd + (blockIdx.x >> 3);
@@ -3409,7 +3442,7 @@ __global__ void __launch_bounds__(256) lat2_dw_kernel(const float *__restrict__ 
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            const float gl = (float)(lred[0] * (1.0 / N::dim(0)));
+            const float gl = (float)(lred[0] * inv_c);
             if (grads) grads[np] = MODE == DW_ACCUM ? grads[np] + gl : gl;
             if (MODE == DW_ADAM && ad.loss_accum) *ad.loss_accum += (double)gl;
         }
@@ -3589,11 +3622,20 @@ struct FusedState {
 
 template <int F, int Z, bool TRAIN>
 static int build_maps(bamd_handle *h, FusedState *st) {
+    // Geometry (tiles, fragment order, slot -> feature) from the instantiated Net<F, Z>; which slots hold a parameter, and the
+    // parameter's canonical index, from the HANDLE's real dimensions: identical for an exact instantiation, and for an instantiation
+    // that serves a class of narrow tables (Impl<F, Z, true>) the class's slots beyond the real width map to nothing (-1 -> a zero
+    // weight / bias in the packed copy, no entry in the gradient map).
     using N = Net<F, Z>;
+    const int nparams_r = (int)h->nparams;
+    auto dim_r = [&](int i) { return h->dims[i]; };
+    auto w_off_r = [&](int l) { return (int)h->w_off[l]; };
+    auto b_off_r = [&](int l) { return (int)h->b_off[l]; };
     std::vector<int> src((size_t)N::packed_f4() * 4, -1);
-    std::vector<int> smap((size_t)N::nparams(), -1);
+    std::vector<int> smap((size_t)nparams_r, -1);
     for (int l = 0; l < N::L; ++l) {
         const int K = N::dim(l), NN = N::dim(l + 1), KT = tiles(K), NT = tiles(NN);
+        const int Kr = dim_r(l), NNr = dim_r(l + 1);
         // forward frags: [q][t][lane].comp[r] = W[n(t, i = lane & 15)][k(q, g = lane >> 4, r)]
         for (int q = 0; q < KT; ++q)
             for (int t = 0; t < NT; ++t)
@@ -3601,8 +3643,8 @@ static int build_maps(bamd_handle *h, FusedState *st) {
                     for (int r = 0; r < 4; ++r) {
                         int i = lane & 15, g = lane >> 4;
                         int nf = slot_feature(NN, t, i / 4, i % 4), kf = slot_feature(K, q, g, r);
-                        if (nf >= 0 && kf >= 0)
-                            src[((size_t)N::wf_off(l) + (q * NT + t) * 64 + lane) * 4 + r] = N::w_off(l) + nf * K + kf;
+                        if (nf >= 0 && kf >= 0 && nf < NNr && kf < Kr)
+                            src[((size_t)N::wf_off(l) + (q * NT + t) * 64 + lane) * 4 + r] = w_off_r(l) + nf * Kr + kf;
                     }
         // backward frags (layers 1..7): [tq][tk][lane].comp[r] = W[n(tq, g, r)][k(tk, i)]
         for (int tq = 0; tq < NT && l >= 1; ++tq)
@@ -3611,15 +3653,15 @@ static int build_maps(bamd_handle *h, FusedState *st) {
                     for (int r = 0; r < 4; ++r) {
                         int i = lane & 15, g = lane >> 4;
                         int nf = slot_feature(NN, tq, g, r), kf = slot_feature(K, tk, i / 4, i % 4);
-                        if (nf >= 0 && kf >= 0)
-                            src[((size_t)N::wb_off(l) + (tq * KT + tk) * 64 + lane) * 4 + r] = N::w_off(l) + nf * K + kf;
+                        if (nf >= 0 && kf >= 0 && nf < NNr && kf < Kr)
+                            src[((size_t)N::wb_off(l) + (tq * KT + tk) * 64 + lane) * 4 + r] = w_off_r(l) + nf * Kr + kf;
                     }
         // bias frags: [t][g].comp[r] = b[n(t, g, r)]
         for (int t = 0; t < NT; ++t)
             for (int g = 0; g < 4; ++g)
                 for (int r = 0; r < 4; ++r) {
                     int nf = slot_feature(NN, t, g, r);
-                    if (nf >= 0) src[((size_t)N::bf_off(l) + t * 4 + g) * 4 + r] = N::b_off(l) + nf;
+                    if (nf >= 0 && nf < NNr) src[((size_t)N::bf_off(l) + t * 4 + g) * 4 + r] = b_off_r(l) + nf;
                 }
         if (!TRAIN) continue;
         // slab map: tile idx = kt*NT + nt; lane (j = lane & 15 -> k slot row 16kt + j), reg r -> n slot row 4g + r
@@ -3631,13 +3673,13 @@ static int build_maps(bamd_handle *h, FusedState *st) {
                     for (int r = 0; r < 4; ++r) {
                         int j = lane & 15, g = lane >> 4;
                         int nf = slot_feature(NN, nt, g, r);
-                        if (nf < 0) continue;
+                        if (nf < 0 || nf >= NNr) continue;
                         int off = ((N::slab_off(l) + kt * NT + nt) * 64 + lane) * 4 + r;
                         int krow = 16 * kt + j;
-                        if (krow == ones_row) smap[N::b_off(l) + nf] = off;
+                        if (krow == ones_row) smap[b_off_r(l) + nf] = off;
                         else if (kt < tiles(K)) {
                             int kf = slot_feature(K, kt, j / 4, j % 4);
-                            if (kf >= 0) smap[N::w_off(l) + nf * K + kf] = off;
+                            if (kf >= 0 && kf < Kr) smap[w_off_r(l) + nf * Kr + kf] = off;
                         }
                     }
     }
@@ -3646,19 +3688,21 @@ static int build_maps(bamd_handle *h, FusedState *st) {
         for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::ef_off(l) * 4 + i] = src[(size_t)N::wf_off(l) * 4 + i];
     for (int l = kSplit - 1; l >= 1; --l)
         for (int i = 0; i < N::wcount(l) * 4; ++i) src[(size_t)N::eb_off(l) * 4 + i] = src[(size_t)N::wb_off(l) * 4 + i];
-    if (TRAIN && N::l4_frags() > 0) {
+    bool exact = true;
+    for (int i = 0; i <= N::L; ++i) exact = exact && h->dims[i] == N::dim(i);
+    if (TRAIN && N::l4_frags() > 0 && exact) {      // (the 4-row chain reads canonical biases at compile-time offsets: exact instantiations only)
         // region L4: GEMM g, step k4, output feature o: component r = W[o][4 k4 + r] (forward: layer g) or its transpose
         // W_l[4 k4 + r][o] (input-gradient product of layer l = 15 - g)
         for (int g = 0; g < 15; ++g) {
-            const int l = g < 8 ? g : 15 - g, K = N::dim(l), NN = N::dim(l + 1);
+            const int l = g < 8 ? g : 15 - g, K = dim_r(l), NN = dim_r(l + 1);      // (region L4 serves exact instantiations only)
             const int NO = N::l4_gemm_n(g);
             for (int k4 = 0; k4 < N::l4_ks(g); ++k4)
                 for (int o = 0; o < NO; ++o)
                     for (int r = 0; r < 4; ++r) {
                         const int c = 4 * k4 + r;
                         const size_t at = ((size_t)N::l4_off() + N::l4_frag_off(g) + (size_t)k4 * NO + o) * 4 + r;
-                        if (g < 8) { if (c < K) src[at] = N::w_off(l) + o * K + c; }
-                        else if (c < NN) src[at] = N::w_off(l) + c * K + o;
+                        if (g < 8) { if (c < K) src[at] = w_off_r(l) + o * K + c; }
+                        else if (c < NN) src[at] = w_off_r(l) + c * K + o;
                     }
         }
     }
@@ -3666,14 +3710,14 @@ static int build_maps(bamd_handle *h, FusedState *st) {
         for (int v : smap)
             if (v < 0) { set_error("fused: incomplete slab map"); return BAMD_ERR_INVALID; }
         std::vector<int> inv((size_t)N::slab_off(N::L) * 64 * 4, -1);   // slab float -> canonical parameter
-        for (int p = 0; p < N::nparams(); ++p) inv[smap[p]] = p;
+        for (int p = 0; p < nparams_r; ++p) inv[smap[p]] = p;
         smap.swap(inv);
     }
     {   // inverse of the pack map: for every parameter the list of packed positions that hold a copy of it
-        std::vector<int> off((size_t)N::nparams() + 1, 0), idx;
+        std::vector<int> off((size_t)nparams_r + 1, 0), idx;
         for (int v : src) if (v >= 0) off[v + 1]++;
-        for (int p = 0; p < N::nparams(); ++p) off[p + 1] += off[p];
-        idx.resize(off[N::nparams()]);
+        for (int p = 0; p < nparams_r; ++p) off[p + 1] += off[p];
+        idx.resize(off[nparams_r]);
         std::vector<int> cur(off.begin(), off.end() - 1);
         for (size_t i = 0; i < src.size(); ++i) if (src[i] >= 0) idx[cur[src[i]]++] = (int)i;
         int rc2 = st->sc_off.ensure(off.size() * sizeof(int));
@@ -3723,48 +3767,60 @@ static int infer_grid(int64_t n) {
     return (int)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg));
 }
 
-template <int F, int Z> struct Impl {
+// RT = true: the instantiation serves a CLASS of narrow tables -- every AE(f, z) with tiles(f + 1) == tiles(F + 1), z <= Z and the
+// reference's hidden widths (models.py:122-139 builds AE(n_features, z_dim) for ANY column count, baler.py:117-123 derives any latent):
+// F = 16 T - 1 is the class width, the real widths are kernel arguments (load_rows / store_rows, RT), the pack / gradient maps leave
+// the class's extra slots empty (build_maps).  Same kernels, same tile counts as the 24-column instantiation for 16..31 columns.
+template <int F, int Z, bool RT = false> struct Impl {
     using N = Net<F, Z>;
     static bool matches(const bamd_handle *h) {
         if (h->L != 8) return false;
+        if (RT) {
+            for (int i = 1; i <= 7; ++i)
+                if (i != 4 && h->dims[i] != N::dim(i)) return false;
+            return h->dims[0] == h->dims[8] && h->dims[0] >= 1 && h->dims[0] <= F && tiles(h->dims[0] + 1) == tiles(F + 1) && h->dims[4] >= 1 &&
+                   h->dims[4] <= Z;
+        }
         for (int i = 0; i <= 8; ++i)
             if (h->dims[i] != N::dim(i)) return false;
         return true;
     }
+    static int fr(const bamd_handle *h) { return h->dims[0]; }
+    static int zr(const bamd_handle *h) { return h->dims[4]; }
     static int setup(bamd_handle *h, FusedState *st) {
         static_assert(N::bf_off(8) - N::bf_off(0) == kBiasF4, "bias fragment count");
         int rc = build_maps<F, Z, true>(h, st);
         if (rc) return rc;
-        BAMD_HIP(hipFuncSetAttribute((const void *)train_dec_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
-        BAMD_HIP(hipFuncSetAttribute((const void *)train_enc_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
+        BAMD_HIP(hipFuncSetAttribute((const void *)train_dec_kernel<F, Z, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
+        BAMD_HIP(hipFuncSetAttribute((const void *)train_enc_kernel<F, Z, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
         return BAMD_OK;
     }
     static int encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
                       hipStream_t s) {
         static const int extra_lds = getenv("BALER_AMD_INFER_LDS") ? atoi(getenv("BALER_AMD_INFER_LDS")) : 0;   // occupancy experiments
-        if (extra_lds) (void)hipFuncSetAttribute((const void *)infer_kernel<F, Z, K_ENCODE>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+        if (extra_lds) (void)hipFuncSetAttribute((const void *)infer_kernel<F, Z, K_ENCODE, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
         if (F <= 64 && infer_pair()) {
-            hipLaunchKernelGGL((infer2_kernel<F <= 64 ? F : 24, Z, K_ENCODE>), dim3(infer_grid((n + 1) / 2)), dim3(256), 0, s,
+            hipLaunchKernelGGL((infer2_kernel<F <= 64 ? F : 24, Z, K_ENCODE, RT>), dim3(infer_grid((n + 1) / 2)), dim3(256), 0, s,
                                (const v4 *)h->packed.p, x, x_dtype == BAMD_F64, n, features, z, z_dtype == BAMD_F64,
-                               (const uint8_t *)nullptr);
+                               (const uint8_t *)nullptr, fr(h), zr(h));
             BAMD_HIP(hipGetLastError());
             return BAMD_OK;
         }
-        hipLaunchKernelGGL((infer_kernel<F, Z, K_ENCODE>), dim3(infer_grid(n)), dim3(256), extra_lds, s, (const v4 *)h->packed.p, x,
-                           x_dtype == BAMD_F64, n, features, z, z_dtype == BAMD_F64, (const uint8_t *)nullptr, (double *)nullptr);
+        hipLaunchKernelGGL((infer_kernel<F, Z, K_ENCODE, RT>), dim3(infer_grid(n)), dim3(256), extra_lds, s, (const v4 *)h->packed.p, x,
+                           x_dtype == BAMD_F64, n, features, z, z_dtype == BAMD_F64, (const uint8_t *)nullptr, (double *)nullptr, fr(h), zr(h));
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
     static int decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features, const uint8_t *int_mask,
                       void *out, int out_dtype, hipStream_t s) {
         if (infer_pair()) {
-            hipLaunchKernelGGL((infer2_kernel<F, Z, K_DECODE>), dim3(infer_grid((n + 1) / 2)), dim3(256), 0, s,
-                               (const v4 *)h->packed.p, z, z_dtype == BAMD_F64, n, features, out, out_dtype == BAMD_F64, int_mask);
+            hipLaunchKernelGGL((infer2_kernel<F, Z, K_DECODE, RT>), dim3(infer_grid((n + 1) / 2)), dim3(256), 0, s,
+                               (const v4 *)h->packed.p, z, z_dtype == BAMD_F64, n, features, out, out_dtype == BAMD_F64, int_mask, fr(h), zr(h));
             BAMD_HIP(hipGetLastError());
             return BAMD_OK;
         }
-        hipLaunchKernelGGL((infer_kernel<F, Z, K_DECODE>), dim3(infer_grid(n)), dim3(256), 0, s, (const v4 *)h->packed.p, z,
-                           z_dtype == BAMD_F64, n, features, out, out_dtype == BAMD_F64, int_mask, (double *)nullptr);
+        hipLaunchKernelGGL((infer_kernel<F, Z, K_DECODE, RT>), dim3(infer_grid(n)), dim3(256), 0, s, (const v4 *)h->packed.p, z,
+                           z_dtype == BAMD_F64, n, features, out, out_dtype == BAMD_F64, int_mask, (double *)nullptr, fr(h), zr(h));
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
@@ -3773,17 +3829,17 @@ template <int F, int Z> struct Impl {
         int grid = infer_grid(n);
         int rc = h->lossp.ensure(sizeof(double) * 1024);
         if (rc) return rc;
-        hipLaunchKernelGGL((infer_kernel<F, Z, K_FORWARD>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x,
+        hipLaunchKernelGGL((infer_kernel<F, Z, K_FORWARD, RT>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x,
                            x_dtype == BAMD_F64, n, features, recon, recon_dtype == BAMD_F64, (const uint8_t *)nullptr,
-                           (double *)h->lossp.p);
-        hipLaunchKernelGGL(sum_loss_k, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, grid, 1.0 / F, loss_sum);
+                           (double *)h->lossp.p, fr(h), zr(h));
+        hipLaunchKernelGGL(sum_loss_k, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, grid, 1.0 / fr(h), loss_sum);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
     static int fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
                        hipStream_t s) {
         FusedState *st = state_of(h);
-        const int np = N::nparams();
+        const int np = (int)h->nparams;
         if (n <= st->latency_max_rows) return small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
         int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
         int grid = (int)(ngroups < st->nwg_max ? ngroups : st->nwg_max);
@@ -3802,15 +3858,15 @@ template <int F, int Z> struct Impl {
         // whole row groups + one round of prefetch overrun (the second kernel loads the next group's record unconditionally)
         rc = st->dz.ensure((size_t)(ngroups + grid) * kRowsPerWG * (kSplit == 2 ? 7 * 64 : 64));
         if (rc) return rc;
-        hipLaunchKernelGGL((train_dec_kernel<F, Z>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
-                           x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (v4 *)st->dz.p);
-        hipLaunchKernelGGL((train_enc_kernel<F, Z>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
-                           x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (const v4 *)st->dz.p);
+        hipLaunchKernelGGL((train_dec_kernel<F, Z, RT>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
+                           x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (v4 *)st->dz.p, fr(h), zr(h));
+        hipLaunchKernelGGL((train_enc_kernel<F, Z, RT>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
+                           x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (const v4 *)st->dz.p, fr(h), zr(h));
         hipLaunchKernelGGL(reduce_slabs_k<float>, dim3(N::slab_off(N::L) + 1), dim3(256), 0, s, (const v4 *)h->slabs.p, grid,
-                           N::slab_off(N::L), (const int *)st->slab_map.p, np, 1.0 / F, (float *)grads);
+                           N::slab_off(N::L), (const int *)st->slab_map.p, np, 1.0 / fr(h), (float *)grads);
         BAMD_HIP(hipGetLastError());
         if (tail_rows > 0) {
-            const char *xt = (const char *)x + (size_t)n * F * (x_dtype == BAMD_F64 ? 8 : 4);
+            const char *xt = (const char *)x + (size_t)n * fr(h) * (x_dtype == BAMD_F64 ? 8 : 4);
             return small_batch(h, xt, x_dtype, tail_rows, features, grads, nullptr, s, true);
         }
         return BAMD_OK;
@@ -3829,16 +3885,22 @@ template <int F, int Z> struct Impl {
         rc = h->lossp.ensure(sizeof(double) * (size_t)(4 * nblk > 1024 ? 4 * nblk : 1024));
         if (rc) return rc;
         int nloss = nblk;
-        if (n <= st->lat4_max_rows) {
-            // one workgroup per FOUR rows: a 512-row batch on 128 CUs (v_mfma_f32_4x4x1_16B_f32: 64 output features x 4 rows per
-            // instruction); same images, so the weight-gradient kernel below does not change
-            nloss = 4 * nblk;
-            hipLaunchKernelGGL((lat4_chain_kernel<F, Z>), dim3(4 * nblk), dim3(256), 0, s, (const v4 *)h->packed.p + N::l4_off(),
-                               (const float *)h->params.p, x, x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
-        } else
+        bool four_row = false;
+        if constexpr (!RT) {      // (the 4-row chain reads canonical biases at compile-time offsets: exact instantiations only)
+            if (n <= st->lat4_max_rows) {
+                // one workgroup per FOUR rows: a 512-row batch on 128 CUs (v_mfma_f32_4x4x1_16B_f32: 64 output features x 4 rows per
+                // instruction); same images, so the weight-gradient kernel below does not change
+                four_row = true;
+                nloss = 4 * nblk;
+                hipLaunchKernelGGL((lat4_chain_kernel<F, Z, RT>), dim3(4 * nblk), dim3(256), 0, s, (const v4 *)h->packed.p + N::l4_off(),
+                                   (const float *)h->params.p, x, x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p,
+                                   fr(h), zr(h));
+            }
+        }
+        if (!four_row)
             // 4 waves per workgroup: a CU has four MFMA units, 8 waves (2 per SIMD) measured no faster (23.4 vs 23.3 us per step)
-            hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 4>), dim3(nblk), dim3(256), 0, s, (const v4 *)h->packed.p, x,
-                               x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p);
+            hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 4, RT>), dim3(nblk), dim3(256), 0, s, (const v4 *)h->packed.p, x,
+                               x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p, fr(h), zr(h));
         const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
         // tiles x block ranges from 8192 rows on (see lat2_dw_kernel); BALER_AMD_DW_SPLIT=0: always one launch
         static const bool split_on = !(getenv("BALER_AMD_DW_SPLIT") && getenv("BALER_AMD_DW_SPLIT")[0] == '0');
@@ -3853,12 +3915,12 @@ template <int F, int Z> struct Impl {
             constexpr int M = decltype(mode)::value;
             if (nsplit > 1) {
                 hipLaunchKernelGGL((lat2_dw_kernel<N, M>), dim3(grid.x, nsplit), dim3(256), 0, s, (const float *)st->imgs.p, nblk,
-                                   (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, aa, part, nsplit, 1);
+                                   (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, aa, part, nsplit, 1, (int)h->nparams, 1.0 / fr(h));
                 hipLaunchKernelGGL((lat2_dw_kernel<N, M>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
-                                   (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, aa, part, nsplit, 2);
+                                   (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, aa, part, nsplit, 2, (int)h->nparams, 1.0 / fr(h));
             } else
                 hipLaunchKernelGGL((lat2_dw_kernel<N, M>), grid, dim3(256), 0, s, (const float *)st->imgs.p, nblk,
-                                   (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, aa, part, 1, 0);
+                                   (const double *)h->lossp.p, nloss, (const int *)st->slab_map.p, (float *)grads, aa, part, 1, 0, (int)h->nparams, 1.0 / fr(h));
         };
         if (ad) launch(std::integral_constant<int, DW_ADAM>{}, *ad);
         else if (accumulate) launch(std::integral_constant<int, DW_ACCUM>{}, AdamArgs{});
@@ -4283,6 +4345,8 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     }
     if (h->mode != BAMD_MODE_F32) return nullptr;
     BAMD_AE24_ALL
+    // any other narrow table: the class instantiations (run-time widths; Impl<F, Z, true>)
+    if (Impl<31, 15, true>::matches(h)) return Impl<31, 15, true>::ops();
     if (ImplWide<512, 6>::matches(h)) {   // BALER_AMD_WIDE512=0: the all-in-registers chain (A/B runs)
         const char *e = getenv("BALER_AMD_WIDE512");
         return (e && e[0] == '0') ? ImplInfer<512, 6>::ops() : ImplWide<512, 6>::ops();

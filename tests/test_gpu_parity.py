@@ -699,6 +699,96 @@ def test_other_latent_sizes_fused(z, data10k):
     assert rel(gg.cpu().numpy()[:-1], go) < TOL32 and rel(gg.cpu().numpy(), grads.cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("F,Z", [(16, 4), (25, 10), (30, 8), (31, 15), (17, 1), (20, 15)])
+def test_any_narrow_table_runs_fused(F, Z):
+    """models.py:122-139 builds AE(n_features, z_dim) for ANY column count and baler.py:117-123 derives any latent: every table of
+    16..31 columns with a latent of at most 15 runs on the fused kernels through ONE class instantiation with run-time widths
+    (Impl<31, 15, true>: same tile counts as the 24-column model) -- encode, decode (+ fused un-normalisation and int truncation),
+    forward + loss, the training pass on both paths (small-batch kernels, throughput pair) and the one-call step, float32 and float64
+    rows, normalise-on-load, ragged row counts, against the fp64 oracle at the fp32 bar and against the layer-wise kernels."""
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 100 + F)
+    h, p = make_handle(dims, flat, "fp32")
+    assert h.path == "fused"
+    rng = np.random.default_rng(F * 100 + Z)
+    for n in (1, 17, 333, 4099):
+        x = rng.random((n, F))
+        z_ref = orc.encode(dims, flat, x)
+        for xin in (dev(x), dev(x, torch.float32)):
+            want = z_ref if xin.dtype == torch.float64 else orc.encode(dims, flat, x.astype(np.float32).astype(np.float64))
+            assert rel(h.encode(xin).cpu().numpy(), want) < TOL32, (n, xin.dtype)
+        rec_ref = orc.decode(dims, flat, z_ref)
+        assert rel(h.decode(dev(z_ref)).cpu().numpy(), rec_ref) < TOL32
+        recon, loss = h.forward_loss(dev(x))
+        fw = orc.forward(dims, flat, x)
+        assert rel(recon.cpu().numpy(), fw) < TOL32 and abs(loss.item() - orc.loss(x, fw)) < TOL32 * loss.item()
+    # normalise-on-load and un-normalise + truncation on store
+    raw = rng.normal(size=(777, F)) * 50 + 7
+    mn, rg = raw.min(0), raw.max(0) - raw.min(0)
+    feats = dev(np.stack([mn, rg]))
+    xn = (raw - mn) / rg
+    zn = orc.encode(dims, flat, xn)
+    assert rel(h.encode(dev(raw), features=feats).cpu().numpy(), zn) < TOL32
+    mask = np.zeros(F, dtype=np.uint8)
+    mask[::3] = 1
+    out = h.decode(dev(zn), features=feats, int_mask=dev(mask), out_dtype=torch.float64).cpu().numpy()
+    pre = orc.decode(dims, flat, zn) * rg + mn
+    m1 = mask == 1
+    assert rel(out[:, ~m1], pre[:, ~m1]) < TOL32
+    edge = np.abs(pre[:, m1] - np.round(pre[:, m1])) < 1e-4 * np.maximum(1.0, np.abs(pre[:, m1]))
+    assert np.array_equal(out[:, m1][~edge], np.trunc(pre[:, m1])[~edge])
+    # training: small-batch kernels (<= 12288 rows) and the throughput pair
+    for n in (1, 100, 513, 20000):
+        x = rng.random((n, F))
+        lo, go = orc.fwd_bwd(dims, flat, x)
+        grads = torch.full_like(p, 3.0)
+        h.fwd_bwd(dev(x), grads)
+        gh = grads.cpu().numpy().astype(np.float64)
+        assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo, n
+        off = 0
+        for l in range(8):      # per tensor too (at 20,000 uniform rows en1.weight's gradient is a sum of 20,000 cancelling float32 terms:
+            for cnt in (dims[l + 1] * dims[l], dims[l + 1]):      # 1.04e-5 rel-L2 on that one tensor; the whole vector, above, holds 1e-5)
+                assert rel(gh[off:off + cnt], go[off:off + cnt]) < (TOL32 if n <= 513 else 2 * TOL32), (n, l, cnt)
+                off += cnt
+    lo2, go2 = orc.fwd_bwd(dims, flat, xn)
+    g2 = torch.zeros_like(p)
+    h.fwd_bwd(dev(raw), g2, features=feats)
+    assert rel(g2.cpu().numpy().astype(np.float64)[:-1], go2) < TOL32
+    # the one-call step == fwd_bwd + adam_step bit for bit, and it refreshes the packed weights
+    x = rng.random((512, F))
+    m1_, v1_, m2_, v2_ = (torch.zeros_like(p) for _ in range(4))
+    p1, p2 = p.clone(), p.clone()
+    h1, _ = make_handle(dims, flat, "fp32")
+    h1.train_step(dev(x), p1, m1_, v1_, 1, 1e-3)
+    g = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), g)
+    h.adam_step(p2, g, m2_, v2_, 1, 1e-3)
+    assert torch.equal(p1[:-1], p2[:-1]) and torch.equal(m1_[:-1], m2_[:-1])
+    st = orc.FitState(dims, flat)
+    _, g_o = orc.fwd_bwd(dims, flat, x)
+    orc.adam_step(st.params, g_o, st.m, st.v, 1, 1e-3)
+    # (rel-L2: the first Adam step moves a parameter by lr g / (|g| + eps) -- where |g| ~ eps a float32 gradient's last bits decide
+    # the step of that one element, a max-norm bar would be measuring eps, not the kernels)
+    assert rel_l2(p1.cpu().numpy().astype(np.float64)[:-1], st.params) < TOL32
+    assert rel(h1.encode(dev(x)).cpu().numpy(), orc.encode(dims, st.params, x)) < 2 * TOL32
+
+
+@pytest.mark.parametrize("F,Z", [(48, 12), (64, 16), (24, 16), (33, 8)])
+def test_wider_narrow_tables_say_where_they_run(F, Z):
+    """Beyond the class instantiation (32 columns and more, or a latent above 15) a model runs on the layer-wise kernels -- correctly,
+    and bamd_path_of says so."""
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 7)
+    h, p = make_handle(dims, flat, "fp32")
+    assert h.path == "generic"
+    x = np.random.default_rng(1).random((300, F))
+    assert rel(h.encode(dev(x)).cpu().numpy(), orc.encode(dims, flat, x)) < TOL32
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    grads = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), grads)
+    assert rel(grads.cpu().numpy().astype(np.float64)[:-1], go) < TOL32
+
+
 @pytest.mark.parametrize("z,n", [(15, 130), (15, 2048), (15, 5003), (6, 20000)])
 def test_layer_wise_training_short_side_weight_gradients(z, n, data10k, monkeypatch):
     """Layer-wise float32 training pass (>= 128 rows): the weight gradients run on the short-side kernels (1, 2, 4, 7 and 13
