@@ -3767,7 +3767,7 @@ static int infer_grid(int64_t n) {
     return (int)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg));
 }
 
-// RT = true: the instantiation serves a CLASS of narrow tables -- every AE(f, z) with tiles(f + 1) == tiles(F + 1), z <= Z and the
+// RT = true: the instantiation serves a CLASS of narrow tables -- every AE(f, z) with f <= F, z <= Z and the
 // reference's hidden widths (models.py:122-139 builds AE(n_features, z_dim) for ANY column count, baler.py:117-123 derives any latent):
 // F = 16 T - 1 is the class width, the real widths are kernel arguments (load_rows / store_rows, RT), the pack / gradient maps leave
 // the class's extra slots empty (build_maps).  Same kernels, same tile counts as the 24-column instantiation for 16..31 columns.
@@ -3778,21 +3778,21 @@ template <int F, int Z, bool RT = false> struct Impl {
         if (RT) {
             for (int i = 1; i <= 7; ++i)
                 if (i != 4 && h->dims[i] != N::dim(i)) return false;
-            return h->dims[0] == h->dims[8] && h->dims[0] >= 1 && h->dims[0] <= F && tiles(h->dims[0] + 1) == tiles(F + 1) && h->dims[4] >= 1 &&
-                   h->dims[4] <= Z;
+            return h->dims[0] == h->dims[8] && h->dims[0] >= 1 && h->dims[0] <= F && h->dims[4] >= 1 && h->dims[4] <= Z;
         }
         for (int i = 0; i <= 8; ++i)
             if (h->dims[i] != N::dim(i)) return false;
         return true;
     }
+    static constexpr int train_lds = (kImgA + kImgB) * kQS * (int)sizeof(float) + (N::bf_off(8) - N::bf_off(0)) * 16;      // images + bias fragments
     static int fr(const bamd_handle *h) { return h->dims[0]; }
     static int zr(const bamd_handle *h) { return h->dims[4]; }
     static int setup(bamd_handle *h, FusedState *st) {
-        static_assert(N::bf_off(8) - N::bf_off(0) == kBiasF4, "bias fragment count");
+        static_assert(RT || N::bf_off(8) - N::bf_off(0) == kBiasF4, "bias fragment count");
         int rc = build_maps<F, Z, true>(h, st);
         if (rc) return rc;
-        BAMD_HIP(hipFuncSetAttribute((const void *)train_dec_kernel<F, Z, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
-        BAMD_HIP(hipFuncSetAttribute((const void *)train_enc_kernel<F, Z, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, kTrainLds));
+        BAMD_HIP(hipFuncSetAttribute((const void *)train_dec_kernel<F, Z, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, train_lds));
+        BAMD_HIP(hipFuncSetAttribute((const void *)train_enc_kernel<F, Z, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, train_lds));
         return BAMD_OK;
     }
     static int encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
@@ -3858,9 +3858,9 @@ template <int F, int Z, bool RT = false> struct Impl {
         // whole row groups + one round of prefetch overrun (the second kernel loads the next group's record unconditionally)
         rc = st->dz.ensure((size_t)(ngroups + grid) * kRowsPerWG * (kSplit == 2 ? 7 * 64 : 64));
         if (rc) return rc;
-        hipLaunchKernelGGL((train_dec_kernel<F, Z, RT>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
+        hipLaunchKernelGGL((train_dec_kernel<F, Z, RT>), dim3(grid), dim3(256), train_lds, s, (const v4 *)h->packed.p, x,
                            x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (v4 *)st->dz.p, fr(h), zr(h));
-        hipLaunchKernelGGL((train_enc_kernel<F, Z, RT>), dim3(grid), dim3(256), kTrainLds, s, (const v4 *)h->packed.p, x,
+        hipLaunchKernelGGL((train_enc_kernel<F, Z, RT>), dim3(grid), dim3(256), train_lds, s, (const v4 *)h->packed.p, x,
                            x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (const v4 *)st->dz.p, fr(h), zr(h));
         hipLaunchKernelGGL(reduce_slabs_k<float>, dim3(N::slab_off(N::L) + 1), dim3(256), 0, s, (const v4 *)h->slabs.p, grid,
                            N::slab_off(N::L), (const int *)st->slab_map.p, np, 1.0 / fr(h), (float *)grads);
@@ -4346,6 +4346,9 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     if (h->mode != BAMD_MODE_F32) return nullptr;
     BAMD_AE24_ALL
     // any other narrow table: the class instantiations (run-time widths; Impl<F, Z, true>)
+    // (up to 31 columns and a latent of at most 15: what the images and the exchange buffers of the training kernels are sized for.
+    // Wider classes need kImgA / kImgB, the small-batch chain's one-latent-tile exchange and the decoder-gradient kernel's 481
+    // registers re-budgeted: 32..64 columns or a latent of 16..32 run on generic.hip for now -- DESIGN.md section 8)
     if (Impl<31, 15, true>::matches(h)) return Impl<31, 15, true>::ops();
     if (ImplWide<512, 6>::matches(h)) {   // BALER_AMD_WIDE512=0: the all-in-registers chain (A/B runs)
         const char *e = getenv("BALER_AMD_WIDE512");
