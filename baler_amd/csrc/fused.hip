@@ -1412,36 +1412,70 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
     }
 }
 
+// Decode.  Two things bound the round-3 kernel (200-236 M frames/s, 0.25-0.30 of HBM; 532 M without its stores): every wave fetched
+// all 7 fragments of an output tile for itself, and -- what mattered -- those loads sat in the same in-order queue as the wave's
+// stores: vector-memory operations of a wave retire in order (vmcnt counts loads AND stores), so every wait for a fragment also
+// waited for the 1-KiB stores issued before it, i.e. for an HBM write acknowledgement (~4 us under load) every four tiles.  Here a
+// FIFTH wave does all the fragment traffic: it streams the tiles' fragments (7 KiB each, L2-resident) into a 4-slot LDS stage with
+// direct-to-LDS loads, two tiles ahead, one workgroup barrier per tile; the four compute waves read their A operands from the stage
+// and their vector-memory queue holds NOTHING BUT STORES, which they never wait for.
+constexpr int kDecSlots = 4;
 template <int F, int Z, bool OUT64>
-__global__ void __launch_bounds__(256) wide_bf16_decode_kernel(const v4 *packed, const v4 *w7b, const v4 *wcd, const void *__restrict__ zin, int in_f64,
+__global__ void __launch_bounds__(320) wide_bf16_decode_kernel(const v4 *packed, const v4 *w7b, const v4 *wcd, const void *__restrict__ zin, int in_f64,
                                                                int64_t n, void *__restrict__ out) {
     constexpr int out_f64 = OUT64 ? 1 : 0;
     using N = Net<F, Z>;
-    using S = StreamWideDec<N>;
     constexpr int KT = tiles(F);                   // output tiles
-    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
     // per wave: kTG output tiles of its 32 rows, row-major, rows 16 bytes longer than the data (the C-layout writes of 16 rows
     // would otherwise all fall on the same banks) -- the transposing stage of the contiguous row segments below
     constexpr int kTG = 4, kTS = 16 * kTG + 4;     // 256-byte segments (512-byte ones measured the same and cost 68 KB of LDS)
-    __shared__ __attribute__((aligned(16))) float tstage[4][32][kTS];
-    stage_bias<N>(bias_lds, packed);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int64_t npair = (n + 31) / 32;
+    constexpr int nb = N::bf_off(N::L) - N::bf_off(4);                                     // biases of layers 4..7
+    extern __shared__ __attribute__((aligned(1024))) unsigned char dec_lds[];
+    v4 (*const wst)[7][64] = (v4 (*)[7][64])dec_lds;                                       // [kDecSlots][7][64]
+    float (*const tstage)[32][kTS] = (float (*)[32][kTS])(dec_lds + kDecSlots * 7 * 1024);  // [4][32][kTS]
+    v4 *const bias_lds = (v4 *)(dec_lds + kDecSlots * 7 * 1024 + 4 * 32 * kTS * 4);
+    for (int i = threadIdx.x; i < nb; i += 320) bias_lds[i] = packed[N::bf_off(4) + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 127) / 128;
+    if (wave == 4) {
+        // ---- loader: tile after tile, group after group: 7 direct-to-LDS loads per tile, two tiles in flight ----------------------
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)w7b, 0, KT * 7 * 1024, 0x00020000);
+        const unsigned st0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)dec_lds;
+        int ti = 0, si = 0;                        // issue cursor: tile, stage slot
+        auto issue = [&]() {
+#pragma unroll
+            for (int c = 0; c < 7; ++c)
+                lds_dma_b128(__builtin_amdgcn_readfirstlane(st0 + (unsigned)(si * 7 + c) * 1024u), lane * 16, rs, (ti * 7 + c) * 1024);
+            if (++ti == KT) ti = 0;
+            si = (si + 1) & (kDecSlots - 1);
+        };
+        issue(); issue(); issue();
+        for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x)
+            for (int t = 0; t < KT; ++t) {
+                asm volatile("s_waitcnt vmcnt(14)" ::: "memory");        // all but the two youngest tiles: tile t is in the stage
+                __builtin_amdgcn_s_barrier();                            // barrier t
+                issue();                                                 // tile t + 3 into the slot of tile t - 1
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     WStream wc = make_stream(wcd, chain_bf16_frags<N, 4>() * 1024, lane);
-    WStream ww = make_stream(w7b, KT * 7 * 1024, lane);
-    const v4 *bias7 = bias_lds + (N::bf_off(7) - N::bf_off(0));
-    for (int64_t pr = (int64_t)blockIdx.x * 4 + wave; pr < npair; pr += (int64_t)gridDim.x * 4) {
+    const v4 *bias7 = bias_lds + (N::bf_off(7) - N::bf_off(4));
+    int slot = 0;
+    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+        const int64_t pr = grp * 4 + wave;
         const int64_t r0 = pr * 32 + (lane & 15), r1 = r0 + 16;
         const bool v0 = r0 < n, v1 = r1 < n;
-        asm volatile("" : "+v"(wc.voff), "+v"(ww.voff));
+        asm volatile("" : "+v"(wc.voff));
         bf8 qa[7], qb[7];                          // a7 of both row tiles as bf16 B operands (k chunk c = tiles 2 c, 2 c + 1)
         {   // the narrow layers on the bf16 MFMA (chain_bf16_pair: 70 MFMAs of 16 cycles per tile instead of 508 of 32 on the float32 chain)
             v4 a4[tiles(Z)], b4[tiles(Z)], a5[4], b5[4], a6[7], b6[7], a7[13], b7[13];
             load_rows<Z>(a4, zin, in_f64, r0, v0, lane, nullptr);
             load_rows<Z>(b4, zin, in_f64, r1, v1, lane, nullptr);
-            fwd_layer_bf16_pair<N, 4, 4>(a4, b4, a5, b5, wc, bias_lds + (N::bf_off(4) - N::bf_off(0)), lane);
-            fwd_layer_bf16_pair<N, 5, 4>(a5, b5, a6, b6, wc, bias_lds + (N::bf_off(5) - N::bf_off(0)), lane);
-            fwd_layer_bf16_pair<N, 6, 4>(a6, b6, a7, b7, wc, bias_lds + (N::bf_off(6) - N::bf_off(0)), lane);
+            fwd_layer_bf16_pair<N, 4, 4>(a4, b4, a5, b5, wc, bias_lds, lane);
+            fwd_layer_bf16_pair<N, 5, 4>(a5, b5, a6, b6, wc, bias_lds + (N::bf_off(5) - N::bf_off(4)), lane);
+            fwd_layer_bf16_pair<N, 6, 4>(a6, b6, a7, b7, wc, bias_lds + (N::bf_off(6) - N::bf_off(4)), lane);
             const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 7; ++c) {
@@ -1449,26 +1483,20 @@ __global__ void __launch_bounds__(256) wide_bf16_decode_kernel(const v4 *packed,
                 qb[c] = to_bf8(b7[2 * c], 2 * c + 1 < 13 ? b7[2 * c + 1 < 13 ? 2 * c + 1 : 12] : zero);
             }
         }
-        // fragments three output tiles ahead in four rotating register buffers (a tile is 14 MFMAs: one tile ahead left every
-        // tile waiting for an L2 round trip, 185 M frames/s)
-        bf8 wr[4][7];
-        auto load_w = [&](bf8 (&w)[7], int t) {
-            t = t < KT ? t : KT - 1;
-#pragma unroll
-            for (int c = 0; c < 7; ++c) w[c] = frag_bf(ww, t * 7 + c);
-        };
         // Output: a lane holds 16 bytes of a row per tile, i.e. the wave wrote 32 rows x 64 bytes per tile -- half cache lines
-        // that only the L2 could merge (180 M frames/s; non-temporal: 95 M; without stores: 532 M).  Float32 output goes through
+        // that only the L2 could merge (180 M frames/s; non-temporal: 95 M).  Float32 output goes through
         // the stage instead: four tiles are collected per row, then every store instruction writes 4 rows x 256 contiguous bytes.
-        auto tile_out = [&](const bf8 (&w)[7], int t, auto jj) {
+        auto tile = [&](int t, auto jj) {
             constexpr int J = decltype(jj)::value % kTG;           // t % kTG
-            if (t >= KT) return;
+            if (t >= KT) return;                                   // (the same in all waves)
+            __builtin_amdgcn_s_barrier();                          // barrier t: the loader has tile t in stage slot `slot`
+            bf8 w[7];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) w[c] = __builtin_bit_cast(bf8, wst[slot][c][lane]);
+            slot = (slot + 1) & (kDecSlots - 1);
             v4 o0 = bias7[t * 4 + g], o1 = o0;
 #pragma unroll
             for (int c = 0; c < 7; ++c) { o0 = mfma_bf(w[c], qa[c], o0); o1 = mfma_bf(w[c], qb[c], o1); }
-#if defined(BAMD_WB_ABL) && BAMD_WB_ABL == 1
-            asm volatile("" :: "v"(o0), "v"(o1));
-#else
             if (!OUT64 && t + (kTG - 1 - J) < F / 16) {            // the whole group is made of full tiles
                 *(v4 *)&tstage[wave][lane & 15][16 * J + 4 * g] = o0;
                 *(v4 *)&tstage[wave][16 + (lane & 15)][16 * J + 4 * g] = o1;
@@ -1486,38 +1514,13 @@ __global__ void __launch_bounds__(256) wide_bf16_decode_kernel(const v4 *packed,
                 if (v0) wide_store_tile<F>(o0, out, out_f64, r0, t, g);
                 if (v1) wide_store_tile<F>(o1, out, out_f64, r1, t, g);
             }
-#endif
+            __builtin_amdgcn_sched_barrier(0);
         };
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-        using I3 = std::integral_constant<int, 3>;
-        load_w(wr[0], 0);
-        load_w(wr[1], 1);
-        load_w(wr[2], 2);
-        for (int t0 = 0; t0 < KT; t0 += 8) {
-            load_w(wr[3], t0 + 3);
-            tile_out(wr[0], t0, I0());
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(wr[0], t0 + 4);
-            tile_out(wr[1], t0 + 1, I1());
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(wr[1], t0 + 5);
-            tile_out(wr[2], t0 + 2, I2());
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(wr[2], t0 + 6);
-            tile_out(wr[3], t0 + 3, I3());
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(wr[3], t0 + 7);
-            tile_out(wr[0], t0 + 4, std::integral_constant<int, 4>());
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(wr[0], t0 + 8);
-            tile_out(wr[1], t0 + 5, std::integral_constant<int, 5>());
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(wr[1], t0 + 9);
-            tile_out(wr[2], t0 + 6, std::integral_constant<int, 6>());
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(wr[2], t0 + 10);
-            tile_out(wr[3], t0 + 7, std::integral_constant<int, 7>());
-            __builtin_amdgcn_sched_barrier(0);
+        for (int t0 = 0; t0 < KT; t0 += 4) {
+            tile(t0, std::integral_constant<int, 0>());
+            tile(t0 + 1, std::integral_constant<int, 1>());
+            tile(t0 + 2, std::integral_constant<int, 2>());
+            tile(t0 + 3, std::integral_constant<int, 3>());
         }
     }
 }
@@ -4112,6 +4115,11 @@ template <int F, int Z> struct ImplWideBf16 {
     static constexpr int KB = (F + 31) / 32, KT = tiles(F);
     // float32 rows of a multiple of 16 bytes take the encode kernel with the decoupled row stream (wide_bf16_encode_dma_kernel)
     static constexpr bool kDma = (F * 4) % 16 == 0 && F / 32 >= kDmaRing;
+    static constexpr size_t dec_lds_bytes() { return (size_t)kDecSlots * 7 * 1024 + 4 * 32 * (16 * 4 + 4) * 4 + (size_t)(N::bf_off(N::L) - N::bf_off(4)) * 16; }
+    static int dec_grid(const FusedState *st, int64_t rows) {      // persistent: the loader streams tile after tile across row groups
+        const int64_t g = (rows + 127) / 128;
+        return (int)(g < 1 ? 1 : (g > 2 * st->nwg_max ? 2 * st->nwg_max : g));
+    }
     static constexpr size_t dma_lds_bytes() { return (size_t)kDmaRing * kDmaChunk + 2 * 13 * 1024 + (size_t)(N::bf_off(4) - N::bf_off(0)) * 16; }
     static int setup(bamd_handle *h, FusedState *st) {
         int rc = build_maps<F, Z, false>(h, st);
@@ -4178,6 +4186,8 @@ template <int F, int Z> struct ImplWideBf16 {
         const std::vector<int> *srcs[6] = {&s0, &s7, &s7t, &s0p, &sce, &scd};
         if constexpr (kDma)
             BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_encode_dma_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes()));
+        BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_decode_kernel<F, Z, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_lds_bytes()));
+        BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_decode_kernel<F, Z, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_lds_bytes()));
         for (int k = 0; k < 6; ++k) {
             st->wb_count[k] = (int)srcs[k]->size();
             rc = st->wb_src[k].ensure(srcs[k]->size() * sizeof(int));
@@ -4258,10 +4268,10 @@ template <int F, int Z> struct ImplWideBf16 {
                 kout_f64 = 0;
             }
             if (kout_f64)
-                hipLaunchKernelGGL((wide_bf16_decode_kernel<F, Z, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                hipLaunchKernelGGL((wide_bf16_decode_kernel<F, Z, true>), dim3(dec_grid(st, rows)), dim3(320), dec_lds_bytes(), s, (const v4 *)h->packed.p,
                                    (const v4 *)st->wb[1].p, (const v4 *)st->wb[5].p, (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout);
             else
-                hipLaunchKernelGGL((wide_bf16_decode_kernel<F, Z, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                hipLaunchKernelGGL((wide_bf16_decode_kernel<F, Z, false>), dim3(dec_grid(st, rows)), dim3(320), dec_lds_bytes(), s, (const v4 *)h->packed.p,
                                    (const v4 *)st->wb[1].p, (const v4 *)st->wb[5].p, (const void *)((const char *)z + (size_t)r0 * Z * zes), z_dtype == BAMD_F64, rows, kout);
             if (features) {
                 int rc = launch_renormalize(kout, BAMD_F32, rows, F, features, int_mask, (double *)dst, s);
