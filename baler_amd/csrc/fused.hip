@@ -1420,6 +1420,10 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
 // direct-to-LDS loads, two tiles ahead, one workgroup barrier per tile; the four compute waves read their A operands from the stage
 // and their vector-memory queue holds NOTHING BUT STORES, which they never wait for.
 constexpr int kDecSlots = 4;
+#ifndef BAMD_DEC_DIRECT
+#define BAMD_DEC_DIRECT 0
+#endif
+constexpr bool kDecDirect = BAMD_DEC_DIRECT;      // 1: C tiles stored as they stand (16 rows x 64 B per instruction), no transposing stage
 template <int F, int Z, bool OUT64>
 __global__ void __launch_bounds__(320) wide_bf16_decode_kernel(const v4 *packed, const v4 *w7b, const v4 *wcd, const void *__restrict__ zin, int in_f64,
                                                                int64_t n, void *__restrict__ out) {
@@ -1432,8 +1436,11 @@ __global__ void __launch_bounds__(320) wide_bf16_decode_kernel(const v4 *packed,
     constexpr int nb = N::bf_off(N::L) - N::bf_off(4);                                     // biases of layers 4..7
     extern __shared__ __attribute__((aligned(1024))) unsigned char dec_lds[];
     v4 (*const wst)[7][64] = (v4 (*)[7][64])dec_lds;                                       // [kDecSlots][7][64]
-    float (*const tstage)[32][kTS] = (float (*)[32][kTS])(dec_lds + kDecSlots * 7 * 1024);  // [4][32][kTS]
-    v4 *const bias_lds = (v4 *)(dec_lds + kDecSlots * 7 * 1024 + 4 * 32 * kTS * 4);
+    constexpr bool kAligned = !OUT64 && F % 4 == 0 && !kDecDirect;     // float32 rows of a multiple of 16 bytes: line-aligned window stores
+    constexpr int kFullTiles = F / 16, kRS = 128 + 4;                  // ring: 128 columns per row (+ 16 bytes: bank spread of the C-layout writes)
+    float (*const tstage)[32][kTS] = (float (*)[32][kTS])(dec_lds + kDecSlots * 7 * 1024);  // [4][32][kTS]   (!kAligned)
+    float (*const tring)[32][kRS] = (float (*)[32][kRS])(dec_lds + kDecSlots * 7 * 1024);   // [4][32][kRS]   (kAligned)
+    v4 *const bias_lds = (v4 *)(dec_lds + kDecSlots * 7 * 1024 + 4 * 32 * kRS * 4);
     for (int i = threadIdx.x; i < nb; i += 320) bias_lds[i] = packed[N::bf_off(4) + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
@@ -1497,7 +1504,47 @@ __global__ void __launch_bounds__(320) wide_bf16_decode_kernel(const v4 *packed,
             v4 o0 = bias7[t * 4 + g], o1 = o0;
 #pragma unroll
             for (int c = 0; c < 7; ++c) { o0 = mfma_bf(w[c], qa[c], o0); o1 = mfma_bf(w[c], qb[c], o1); }
-            if (!OUT64 && t + (kTG - 1 - J) < F / 16) {            // the whole group is made of full tiles
+            if constexpr (kAligned) {
+                // LINE-ALIGNED stores.  A C4 row is 10,000 bytes: rows start at every 16-byte phase of a 128-byte line, and a store
+                // of row segments at fixed columns leaves every segment's first and last line partly written -- written back and
+                // touched again by the next segment (tools/probe/hbm_store_pattern_probe: 3.56 TB/s for 256-byte segments of
+                // 10,000-byte rows against 5.5 TB/s for rows of a multiple of 128 bytes).  So each row stores 256-byte windows that
+                // start on ITS OWN line boundaries: column a_r + 64 k with a_r = (-row * F) mod 32 floats.  The last eight tiles
+                // of the wave's 32 rows live in a ring (128 columns per row); window k is complete once tile 4 k + 5 is in.
+                if (t < kFullTiles) {
+                    *(v4 *)&tring[wave][lane & 15][16 * (t & 7) + 4 * g] = o0;
+                    *(v4 *)&tring[wave][16 + (lane & 15)][16 * (t & 7) + 4 * g] = o1;
+                } else {                                   // the partial last tile: element by element
+                    if (v0) wide_store_tile<F>(o0, out, out_f64, r0, t, g);
+                    if (v1) wide_store_tile<F>(o1, out, out_f64, r1, t, g);
+                }
+                const int64_t rb = pr * 32;
+                const int p = lane & 15;
+                auto window = [&](int col0 /* first column of the window of a row with a_r = 0 */, bool head, bool tail) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int rl = 4 * k + (lane >> 4);
+                        const int64_t R = rb + rl;
+                        const int ar = (32 - (int)((R * (F % 32)) & 31)) & 31;
+                        int col = head ? 4 * p : col0 + ar + 4 * p;
+                        const bool ok = R < n && (head ? 4 * p < ar : (!tail || col < 16 * kFullTiles));
+                        col = ok ? col : 0;
+                        const v4 v = *(const v4 *)&tring[wave][rl][col & 127];
+                        if (ok) *(v4 *)((float *)out + R * F + col) = v;
+                    }
+                };
+                if (J == 1 && t >= 5 && t < kFullTiles) {
+                    if (t == 5) window(0, true, false);                   // the columns in front of the row's first line boundary
+                    window(16 * (t - 5), false, false);
+                }
+                if (t == kFullTiles - 1) {                                // what is left behind the last complete window: <= 2 masked rounds
+                    constexpr int tl = kFullTiles - 1 - ((kFullTiles - 1 - 5) % 4 + 4) % 4;      // the last t that stored a window (t % 4 == 1, t >= 5)
+                    constexpr int c0 = kFullTiles > 5 ? 16 * (tl - 5) + 64 : 0;
+                    if (kFullTiles <= 5) window(0, true, false);
+                    window(c0, false, true);
+                    window(c0 + 64, false, true);
+                }
+            } else if (!kDecDirect && !OUT64 && t + (kTG - 1 - J) < F / 16) {            // the whole group is made of full tiles
                 *(v4 *)&tstage[wave][lane & 15][16 * J + 4 * g] = o0;
                 *(v4 *)&tstage[wave][16 + (lane & 15)][16 * J + 4 * g] = o1;
                 if (J == kTG - 1) {
@@ -4115,7 +4162,7 @@ template <int F, int Z> struct ImplWideBf16 {
     static constexpr int KB = (F + 31) / 32, KT = tiles(F);
     // float32 rows of a multiple of 16 bytes take the encode kernel with the decoupled row stream (wide_bf16_encode_dma_kernel)
     static constexpr bool kDma = (F * 4) % 16 == 0 && F / 32 >= kDmaRing;
-    static constexpr size_t dec_lds_bytes() { return (size_t)kDecSlots * 7 * 1024 + 4 * 32 * (16 * 4 + 4) * 4 + (size_t)(N::bf_off(N::L) - N::bf_off(4)) * 16; }
+    static constexpr size_t dec_lds_bytes() { return (size_t)kDecSlots * 7 * 1024 + 4 * 32 * (128 + 4) * 4 + (size_t)(N::bf_off(N::L) - N::bf_off(4)) * 16; }
     static int dec_grid(const FusedState *st, int64_t rows) {      // persistent: the loader streams tile after tile across row groups
         const int64_t g = (rows + 127) / 128;
         return (int)(g < 1 ? 1 : (g > 2 * st->nwg_max ? 2 * st->nwg_max : g));
