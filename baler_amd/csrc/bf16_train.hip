@@ -105,29 +105,15 @@ template <int F, int Z> struct TNet {
 
 // Which layers a launch covers.  PART 0: forward 0..7, loss, backward 7..2 (input-gradient chain down to dZ_1).
 // PART 1: forward 0, backward 1..0.
-// BAMD_BF16_HANDX = 1: PART 0 also hands X_0 (the bf16 input image) and X_1 (layer 0's output) over, so PART 1 neither reads the rows
-// nor recomputes layer 0 (its rows phase + layer 0 were 2.7k of its 7.5k cycles per iteration); the hand-off record is TILE-major per
-// 64-row group -- [slot][64 rows][32 B], slots = 7 tiles of dZ_1, 13 of X_1, 2 halves of X_0 = 704 B per row -- so that PART 0's
-// 8-byte tile stores and PART 1's 32-byte row-slot loads are both contiguous per instruction.  0 (default): PART 1 reads the rows and
-// recomputes layer 0; dZ_1 only is handed over, row-major, 224 B per row.
-// MEASURED AND REJECTED: identical results, 0.811 vs 0.774 ms per 1M rows -- PART 0 610 -> 641 us (14 more tile stores per lane and
-// iteration), PART 1 243 -> 247 us: it moves 704 instead of 416 B per row (2.9 TB/s with its slabs) one iteration ahead and is bound
-// by that, not by the layer-0 work it no longer does.  The fp32 pair showed the same (fused.hip, "hand en1's output").
-#ifndef BAMD_BF16_HANDX
-#define BAMD_BF16_HANDX 0
-#endif
-constexpr bool kHandX = BAMD_BF16_HANDX;
+// dZ_1 only is handed over (row-major, 224 B per row); PART 1 reads the rows again and recomputes layer 0.  Handing X_0 and X_1 over as
+// well (704 B per row, tile-major) was measured and rejected in round 3: identical results, 0.811 vs 0.774 ms per 1M rows -- PART 1 is
+// bound by the record it streams one iteration ahead, not by the layer-0 work it would drop.
 // PART 1 requests the NEXT iteration's rows and hand-off records right after the last fragment wait of its input-gradient product
-// (layer 1) instead of at the top of the iteration.  Loads of a wave retire in order: requested at the top, these HBM fetches (~2 us)
+// (layer 1), not at the top of the iteration.  Loads of a wave retire in order: requested at the top, these HBM fetches (~2 us)
 // stood in front of every fragment requested after them, and the product's third k block -- 3,000 cycles later -- waited for them.
-// From the new place the next wait on a younger load is a whole epilogue + two weight-gradient phases + the rows phase away.
-#ifndef BAMD_BF16_LATE_PF
-#define BAMD_BF16_LATE_PF 1
-#endif
-constexpr bool kLatePf = BAMD_BF16_LATE_PF;
-constexpr int kHandSlots = 7 + 13 + 2, kHandGroupBytes = kHandSlots * 2048;
+// From the late place the next wait on a younger load is a whole epilogue + two weight-gradient phases + the rows phase away.
 template <int PART> struct Part {
-    static constexpr int fwd_end = PART == 1 ? (kHandX ? 0 : 1) : 8;        // forward layers [0, fwd_end)
+    static constexpr int fwd_end = PART == 1 ? 1 : 8;        // forward layers [0, fwd_end)
     static constexpr int bwd_hi = PART == 1 ? 1 : 7;         // backward layers bwd_hi .. bwd_lo
     static constexpr int bwd_lo = PART == 0 ? 2 : 0;
     __host__ __device__ static constexpr bool has(int l) { return l <= bwd_hi && l >= bwd_lo; }
@@ -137,10 +123,7 @@ template <int PART> struct Part {
 // A STEP is one k block of one chain product; every wave loads at most 4 fragments per step, two steps ahead of the
 // MFMAs, into a ring of 3 step buffers.  The step count is padded to a multiple of 3 so that the ring wraps across
 // persistent iterations (padding steps load nothing).
-#undef BAMD_BF16_RING
-#ifndef BAMD_BF16_RINGD
-#define BAMD_BF16_RINGD 3
-#endif
+constexpr int kRD = 3;      // step buffers of the fragment ring (fragments run kRD - 1 steps ahead; 2 / 3 / 5 measured: 3)
 struct StepInfo { int bwd, l, q, valid, msplit; };
 // steps of a product: N-split = one per k block (<= 4 fragments per wave); M-split = its kb x nt fragments, in MFMA order
 // [k block][tile], four per step (every wave loads all of them)
@@ -152,7 +135,7 @@ template <class N, int PART> struct Sched {
     __host__ __device__ static constexpr int fstep(int l) { int s = 0; for (int j = 0; j < l; ++j) s += nf(j); return s; }
     __host__ __device__ static constexpr int bstep(int l) { int s = fstep(P::fwd_end); for (int j = P::bwd_hi; j > l; --j) s += nb(j); return s; }
     static constexpr int real = bstep(chain_lo()) + nb(chain_lo());
-    static constexpr int total = cdiv(real, BAMD_BF16_RINGD) * BAMD_BF16_RINGD;
+    static constexpr int total = cdiv(real, kRD) * kRD;
     __host__ __device__ static constexpr StepInfo info(int s) {
         s %= total;
         if (s >= real) return {0, 0, 0, 0, 0};
@@ -163,26 +146,16 @@ template <class N, int PART> struct Sched {
         return {0, 0, 0, 0, 0};
     }
 };
-constexpr int kRD = BAMD_BF16_RINGD;      // step buffers of the fragment ring (fragments run kRD - 1 steps ahead)
 
 // How the NT output tiles of a chain product are split over the 4 waves.  N-split slot i: tile wave + 4 i for ALL four
 // row tiles (the fragment is loaded by one wave only); M-split tile k: every wave computes it for ITS row tile (fragment
 // loaded by all four).  NT = 13 -> 3 N-split + tile 12 M-split; 7 -> 2 N-split slots (wave 3's second is empty);
 // 4 -> 1; 2 and 1 -> M-split.
 template <int NT> struct Split {
-#ifndef BAMD_BF16_SPLIT_BALANCED
     static constexpr int R = NT % 4;
     static constexpr int NS = NT < 4 ? 0 : (R == 1 ? NT / 4 : cdiv(NT, 4));
     static constexpr int MS = NT < 4 ? NT : (R == 1 ? 1 : 0);
     static constexpr bool ragged = NT >= 4 && R != 1 && R != 0;   // the last N-split slot does not exist on every wave
-#else
-    // (experiment, measured 14 % SLOWER: 0.889 vs 0.781 ms) NT / 4 N-split slots, the remaining NT % 4 tiles M-split: 7 tiles =
-    // 1 slot + 3 own-row tiles = 7 MFMAs per k block on EVERY wave instead of 8 / 8 / 8 / 4 -- but 16 instead of 7 fragment
-    // loads per k block and workgroup: the kernel is that sensitive to fragment traffic through the 64 B/clk L1 path
-    static constexpr int NS = NT / 4;
-    static constexpr int MS = NT % 4;
-    static constexpr bool ragged = false;
-#endif
     static constexpr int NF = NS + MS;                        // fragments per step and wave
     static constexpr int m0 = 4 * NS;                         // first M-split tile
     static_assert(NF <= 4, "ring step buffers hold 4 fragments");
@@ -271,17 +244,11 @@ template <int S> __device__ __forceinline__ bf8 tr_operand(lds_p base, int kh) {
 }
 
 __device__ __forceinline__ void lrelu4(v4 &a) {
-#ifdef BAMD_BF16_SCALAR_MUL
-    v4 m;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { m[r] = a[r] * 0.01f; asm("" : "+v"(m[r])); }      // four v_mul_f32 (a packed multiply costs more than two of them in a VALU burst)
-#else
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f k2 = (v2f){0.01f, 0.01f};
     asm("" : "+v"(k2));                       // register pair, vector product: v_pk_mul_f32 (see fused.hip lrelu)
     v4 m = a * (v4){k2[0], k2[1], k2[0], k2[1]};
     asm("" : "+v"(m));
-#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] = __builtin_elementwise_maximum(a[r], m[r]);
 }
@@ -296,17 +263,11 @@ __device__ __forceinline__ u2 pack4(const v4 &a) {
 // (v_pk_ashrrev_i16) with one v_bfi_b32 per pair: 2.5 VALU instructions per value including the conversion
 // (compare + select on the fp32 values: 3; mask arithmetic on the slope bits: 5.5).
 __device__ __forceinline__ u2 lrelu_bwd_pack4(const v4 &d, u2 y) {
-#ifdef BAMD_BF16_SCALAR_MUL
-    v4 m;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { m[r] = d[r] * 0.01f; asm("" : "+v"(m[r])); }
-#else
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f k2 = (v2f){0.01f, 0.01f};
     asm("" : "+v"(k2));
     v4 m = d * (v4){k2[0], k2[1], k2[0], k2[1]};
     asm("" : "+v"(m));
-#endif
     const u2 p1 = pack4(d), p2 = pack4(m);
     unsigned sh = 0x000F000Fu;      // shift count per half (an inline constant would reach the low half only)
     u2 o;
@@ -329,10 +290,7 @@ template <int NT> struct ChainAcc {
     v4 am[SP::MS > 0 ? SP::MS : 1];
 };
 
-#ifndef BAMD_BF16_BDEPTH
-#define BAMD_BF16_BDEPTH 1
-#endif
-constexpr int kBD = BAMD_BF16_BDEPTH;      // k blocks the B operand reads run ahead of the MFMAs (LDS latency under load: 150-200 cycles)
+constexpr int kBD = 1;      // k blocks the B operand reads run ahead of the MFMAs (LDS latency under load: 150-200 cycles)
 // B operands of one k block: [0..3] the four row tiles (N-split slots), [4] this wave's own row tile (M-split tiles)
 template <int NT, int SIN>
 __device__ __forceinline__ void chain_load_b(bf8 (&dst)[5], lds_p in_row, int wave, int q) {
@@ -366,9 +324,6 @@ __device__ __forceinline__ void chain_step(ChainAcc<NT> &acc, bf8 (&b)[kBD + 1][
     for (int k = 0; k < SP::MS; ++k) acc.am[k] = mfma(ring.buf[(STEP0 + Q) % kRD][SP::NS + k], bq[4], Q == 0 ? zero : acc.am[k]);
     __builtin_amdgcn_sched_barrier(0);
 }
-#ifndef BAMD_BF16_MONLY_AHEAD
-#define BAMD_BF16_MONLY_AHEAD 1
-#endif
 template <class N, int PART, int STEP0, int KB, int NT, int Q>
 __device__ __forceinline__ void monly_step(ChainAcc<NT> &acc, const bf8 (&b)[KB], Ring &ring, const WStream &ws, int wave) {
     using SP = Split<NT>;
@@ -383,10 +338,7 @@ __device__ __forceinline__ void chain_mm_impl(ChainAcc<NT> &acc, lds_p in_row, R
                                               std::integer_sequence<int, Q...>) {
     using SP = Split<NT>;
     const bool last_ok = !SP::ragged || wave + 4 * (SP::NS - 1) < NT;      // wave-uniform
-#ifdef BAMD_ABLATE_CHAIN
-    return;
-#endif
-    if constexpr (SP::NS == 0 && BAMD_BF16_MONLY_AHEAD) {
+    if constexpr (SP::NS == 0) {
         // M-split only (layer 7: two tiles, 7 k blocks of 2 MFMAs): one k block ahead = 32 MFMA cycles, every step waited for
         // its LDS round trip -- read all k blocks of this wave's row tile first (KB x 4 registers)
         bf8 ball[KB];
@@ -411,9 +363,6 @@ __device__ __forceinline__ void chain_mm(ChainAcc<NT> &acc, lds_p in_row /* imag
 template <int NT, int SOUT, class Fn>
 __device__ __forceinline__ void acc_visit(ChainAcc<NT> &acc, lds_p img, const Lay &lay, int wave, Fn fn) {
     using SP = Split<NT>;
-#ifdef BAMD_ABLATE_EPILOGUE
-    return;
-#endif
     // N-split slot k: tile t = wave + 4 k: parity of t = parity of wave, chunk pair 2 t -> 32 (t & ~1) bytes
     const lds_p wn = img + lay.wr(wave & 1) + 32 * (wave & ~1);
 #pragma unroll
@@ -455,9 +404,6 @@ __device__ __forceinline__ void acc_visit_idx(ChainAcc<NT> &acc, lds_p img, cons
 template <int NT, int SOUT, class Pre, class Fn>
 __device__ __forceinline__ void acc_visit_pre(ChainAcc<NT> &acc, lds_p img, const Lay &lay, int wave, Pre pre, Fn fn) {
     using SP = Split<NT>;
-#ifdef BAMD_ABLATE_EPILOGUE
-    return;
-#endif
     const lds_p wn = img + lay.wr(wave & 1) + 32 * (wave & ~1);
     const lds_p wm0 = img + 16 * wave * SOUT;
     u2 ym[SP::MS > 0 ? SP::MS : 1];
@@ -493,53 +439,6 @@ __device__ __forceinline__ void acc_visit_pre(ChainAcc<NT> &acc, lds_p img, cons
     }
 }
 
-// The backward epilogue again, cut into per-tile UNITS (unit U < 4 NS: N-split slot U / 4, row tile U % 4; then the M-split tiles)
-// that dw_phase spreads between the MFMAs of the layer's weight-gradient tiles: those MFMAs read dZ_l and X_l, the epilogue
-// writes dZ_{l-1} into a third region, so the two are independent -- and run one after the other the epilogue's ~94 cycles per
-// tile (LDS round trips more than its 10 VALU instructions) and the MFMAs' 16 each simply added up.  A slot the wave does not
-// own (ragged split) runs on whatever its registers hold and stores into a per-wave scratch row: uniform code, no branch.
-// MEASURED AND REJECTED (default off): epilogue + weight-gradient tiles take exactly as long dealt together as one after the
-// other (bwd 6: 1,884 vs 744 + 1,228 cycles; bwd 1: 2,496 vs 2,496) and the kernel pair gets 6.6 % slower (0.823 vs 0.769 ms):
-// neither part is bound by its VALU or MFMA issue but by LDS round trips in the wave's one in-order LDS queue, which the
-// mixture does not shorten.
-#ifndef BAMD_BF16_EPIMIX
-#define BAMD_BF16_EPIMIX 0
-#endif
-template <int NT> struct EpiGeo {
-    using SP = Split<NT>;
-    static constexpr int E = 4 * SP::NS + SP::MS;
-};
-template <int NT, int SOUT, int U> __device__ __forceinline__ lds_p epi_addr(lds_p img, const Lay &lay, int wave) {
-    using SP = Split<NT>;
-    if constexpr (U < 4 * SP::NS) {
-        constexpr int k = U / 4, m = U % 4;
-        const bool own = !(SP::ragged && k == SP::NS - 1) || wave + 4 * k < NT;
-        return img + lay.wr(wave & 1) + 32 * (wave & ~1) + (own ? 128 * k : 0) + 16 * m * SOUT;
-    } else {
-        constexpr int t = SP::m0 + (U - 4 * SP::NS);
-        return img + 16 * wave * SOUT + lay.wr(t & 1) + 32 * (t & ~1);
-    }
-}
-template <int NT, int U> __device__ __forceinline__ bool epi_owned(int wave) {
-    using SP = Split<NT>;
-    return !(SP::ragged && U < 4 * SP::NS && U / 4 == SP::NS - 1) || wave + 4 * (U / 4) < NT;
-}
-template <int NT, int U> __device__ __forceinline__ v4 &epi_acc(ChainAcc<NT> &acc) {
-    using SP = Split<NT>;
-    if constexpr (U < 4 * SP::NS) return acc.an[U / 4][U % 4];
-    else return acc.am[U - 4 * SP::NS];
-}
-template <int NT, int SOUT, int... U>
-__device__ __forceinline__ void epi_pre(u2 (&y)[EpiGeo<NT>::E], lds_p img, const Lay &lay, int wave, std::integer_sequence<int, U...>) {
-    ((y[U] = lds_b64(epi_addr<NT, SOUT, U>(img, lay, wave))), ...);
-}
-template <int U0, int U1, class Fn> __device__ __forceinline__ void epi_units(Fn &fn) {
-    if constexpr (U0 < U1) {
-        fn(std::integral_constant<int, U0>{});
-        epi_units<U0 + 1, U1>(fn);
-    }
-}
-
 // ---- weight-gradient tiles of layer l --------------------------------------------------------------------------------
 // A operand: dZ_l^T (image ZI, stride SZ), B operand: [X_l | 1] (image XI, stride SX), both by transposed reads;
 // contraction over the 64 rows = 2 MFMAs per tile.  Tiles owned by this wave: see TNet::by_nt.
@@ -550,10 +449,7 @@ template <int U0, int U1, class Fn> __device__ __forceinline__ void epi_units(Fn
 // LDS round trip of 150-200 cycles (13 steps of dW_6 took 2,280 cycles for 832 cycles of MFMAs).
 // An owned slot that does not exist on this wave (13 tiles over 4 waves) is computed on a clamped address and never flushed:
 // uniform code, and that wave would wait at the barrier anyway.
-#ifndef BAMD_BF16_DWDEPTH
-#define BAMD_BF16_DWDEPTH 2
-#endif
-constexpr int kDWD = BAMD_BF16_DWDEPTH;
+constexpr int kDWD = 2;
 template <class N, int l> struct DwGeo {
     static constexpr int NT = N::nt(l), KT = N::kt(l);
     static constexpr bool BYN = N::by_nt(l);
@@ -561,10 +457,9 @@ template <class N, int l> struct DwGeo {
     static constexpr int OWN = BYN ? NT : KT;                       // tiles on the owned side
     static constexpr int NS = BYN ? KT : NT;                        // streamed tiles
 };
-struct NoEpi { template <class U> __device__ __forceinline__ void operator()(U) {} };
-template <class N, int l, int SZ, int SX, int E, int S, class Epi>
+template <class N, int l, int SZ, int SX, int S>
 __device__ __forceinline__ void dw_step(v4 (&acc)[N::dwn(l)], const bf8 (&own)[DwGeo<N, l>::NO][2], bf8 (&ring)[kDWD + 1][2], lds_p sbase0,
-                                        lds_p sbase1, Epi &epi) {
+                                        lds_p sbase1) {
     using G = DwGeo<N, l>;
     constexpr int SS = G::BYN ? SX : SZ;          // stride of the streamed image
     if constexpr (S + kDWD < G::NS) {
@@ -582,21 +477,10 @@ __device__ __forceinline__ void dw_step(v4 (&acc)[N::dwn(l)], const bf8 (&own)[D
             v4 &c = acc[i * G::NS + S];
             c = G::BYN ? mfma(own[i][h], st[h], c) : mfma(st[h], own[i][h], c);      // A = dZ^T tile, B = [X | 1] tile
         }
-    // this step's share of the E epilogue units, dealt between its 2 NO MFMAs (10 VALU instructions per unit)
-    constexpr int u0 = S * E / G::NS, u1 = (S + 1) * E / G::NS;
-    if constexpr (u1 > u0) {
-        epi_units<u0, u1>(epi);
-        constexpr int per = cdiv(10 * (u1 - u0), 2 * G::NO);
-#pragma unroll
-        for (int i = 0; i < 2 * G::NO; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
-        }
-    }
     __builtin_amdgcn_sched_barrier(0);
 }
-template <class N, int l, int SZ, int SX, int E, class Epi, int... S>
-__device__ __forceinline__ void dw_phase_impl(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave, Epi &epi,
+template <class N, int l, int SZ, int SX, int... S>
+__device__ __forceinline__ void dw_phase_impl(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave,
                                               std::integer_sequence<int, S...>) {
     using G = DwGeo<N, l>;
     constexpr int SO = G::BYN ? SZ : SX, SS = G::BYN ? SX : SZ;
@@ -618,21 +502,12 @@ __device__ __forceinline__ void dw_phase_impl(v4 (&acc)[N::dwn(l)], lds_p zimg, 
         ring[t][0] = tr_operand<SS>(sb, 0);
         ring[t][1] = tr_operand<SS>(sb, 1);
     }
-    (dw_step<N, l, SZ, SX, E, S>(acc, own, ring, sb0, sb1, epi), ...);
-}
-// E epilogue units (epi(integral_constant<int, U>)) are spread over the steps; E = 0: none
-template <class N, int l, int SZ, int SX, int E, class Epi>
-__device__ __forceinline__ void dw_phase_epi(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave, Epi &epi) {
-    static_assert(N::dwn(l) == DwGeo<N, l>::NO * DwGeo<N, l>::NS, "accumulator count");
-    dw_phase_impl<N, l, SZ, SX, E>(acc, zimg, ximg, lz, lx, wave, epi, std::make_integer_sequence<int, DwGeo<N, l>::NS>{});
+    (dw_step<N, l, SZ, SX, S>(acc, own, ring, sb0, sb1), ...);
 }
 template <class N, int l, int SZ, int SX>
 __device__ __forceinline__ void dw_phase(v4 (&acc)[N::dwn(l)], lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave) {
-#ifdef BAMD_ABLATE_DW
-    return;
-#endif
-    NoEpi none;
-    dw_phase_epi<N, l, SZ, SX, 0>(acc, zimg, ximg, lz, lx, wave, none);
+    static_assert(N::dwn(l) == DwGeo<N, l>::NO * DwGeo<N, l>::NS, "accumulator count");
+    dw_phase_impl<N, l, SZ, SX>(acc, zimg, ximg, lz, lx, wave, std::make_integer_sequence<int, DwGeo<N, l>::NS>{});
 }
 
 template <class N, int l>
@@ -764,26 +639,15 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     if constexpr (kRD > 4) issue<N, PART, 3>(ring, ws, wave);
     if constexpr (kRD > 5) issue<N, PART, 4>(ring, ws, wave);
     static_assert(kRD >= 2 && kRD <= 6, "ring depth");
-    constexpr bool kRowsIn = PART == 0 || !kHandX;           // this launch reads the input rows
     RawX<F> xraw;
-    if constexpr (kRowsIn) x_issue<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15), n, lane >> 4);
+    x_issue<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15), n, lane >> 4);
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    constexpr int HB = N::hand_tiles * 32;                   // hand-off bytes per row (kHandX = 0)
+    constexpr int HB = N::hand_tiles * 32;                   // hand-off bytes per row
     static_assert(N::iblocks(2) * 64 >= HB, "hand-off row fits the image row");
-    static_assert(!kHandX || (N::hand_tiles == 7 && N::nt(0) == 13 && N::istride(0) == 64), "hand-off slots");
     const int hr = threadIdx.x >> 2, hp = threadIdx.x & 3;
-    u4v hand[PART == 1 ? (kHandX ? 12 : 4) : 1];
-    // kHandX: thread (row = lane, wave q) moves the row's 32 bytes of slots q, q + 4, .., q + 20 (< 22): two 16-byte chunks each
+    u4v hand[PART == 1 ? 4 : 1];
     auto hand_load = [&](int64_t g_) {
-        if constexpr (PART == 1 && kHandX) {
-            const u4v *src = (const u4v *)((const unsigned char *)dz + g_ * kHandGroupBytes + lane * 32);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int sl = wave + 4 * i < kHandSlots ? wave + 4 * i : 0;
-                hand[2 * i] = src[sl * 128];
-                hand[2 * i + 1] = src[sl * 128 + 1];
-            }
-        } else if constexpr (PART == 1) {
+        if constexpr (PART == 1) {
             const u4v *src = (const u4v *)((const unsigned char *)dz + (g_ * kRows + hr) * HB) + hp;
 #pragma unroll
             for (int i = 0; i < 4; ++i) hand[i] = src[(16 * (hp + 4 * i) < HB) ? 4 * i : 0];
@@ -801,8 +665,7 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
         const int64_t row = grp * kRows + 16 * wave + j;
         const bool valid = row < n;
         // ---- input rows -> image 0 (bf16, with the ones slot) and the fp32 copy the loss uses -------------------------
-        u2 *const hgrp = dz + grp * (kHandGroupBytes / 8);       // this group's hand-off record (kHandX), in 8-byte units
-        if constexpr (kRowsIn) {
+        {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -819,37 +682,17 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                 float *xr = xf + (16 * wave + j) * 32 + 8 * g;
                 *(float4 *)xr = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4 *)(xr + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                if constexpr (kHandX)      // X_0 for the second launch: slots 20 / 21 = features 0..15 / 16..31 of the row
-                    *(bf8 *)((unsigned char *)hgrp + (20 + (g >> 1)) * 2048 + (16 * wave + j) * 32 + 16 * (g & 1)) = o;
             }
-            if constexpr (!(PART == 1 && kLatePf))
+            if constexpr (PART == 0)
                 x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);       // next iteration's rows, a whole iteration ahead
         }
-        if constexpr (PART == 1 && kHandX) {
-            // dZ_1, X_1, X_0 of these rows from the first launch -> regions 2, 1, 0, at their swizzled places; requested a whole
-            // iteration ahead, like the rows of the first launch
-            const int sg = (lane >> 1) & 3;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int sl = wave + 4 * i;              // wave-uniform
-                if (sl < kHandSlots) {
-                    const int off = sl < 7 ? N::zoff(1) : (sl < 20 ? N::ioff(1) : N::ioff(0));
-                    const int st = sl < 7 ? N::istride(2) : (sl < 20 ? N::istride(1) : N::istride(0));
-                    const int t = sl < 7 ? sl : (sl < 20 ? sl - 7 : sl - 20);
-                    const int o0 = off + lane * st + (((2 * t) ^ sg) << 4);      // chunks 2 t, 2 t + 1 of the row: the second = bit 4 flipped
-                    *(u4v __attribute__((address_space(3))) *)(img + o0) = hand[2 * i];
-                    *(u4v __attribute__((address_space(3))) *)(img + (o0 ^ 16)) = hand[2 * i + 1];
-                }
-            }
-            hand_load(grp + gridDim.x < ngroups ? grp + gridDim.x : ngroups - 1);
-        } else if constexpr (PART == 1) {
+        if constexpr (PART == 1) {
             // dZ_1 of these rows from the first launch (row-major, 224 B per row) -> region 2: thread (r, p) moves chunks
             // p, p + 4, p + 8 (and p + 12 for p < 2) of row r to their swizzled places; requested a whole iteration ahead, like the rows
             const lds_p dst = img + N::zoff(1) + hr * N::istride(2) + ((hp ^ ((hr >> 1) & 3)) << 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (16 * (hp + 4 * i) < HB) *(u4v __attribute__((address_space(3))) *)(dst + 64 * i) = hand[i];
-            if constexpr (!kLatePf) hand_load(grp + gridDim.x < ngroups ? grp + gridDim.x : ngroups - 1);
         }
         __syncthreads();
         BT(1);
@@ -882,23 +725,7 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
             }                                                                                                                \
         }
         if constexpr (P::fwd_end >= 1) {
-            if constexpr (PART == 0 && kHandX) {      // layer 0 with its output tiles also handed to the second launch (slots 7 + t)
-                ChainAcc<N::nt(0)> acc;
-                chain_mm<N, PART, SC::fstep(0), N::kb(0), N::nt(0), N::istride(0)>(acc, img + N::ioff(0) + lay_of<N::istride(0)>(ls).row, ring, ws, wave);
-                BT(40);
-                acc_visit_idx<N::nt(0), N::istride(1)>(acc, img + N::ioff(1), lay_of<N::istride(1)>(ls), wave,
-                                                       [&](v4 &a, lds_p dst, int t, int m) {
-                                                           lrelu4(a);
-                                                           const u2 pk = pack4(a);
-                                                           lds_w64(dst, pk);
-                                                           hgrp[(7 + t) * 256 + (16 * m + j) * 4 + g] = pk;
-                                                       });
-                BT(41);
-                __syncthreads();
-                BT(2);
-            } else {
-                BAMD_FWD(0)
-            }
+            BAMD_FWD(0)
         }
         if constexpr (P::fwd_end == 8) {
             BAMD_FWD(1)
@@ -956,36 +783,20 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
                 ChainAcc<NTB> acc;                                                                                           \
                 chain_mm<N, PART, SC::bstep(l), N::kbb(l), NTB, SZ>(acc, zimg + lay_of<SZ>(ls).row, ring, ws, wave);         \
                 BT(70 + 2 * (l));                                                                                            \
-                if constexpr (PART == 1 && (l) == 1 && kLatePf && !kHandX) {                                                 \
+                if constexpr (PART == 1 && (l) == 1) {                                                                         \
                     x_issue<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);                                   \
                     hand_load(grp + gridDim.x < ngroups ? grp + gridDim.x : ngroups - 1);                                    \
                 }                                                                                                            \
                 constexpr int DELTA = N::zoff((l) - 1) - N::ioff(l);   /* same stride, same lane offsets: a constant shift */ \
-                if constexpr (N::act((l) - 1) && BAMD_BF16_EPIMIX) {                                                         \
-                    constexpr int E = EpiGeo<NTB>::E;                                                                        \
-                    const lds_p ximg = img + N::ioff(l);                                                                     \
-                    const Lay &lo = lay_of<SO>(ls);                                                                          \
-                    u2 y[E];                                                                                                 \
-                    epi_pre<NTB, SO>(y, ximg, lo, wave, std::make_integer_sequence<int, E>{});                               \
-                    auto epi = [&](auto U) {                                                                                 \
-                        constexpr int u = decltype(U)::value;                                                                \
-                        const lds_p a = epi_addr<NTB, SO, u>(ximg, lo, wave);                                                \
-                        const lds_p dst = epi_owned<NTB, u>(wave) ? a + DELTA : scratch;                                     \
-                        lds_w64(dst, lrelu_bwd_pack4(epi_acc<NTB, u>(acc), y[u]));                                           \
-                    };                                                                                                       \
-                    BT(20 + 2 * (l));                                                                                        \
-                    dw_phase_epi<N, l, SZ, SO, E>(G, zimg, ximg, lay_of<SZ>(ls), lo, wave, epi);                             \
-                } else {                                                                                                     \
-                    if constexpr (N::act((l) - 1))                                                                           \
-                        acc_visit_pre<NTB, SO>(acc, img + N::ioff(l), lay_of<SO>(ls), wave,                                  \
-                                               [&](lds_p src) { return lds_b64(src); },                                      \
-                                               [&](v4 &a, lds_p src, u2 y) { lds_w64(src + DELTA, lrelu_bwd_pack4(a, y)); }); \
-                    else                                                                                                     \
-                        acc_visit<NTB, SO>(acc, img + N::ioff(l), lay_of<SO>(ls), wave,                                      \
-                                           [&](v4 &a, lds_p src) { lds_w64(src + DELTA, pack4(a)); });                       \
-                    BT(20 + 2 * (l));                                                                                        \
-                    dw_phase<N, l, SZ, SO>(G, zimg, img + N::ioff(l), lay_of<SZ>(ls), lay_of<SO>(ls), wave);                 \
-                }                                                                                                            \
+                if constexpr (N::act((l) - 1))                                                                           \
+                    acc_visit_pre<NTB, SO>(acc, img + N::ioff(l), lay_of<SO>(ls), wave,                                  \
+                                           [&](lds_p src) { return lds_b64(src); },                                      \
+                                           [&](v4 &a, lds_p src, u2 y) { lds_w64(src + DELTA, lrelu_bwd_pack4(a, y)); }); \
+                else                                                                                                     \
+                    acc_visit<NTB, SO>(acc, img + N::ioff(l), lay_of<SO>(ls), wave,                                      \
+                                       [&](v4 &a, lds_p src) { lds_w64(src + DELTA, pack4(a)); });                       \
+                BT(20 + 2 * (l));                                                                                        \
+                dw_phase<N, l, SZ, SO>(G, zimg, img + N::ioff(l), lay_of<SZ>(ls), lay_of<SO>(ls), wave);                 \
             } else {                                                                                                         \
                 BT(20 + 2 * (l));                                                                                            \
                 dw_phase<N, l, SZ, N::istride(l)>(G, zimg, img + N::ioff(l), lay_of<SZ>(ls), lay_of<N::istride(l)>(ls), wave); \
@@ -1034,8 +845,7 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
             static_assert(N::ntb(2) == N::hand_tiles, "hand-off width");
 #pragma unroll
             for (int t = 0; t < N::ntb(2); ++t) {
-                if constexpr (kHandX) hgrp[t * 256 + (16 * wave + j) * 4 + g] = q1[t];      // slot t, tile-major
-                else dz[row * (4 * N::hand_tiles) + 4 * t + g] = q1[t];
+                dz[row * (4 * N::hand_tiles) + 4 * t + g] = q1[t];
             }
             BT(56);
             __syncthreads();
@@ -1235,8 +1045,7 @@ template <int F, int Z> struct TImpl {
         // tiles + one double per workgroup for the loss
         int rc = h->slabs.ensure(((size_t)st->ntiles * 1024 + 16) * (size_t)grid);
         if (rc) return rc;
-        rc = st->dz.ensure(kHandX ? (size_t)ngroups * kHandGroupBytes              // dZ_1 + X_1 + X_0: 704 B per row, whole row groups
-                                  : (size_t)ngroups * kRows * N::hand_tiles * 32);
+        rc = st->dz.ensure((size_t)ngroups * kRows * N::hand_tiles * 32);
         if (rc) return rc;
         hipLaunchKernelGGL((bf16_train_kernel<F, Z, 0>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
         hipLaunchKernelGGL((bf16_train_kernel<F, Z, 1>), dim3(grid), dim3(256), lds_bytes(), s, (const uint4 *)st->w.p, x, x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);

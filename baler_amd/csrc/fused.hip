@@ -174,11 +174,7 @@ __device__ __forceinline__ void chain_gemm(const v4 (&in)[tiles(KD)], v4 (&out)[
                     out[(f + j) % NT] = mfma(ring.slot[(BASE + f + j) % kRing][r], in[(f + j) / NT][r], out[(f + j) % NT]);
 #pragma unroll
         for (int j = 0; j < W; ++j)
-#ifdef BAMD_ABLATE_HALF_LOADS
-            if (f + j < NF && ((f + j) & 1) == 0)
-#else
             if (f + j < NF)
-#endif
                 ring.slot[(BASE + f + j) % kRing] = frag(ws, (BASE + f + j + kRing) % pad_total(TOTAL));
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -213,9 +209,6 @@ template <int NT> __device__ __forceinline__ void zero_tiles(v4 (&out)[NT]) {
     for (int t = 0; t < NT; ++t) out[t] = (v4){0.f, 0.f, 0.f, 0.f};
 }
 template <int NT> __device__ __forceinline__ void lrelu(v4 (&a)[NT]) {
-#ifdef BAMD_ABLATE_LRELU
-    return;
-#endif
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f k2 = (v2f){0.01f, 0.01f};
     asm volatile("" : "+v"(k2));   // a register pair, not a literal: with the literal hipcc scalarises back to v_mul_f32
@@ -235,9 +228,6 @@ template <int NT> __device__ __forceinline__ void lrelu(v4 (&a)[NT]) {
 }
 // dZ = dY * lrelu'(pre) ; sign(pre) == sign(post-activation y)
 template <int NT> __device__ __forceinline__ void lrelu_bwd(v4 (&d)[NT], const v4 (&y)[NT]) {
-#ifdef BAMD_ABLATE_LRELU
-    return;
-#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         v4 sl;                                    // slope per register (v_cmp + v_cndmask), then one vector multiply
@@ -330,11 +320,6 @@ __device__ __forceinline__ void load_rows_issue(RawRows<D> &raw, const void *x, 
     // unmapped gradient slots, rows beyond n get a zero loss gradient / are not stored.
     constexpr int NS = tiles(D) * 4;
     const int g = lane >> 4;
-#ifdef BAMD_ABLATE_XLOAD
-#pragma unroll
-    for (int s = 0; s < NS; ++s) raw.v[s] = 0.0;
-    return;
-#endif
     const int64_t base = (valid ? row : 0) * (RT ? dr : D);
     // slot (t, r) holds a feature on SOME lane group iff the tile is full or 4r < its valid count (r-major partial tiles)
     auto used = [](int s) { return D - 16 * (s >> 2) >= 16 || 4 * (s & 3) < D - 16 * (s >> 2); };
@@ -617,41 +602,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         asm volatile("" : "+v"(ws.voff));   // keep the weight loads inside the loop (see infer_kernel)
         if constexpr (KIND == K_ENCODE) {
             v4 a0[tiles(F)], b0[tiles(F)], a1[13], b1[13], a2[7], b2[7], a3[4], b3[4], a4[tiles(Z)], b4[tiles(Z)];
-#ifdef BAMD_INFER_NOPF
-            load_rows<F, RT>(a0, xin, in_f64, r0, v0, lane, feats, fr);
-            load_rows<F, RT>(b0, xin, in_f64, r1, v1, lane, feats, fr);
-#else
             load_rows_finish<F, RT>(a0, ra, v0, lane, feats, fr);
             load_rows_finish<F, RT>(b0, rb, v1, lane, feats, fr);
-#endif
             fwd_layer2<N, S, 0>(a0, b0, a1, b1, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 1>(a1, b1, a2, b2, ring, ws, bias_lds, lane);
-#ifndef BAMD_INFER_NOPF
             __builtin_amdgcn_sched_barrier(0);
             load_rows_issue<F, RT>(ra, xin, in_f64, n0, n0 < n, lane, fr);      // (behind the widest layer: the raw rows do not add to the register peak)
             load_rows_issue<F, RT>(rb, xin, in_f64, n1, n1 < n, lane, fr);
             __builtin_amdgcn_sched_barrier(0);
-#endif
             fwd_layer2<N, S, 2>(a2, b2, a3, b3, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 3>(a3, b3, a4, b4, ring, ws, bias_lds, lane);
             store_rows<Z, RT>(a4, out, out_f64, r0, v0, lane, nullptr, nullptr, zr);
             store_rows<Z, RT>(b4, out, out_f64, r1, v1, lane, nullptr, nullptr, zr);
         } else {
             v4 a4[tiles(Z)], b4[tiles(Z)], a5[4], b5[4], a6[7], b6[7], a7[13], b7[13], a8[tiles(F)], b8[tiles(F)];
-#ifdef BAMD_INFER_NOPF
-            load_rows<Z, RT>(a4, xin, in_f64, r0, v0, lane, nullptr, zr);
-            load_rows<Z, RT>(b4, xin, in_f64, r1, v1, lane, nullptr, zr);
-#else
             load_rows_finish<Z, RT>(a4, ra, v0, lane, nullptr, zr);
             load_rows_finish<Z, RT>(b4, rb, v1, lane, nullptr, zr);
-#endif
             fwd_layer2<N, S, 4>(a4, b4, a5, b5, ring, ws, bias_lds, lane);
-#ifndef BAMD_INFER_NOPF
             __builtin_amdgcn_sched_barrier(0);
             load_rows_issue<Z, RT>(ra, xin, in_f64, n0, n0 < n, lane, zr);
             load_rows_issue<Z, RT>(rb, xin, in_f64, n1, n1 < n, lane, zr);
             __builtin_amdgcn_sched_barrier(0);
-#endif
             fwd_layer2<N, S, 5>(a5, b5, a6, b6, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 6>(a6, b6, a7, b7, ring, ws, bias_lds, lane);
             fwd_layer2<N, S, 7>(a7, b7, a8, b8, ring, ws, bias_lds, lane);
@@ -695,108 +666,6 @@ __device__ __forceinline__ v4 wide_x_chunk(const void *x, int in_f64, int64_t ro
     return v;
 }
 
-// acc[13 tiles of the 200-feature side] += sum over the wide dimension of frag(chunk kc, tile t) . x^T[chunk kc]: the streamed
-// product of en1 (fragments Wf(0), x = input rows) and of de4's input gradient (fragments Wb(7), x = dL/drecon rows).
-// x runs kXA chunks ahead (first touch of a row segment comes from HBM: ~2 us against 0.8 us of MFMAs per chunk; 4 ahead left
-// SQ_WAIT_ANY at 23 %), the fragments (L2-resident) one chunk ahead in ping-pong buffers (no register copies); out-of-range
-// prefetches re-read chunk 0.
-template <int F>
-__device__ __forceinline__ void wide_in_product(v4 (&acc)[13], const WStream &ww, const void *xin, int in_f64, int64_t rrow, int g) {
-    constexpr int KC = tiles(F);
-    v4 wa[13], wb[13];
-    auto load_w = [&](v4 (&w)[13], int kc) {
-#pragma unroll
-        for (int t = 0; t < 13; ++t) w[t] = frag_rt(ww, kc * 13 + t);
-    };
-    auto mm = [&](const v4 (&w)[13], const v4 &xv, int kc) {
-        // 13 independent accumulators: consecutive MFMAs never wait on each other
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (16 * kc + 16 <= F || r < tile_steps(F, KC - 1)) {
-#pragma unroll
-                for (int t = 0; t < 13; ++t) acc[t] = mfma(w[t][r], xv[r], acc[t]);
-            }
-    };
-    constexpr int kXA = 8;
-    v4 xr[kXA];
-    auto load_x = [&](int kc) { return wide_x_chunk<F>(xin, in_f64, rrow, kc < KC ? kc : 0, g); };
-    auto clampw = [&](int kc) { return kc < KC ? kc : KC - 1; };
-    const int last = (F % 16) ? KC - 1 : -1;       // index of the partial chunk
-    load_w(wa, 0);
-#pragma unroll
-    for (int u = 0; u < kXA; ++u) xr[u] = load_x(u);
-    int kc = 0;
-    for (; kc + kXA <= KC; kc += kXA) {
-#pragma unroll
-        for (int p = 0; p < kXA / 2; ++p) {
-            load_w(wb, clampw(kc + 2 * p + 1));
-            mm(wa, xr[2 * p], kc + 2 * p == last ? KC - 1 : 0);
-            xr[2 * p] = load_x(kc + 2 * p + kXA);
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(wa, clampw(kc + 2 * p + 2));
-            mm(wb, xr[2 * p + 1], kc + 2 * p + 1 == last ? KC - 1 : 0);
-            xr[2 * p + 1] = load_x(kc + 2 * p + 1 + kXA);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // the last KC % kXA chunks: wa holds chunk kc's fragments, xr[u] chunk kc + u
-#pragma unroll
-    for (int u = 0; u < kXA - 1; ++u) {
-        if (kc + u < KC) {
-            if (kc + u + 1 < KC) load_w(wb, kc + u + 1);
-            mm(wa, xr[u], (kc + u == last) ? KC - 1 : 0);
-            if (kc + u + 1 < KC) {
-#pragma unroll
-                for (int t = 0; t < 13; ++t) wa[t] = wb[t];
-            }
-        }
-    }
-}
-
-// out tile t of the wide side = bias + sum over the 13 tiles of the 200-feature side (de4): one tile at a time, fragments one
-// tile ahead in ping-pong buffers; `emit(o, t, slot)` consumes the finished tile (C layout: register r = slot_feature(F, t, g, r)).
-// The 13 k tiles alternate between TWO accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, an independent one 32).
-template <int F, int NS, class Emit>
-__device__ __forceinline__ void wide_out_product(const v4 (&a7)[13], const WStream &ww, const v4 *bias7, int g, Emit emit) {
-    constexpr int KC = tiles(F);
-    static_assert(NS == 4 || NS == 8, "slots of the caller's prefetch ring");
-    v4 wa[13], wb[13];
-    auto load_w = [&](v4 (&w)[13], int t) {
-        t = t < KC ? t : KC - 1;
-#pragma unroll
-        for (int q = 0; q < 13; ++q) w[q] = frag_rt(ww, q * KC + t);
-    };
-    auto tile_out = [&](const v4 (&w)[13], int t, auto slot) {
-        if (t >= KC) return;
-        v4 o0 = bias7[t * 4 + g], o1 = (v4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 13; q += 2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r < tile_steps(200, q)) o0 = mfma(w[q][r], a7[q][r], o0);
-                if (q + 1 < 13 && r < tile_steps(200, q + 1)) o1 = mfma(w[q + 1][r], a7[q + 1][r], o1);
-            }
-        emit(o0 + o1, t, slot);
-    };
-    auto pair = [&](int t0, auto jj) {          // tiles t0 + 2 j (fragments in wa) and t0 + 2 j + 1 (wb); `emit` sees the slot t % NS
-        constexpr int j = decltype(jj)::value;
-        load_w(wb, t0 + 2 * j + 1);
-        tile_out(wa, t0 + 2 * j, std::integral_constant<int, 2 * j>());
-        __builtin_amdgcn_sched_barrier(0);
-        load_w(wa, t0 + 2 * j + 2);
-        tile_out(wb, t0 + 2 * j + 1, std::integral_constant<int, 2 * j + 1>());
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    load_w(wa, 0);
-    for (int t0 = 0; t0 < KC; t0 += NS) {
-        pair(t0, std::integral_constant<int, 0>());
-        pair(t0, std::integral_constant<int, 1>());
-        if constexpr (NS == 8) {
-            pair(t0, std::integral_constant<int, 2>());
-            pair(t0, std::integral_constant<int, 3>());
-        }
-    }
-}
 // store tile t of a wide row (C layout) as float / double
 template <int F, bool FULL = false>
 __device__ __forceinline__ void wide_store_tile(const v4 &o, void *out, int out_f64, int64_t row, int t, int g) {
@@ -949,32 +818,6 @@ __device__ __forceinline__ bf8 frag_bf(const WStream &ws, int idx) {
     return __builtin_bit_cast(bf8, __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 1024, 0));
 }
 struct XPair { v4 lo, hi; };          // 8 consecutive features of one row (k = 8 g .. 8 g + 7 of a 32-feature chunk)
-template <int F>
-__device__ __forceinline__ XPair wide_x_chunk32(const void *x, int in_f64, int64_t row, int c, int g) {
-    XPair p;
-    const int k0 = 32 * c + 8 * g;
-    if (32 * c + 32 <= F) {
-        const int64_t i = row * F + k0;
-        if (in_f64) {
-            const double *d = (const double *)x + i;
-            const double2 a = *(const double2 *)d, b = *(const double2 *)(d + 2), e = *(const double2 *)(d + 4), f = *(const double2 *)(d + 6);
-            p.lo = (v4){(float)a.x, (float)a.y, (float)b.x, (float)b.y};
-            p.hi = (v4){(float)e.x, (float)e.y, (float)f.x, (float)f.y};
-        } else {
-            p.lo = *(const v4 *)((const float *)x + i);
-            p.hi = *(const v4 *)((const float *)x + i + 4);
-        }
-    } else {                      // the last, partial chunk: element by element, zero beyond the row
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = 0.f;
-            if (k0 + j < F) v = in_f64 ? (float)((const double *)x)[row * F + k0 + j] : ((const float *)x)[row * F + k0 + j];
-            if (j < 4) p.lo[j] = v; else p.hi[j - 4] = v;
-        }
-    }
-    return p;
-}
-
 // Encode.  All loads of a wave retire in order (vmcnt), so a weight fragment fetched "just ahead" would wait for every row chunk
 // fetched "far ahead" before it: the first version (fragments half a chunk ahead in registers, rows three chunks ahead) spent one
 // HBM round trip per chunk (1.9 us; 216 M frames/s).  Here EVERY load has the same lead: the four waves of a workgroup walk the
@@ -1266,19 +1109,13 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
             if (++ci == KB) { ci = 0; gi += gridDim.x; }
             pi = (pi + 1) & (kDmaRing - 1);
         };
-#ifndef BAMD_DMA_LEAD
-#define BAMD_DMA_LEAD (kDmaRing - 1)
-#endif
-        for (int k = 0; k < BAMD_DMA_LEAD; ++k) issue();
+        constexpr int kLead = kDmaRing - 1;      // chunks in flight (2 .. 7 measured the same: the loaders are not latency-bound)
+        for (int k = 0; k < kLead; ++k) issue();
         for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
-#ifndef BAMD_DMA_NOBAR
             __builtin_amdgcn_s_barrier();                                // the compute waves' barrier at the top of a group
-#endif
             for (int c = 0; c < KB; ++c) {
-                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 * (BAMD_DMA_LEAD - 1)) : "memory");        // all but the 6 youngest chunks (8 loads each): chunk c is in LDS
-#ifndef BAMD_DMA_NOBAR
+                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 * (kLead - 1)) : "memory");        // all but the 6 youngest chunks (8 loads each): chunk c is in LDS
                 __builtin_amdgcn_s_barrier();                            // barrier c
-#endif
                 issue();                                                 // chunk c + 7 into the slot of chunk c - 1
             }
         }
@@ -1316,53 +1153,27 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
             };
             wload(wq[0], 0);
             wload(wq[1], 1);
-#ifndef BAMD_DMA_NOBAR
             __syncthreads();              // the previous group's last chunk has been read
-#endif
             wstore(wq[0], 0);
             wload(wq[0], 2);
             auto iter = [&](int c, auto wsl) {
                 constexpr int WS = decltype(wsl)::value;                                 // c % 2
-#ifndef BAMD_DMA_NOBAR
                 __syncthreads();          // barrier c: fragments of chunk c in stage slot WS, its rows in ring slot `slot`; stage slot WS ^ 1 free
-#endif
-#if defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 1      // timing-only build: the loaders alone (compute waves only keep the barriers)
-                slot = (slot + 1) & (kDmaRing - 1);
-                return;
-#endif
-#if !(defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 3)  // 3: no fragment stage (MFMAs on whatever the registers hold)
                 wstore(wq[WS ^ 1], WS ^ 1);                                              // chunk c + 1 (fetched two chunks ago)
-#endif
                 const v4 *xs = (const v4 *)(ring_b + slot * kDmaChunk + wave * 4096) + lane;
                 const v4 l0 = xs[0], h0 = xs[64], l1 = xs[128], h1 = xs[192];
                 slot = (slot + 1) & (kDmaRing - 1);
-#if !(defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 3)
                 wload(wq[WS ^ 1], c + 3);
-#endif
                 const bf8 q0 = to_bf8(l0, h0), q1 = to_bf8(l1, h1);
-#if defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 4      // 4: rows read and converted, nothing else
-                asm volatile("" :: "v"(q0), "v"(q1));
-                return;
-#endif
                 bf8 wl[2][4];
                 auto rd = [&](bf8 (&w)[4], int t0) {
-#if defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 3
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) asm volatile("" : "=v"(w[k]));
-#else
 #pragma unroll
                     for (int k = 0; k < 4; ++k) w[k] = __builtin_bit_cast(bf8, wst[WS][t0 + k < 13 ? t0 + k : 12][lane]);
-#endif
                 };
                 auto mm = [&](const bf8 (&w)[4], int t0) {
-#if defined(BAMD_DMA_ABL) && BAMD_DMA_ABL == 2      // 2: no MFMAs (operands kept alive)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) asm volatile("" :: "v"(w[k]), "v"(q0), "v"(q1));
-#else
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (t0 + k < 13) { a1[t0 + k] = mfma_bf(w[k], q0, a1[t0 + k]); b1[t0 + k] = mfma_bf(w[k], q1, b1[t0 + k]); }
-#endif
                 };
                 rd(wl[0], 0);
                 rd(wl[1], 4);
@@ -1395,10 +1206,6 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
                 }
             }
         }
-#ifdef BAMD_DMA_NOTAIL      // timing-only build: no narrow layers, no stores
-        asm volatile("" :: "v"(a1[0]), "v"(b1[12]));
-        continue;
-#endif
         lrelu(a1);
         lrelu(b1);
         {   // the narrow layers on the bf16 MFMA, both row tiles at once (chain_bf16_pair)
@@ -1420,10 +1227,6 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
 // direct-to-LDS loads, two tiles ahead, one workgroup barrier per tile; the four compute waves read their A operands from the stage
 // and their vector-memory queue holds NOTHING BUT STORES, which they never wait for.
 constexpr int kDecSlots = 4;
-#ifndef BAMD_DEC_DIRECT
-#define BAMD_DEC_DIRECT 0
-#endif
-constexpr bool kDecDirect = BAMD_DEC_DIRECT;      // 1: C tiles stored as they stand (16 rows x 64 B per instruction), no transposing stage
 template <int F, int Z, bool OUT64>
 __global__ void __launch_bounds__(320) wide_bf16_decode_kernel(const v4 *packed, const v4 *w7b, const v4 *wcd, const void *__restrict__ zin, int in_f64,
                                                                int64_t n, void *__restrict__ out) {
@@ -1436,7 +1239,7 @@ __global__ void __launch_bounds__(320) wide_bf16_decode_kernel(const v4 *packed,
     constexpr int nb = N::bf_off(N::L) - N::bf_off(4);                                     // biases of layers 4..7
     extern __shared__ __attribute__((aligned(1024))) unsigned char dec_lds[];
     v4 (*const wst)[7][64] = (v4 (*)[7][64])dec_lds;                                       // [kDecSlots][7][64]
-    constexpr bool kAligned = !OUT64 && F % 4 == 0 && !kDecDirect;     // float32 rows of a multiple of 16 bytes: line-aligned window stores
+    constexpr bool kAligned = !OUT64 && F % 4 == 0;                    // float32 rows of a multiple of 16 bytes: line-aligned window stores
     constexpr int kFullTiles = F / 16, kRS = 128 + 4;                  // ring: 128 columns per row (+ 16 bytes: bank spread of the C-layout writes)
     float (*const tstage)[32][kTS] = (float (*)[32][kTS])(dec_lds + kDecSlots * 7 * 1024);  // [4][32][kTS]   (!kAligned)
     float (*const tring)[32][kRS] = (float (*)[32][kRS])(dec_lds + kDecSlots * 7 * 1024);   // [4][32][kRS]   (kAligned)
@@ -1544,7 +1347,7 @@ __global__ void __launch_bounds__(320) wide_bf16_decode_kernel(const v4 *packed,
                     window(c0, false, true);
                     window(c0 + 64, false, true);
                 }
-            } else if (!kDecDirect && !OUT64 && t + (kTG - 1 - J) < F / 16) {            // the whole group is made of full tiles
+            } else if (!OUT64 && t + (kTG - 1 - J) < F / 16) {            // the whole group is made of full tiles
                 *(v4 *)&tstage[wave][lane & 15][16 * J + 4 * g] = o0;
                 *(v4 *)&tstage[wave][16 + (lane & 15)][16 * J + 4 * g] = o1;
                 if (J == kTG - 1) {
@@ -1822,60 +1625,6 @@ __global__ void __launch_bounds__(256) wide_decode_lds_kernel(const v4 *packed, 
     }
 }
 
-// IN64 = type of the rows that encode reads, as a template parameter: as a run-time flag every row load of the streamed loop
-// sat behind a branch, and hipcc joins such paths with conservative waits (C4 encode at 131072 frames 91.8 -> 97.6 M rows/s;
-// the same treatment of decode's stores measured 5 % SLOWER and is not applied: decode ignores IN64)
-template <int F, int Z, int KIND, bool IN64>
-__global__ void __launch_bounds__(256) wide_infer_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64_, int64_t n,
-                                                         void *__restrict__ out, int out_f64) {
-    const int in_f64 = KIND == K_ENCODE ? (IN64 ? 1 : 0) : in_f64_;
-    using N = Net<F, Z>;
-    static_assert(KIND == K_ENCODE || KIND == K_DECODE, "encode or decode");
-    static_assert(N::dim(1) == 200 && N::dim(7) == 200, "13 register tiles on the narrow side of the wide layers");
-    using S = typename std::conditional<KIND == K_ENCODE, StreamWideEnc<N>, StreamWideDec<N>>::type;
-    constexpr int KC = tiles(F);                   // 16-feature chunks of the wide dimension
-    __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
-    stage_bias<N>(bias_lds, packed);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int64_t ntile = (n + 15) / 16;
-    WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);                 // the chain's fragments
-    constexpr int WL = KIND == K_ENCODE ? 0 : 7;   // the streamed layer
-    WStream ww = make_stream(packed + N::wf_off(WL), N::wcount(WL) * 16, lane);                                  // its fragments: [q][t]
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
-        const int64_t row = tile * 16 + (lane & 15);
-        const bool valid = row < n;
-        const int64_t rrow = valid ? row : 0;      // rows beyond n read row 0 (never stored)
-        asm volatile("" : "+v"(ws.voff), "+v"(ww.voff));   // keep the weight loads inside the loop (see infer_kernel)
-        if (KIND == K_ENCODE) {
-            // ---- en1, streamed over the 2500 input features: a1^T[13 tiles] += W[t][chunk] . x^T[chunk] ------------------
-            v4 a1[13];
-            init_bias(a1, bias_lds + (N::bf_off(0) - N::bf_off(0)), lane);
-            wide_in_product<F>(a1, ww, xin, in_f64, rrow, g);
-            lrelu(a1);
-            // ---- layers 1..3: the register chain ---------------------------------------------------------------------------
-            Ring ring;
-            ring_prime<S::total>(ring, ws);
-            v4 a2[7], a3[4], a4[tiles(Z)];
-            fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
-            fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
-            fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
-            store_rows<Z>(a4, out, out_f64, row, valid, lane, nullptr, nullptr);
-        } else {
-            // ---- layers 4..6: the register chain -------------------------------------------------------------------------
-            Ring ring;
-            ring_prime<S::total>(ring, ws);
-            v4 a4[tiles(Z)], a5[4], a6[7], a7[13];
-            load_rows<Z>(a4, xin, in_f64, row, valid, lane, nullptr);
-            fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
-            fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
-            fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
-            // ---- de4, streamed over the 2500 output features -------------------------------------------------------------
-            wide_out_product<F, 4>(a7, ww, bias_lds + (N::bf_off(7) - N::bf_off(0)), g,
-                                [&](const v4 &o, int t, auto) { if (valid) wide_store_tile<F>(o, out, out_f64, row, t, g); });
-        }
-    }
-}
-
 // ---- wide models: the row-local part of a training pass ---------------------------------------------------------------
 // The weight gradients of a wide model are split-K GEMMs over the whole chunk (generic.hip); everything that is LOCAL to a row --
 // the forward pass, the loss and its gradient, the input-gradient chain -- runs here, one launch each, with the activations and
@@ -1965,21 +1714,15 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
         wide_out_product_lds<F>(a7, wst, w7, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, lane, wave,
             [&](int t, auto slot, auto full) {
                 constexpr int SL = decltype(slot)::value;
-#ifndef BAMD_WT_ABL_X
                 if (decltype(full)::value) xr[SL] = wide_x_chunk<F, true>(x, 0, rrow, t, g);
                 else xr[SL] = wide_x_chunk<F>(x, 0, rrow, t < KC ? t : 0, g);
-#else
-                xr[SL] = (v4){0.f, 0.f, 0.f, 0.f};
-#endif
             },
             [&](const v4 &o, int t, auto slot, auto full) {
                 constexpr int SL = decltype(slot)::value;
                 constexpr bool FL = decltype(full)::value;
                 const v4 d = o - xr[SL];     // padding slots: zero weights and bias against a zero x
                 if (valid) {
-#ifndef BAMD_WT_ABL_LOSS
                     lacc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
-#endif
                     if (TRAIN) wide_store_tile<F, FL>(d * gscale, dz8, 0, row, t, g);
                     else if (dz8) wide_store_tile<F, FL>(o, dz8, out_f64, row, t, g);
                 }
@@ -2460,9 +2203,6 @@ __global__ void __launch_bounds__(256) wide_bf16_train_bwd_kernel(const v4 *pack
 // LDS image helpers: rows = feature slots (16t + 4g + r), columns = the workgroup's 64 batch rows.
 template <int NT>
 __device__ __forceinline__ void q_write(float *__restrict__ q, const v4 (&a)[NT], int lane, int wave) {
-#ifdef BAMD_ABLATE_QWRITE
-    return;
-#endif
     // One base address per register r (slot 4g + r of tile 0); tiles are 16 * kQS floats = 17 x 256 bytes apart, so
     // the stores of tiles t, t+1 pair into ds_write2st64_b32 with IMMEDIATE offsets: 4 address adds per image instead
     // of one per tile (ds_write2_b32 reaches only 1 KiB, which pairs registers r, r+1 and needs a new base every tile).
@@ -2480,9 +2220,6 @@ __device__ __forceinline__ void q_write(float *__restrict__ q, const v4 (&a)[NT]
 template <int D>
 __device__ __forceinline__ void q_write_x(float *__restrict__ q, const v4 (&a)[tiles(D)], int lane, int wave) {
     static_assert(D % 16 != 0, "ones slot lives in the partial last tile");
-#ifdef BAMD_ABLATE_QWRITE
-    return;
-#endif
     constexpr int T = tiles(D) - 1, V = D - 16 * T;      // partial tile, V valid slots; ones slot idx = V
     constexpr int R1 = V / 4, G1 = V % 4;
     typedef float __attribute__((address_space(3))) *lds_f;
@@ -2513,9 +2250,6 @@ template <class N, int l>
 __device__ __forceinline__ void dw_phase(const float *__restrict__ qdz, const float *__restrict__ qx,
                                          v4 (&acc)[DW<N, l>::T], int lane, int wave) {
     using D = DW<N, l>;
-#ifdef BAMD_ABLATE_DW
-    return;
-#endif
     // step u = (tile pair p, 16-row group s): the two tiles of a pair are independent accumulators whose
     // MFMAs alternate (see chain_gemm); LDS fragment reads run one step ahead of the MFMAs.
     constexpr int NP = (D::T + 1) / 2, U = 4 * NP;
@@ -2553,12 +2287,10 @@ __device__ __forceinline__ void dw_phase(const float *__restrict__ qdz, const fl
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (u + 1 < U) lds_frags(u + 1, fa[(u + 1) & 1], fb[(u + 1) & 1]);
-#ifndef BAMD_DW_LOOSE
         // pin the reads of step u + 1 in front of the MFMAs of step u: left free, hipcc sank the second tile's reads to one MFMA
         // before their first use (it reuses the registers of the buffer in use).  Measured neutral (298 M rows/s either way:
         // one MFMA covers most of an LDS round trip here); kept because the schedule no longer depends on the allocator's mood
         __builtin_amdgcn_sched_barrier(0);
-#endif
         const int it0 = 2 * (u >> 2), it1 = it0 + 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -3808,10 +3540,7 @@ struct FusedOps {
 
 static FusedState *state_of(bamd_handle *h) { return (FusedState *)h->fused_state; }
 
-static bool infer_pair() {   // two 16-row tiles per wave in encode / decode (BALER_AMD_INFER_PAIR=0: one tile, for A/B runs)
-    static const bool on = !(getenv("BALER_AMD_INFER_PAIR") && getenv("BALER_AMD_INFER_PAIR")[0] == '0');
-    return on;
-}
+static constexpr bool infer_pair() { return true; }   // two 16-row tiles per wave in encode / decode (+5.5 % / +7 % over one tile)
 static int infer_grid(int64_t n) {
     int64_t wg = ((n + 15) / 16 + 3) / 4;
     return (int)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg));
@@ -3847,8 +3576,7 @@ template <int F, int Z, bool RT = false> struct Impl {
     }
     static int encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
                       hipStream_t s) {
-        static const int extra_lds = getenv("BALER_AMD_INFER_LDS") ? atoi(getenv("BALER_AMD_INFER_LDS")) : 0;   // occupancy experiments
-        if (extra_lds) (void)hipFuncSetAttribute((const void *)infer_kernel<F, Z, K_ENCODE, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, extra_lds);
+        constexpr int extra_lds = 0;
         if (F <= 64 && infer_pair()) {
             hipLaunchKernelGGL((infer2_kernel<F <= 64 ? F : 24, Z, K_ENCODE, RT>), dim3(infer_grid((n + 1) / 2)), dim3(256), 0, s,
                                (const v4 *)h->packed.p, x, x_dtype == BAMD_F64, n, features, z, z_dtype == BAMD_F64,
@@ -3952,9 +3680,8 @@ template <int F, int Z, bool RT = false> struct Impl {
             hipLaunchKernelGGL((lat2_chain_kernel<F, Z, 4, RT>), dim3(nblk), dim3(256), 0, s, (const v4 *)h->packed.p, x,
                                x_dtype == BAMD_F64, n, features, (float *)st->imgs.p, (double *)h->lossp.p, fr(h), zr(h));
         const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
-        // tiles x block ranges from 8192 rows on (see lat2_dw_kernel); BALER_AMD_DW_SPLIT=0: always one launch
-        static const bool split_on = !(getenv("BALER_AMD_DW_SPLIT") && getenv("BALER_AMD_DW_SPLIT")[0] == '0');
-        const int nsplit = split_on && nblk >= 512 ? 4 : 1;
+        // tiles x block ranges from 8192 rows on (see lat2_dw_kernel)
+        const int nsplit = nblk >= 512 ? 4 : 1;
         float *part = nullptr;
         if (nsplit > 1) {
             rc = st->dwpart.ensure((size_t)(N::slab_off(N::L) + 1) * nsplit * 256 * sizeof(float));
@@ -3990,25 +3717,7 @@ template <int F, int Z, bool RT = false> struct Impl {
     }
 };
 
-// Encode-only instantiation for wide tables (the 512-column config, BASELINE.json configs[4]): encode on the
-// register chain; decode, training and forward_loss on the generic layer-wise path (the weight-gradient accumulators of a wide first
-// layer do not fit the register file).
-template <int F, int Z> struct ImplInfer {
-    using N = Net<F, Z>;
-    static bool matches(const bamd_handle *h) {
-        if (h->L != 8) return false;
-        for (int i = 0; i <= 8; ++i)
-            if (h->dims[i] != N::dim(i)) return false;
-        return true;
-    }
-    static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, false>(h, st); }
-    static const FusedOps *ops() {
-        static const FusedOps o = {setup, Impl<F, Z>::encode, nullptr, nullptr, nullptr, nullptr};
-        return &o;
-    }
-};
-
-// Wide models (CFD_dense_AE(2500, 25), BASELINE.json configs[3]): encode and decode as ONE launch each on wide_infer_kernel;
+// Wide models (CFD_dense_AE(2500, 25), BASELINE.json configs[3]): encode and decode as ONE launch each (wide_encode_lds_kernel / wide_encode2_kernel, wide_decode_lds_kernel);
 // training = the two row-local launches wide_fwd / wide_bwd inside generic.hip's layer-wise pass (the weight gradient of a
 // 2500 x 200 layer is 2 MB of accumulators per workgroup: it has to be a split-K product, generic.hip's dw_wide_k); forward_loss
 // layer-wise.  Normalise-on-load / un-normalise-on-store go through a float32 staging buffer
@@ -4053,16 +3762,13 @@ template <int F, int Z> struct ImplWide {
                 hipLaunchKernelGGL((wide_encode2_kernel<F, Z, true>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
             else if (two)
                 hipLaunchKernelGGL((wide_encode2_kernel<F, Z, false>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
-            else if (!(getenv("BALER_AMD_WIDE_LDS") && getenv("BALER_AMD_WIDE_LDS")[0] == '0')) {
-                // fragments shared through LDS (C4, 32768 frames: 92.5 -> 98.5 M rows/s; BALER_AMD_WIDE_LDS=0: per-wave fragments)
+            else {
+                // fragments shared through LDS (C4, 32768 frames: 92.5 -> 98.5 M rows/s against per-wave fragments)
                 const int64_t ng = (rows + 63) / 64;
                 const dim3 gl((unsigned)(ng > 2048 ? 2048 : ng));
                 if (src_f64) hipLaunchKernelGGL((wide_encode_lds_kernel<F, Z, true>), gl, dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
                 else hipLaunchKernelGGL((wide_encode_lds_kernel<F, Z, false>), gl, dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
-            } else if (src_f64)
-                hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_ENCODE, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, src, 1, rows, zo, z64);
-            else
-                hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_ENCODE, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, src, 0, rows, zo, z64);
+            }
         }
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
@@ -4083,10 +3789,7 @@ template <int F, int Z> struct ImplWide {
                 kout_f64 = 0;
             }
             const void *zi = (const void *)((const char *)z + (size_t)r0 * Z * zes);
-            if (getenv("BALER_AMD_WIDE_LDS") && getenv("BALER_AMD_WIDE_LDS")[0] == '0')
-                hipLaunchKernelGGL((wide_infer_kernel<F, Z, K_DECODE, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
-                                   zi, z_dtype == BAMD_F64, rows, kout, kout_f64);
-            else if (kout_f64)
+            if (kout_f64)
                 hipLaunchKernelGGL((wide_decode_lds_kernel<F, Z, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, zi,
                                    z_dtype == BAMD_F64, rows, kout);
             else
@@ -4277,10 +3980,8 @@ template <int F, int Z> struct ImplWideBf16 {
             const int64_t ngroup = (rows + 127) / 128;
             const dim3 grid((unsigned)(ngroup > 2048 ? 2048 : ngroup));
             void *zo = (void *)((char *)z + (size_t)r0 * Z * zes);
-            const char *dma_env = getenv("BALER_AMD_WIDE_DMA");        // =0: the register-streamed kernel (A/B runs, tools/ab_c4_bf16.py)
-            const bool dma_on = !(dma_env && dma_env[0] == '0');
             if constexpr (kDma) {
-                if (!src_f64 && dma_on) {      // persistent: one workgroup (4 compute + 2 loader waves, 156 KiB of LDS) per CU
+                if (!src_f64) {      // persistent: one workgroup (4 compute + 2 loader waves, 156 KiB of LDS) per CU
                     hipLaunchKernelGGL((wide_bf16_encode_dma_kernel<F, Z>), dim3((unsigned)(ngroup > st->nwg_max ? st->nwg_max : ngroup)), dim3(384),
                                        dma_lds_bytes(), s, (const v4 *)h->packed.p, (const v4 *)st->wb[3].p, (const v4 *)st->wb[4].p, (const float *)src, rows, zo,
                                        z_dtype == BAMD_F64);
@@ -4407,10 +4108,7 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     // Wider classes need kImgA / kImgB, the small-batch chain's one-latent-tile exchange and the decoder-gradient kernel's 481
     // registers re-budgeted: 32..64 columns or a latent of 16..32 run on generic.hip for now -- DESIGN.md section 8)
     if (Impl<31, 15, true>::matches(h)) return Impl<31, 15, true>::ops();
-    if (ImplWide<512, 6>::matches(h)) {   // BALER_AMD_WIDE512=0: the all-in-registers chain (A/B runs)
-        const char *e = getenv("BALER_AMD_WIDE512");
-        return (e && e[0] == '0') ? ImplInfer<512, 6>::ops() : ImplWide<512, 6>::ops();
-    }
+    if (ImplWide<512, 6>::matches(h)) return ImplWide<512, 6>::ops();
     if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();
     if (ImplWide<625, 7>::matches(h)) return ImplWide<625, 7>::ops();
     return nullptr;

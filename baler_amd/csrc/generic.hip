@@ -597,9 +597,6 @@ __global__ void __launch_bounds__(256) dw_wide_k(const float *__restrict__ dzm, 
         for (int t = 0; t < 13; ++t) acc[u][t] = (v4){0.f, 0.f, 0.f, 0.f};
     struct Frags { v4 pg[3][4]; v4 pl; v4 q[4]; };                 // [group][step], plain tile [step], [step]
     auto load = [&](Frags &f, int64_t rb, bool tail) {
-#ifdef BAMD_DW_NOLOAD        // ablation: operands of the first block only (pure MFMA time)
-        if (rb > 16) return;
-#endif
         const int sp = (int)rb * DP * 4, sq = (int)rb * DQ * 4;
         const int64_t nr = r_end - r_begin;
 #pragma unroll
@@ -1203,7 +1200,7 @@ struct ShortPlan {
 static ShortPlan plan_short_dw(const bamd_handle *h, int64_t rows) {
     ShortPlan pl;
     const char *e = getenv("BALER_AMD_SHORT_DW");
-    static const int64_t min_rows = getenv("BALER_AMD_SHORT_DW_MIN") ? atoll(getenv("BALER_AMD_SHORT_DW_MIN")) : 128;   // C4 at 512 frames: 796 -> 580 us per pass; 60 frames: no difference
+    constexpr int64_t min_rows = 128;   // C4 at 512 frames: 796 -> 580 us per pass; 60 frames: no difference
     if ((e && e[0] == '0') || h->L > 8 || rows < min_rows) return pl;
     constexpr int TQ = 2;
     int64_t base = 0;
@@ -1218,8 +1215,7 @@ static ShortPlan plan_short_dw(const bamd_handle *h, int64_t rows) {
         const int cq = pn ? K + 1 : N;
         // 13 tiles on the short side and 16-byte rows: the kernel with 16-byte operand loads (one 64-column group of Q per wave,
         // one workgroup per CU); otherwise two 16-column tiles of Q per wave, two workgroups per CU
-        static const bool wide_on = !(getenv("BALER_AMD_DW_WIDE") && getenv("BALER_AMD_DW_WIDE")[0] == '0');
-        pl.wide[l] = wide_on && pl.pt[l] == 13 && K % 4 == 0 && N % 4 == 0 && (pn ? N : K) >= 192;
+        pl.wide[l] = pl.pt[l] == 13 && K % 4 == 0 && N % 4 == 0 && (pn ? N : K) >= 192;
         const int per_wg = pl.wide[l] ? 256 : 16 * 4 * TQ;
         pl.ncol[l] = (cq + per_wg - 1) / per_wg;
         // every split at least 64 rows and a multiple of 16
