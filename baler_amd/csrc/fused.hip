@@ -1053,19 +1053,28 @@ template <class N, int CB> constexpr int chain_bf16_frags() {
 // The kernel above is HBM-bound on paper (10 KB of float32 per C4 frame against 26 bf16 MFMAs per 4 KB) and ran at 0.40 of the HBM
 // roof: its rows travel through REGISTERS, three chunks (12 KB) ahead per wave at 300 registers and one wave per SIMD, i.e. 48 KB in
 // flight per CU -- under Little's law for 8 TB/s x 2-3 us.  Here two LOADER waves (waves 4, 5; 384-thread workgroups) do nothing but
-// stream the workgroup's 128 rows into an 8-slot LDS ring with direct-to-LDS buffer loads (buffer_load_dwordx4 ... lds: no VGPRs,
-// 7 chunks = 112 KB in flight per CU; one wave can have at most 63 loads outstanding, hence two loaders with 56 each), and their
-// vector-memory queue holds NOTHING ELSE, so the lead is the ring depth (loads of a wave retire in order: in the compute waves every
-// fragment wait also waited for the rows requested before it).  The compute waves keep the fragment stage of the kernel above
-// (plain loads, counted by hipcc; the DMA is inline asm in the loader branch only) and take their B operands from the ring.
+// stream the workgroup's 128 rows into a 6-slot LDS ring, and the 13 weight fragments of every chunk into a 4-slot stage, with
+// direct-to-LDS buffer loads (buffer_load_dwordx4 ... lds: no VGPRs, 3 chunks = 87 KB in flight per CU; a wave can have at most 63
+// loads outstanding, hence two loaders with 45 each).  Their vector-memory queue holds NOTHING ELSE, so the lead is theirs to keep
+// (loads of a wave retire in order: in the compute waves of the kernel above every fragment wait also waited for the rows
+// requested before it); the compute waves issue no vector-memory instruction in the chunk loop at all -- operands A and B both
+// come from LDS.  (The DMA is inline asm in the loader branch only; the waits there are hand-counted.)
+//   What bounds it (timing-only ablation builds, profiles/r4_c4_bf16_encode_ablation.txt): the CU's vector-memory path.  The row
+//   stream alone runs at 5.3 TB/s; the 13 KiB of L2-resident fragments per 16 KiB of rows cost it ~0.45 bytes each (-> 3.9-4.0);
+//   who fetches them (compute waves through registers, loaders by DMA: 3.89 -> 3.95 TB/s) and how far ahead (lead 2 .. 7) do not
+//   matter.  More rows per fragment byte needs 64 rows = 208 accumulator registers per wave, i.e. one wave per SIMD issuing its
+//   own DMA: built (256-row groups, 32-KiB chunks) and measured at 3.65-3.78 TB/s -- half the fragment bytes, but the row stream
+//   of four self-serving waves is slower (4.45 TB/s without any fragments) than that of dedicated loaders.  Not kept.
 //   * ring slot = [compute wave][row tile][half][64 lanes x 16 B]: a 1-KiB block is one DMA instruction, whose lane (i, g) fetches
 //     bytes 64 h + 16 g .. + 15 of the chunk of row i -- 64 contiguous bytes per row and instruction -- and it is read back with one
 //     linear, conflict-free ds_read_b128 by the same lane of the compute wave: that lane then holds k slots (g, j) <-> features
 //     16 (j >> 2) + 4 g + (j & 3) of the chunk, the order the fragments `w0p` are packed in (ImplWideBf16::setup);
-//   * per chunk ONE workgroup barrier (it already existed for the fragment stage): a loader waits (counted vmcnt, asm) until its
-//     share of chunk c has landed, joins barrier c, then refills the slot of chunk c - 1, which every compute wave finished
-//     reading before it joined barrier c.  The loaders run ahead across row groups: no bubble at a group's start.
-constexpr int kDmaRing = 8;             // ring slots: 8 x 16 KiB (+ 26 KiB fragment stage + biases = 156 KiB of the 160)
+//   * per chunk ONE workgroup barrier: a loader waits (counted vmcnt, asm) until its share of chunk c has landed, joins barrier c,
+//     then issues chunk c + 3 into the ring slot of chunk c - 3 and the stage slot of chunk c - 1, which every compute wave
+//     finished reading before it joined barrier c.  The loaders run ahead across row groups: no bubble at a group's start.
+constexpr int kDmaRing = 6;             // row ring: 6 x 16 KiB
+constexpr int kDmaStage = 4;            // fragment stage: 4 x 13 KiB (ring + stage + biases = 150 KiB of the 160)
+constexpr int kDmaLead = 3;             // chunks in flight per loader wave: 3 x 15 loads (a wave counts at most 63)
 constexpr int kDmaChunk = 16384;        // 128 rows x 32 float32 features
 __device__ __forceinline__ void lds_dma_b128(unsigned lds_addr, int voff, __amdgpu_buffer_rsrc_t rs, int soff) {
     unsigned keep;      // M0 (the LDS base of a direct-to-LDS load) is not preserved by hipcc around asm: set and restore it here
@@ -1082,7 +1091,7 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
     extern __shared__ __attribute__((aligned(1024))) unsigned char dma_lds[];
     unsigned char *const ring_b = dma_lds;
     v4 (*const wst)[13][64] = (v4 (*)[13][64])(dma_lds + kDmaRing * kDmaChunk);
-    v4 *const bias_lds = (v4 *)(dma_lds + kDmaRing * kDmaChunk + 2 * 13 * 1024);
+    v4 *const bias_lds = (v4 *)(dma_lds + kDmaRing * kDmaChunk + kDmaStage * 13 * 1024);
     constexpr int nb = N::bf_off(4) - N::bf_off(0);                      // biases of layers 0..3
     for (int i = threadIdx.x; i < nb; i += 384) bias_lds[i] = packed[N::bf_off(0) + i];
     __syncthreads();
@@ -1092,8 +1101,10 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
         // ---- loader: rows 64 L .. 64 L + 63 of every group of this workgroup, chunk after chunk, group after group ------------
         const int L = wave - 4;
         const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring_b + (unsigned)L * 8192u;
-        int64_t gi = blockIdx.x;            // issue cursor: group, chunk, ring slot
-        int ci = 0, pi = 0;
+        const unsigned stage0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring_b + (unsigned)(kDmaRing * kDmaChunk);
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)w0p, 0, KBT * 13 * 1024, 0x00020000);
+        int64_t gi = blockIdx.x;            // issue cursor: group, chunk, ring slot, stage slot
+        int ci = 0, pi = 0, si = 0;
         auto issue = [&]() {
             const int64_t gg = gi < ngroup ? gi : ngroup - 1;            // past the end: harmless re-reads keep the DMA count uniform
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xin + (size_t)gg * 128 * F), 0, 0x7fffffff, 0x00020000);
@@ -1106,17 +1117,24 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
                 lds_dma_b128(dst, voff, rs, soff);
                 lds_dma_b128(dst + 1024u, voff, rs, soff + 64);
             }
+            // the chunk's 13 weight fragments (L2-resident, 1 KiB each) into the stage: tiles 0..6 by loader 0, 7..12 by loader 1
+            // (which fetches tile 12 twice: both loaders count 15 loads per chunk)
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int t = 7 * L + k < 13 ? 7 * L + k : 12;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(stage0 + (unsigned)(si * 13 + t) * 1024u);
+                lds_dma_b128(dst, lane * 16, wrs, (ci * 13 + t) * 1024);
+            }
             if (++ci == KB) { ci = 0; gi += gridDim.x; }
-            pi = (pi + 1) & (kDmaRing - 1);
+            pi = pi + 1 == kDmaRing ? 0 : pi + 1;
+            si = (si + 1) & (kDmaStage - 1);
         };
-        constexpr int kLead = kDmaRing - 1;      // chunks in flight (2 .. 7 measured the same: the loaders are not latency-bound)
-        for (int k = 0; k < kLead; ++k) issue();
+        for (int k = 0; k < kDmaLead; ++k) issue();
         for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
-            __builtin_amdgcn_s_barrier();                                // the compute waves' barrier at the top of a group
             for (int c = 0; c < KB; ++c) {
-                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(8 * (kLead - 1)) : "memory");        // all but the 6 youngest chunks (8 loads each): chunk c is in LDS
-                __builtin_amdgcn_s_barrier();                            // barrier c
-                issue();                                                 // chunk c + 7 into the slot of chunk c - 1
+                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(15 * (kDmaLead - 1)) : "memory");    // all but the youngest chunks: chunk c is in LDS
+                __builtin_amdgcn_s_barrier();                            // barrier c: the compute waves have finished chunk c - 1
+                issue();                                                 // chunk c + 3: ring slot of chunk c - 3, stage slot of chunk c - 1
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // nothing may land in LDS after the workgroup has gone
@@ -1125,7 +1143,7 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
     // ---- compute waves: wave w owns rows 32 w .. 32 w + 31 of the group (two 16-row tiles) -------------------------------------
     WStream ww = make_stream(w0p, KBT * 13 * 1024, lane);
     WStream wc = make_stream(wce, chain_bf16_frags<N, 1>() * 1024, lane);
-    int slot = 0;
+    int slot = 0, ws = 0;
     for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
         const int64_t r0 = (grp * 4 + wave) * 32 + (lane & 15), r1 = r0 + 16;
         const bool v0 = r0 < n, v1 = r1 < n;
@@ -1135,40 +1153,18 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
 #pragma unroll
         for (int t = 0; t < 13; ++t) b1[t] = a1[t];
         {
-            bf8 wq[2][4];                 // this wave's share (tiles wave, wave + 4, wave + 8, 12 for wave 0) of two chunks in flight
-            auto wload = [&](bf8 (&w)[4], int c) {
-                c = c < KB ? c : KB - 1;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int t = wave + 4 * k;
-                    if (t < 13) w[k] = frag_bf(ww, c * 13 + t);      // 13 loads per chunk and workgroup, not 16: every fragment byte through the
-                }                                                    // CU's vector-memory path costs the row stream ~0.45 bytes (hbm_stream_mix_probe)
-            };
-            auto wstore = [&](const bf8 (&w)[4], int sl) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int t = wave + 4 * k;
-                    if (t < 13) wst[sl][t][lane] = __builtin_bit_cast(v4, w[k]);
-                }
-            };
-            wload(wq[0], 0);
-            wload(wq[1], 1);
-            __syncthreads();              // the previous group's last chunk has been read
-            wstore(wq[0], 0);
-            wload(wq[0], 2);
-            auto iter = [&](int c, auto wsl) {
-                constexpr int WS = decltype(wsl)::value;                                 // c % 2
-                __syncthreads();          // barrier c: fragments of chunk c in stage slot WS, its rows in ring slot `slot`; stage slot WS ^ 1 free
-                wstore(wq[WS ^ 1], WS ^ 1);                                              // chunk c + 1 (fetched two chunks ago)
+            for (int c = 0; c < KB; ++c) {
+                __syncthreads();          // barrier c: rows of chunk c in ring slot `slot`, its fragments in stage slot `ws`
                 const v4 *xs = (const v4 *)(ring_b + slot * kDmaChunk + wave * 4096) + lane;
+                const v4 (*const wf)[64] = wst[ws];
                 const v4 l0 = xs[0], h0 = xs[64], l1 = xs[128], h1 = xs[192];
-                slot = (slot + 1) & (kDmaRing - 1);
-                wload(wq[WS ^ 1], c + 3);
+                slot = slot + 1 == kDmaRing ? 0 : slot + 1;
+                ws = (ws + 1) & (kDmaStage - 1);
                 const bf8 q0 = to_bf8(l0, h0), q1 = to_bf8(l1, h1);
                 bf8 wl[2][4];
                 auto rd = [&](bf8 (&w)[4], int t0) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) w[k] = __builtin_bit_cast(bf8, wst[WS][t0 + k < 13 ? t0 + k : 12][lane]);
+                    for (int k = 0; k < 4; ++k) w[k] = __builtin_bit_cast(bf8, wf[t0 + k < 13 ? t0 + k : 12][lane]);
                 };
                 auto mm = [&](const bf8 (&w)[4], int t0) {
 #pragma unroll
@@ -1187,11 +1183,7 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
                 mm(wl[0], 8);
                 mm(wl[1], 12);
                 __builtin_amdgcn_sched_barrier(0);
-            };
-            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-            int c = 0;
-            for (; c + 2 <= KB; c += 2) { iter(c, I0()); iter(c + 1, I1()); }
-            if (c < KB) iter(c, I0());
+            }
             if (F % 32 != 0) {            // the remaining F % 32 features: one partial chunk, rows and fragments straight from L2 (natural k order)
                 const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(xin + (size_t)(grp * 128) * F), 0, 0x7fffffff, 0x00020000);
                 const int lr0 = wave * 32 + (lane & 15);
@@ -3870,7 +3862,7 @@ template <int F, int Z> struct ImplWideBf16 {
         const int64_t g = (rows + 127) / 128;
         return (int)(g < 1 ? 1 : (g > 2 * st->nwg_max ? 2 * st->nwg_max : g));
     }
-    static constexpr size_t dma_lds_bytes() { return (size_t)kDmaRing * kDmaChunk + 2 * 13 * 1024 + (size_t)(N::bf_off(4) - N::bf_off(0)) * 16; }
+    static constexpr size_t dma_lds_bytes() { return (size_t)kDmaRing * kDmaChunk + kDmaStage * 13 * 1024 + (size_t)(N::bf_off(4) - N::bf_off(0)) * 16; }
     static int setup(bamd_handle *h, FusedState *st) {
         int rc = build_maps<F, Z, false>(h, st);
         if (rc) return rc;
@@ -3981,7 +3973,7 @@ template <int F, int Z> struct ImplWideBf16 {
             const dim3 grid((unsigned)(ngroup > 2048 ? 2048 : ngroup));
             void *zo = (void *)((char *)z + (size_t)r0 * Z * zes);
             if constexpr (kDma) {
-                if (!src_f64) {      // persistent: one workgroup (4 compute + 2 loader waves, 156 KiB of LDS) per CU
+                if (!src_f64) {      // persistent: one workgroup (4 compute + 2 loader waves, 150 KiB of LDS) per CU
                     hipLaunchKernelGGL((wide_bf16_encode_dma_kernel<F, Z>), dim3((unsigned)(ngroup > st->nwg_max ? st->nwg_max : ngroup)), dim3(384),
                                        dma_lds_bytes(), s, (const v4 *)h->packed.p, (const v4 *)st->wb[3].p, (const v4 *)st->wb[4].p, (const float *)src, rows, zo,
                                        z_dtype == BAMD_F64);
