@@ -116,14 +116,16 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
         if (rc) { bamd_destroy(h); return rc; }
     }
     *out = h;
-    if (bamd_path_of(h) == BAMD_PATH_GENERIC) {
+    const int path = bamd_path_of(h);
+    if (path == BAMD_PATH_GENERIC || path == BAMD_PATH_FUSED_INFER) {
         const char *q = getenv("BALER_AMD_QUIET");
         if (!(q && q[0] == '1')) {
             std::string d;
             for (int l = 0; l <= n_layers; ++l) d += (l ? "-" : "") + std::to_string(dims[l]);
-            fprintf(stderr, "[baler_amd] model %s (%s) has no fused kernel instantiation: encode / decode / training run layer by layer "
-                            "(generic.hip, activations through HBM)\n", d.c_str(),
-                    mode == BAMD_MODE_F64 ? "fp64" : mode == BAMD_MODE_BF16 ? "bf16" : "fp32");
+            fprintf(stderr, "[baler_amd] model %s (%s) has no fused %s: %s run layer by layer (generic.hip, activations through HBM)\n",
+                    d.c_str(), mode == BAMD_MODE_F64 ? "fp64" : mode == BAMD_MODE_BF16 ? "bf16" : "fp32",
+                    path == BAMD_PATH_GENERIC ? "kernel instantiation" : "training kernels (encode / decode / validation are fused)",
+                    path == BAMD_PATH_GENERIC ? "encode / decode / training" : "training steps");
         }
     }
     return BAMD_OK;
@@ -133,7 +135,8 @@ int bamd_path_of(const bamd_handle *h) {
     BAMD_REQUIRE(h, "null handle");
     if (h->mode == BAMD_MODE_BF16 && h->bf16_state) return BAMD_PATH_BF16;
     if (h->mode == BAMD_MODE_F64) return h->fused64_state ? BAMD_PATH_FUSED : BAMD_PATH_GENERIC;
-    return h->fused_ok ? BAMD_PATH_FUSED : BAMD_PATH_GENERIC;
+    if (!h->fused_ok) return BAMD_PATH_GENERIC;
+    return fused_trains(h) ? BAMD_PATH_FUSED : BAMD_PATH_FUSED_INFER;
 }
 
 void bamd_destroy(bamd_handle *h) {

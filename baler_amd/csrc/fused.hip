@@ -3528,6 +3528,7 @@ struct FusedOps {
     int (*wide_fwd)(bamd_handle *, const float *, int64_t, float *const *, float *, double *, int *, hipStream_t);
     int (*wide_bwd)(bamd_handle *, int64_t, float *const *, float *const *, const float *, hipStream_t);
     int (*pack_extra)(bamd_handle *, FusedState *, hipStream_t);    // further packed copies of the parameters (bf16 fragments)
+    bool throughput_training = true;      // false: large-batch training of this shape runs on generic.hip (bamd_path_of: FUSED_INFER)
 };
 
 static FusedState *state_of(bamd_handle *h) { return (FusedState *)h->fused_state; }
@@ -3705,6 +3706,34 @@ template <int F, int Z, bool RT = false> struct Impl {
     }
     static const FusedOps *ops() {
         static const FusedOps o = {setup, encode, decode, forward_loss, fwd_bwd, train_step};
+        return &o;
+    }
+};
+
+// Classes beyond what the throughput training pair's LDS images hold (32..63 columns, a latent of 16..31): encode / decode /
+// forward + loss are the register-chained kernels above (they have no images).  Training: with a latent of up to 15 the SMALL-BATCH
+// kernels serve them too (lat2_chain_kernel exchanges one latent tile; its images live in global memory) -- the reference's 512-row
+// steps; larger batches, and every batch of a latent above 15, run on the layer-wise kernels (api.hip falls through on a null
+// entry / BAMD_ERR_UNSUPPORTED).  bamd_path_of() = BAMD_PATH_FUSED_INFER.
+template <int F, int Z> struct ImplInferClass {
+    using B = Impl<F, Z, true>;
+    static constexpr bool kSmall = Z <= 15;
+    static_assert(F <= 63 && F % 16 == 15 && Z % 16 == 15, "class widths are 16 T - 1; the two-tile inference kernels take up to 4 input tiles");
+    static bool matches(const bamd_handle *h) { return B::matches(h); }
+    static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, kSmall>(h, st); }
+    static int fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, hipStream_t s) {
+        if constexpr (kSmall)
+            if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
+        return generic_fwd_bwd(h, x, x_dtype, n, features, grads, s);
+    }
+    static int train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
+                          const AdamArgs &ad, hipStream_t s) {
+        if constexpr (kSmall)
+            if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, &ad, s);
+        return BAMD_ERR_UNSUPPORTED;
+    }
+    static const FusedOps *ops() {
+        static const FusedOps o = {setup, B::encode, B::decode, B::forward_loss, fwd_bwd, train_step, nullptr, nullptr, nullptr, /*throughput_training=*/false};
         return &o;
     }
 };
@@ -4100,6 +4129,10 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     // Wider classes need kImgA / kImgB, the small-batch chain's one-latent-tile exchange and the decoder-gradient kernel's 481
     // registers re-budgeted: 32..64 columns or a latent of 16..32 run on generic.hip for now -- DESIGN.md section 8)
     if (Impl<31, 15, true>::matches(h)) return Impl<31, 15, true>::ops();
+    if (ImplInferClass<47, 15>::matches(h)) return ImplInferClass<47, 15>::ops();
+    if (ImplInferClass<63, 15>::matches(h)) return ImplInferClass<63, 15>::ops();
+    if (ImplInferClass<31, 31>::matches(h)) return ImplInferClass<31, 31>::ops();
+    if (ImplInferClass<63, 31>::matches(h)) return ImplInferClass<63, 31>::ops();
     if (ImplWide<512, 6>::matches(h)) return ImplWide<512, 6>::ops();
     if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();
     if (ImplWide<625, 7>::matches(h)) return ImplWide<625, 7>::ops();
@@ -4177,6 +4210,10 @@ int fused_pack(bamd_handle *h, hipStream_t s) {
     return BAMD_OK;
 }
 
+bool fused_trains(const bamd_handle *h) {   // false: large-batch training of this handle runs layer by layer
+    if (!h->fused_ok) return false;
+    return ((const FusedState *)h->fused_state)->ops->throughput_training;
+}
 bool fused_serves_bf16_inference(const bamd_handle *h) {   // wide models in the bf16 mode: encode / decode live in fused.hip
     return h->fused_ok && ((const FusedState *)h->fused_state)->ops->pack_extra != nullptr;
 }

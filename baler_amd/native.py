@@ -276,8 +276,9 @@ class Handle:
 
     @property
     def path(self):
-        """"fused" | "bf16" | "generic": which kernels serve this shape's throughput calls (bamd_path_of)."""
-        return {0: "generic", 1: "fused", 2: "bf16"}[int(lib().bamd_path_of(self._h))]
+        """"fused" | "bf16" | "generic" | "fused-infer" (fused encode / decode / validation, layer-wise training): which kernels
+        serve this shape's throughput calls (bamd_path_of)."""
+        return {0: "generic", 1: "fused", 2: "bf16", 3: "fused-infer"}[int(lib().bamd_path_of(self._h))]
 
     def load_params(self, flat):
         flat = _dev_tensor(flat)

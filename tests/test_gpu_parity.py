@@ -775,20 +775,57 @@ def test_any_narrow_table_runs_fused(F, Z):
     assert rel(h1.encode(dev(x)).cpu().numpy(), orc.encode(dims, st.params, x)) < 2 * TOL32
 
 
-@pytest.mark.parametrize("F,Z", [(48, 12), (64, 16), (24, 16), (33, 8)])
-def test_wider_narrow_tables_say_where_they_run(F, Z):
-    """Beyond the class instantiation (32 columns and more, or a latent above 15) a model runs on the layer-wise kernels -- correctly,
-    and bamd_path_of says so."""
+@pytest.mark.parametrize("F,Z,path", [(48, 12, "fused-infer"), (33, 8, "fused-infer"), (24, 16, "fused-infer"), (63, 31, "fused-infer"),
+                                      (32, 1, "fused-infer"), (47, 15, "fused-infer"), (64, 16, "generic"), (63, 32, "generic")])
+def test_wider_narrow_tables_say_where_they_run(F, Z, path):
+    """Beyond the full class instantiation (32 columns and more, or a latent above 15): up to 63 columns / a latent of up to 31,
+    encode / decode / forward + loss run on the fused kernels of an inference-only class and training runs layer by layer; wider
+    still, everything runs layer by layer.  Correct either way, and bamd_path_of says which."""
     dims = orc.ae_dims(F, Z)
     flat = orc.formula_params(dims, 7)
     h, p = make_handle(dims, flat, "fp32")
-    assert h.path == "generic"
+    assert h.path == path
+    for n in (1, 37, 300, 4099):
+        x = np.random.default_rng(n).random((n, F))
+        z_ref = orc.encode(dims, flat, x)
+        for xin in (dev(x), dev(x, torch.float32)):
+            assert rel(h.encode(xin).cpu().numpy(), z_ref) < TOL32, (F, Z, n)
+        assert rel(h.decode(dev(z_ref)).cpu().numpy(), orc.decode(dims, flat, z_ref)) < TOL32, (F, Z, n)
+        recon, loss = h.forward_loss(dev(x))
+        want = orc.forward(dims, flat, x)
+        assert rel(recon.cpu().numpy(), want) < TOL32
+        assert abs(loss.item() - ((want - x) ** 2).sum() / F) < TOL32 * max(1.0, ((want - x) ** 2).sum() / F)
+    # fused (un)normalisation and the int mask through the class kernels
+    raw = np.random.default_rng(3).uniform(-40, 90, size=(257, F))
+    feats = orc.find_minmax(raw)
+    z1 = h.encode(dev(raw), features=dev(feats)).cpu().numpy()
+    assert rel(z1, orc.encode(dims, flat, orc.normalize(raw))) < TOL32
+    mask = np.zeros(F, dtype=np.uint8)
+    mask[[0, F - 1]] = 1
+    out = h.decode(dev(z1), features=dev(feats), int_mask=dev(mask)).cpu().numpy()
+    want = orc.renormalize(orc.decode(dims, flat, z1.astype(np.float64)), feats[0], feats[1])
+    cols = mask == 0
+    assert rel(out[:, cols], want[:, cols]) < TOL32
+    assert np.mean(out[:, ~cols] == np.trunc(want[:, ~cols])) > 0.99
+    # training behind the same entry points: the small-batch kernels up to 12288 rows when the latent is at most 15 (1 .. 513 rows:
+    # ragged 16-row blocks; 12288 / 12289: either side of the switch), the layer-wise kernels otherwise; the fused copy of the
+    # parameters follows the optimiser step
+    for n in (1, 300, 513, 12288, 12289):
+        x = np.random.default_rng(n).random((n, F))
+        lo, go = orc.fwd_bwd(dims, flat, x)
+        grads = torch.zeros_like(p)
+        h.fwd_bwd(dev(x), grads)
+        gh = grads.cpu().numpy().astype(np.float64)
+        assert rel_l2(gh[:-1], go) < 1e-5 and np.abs(gh[:-1] - go).max() < 2e-5 * np.abs(go).max(), (F, Z, n)
+        assert abs(gh[-1] - lo) < TOL32 * lo
     x = np.random.default_rng(1).random((300, F))
-    assert rel(h.encode(dev(x)).cpu().numpy(), orc.encode(dims, flat, x)) < TOL32
     lo, go = orc.fwd_bwd(dims, flat, x)
-    grads = torch.zeros_like(p)
-    h.fwd_bwd(dev(x), grads)
-    assert rel(grads.cpu().numpy().astype(np.float64)[:-1], go) < TOL32
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    h.train_step(dev(x), p, m, v, 1, 1e-3)
+    st = orc.FitState(dims, flat)
+    orc.adam_step(st.params, go, st.m, st.v, 1, 1e-3)
+    assert rel_l2(p.cpu().numpy().astype(np.float64)[:-1], st.params) < TOL32
+    assert rel(h.encode(dev(x)).cpu().numpy(), orc.encode(dims, st.params, x)) < 2 * TOL32      # the fused copy follows the step
 
 
 @pytest.mark.parametrize("z,n", [(15, 130), (15, 2048), (15, 5003), (6, 20000)])
