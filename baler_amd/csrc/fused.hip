@@ -2306,7 +2306,14 @@ __device__ __forceinline__ void dw_flush(v4 *__restrict__ slab, const v4 (&acc)[
 
 // Image buffers alternate between two LDS regions (A: 240 slot rows, B: 320 slot rows) so that the next
 // layer's image writes never touch what a slower wave is still reading: ONE barrier per layer.
-constexpr int kImgA = 240, kImgB = 320;
+constexpr int kImgB = 320;
+template <class N> constexpr int img_a_rows() {     // 240 up to 31 columns, 256 for the 47-column class (its [X_7 | dZ_7] and [X_0 | dZ_0] images)
+    int m = 240;
+    const int need[] = {DW<N, 7>::rows_x + DW<N, 7>::rows_dz, DW<N, 5>::rows_x + DW<N, 5>::rows_dz, DW<N, 2>::rows_x + DW<N, 2>::rows_dz,
+                        DW<N, 0>::rows_x + DW<N, 0>::rows_dz};
+    for (int v : need) m = v > m ? v : m;
+    return m;
+}
 
 template <int F, int Z, bool RT = false>
 __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const void *__restrict__ xin, int in_f64,
@@ -2314,6 +2321,7 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
                                                         v4 *__restrict__ dz_out, int fr, int zr) {
     using N = Net<F, Z>;
     using S = StreamTrainDec<N>;
+    constexpr int kImgA = img_a_rows<N>();
     static_assert(DW<N, 7>::rows_x + DW<N, 7>::rows_dz <= kImgA && DW<N, 6>::rows_x + DW<N, 6>::rows_dz <= kImgB &&
                   DW<N, 5>::rows_x + DW<N, 5>::rows_dz <= kImgA && DW<N, 4>::rows_x + DW<N, 4>::rows_dz <= kImgB, "image buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2447,6 +2455,7 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
                                                         const v4 *__restrict__ dz_in, int fr, int zr) {
     using N = Net<F, Z>;
     using S = StreamTrainEnc<N>;
+    constexpr int kImgA = img_a_rows<N>();
     static_assert(DW<N, 1>::rows_x + DW<N, 1>::rows_dz <= kImgB && DW<N, 0>::rows_x + DW<N, 0>::rows_dz <= kImgA, "image buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *imgA = lds, *imgB = lds + kImgA * kQS;
@@ -2504,6 +2513,7 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
     using N = Net<F, Z>;
     using S = StreamTrainEnc<N>;
     static_assert(Z <= 16, "dL/dz hand-off is one tile per row");
+    constexpr int kImgA = img_a_rows<N>();
     static_assert(DW<N, 3>::rows_x + DW<N, 3>::rows_dz <= kImgB && DW<N, 2>::rows_x + DW<N, 2>::rows_dz <= kImgA &&
                   DW<N, 1>::rows_x + DW<N, 1>::rows_dz <= kImgB && DW<N, 0>::rows_x + DW<N, 0>::rows_dz <= kImgA, "image buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -3513,7 +3523,6 @@ static int build_maps(bamd_handle *h, FusedState *st) {
 }
 
 constexpr int kBiasF4 = Net<24, 15>::bf_off(8) - Net<24, 15>::bf_off(0);   // 51 tiles x 4 lane groups for every Z <= 16
-constexpr int kTrainLds = (kImgA + kImgB) * kQS * (int)sizeof(float) + kBiasF4 * 16;
 
 // entry points of one instantiated shape
 struct FusedOps {
@@ -3556,11 +3565,12 @@ template <int F, int Z, bool RT = false> struct Impl {
             if (h->dims[i] != N::dim(i)) return false;
         return true;
     }
-    static constexpr int train_lds = (kImgA + kImgB) * kQS * (int)sizeof(float) + (N::bf_off(8) - N::bf_off(0)) * 16;      // images + bias fragments
+    static constexpr int train_lds = (img_a_rows<N>() + kImgB) * kQS * (int)sizeof(float) + (N::bf_off(8) - N::bf_off(0)) * 16;      // images + bias fragments
     static int fr(const bamd_handle *h) { return h->dims[0]; }
     static int zr(const bamd_handle *h) { return h->dims[4]; }
     static int setup(bamd_handle *h, FusedState *st) {
         static_assert(RT || N::bf_off(8) - N::bf_off(0) == kBiasF4, "bias fragment count");
+        static_assert(train_lds <= 160 * 1024, "LDS of the training pair");
         int rc = build_maps<F, Z, true>(h, st);
         if (rc) return rc;
         BAMD_HIP(hipFuncSetAttribute((const void *)train_dec_kernel<F, Z, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, train_lds));
@@ -4129,7 +4139,7 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     // Wider classes need kImgA / kImgB, the small-batch chain's one-latent-tile exchange and the decoder-gradient kernel's 481
     // registers re-budgeted: 32..64 columns or a latent of 16..32 run on generic.hip for now -- DESIGN.md section 8)
     if (Impl<31, 15, true>::matches(h)) return Impl<31, 15, true>::ops();
-    if (ImplInferClass<47, 15>::matches(h)) return ImplInferClass<47, 15>::ops();
+    if (Impl<47, 15, true>::matches(h)) return Impl<47, 15, true>::ops();
     if (ImplInferClass<63, 15>::matches(h)) return ImplInferClass<63, 15>::ops();
     if (ImplInferClass<31, 31>::matches(h)) return ImplInferClass<31, 31>::ops();
     if (ImplInferClass<63, 31>::matches(h)) return ImplInferClass<63, 31>::ops();

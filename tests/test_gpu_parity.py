@@ -775,12 +775,12 @@ def test_any_narrow_table_runs_fused(F, Z):
     assert rel(h1.encode(dev(x)).cpu().numpy(), orc.encode(dims, st.params, x)) < 2 * TOL32
 
 
-@pytest.mark.parametrize("F,Z,path", [(48, 12, "fused-infer"), (33, 8, "fused-infer"), (24, 16, "fused-infer"), (63, 31, "fused-infer"),
-                                      (32, 1, "fused-infer"), (47, 15, "fused-infer"), (64, 16, "generic"), (63, 32, "generic")])
+@pytest.mark.parametrize("F,Z,path", [(48, 12, "fused-infer"), (33, 8, "fused"), (24, 16, "fused-infer"), (63, 31, "fused-infer"),
+                                      (32, 1, "fused"), (47, 15, "fused"), (63, 15, "fused-infer"), (64, 16, "generic"), (63, 32, "generic")])
 def test_wider_narrow_tables_say_where_they_run(F, Z, path):
-    """Beyond the full class instantiation (32 columns and more, or a latent above 15): up to 63 columns / a latent of up to 31,
-    encode / decode / forward + loss run on the fused kernels of an inference-only class and training runs layer by layer; wider
-    still, everything runs layer by layer.  Correct either way, and bamd_path_of says which."""
+    """32..47 columns with a latent of at most 15: the second full class instantiation (every kernel).  48..63 columns / a latent of
+    16..31: encode / decode / forward + loss on the fused kernels, training on the small-batch kernels (latent <= 15, <= 12288 rows)
+    or layer by layer; wider still, everything layer by layer.  Correct either way, and bamd_path_of says which."""
     dims = orc.ae_dims(F, Z)
     flat = orc.formula_params(dims, 7)
     h, p = make_handle(dims, flat, "fp32")
@@ -810,7 +810,7 @@ def test_wider_narrow_tables_say_where_they_run(F, Z, path):
     # training behind the same entry points: the small-batch kernels up to 12288 rows when the latent is at most 15 (1 .. 513 rows:
     # ragged 16-row blocks; 12288 / 12289: either side of the switch), the layer-wise kernels otherwise; the fused copy of the
     # parameters follows the optimiser step
-    for n in (1, 300, 513, 12288, 12289):
+    for n in (1, 300, 513, 12288, 12289, 20001):
         x = np.random.default_rng(n).random((n, F))
         lo, go = orc.fwd_bwd(dims, flat, x)
         grads = torch.zeros_like(p)
