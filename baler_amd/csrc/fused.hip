@@ -2716,7 +2716,7 @@ __global__ void __launch_bounds__(64 * W) lat2_chain_kernel(const v4 *packed, co
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
     WStream ws = make_stream(packed, N::packed_f4() * 16, lane);
     constexpr int TF = tiles(F), TZ = tiles(Z);
-    static_assert(TF <= 4 && TZ == 1, "input / latent tiles");
+    static_assert(TF <= 4 && TZ <= 2, "input / latent tiles");
     LAT_T(0);
     // the rows first (layer 0 waits for them), then the ring's first D fragments queue up behind them
     const int64_t row = (int64_t)blockIdx.x * 16 + (lane & 15);
@@ -3720,26 +3720,22 @@ template <int F, int Z, bool RT = false> struct Impl {
     }
 };
 
-// Classes beyond what the throughput training pair's LDS images hold (32..63 columns, a latent of 16..31): encode / decode /
-// forward + loss are the register-chained kernels above (they have no images).  Training: with a latent of up to 15 the SMALL-BATCH
-// kernels serve them too (lat2_chain_kernel exchanges one latent tile; its images live in global memory) -- the reference's 512-row
-// steps; larger batches, and every batch of a latent above 15, run on the layer-wise kernels (api.hip falls through on a null
-// entry / BAMD_ERR_UNSUPPORTED).  bamd_path_of() = BAMD_PATH_FUSED_INFER.
+// Classes beyond what the throughput training pair's LDS images hold (48..63 columns: 164 KB): encode / decode / forward + loss
+// are the register-chained kernels above (they have no images), training steps of up to 12288 rows run on the small-batch kernels
+// (their images live in global memory) -- the reference's 512-row steps -- and larger batches on the layer-wise kernels
+// (generic_fwd_bwd below; bamd_train_step falls through on BAMD_ERR_UNSUPPORTED).  bamd_path_of() = BAMD_PATH_FUSED_INFER.
 template <int F, int Z> struct ImplInferClass {
     using B = Impl<F, Z, true>;
-    static constexpr bool kSmall = Z <= 15;
     static_assert(F <= 63 && F % 16 == 15 && Z % 16 == 15, "class widths are 16 T - 1; the two-tile inference kernels take up to 4 input tiles");
     static bool matches(const bamd_handle *h) { return B::matches(h); }
-    static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, kSmall>(h, st); }
+    static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, true>(h, st); }
     static int fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, hipStream_t s) {
-        if constexpr (kSmall)
-            if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
+        if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
         return generic_fwd_bwd(h, x, x_dtype, n, features, grads, s);
     }
     static int train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
                           const AdamArgs &ad, hipStream_t s) {
-        if constexpr (kSmall)
-            if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, &ad, s);
+        if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, &ad, s);
         return BAMD_ERR_UNSUPPORTED;
     }
     static const FusedOps *ops() {
@@ -4134,14 +4130,15 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     }
     if (h->mode != BAMD_MODE_F32) return nullptr;
     BAMD_AE24_ALL
-    // any other narrow table: the class instantiations (run-time widths; Impl<F, Z, true>)
-    // (up to 31 columns and a latent of at most 15: what the images and the exchange buffers of the training kernels are sized for.
-    // Wider classes need kImgA / kImgB, the small-batch chain's one-latent-tile exchange and the decoder-gradient kernel's 481
-    // registers re-budgeted: 32..64 columns or a latent of 16..32 run on generic.hip for now -- DESIGN.md section 8)
+    // any other narrow table: the class instantiations (run-time widths; Impl<F, Z, true>): up to 47 columns with a latent of up to
+    // 31 on every kernel, 48..63 columns on the inference and small-batch kernels (ImplInferClass).  64 columns and more, or a
+    // latent above 31, run on generic.hip (the two-tile inference kernels take 4 input tiles, the small-batch chain 2 latent
+    // tiles) -- DESIGN.md section 8
     if (Impl<31, 15, true>::matches(h)) return Impl<31, 15, true>::ops();
     if (Impl<47, 15, true>::matches(h)) return Impl<47, 15, true>::ops();
+    if (Impl<31, 31, true>::matches(h)) return Impl<31, 31, true>::ops();
+    if (Impl<47, 31, true>::matches(h)) return Impl<47, 31, true>::ops();
     if (ImplInferClass<63, 15>::matches(h)) return ImplInferClass<63, 15>::ops();
-    if (ImplInferClass<31, 31>::matches(h)) return ImplInferClass<31, 31>::ops();
     if (ImplInferClass<63, 31>::matches(h)) return ImplInferClass<63, 31>::ops();
     if (ImplWide<512, 6>::matches(h)) return ImplWide<512, 6>::ops();
     if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();
