@@ -732,7 +732,34 @@ def other_configs(dev):
     res["c5_encode_512col"] = {"rows": n, "encode_rows_per_s": n / ms * 1e3,
                                "encode_frac_of_mfma_peak": FLOP_C5_ENCODE * n / ms / 1e9 / PEAK_TFLOPS["fp32"],
                                "input_stream_gbs": 2048 * n / ms / 1e6}
+    hwb = native.Handle([512, 200, 100, 50, 6, 50, 100, 200, 512], "bf16")
+    hwb.load_params(mw.flat)
+    ms_b = event_ms(lambda: hwb.encode(xw, out_dtype=torch.float32), 3)
+    res["c5_encode_512col"].update({"bf16_encode_rows_per_s": n / ms_b * 1e3, "bf16_encode_frac_of_hbm": (2048 + 24) * n / ms_b / 1e6 / PEAK_HBM_GBS})
+    hwb.close()
     hw_.close()
+    del xw
+    # narrow tables other than the 24-column one (models.py:122-139 builds AE(n_features, z_dim) for any width): class instantiations
+    # with run-time widths up to 47 columns / a latent of 31; 48..63 columns fused for inference and small batches; beyond: layer-wise
+    n = 1_000_000
+    res["narrow_tables"] = {}
+    for F, Z in ((30, 8), (47, 31), (63, 31), (64, 16)):
+        xn = torch.rand((n, F), dtype=torch.float64, device=dev)
+        mn = models.AE(F, Z, mode="fp32").to(dev)
+        hn = mn.handle()
+        gn = torch.zeros_like(mn.flat)
+        mo, vo = torch.zeros_like(mn.flat), torch.zeros_like(mn.flat)
+        step = {"t": 0}
+
+        def steps512():
+            for i in range(50):
+                step["t"] += 1
+                hn.train_step(xn[i * 512:(i + 1) * 512], mn.flat, mo, vo, step["t"], 1e-3)
+        ms_e, ms_t, ms_s = event_ms(lambda: hn.encode(xn), 3), event_ms(lambda: hn.fwd_bwd(xn, gn), 2), event_ms(steps512, 1) / 50
+        res["narrow_tables"][f"ae_{F}_{Z}"] = {"path": hn.path, "encode_rows_per_s": n / ms_e * 1e3, "train_fwd_bwd_rows_per_s": n / ms_t * 1e3,
+                                               "train_bs512_us_per_step": ms_s * 1e3}
+        hn.close()
+        del xn, gn, mo, vo
     return res
 
 
