@@ -540,34 +540,41 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
 // (blockIdx.y); partial tiles go to `part`, dw64_kernel(nsplit) finishes.  Tiles beyond a layer's edge run on a clamped slice and are not
 // stored: uniform code.  (The fp32 twin of this kernel gained 1-5 % at <= 12,288 rows, where unique image bytes bound the step:
 // fused.hip history / DESIGN.md section 4.1; fp64 batches run this decomposition up to 262,144 rows, where the re-reads dominate.)
-template <class N, int MN, int MK> struct Dwm64 {
-    __host__ __device__ static constexpr int mn(int l) { return (tiles(N::dim(l + 1)) + MN - 1) / MN; }
-    __host__ __device__ static constexpr int mk(int l) { return (tiles(N::dim(l) + 1) + MK - 1) / MK; }
+// Tile blocks of the weight-gradient product: a workgroup owns MN output x MK input tiles of ONE layer and walks a range of 16-row
+// blocks; per block it loads MN + MK image slices (32 bytes per lane each) for 4 MN MK MFMAs.  The kernel is bound by those loads
+// (12 per 64 MFMAs with 2 x 4 blocks: 48 B/clk/CU), so the blocks are 16 tiles where the layer has them, and their ORIENTATION is
+// chosen per layer to waste the fewest padded tiles: 13 x 2 tiles -> 8 x 2, 7 x 13 -> 8 x 2, 13 x 7 -> 2 x 8, 2 x 13 -> 2 x 8,
+// 4 x 7 / 7 x 4 -> 4 x 4, the two latent layers 2 x 4 / 4 x 2: 368 tile slots for the 298 tiles (2 x 4 everywhere: 416), 8-10 loads
+// per 64 MFMAs.  Measured at 262,144 rows (bamd_fwd_bwd): 2 x 4 everywhere 3.26 ms, 4 x 4 everywhere 3.08, per-layer shapes: see DESIGN 4.8.
+struct DwShape { int mn, mk; };
+template <class N, bool BIG> struct Dwm64 {      // BIG: batches of >= 16,384 rows (below, 2 x 4 blocks over 8 ranges fill the chip better)
+    __host__ __device__ static constexpr DwShape shape(int l) {
+        if (!BIG) return DwShape{2, 4};
+        const int nt = tiles(N::dim(l + 1)), kt = tiles(N::dim(l) + 1);
+        const DwShape cand[5] = {{4, 4}, {8, 2}, {2, 8}, {2, 4}, {4, 2}};      // 16-tile blocks first: ties go to them, then to fewer loads
+        int best = 0, best_slots = 1 << 30;
+        for (int c = 0; c < 5; ++c) {
+            const int slots = ((nt + cand[c].mn - 1) / cand[c].mn) * cand[c].mn * (((kt + cand[c].mk - 1) / cand[c].mk) * cand[c].mk);
+            if (slots < best_slots) { best_slots = slots; best = c; }
+        }
+        return cand[best];
+    }
+    __host__ __device__ static constexpr int mn(int l) { return (tiles(N::dim(l + 1)) + shape(l).mn - 1) / shape(l).mn; }
+    __host__ __device__ static constexpr int mk(int l) { return (tiles(N::dim(l) + 1) + shape(l).mk - 1) / shape(l).mk; }
     __host__ __device__ static constexpr int off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += mn(j) * mk(j); return s; }
     static constexpr int total = off(N::L);
     static constexpr int per_xcd = (total + 7) / 8;
 };
-template <class N, int MN, int MK>
-__global__ void __launch_bounds__(256) dw64m_kernel(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total,
-                                                    int split0) {
-    // this launch covers block ranges split0 .. split0 + gridDim.y - 1 of the nsplit_total ranges the finishing launch adds up (a batch
-    // beyond State64::chunk_rows runs chunk after chunk over the same image buffer: one launch of this kernel per chunk)
+// one tile block of layer l (compile-time shape): accumulate over this workgroup's block range, sum the four waves' accumulators
+// through LDS in a fixed order, store the range partial
+template <class N, bool BIG, int l>
+__device__ __forceinline__ void dw64m_block(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total, int split0,
+                                            int idx, d4 *red) {
+    using D = Dwm64<N, BIG>;
+    constexpr int MN = D::shape(l).mn, MK = D::shape(l).mk, NA = MN * MK, U = NA >= 16 ? 1 : 2, HALF = NA / 2;
+    constexpr int ntc = tiles(N::dim(l + 1)), ktc = tiles(N::dim(l) + 1), mnc = D::mn(l), soff = N::slab_off(l), xo = N::x_off(l), zo = N::z_off(l);
     const int nsplit = (int)gridDim.y;
-    using D = Dwm64<N, MN, MK>;
-    constexpr int NA = MN * MK, U = 2, HALF = NA / 2;
-    static_assert(NA % 2 == 0, "the reduction runs in two halves");
-    __shared__ __attribute__((aligned(32))) d4 red[HALF * 4 * 64];       // 32 KB
-    const int mac = (blockIdx.x & 7) * D::per_xcd + (blockIdx.x >> 3);
-    if (mac >= D::total) return;
-    int l = 0;
-#pragma unroll
-    for (int j = 1; j < N::L; ++j) if (mac >= D::off(j)) l = j;
-    int ntc = tiles(N::dim(1)), ktc = tiles(N::dim(0) + 1), mnc = D::mn(0), moff = 0, soff = 0, xo = N::x_off(0), zo = N::z_off(0);
-#pragma unroll
-    for (int j = 1; j < N::L; ++j)
-        if (l == j) { ntc = tiles(N::dim(j + 1)); ktc = tiles(N::dim(j) + 1); mnc = D::mn(j); moff = D::off(j); soff = N::slab_off(j);
-                      xo = N::x_off(j); zo = N::z_off(j); }
-    const int idx = mac - moff, mkt = idx / mnc, mnt = idx - mkt * mnc;
+    const int mkt = idx / mnc, mnt = idx - mkt * mnc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
     const double *pz[MN], *px[MK];
     int nt[MN], kt[MK];
@@ -626,6 +633,22 @@ __global__ void __launch_bounds__(256) dw64m_kernel(const double *__restrict__ i
             part[((int64_t)tile * nsplit_total + split0 + blockIdx.y) * 256 + e] = gsum;
         }
     }
+}
+template <class N, bool BIG>
+__global__ void __launch_bounds__(256) dw64m_kernel(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total,
+                                                    int split0) {
+    // this launch covers block ranges split0 .. split0 + gridDim.y - 1 of the nsplit_total ranges the finishing launch adds up (a batch
+    // beyond State64::chunk_rows runs chunk after chunk over the same image buffer: one launch of this kernel per chunk)
+    using D = Dwm64<N, BIG>;
+    __shared__ __attribute__((aligned(32))) d4 red[(BIG ? 8 : 4) * 4 * 64];      // half of a block's accumulators from four waves: 64 / 32 KB
+    const int mac = (blockIdx.x & 7) * D::per_xcd + (blockIdx.x >> 3);
+    if (mac >= D::total) return;
+    static_assert(N::L == 8, "one case per layer below");
+#define BAMD_DW64M_CASE(l_) \
+    if (mac >= D::off(l_) && mac < D::off(l_ + 1)) { dw64m_block<N, BIG, l_>(imgs, nblk, part, nsplit_total, split0, mac - D::off(l_), red); return; }
+    BAMD_DW64M_CASE(0) BAMD_DW64M_CASE(1) BAMD_DW64M_CASE(2) BAMD_DW64M_CASE(3)
+    BAMD_DW64M_CASE(4) BAMD_DW64M_CASE(5) BAMD_DW64M_CASE(6) BAMD_DW64M_CASE(7)
+#undef BAMD_DW64M_CASE
 }
 
 __global__ void __launch_bounds__(256) pack64_k(const double *__restrict__ params, const int *__restrict__ src, int count,
@@ -752,8 +775,11 @@ template <int F, int Z> struct Impl64 {
         // 4,096: 0.068 / 0.094, 16,384: 0.227 / 0.341, 65,536: 0.85 / 1.32, 262,144: 3.22 / 5.51 (0.37 / 0.22 of the fp64 MFMA peak)
         static const int macro_blks = getenv("BALER_AMD_DW64_MACRO_BLKS") ? atoi(getenv("BALER_AMD_DW64_MACRO_BLKS")) : 64;
         const bool macro = nchunk > 1 || (macro_blks > 0 && nblk_all >= macro_blks);
-        // block ranges per chunk: 16 from 4,096 blocks on, else 8; every chunk but the last is a full one
-        auto splits_of = [](int64_t blks) { return blks >= 4096 ? 16 : 8; };
+        // tile-block shape by batch size; block ranges per chunk (tile blocks x ranges = workgroups): per-layer 16-tile blocks (24 of them)
+        // over 32 ranges from 4,096 blocks on, over 16 from 1,024; below that 2 x 4 blocks (52) over 8 ranges, at least 4 blocks per range.
+        // Every chunk but the last is a full one
+        const bool big = nblk_all >= 1024;
+        auto splits_of = [big](int64_t blks) { return (int)std::min<int64_t>(big ? (blks >= 4096 ? 32 : 16) : 8, std::max<int64_t>(1, blks / 4)); };
         int nsplit = 0;
         if (macro) {
             for (int k = 0; k < nchunk; ++k) nsplit += splits_of((std::min(n - k * chunk, chunk) + 15) / 16);
@@ -769,10 +795,13 @@ template <int F, int Z> struct Impl64 {
                                (const void *)((const char *)x + (size_t)r0 * F * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
                                (double *)h->lossp.p + r0 / 16);
             if (macro) {
-                using D = Dwm64<N, 2, 4>;
                 const int ns = splits_of(nblk);
-                hipLaunchKernelGGL((dw64m_kernel<N, 2, 4>), dim3(8 * D::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
-                                   (double *)st->dwpart.p, nsplit, split0);
+                if (big)
+                    hipLaunchKernelGGL((dw64m_kernel<N, true>), dim3(8 * Dwm64<N, true>::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
+                                       (double *)st->dwpart.p, nsplit, split0);
+                else
+                    hipLaunchKernelGGL((dw64m_kernel<N, false>), dim3(8 * Dwm64<N, false>::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
+                                       (double *)st->dwpart.p, nsplit, split0);
                 split0 += ns;
             }
         }
