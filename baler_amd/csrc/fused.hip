@@ -1215,10 +1215,11 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
 // all 7 fragments of an output tile for itself, and -- what mattered -- those loads sat in the same in-order queue as the wave's
 // stores: vector-memory operations of a wave retire in order (vmcnt counts loads AND stores), so every wait for a fragment also
 // waited for the 1-KiB stores issued before it, i.e. for an HBM write acknowledgement (~4 us under load) every four tiles.  Here a
-// FIFTH wave does all the fragment traffic: it streams the tiles' fragments (7 KiB each, L2-resident) into a 4-slot LDS stage with
-// direct-to-LDS loads, two tiles ahead, one workgroup barrier per tile; the four compute waves read their A operands from the stage
+// FIFTH wave does all the fragment traffic: it streams the tiles' fragments (7 KiB each, L2-resident) into a 6-slot LDS stage with
+// direct-to-LDS loads, five tiles ahead, one workgroup barrier per tile; the four compute waves read their A operands from the stage
 // and their vector-memory queue holds NOTHING BUT STORES, which they never wait for.
-constexpr int kDecSlots = 4;
+constexpr int kDecSlots = 6;             // stage slots: 5 tiles of fragments (35 KiB) in flight; 3 left the loader latency-bound (4 slots: 0.35-0.39 of HBM at
+                                         // 131,072 frames, 6 / 8 / 10 slots: 0.40-0.44)
 template <int F, int Z, bool OUT64>
 __global__ void __launch_bounds__(320) wide_bf16_decode_kernel(const v4 *packed, const v4 *w7b, const v4 *wcd, const void *__restrict__ zin, int in_f64,
                                                                int64_t n, void *__restrict__ out) {
@@ -1250,14 +1251,14 @@ __global__ void __launch_bounds__(320) wide_bf16_decode_kernel(const v4 *packed,
             for (int c = 0; c < 7; ++c)
                 lds_dma_b128(__builtin_amdgcn_readfirstlane(st0 + (unsigned)(si * 7 + c) * 1024u), lane * 16, rs, (ti * 7 + c) * 1024);
             if (++ti == KT) ti = 0;
-            si = (si + 1) & (kDecSlots - 1);
+            si = si + 1 == kDecSlots ? 0 : si + 1;
         };
-        issue(); issue(); issue();
+        for (int k = 0; k < kDecSlots - 1; ++k) issue();
         for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x)
             for (int t = 0; t < KT; ++t) {
-                asm volatile("s_waitcnt vmcnt(14)" ::: "memory");        // all but the two youngest tiles: tile t is in the stage
+                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(7 * (kDecSlots - 2)) : "memory");      // all but the youngest tiles: tile t is in the stage
                 __builtin_amdgcn_s_barrier();                            // barrier t
-                issue();                                                 // tile t + 3 into the slot of tile t - 1
+                issue();                                                 // tile t + 5 into the slot of tile t - 1
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
@@ -1295,7 +1296,7 @@ __global__ void __launch_bounds__(320) wide_bf16_decode_kernel(const v4 *packed,
             bf8 w[7];
 #pragma unroll
             for (int c = 0; c < 7; ++c) w[c] = __builtin_bit_cast(bf8, wst[slot][c][lane]);
-            slot = (slot + 1) & (kDecSlots - 1);
+            slot = slot + 1 == kDecSlots ? 0 : slot + 1;
             v4 o0 = bias7[t * 4 + g], o1 = o0;
 #pragma unroll
             for (int c = 0; c < 7; ++c) { o0 = mfma_bf(w[c], qa[c], o0); o1 = mfma_bf(w[c], qb[c], o1); }
