@@ -278,6 +278,167 @@ __global__ void __launch_bounds__(64 * W) chain64_kernel(const d4 *packed, const
     }
 }
 
+// ---- the training chain for LARGE fp64 batches: one WAVE per 16-row block, activations in registers ------------------------------
+// chain64_kernel gives a block to a whole workgroup (4 waves split every layer's tiles and swap them through LDS, one barrier per
+// layer): right for the 512-row step, but at 262,144 rows it spends 1.6 ms at 55 % MFMA busy -- 15 barriers per block, and every
+// block's workgroup streams the whole model.  infer64_kernel shows what the fp64 MFMA does when a wave owns all tiles of its rows
+// (85-89 % busy).  This is that formulation for training: Seq<N, 1, D> is the 15-GEMM fragment sequence of ONE wave (forward 0..7,
+// then the transposed fragments of layers 7..1), a layer's output tiles are the next GEMM's B operand as they stand, nothing is
+// exchanged, no barrier after the bias fragments are staged.  The images ([slot][16 rows], global) are written exactly as
+// chain64_kernel writes them -- same values bit for bit: every output element still accumulates its k blocks in order -- so the
+// weight-gradient kernels do not change.  The activations are not kept for the backward masks (392 registers): LeakyReLU records
+// the SIGN of each value in a bit mask (4 bits per tile and lane: 12 registers for the six activated layers).
+template <int NL> __device__ __forceinline__ void lrelu_rec(d4 (&a)[NL], unsigned long long &mask) {
+    mask = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool pos = a[i][r] > 0.0;
+            a[i][r] = pos ? a[i][r] : a[i][r] * kSlope;
+            mask |= (unsigned long long)pos << (4 * i + r);
+        }
+}
+template <int NL> __device__ __forceinline__ void lrelu_bwd_mask(d4 (&d)[NL], unsigned long long mask) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[i][r] = ((mask >> (4 * i + r)) & 1ull) ? d[i][r] : d[i][r] * kSlope;
+}
+template <int F, int Z>
+__global__ void __launch_bounds__(256) chain64r_kernel(const d4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
+                                                       const double *__restrict__ feats, double *__restrict__ imgs,
+                                                       double *__restrict__ loss_part, int nblk) {
+    using N = Net64<F, Z>;
+    constexpr int TF = tiles(F), TZ = tiles(Z);
+    static_assert(TZ == 1 && F % 16 != 0, "input / latent tiles");
+    constexpr int kNB = N::bf_off(N::L) - N::bf_off(0);
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    d4 *bias_lds = (d4 *)lds_raw;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    for (int i = threadIdx.x; i < kNB; i += 256) bias_lds[i] = packed[N::bf_off(0) + i];
+    __syncthreads();
+    const int blk = (int)blockIdx.x * 4 + wave;
+    if (blk >= nblk) return;
+    WStream ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)packed, 0, N::packed_d4() * 32, 0x00020000);
+    ws.voff = lane * 32;
+    const int64_t row = (int64_t)blk * 16 + (lane & 15);
+    const bool valid = row < n;
+    const int64_t rbase = (valid ? row : 0) * F;
+    d4 a0[TF];
+#pragma unroll
+    for (int t = 0; t < TF; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = creg_feature(F, t, g, r);
+            const int fc = f >= 0 ? f : 0;                        // padding slots read feature 0 (finite, meets zero weights)
+            double v = in_f64 ? ((const double *)xin)[rbase + fc] : (double)((const float *)xin)[rbase + fc];
+            if (feats) v = (v - feats[fc]) / feats[F + fc];
+            a0[t][r] = f >= 0 ? v : 0.0;
+        }
+    using SQ = Seq<N, 1, 8>;
+    d4 ring[SQ::D];
+    seq_prologue<SQ>(ring, ws, 0, std::make_integer_sequence<int, SQ::D>{});
+    double *img = imgs + (int64_t)blk * N::img_doubles;
+#define BIAS64R(loc, l, NTl)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < NTl; ++i) loc[i] = bias_lds[(N::bf_off(l) - N::bf_off(0)) + i * 4 + g];
+    unsigned long long m1, m2, m3, m5, m6, m7;
+    double lacc = 0.0;
+    d4 o8[TF];
+    publish<F, true, 1>(nullptr, img, N::x_off(0), a0, lane, 0);
+    {   // ---------------- forward: a layer's tiles live until the next layer has consumed them ----------------
+        d4 s7[13];
+        {
+            d4 s6[7];
+            {
+                d4 s5[4];
+                {
+                    d4 s4[1];
+                    {
+                        d4 s3[4];
+                        {
+                            d4 s2[7];
+                            {
+                                d4 s1[13];
+                                BIAS64R(s1, 0, 13) seq_mm<SQ, 0>(a0, s1, ring, ws, 0); lrelu_rec(s1, m1);
+                                publish<200, true, 1>(nullptr, img, N::x_off(1), s1, lane, 0);
+                                BIAS64R(s2, 1, 7) seq_mm<SQ, 1>(s1, s2, ring, ws, 0); lrelu_rec(s2, m2);
+                            }
+                            publish<100, true, 1>(nullptr, img, N::x_off(2), s2, lane, 0);
+                            BIAS64R(s3, 2, 4) seq_mm<SQ, 2>(s2, s3, ring, ws, 0); lrelu_rec(s3, m3);
+                        }
+                        publish<50, true, 1>(nullptr, img, N::x_off(3), s3, lane, 0);
+                        BIAS64R(s4, 3, TZ) seq_mm<SQ, 3>(s3, s4, ring, ws, 0);                                   // en4: no activation
+                    }
+                    publish<Z, true, 1>(nullptr, img, N::x_off(4), s4, lane, 0);
+                    BIAS64R(s5, 4, 4) seq_mm<SQ, 4>(s4, s5, ring, ws, 0); lrelu_rec(s5, m5);
+                }
+                publish<50, true, 1>(nullptr, img, N::x_off(5), s5, lane, 0);
+                BIAS64R(s6, 5, 7) seq_mm<SQ, 5>(s5, s6, ring, ws, 0); lrelu_rec(s6, m6);
+            }
+            publish<100, true, 1>(nullptr, img, N::x_off(6), s6, lane, 0);
+            BIAS64R(s7, 6, 13) seq_mm<SQ, 6>(s6, s7, ring, ws, 0); lrelu_rec(s7, m7);
+        }
+        publish<200, true, 1>(nullptr, img, N::x_off(7), s7, lane, 0);
+        BIAS64R(o8, 7, TF) seq_mm<SQ, 7>(s7, o8, ring, ws, 0);                                                   // de4: no activation
+    }
+#undef BIAS64R
+    // ---------------- loss, dL/drecon = 2 (r - x) / C (utils.py:195-199) ----------------
+#pragma unroll
+    for (int t = 0; t < TF; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double d = o8[t][r] - a0[t][r];
+            const bool live = valid && creg_feature(F, t, g, r) >= 0;
+            if (live) lacc += d * d;
+            o8[t][r] = live ? d * (2.0 / (double)F) : 0.0;
+        }
+    publish<F, false, 1>(nullptr, img, N::z_off(7), o8, lane, 0);
+    // ---------------- backward chain (input gradients), publishing the dZ images ----------------
+#define ZERO64(a, NTl) _Pragma("unroll") for (int i = 0; i < NTl; ++i) a[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    {
+        d4 d1[13];
+        {
+            d4 d2[7];
+            {
+                d4 d3[4];
+                {
+                    d4 d4_[1];
+                    {
+                        d4 d5[4];
+                        {
+                            d4 d6[7];
+                            {
+                                d4 d7[13];
+                                ZERO64(d7, 13) seq_mm<SQ, 8>(o8, d7, ring, ws, 0); lrelu_bwd_mask(d7, m7);
+                                publish<200, false, 1>(nullptr, img, N::z_off(6), d7, lane, 0);
+                                ZERO64(d6, 7) seq_mm<SQ, 9>(d7, d6, ring, ws, 0); lrelu_bwd_mask(d6, m6);
+                            }
+                            publish<100, false, 1>(nullptr, img, N::z_off(5), d6, lane, 0);
+                            ZERO64(d5, 4) seq_mm<SQ, 10>(d6, d5, ring, ws, 0); lrelu_bwd_mask(d5, m5);
+                        }
+                        publish<50, false, 1>(nullptr, img, N::z_off(4), d5, lane, 0);
+                        ZERO64(d4_, 1) seq_mm<SQ, 11>(d5, d4_, ring, ws, 0);                                     // dL/dz: en4 has no activation
+                    }
+                    publish<Z, false, 1>(nullptr, img, N::z_off(3), d4_, lane, 0);
+                    ZERO64(d3, 4) seq_mm<SQ, 12>(d4_, d3, ring, ws, 0); lrelu_bwd_mask(d3, m3);
+                }
+                publish<50, false, 1>(nullptr, img, N::z_off(2), d3, lane, 0);
+                ZERO64(d2, 7) seq_mm<SQ, 13>(d3, d2, ring, ws, 0); lrelu_bwd_mask(d2, m2);
+            }
+            publish<100, false, 1>(nullptr, img, N::z_off(1), d2, lane, 0);
+            ZERO64(d1, 13) seq_mm<SQ, 14>(d2, d1, ring, ws, 0); lrelu_bwd_mask(d1, m1);
+        }
+        publish<200, false, 1>(nullptr, img, N::z_off(0), d1, lane, 0);
+    }
+#undef ZERO64
+    // loss partial of this 16-row block: the wave's lanes in a fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lacc += __shfl_down(lacc, off);
+    if (lane == 0) loss_part[blk] = lacc;
+}
+
 // ---- fp64 throughput inference: encode / decode / forward + loss at any row count ---------------------------------------------
 // The reference computes in fp64 (models.py:128-136); until round 3 bamd_encode / bamd_decode / bamd_forward_loss of an F64 handle
 // ran layer by layer (activations through HBM, LDS-tiled GEMMs).  Here every WAVE pushes its own 16 rows through the layers with
@@ -683,6 +844,7 @@ State64 *st64(bamd_handle *h) { return (State64 *)h->fused64_state; }
 template <int F, int Z> struct Impl64 {
     using N = Net64<F, Z>;
     static constexpr int kLds = (2 * 13 * 64 + (N::bf_off(N::L) - N::bf_off(0))) * 32;
+    static constexpr int kLdsR = (N::bf_off(N::L) - N::bf_off(0)) * 32;       // chain64r_kernel: the bias fragments only
     static bool matches(const bamd_handle *h) {
         if (h->L != 8) return false;
         for (int i = 0; i <= 8; ++i)
@@ -791,9 +953,19 @@ template <int F, int Z> struct Impl64 {
         for (int k = 0; k < nchunk; ++k) {
             const int64_t r0 = k * chunk, rows = std::min(n - r0, chunk);
             const int nblk = (int)((rows + 15) / 16);
-            hipLaunchKernelGGL((chain64_kernel<F, Z, 4>), dim3(nblk), dim3(256), kLds, s, (const d4 *)st->packed.p,
-                               (const void *)((const char *)x + (size_t)r0 * F * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
-                               (double *)h->lossp.p + r0 / 16);
+            // one wave per 16-row block (register chain) once the blocks fill the chip's wave slots (1,024 blocks = one wave per SIMD:
+            // 16,384 rows 0.233 -> 0.201 ms, 8,192 rows 0.123 -> 0.141); one workgroup per block below.  BALER_AMD_F64_REGCHAIN_BLKS
+            // moves the switch (0: always, read per call: the parity tests run both kernels on the same batch)
+            const char *re = getenv("BALER_AMD_F64_REGCHAIN_BLKS");
+            const int64_t rmin = re ? atoll(re) : 1024;
+            if (nblk_all >= rmin)
+                hipLaunchKernelGGL((chain64r_kernel<F, Z>), dim3((nblk + 3) / 4), dim3(256), kLdsR, s, (const d4 *)st->packed.p,
+                                   (const void *)((const char *)x + (size_t)r0 * F * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
+                                   (double *)h->lossp.p + r0 / 16, nblk);
+            else
+                hipLaunchKernelGGL((chain64_kernel<F, Z, 4>), dim3(nblk), dim3(256), kLds, s, (const d4 *)st->packed.p,
+                                   (const void *)((const char *)x + (size_t)r0 * F * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
+                                   (double *)h->lossp.p + r0 / 16);
             if (macro) {
                 const int ns = splits_of(nblk);
                 if (big)

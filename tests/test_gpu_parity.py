@@ -287,6 +287,31 @@ def test_fp64_fused_step_ragged(n, data10k):
     assert rel(g4.cpu().numpy()[:-1], go2) < TOL64
 
 
+@pytest.mark.parametrize("n", [1, 33, 1000, 16385, 70001])
+def test_fp64_register_chain_equals_exchange_chain(n, monkeypatch):
+    """The two fp64 training chains -- one workgroup per 16-row block exchanging every layer through LDS (chain64_kernel: the 512-row
+    step) and one WAVE per block with the activations in registers and the LeakyReLU signs in bit masks (chain64r_kernel: from 1,024
+    blocks on) -- write the same images bit for bit (every output element accumulates its k blocks in the same order), so the
+    gradients are IDENTICAL and only the loss sum (another order over the block's lanes) may differ in its last bits.  Both against
+    the oracle at 1e-11; normalise-on-load through both."""
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 23)
+    raw = synth.cms_rows(n, row0=11)
+    feats = orc.find_minmax(synth.cms_rows(max(n, 64), row0=11))
+    x = (raw - feats[0]) / feats[1]
+    h, p = make_handle(dims, flat, "fp64")
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    got = {}
+    for tag, blks in (("registers", "0"), ("exchange", "1000000000")):
+        monkeypatch.setenv("BALER_AMD_F64_REGCHAIN_BLKS", blks)
+        g = torch.zeros_like(p)
+        h.fwd_bwd(dev(raw), g, features=dev(feats))
+        got[tag] = g.cpu().numpy()
+        assert rel(got[tag][:-1], go) < TOL64 and abs(got[tag][-1] - lo) < TOL64 * max(lo, 1e-300), tag
+    assert np.array_equal(got["registers"][:-1], got["exchange"][:-1])
+    assert abs(got["registers"][-1] - got["exchange"][-1]) <= 1e-13 * max(abs(got["exchange"][-1]), 1e-300)
+
+
 @pytest.mark.parametrize("n,chunk", [(70001, 4096), (20000, 16), (300_001, None), (1_000_003, None)])
 def test_fp64_fused_step_beyond_one_chunk(n, chunk, monkeypatch):
     """fp64 batches beyond 262,144 rows (the images of the fused pair take 13 KB per row) run chunk after chunk over the same image
