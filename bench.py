@@ -527,7 +527,7 @@ def main():
             # over one image buffer (fused64.hip, round 4); and the 65,536-row point of rounds 2-3 beside it
             for key, n64t in (("train_f64", a.rows), ("train_f64_64k", min(a.rows, 65536))):
                 ms = event_ms(lambda: h64.fwd_bwd(x[:n64t], g64), 3)
-                extra_roof[key] = {"bound": "mfma", "kernel": "bamd_fwd_bwd, BAMD_MODE_F64 (chain64_kernel + dw64m_kernel per 262,144-row chunk + one finishing dw64_kernel: the fused pair, weight-gradient tiles in 16-tile blocks oriented per layer from 16,384 rows on, 2 x 4 blocks below)", "rows": n64t,
+                extra_roof[key] = {"bound": "mfma", "kernel": "bamd_fwd_bwd, BAMD_MODE_F64 (chain64r_kernel (one wave per 16-row block, activations in registers; chain64_kernel below 1,024 blocks) + dw64m_kernel per 262,144-row chunk + one finishing dw64_kernel: the fused pair, weight-gradient tiles in 16-tile blocks oriented per layer from 16,384 rows on, 2 x 4 blocks below)", "rows": n64t,
                                    "launch_ms": ms, "unit": "TFLOP/s", "achieved": FLOP_TRAIN_ROW * n64t / ms / 1e9, "peak": PEAK_TFLOPS["fp64"],
                                    "frac": FLOP_TRAIN_ROW * n64t / ms / 1e9 / PEAK_TFLOPS["fp64"], "rows_per_s": n64t / ms * 1e3}
             t64 = {"t": 0}

@@ -17,7 +17,7 @@ R = os.path.join(REPO, "gpurun_out", "r4p")
 KEYS = (("train_dec_kernel", "train_dec"), ("train_enc_kernel", "train_enc"), ("reduce_slabs_k", "reduce_slabs"),
         ("lat2_chain_kernel", "lat2_chain"), ("lat4_chain_kernel", "lat4_chain"), ("lat2_dw_kernel", "lat2_dw"), ("adam_k", "adam_k"),
         ("infer64_kernel<ENCODE>", "infer64_kernel<24, 15, 0>"), ("infer64_kernel<DECODE>", "infer64_kernel<24, 15, 1>"),
-        ("infer64_kernel<FORWARD>", "infer64_kernel<24, 15, 2>"), ("chain64_kernel", "chain64_kernel"), ("dw64m_kernel", "dw64m_kernel"), ("dw64_kernel", "dw64_kernel"),
+        ("infer64_kernel<FORWARD>", "infer64_kernel<24, 15, 2>"), ("chain64_kernel", "chain64_kernel<"), ("chain64r_kernel", "chain64r_kernel"), ("dw64m_kernel", "dw64m_kernel"), ("dw64_kernel", "dw64_kernel"),
         ("bf16_train_kernel<PART 0>", "bf16_train_kernel<24, 15, 0>"), ("bf16_train_kernel<PART 1>", "bf16_train_kernel<24, 15, 1>"),
         ("reduce_tiles_k", "reduce_tiles_k"),
         ("wide_encode_lds_kernel", "wide_encode_lds_kernel<2500, 25"), ("wide_infer_kernel<DECODE>", "wide_infer_kernel<2500, 25, 1"), ("wide_decode_lds_kernel", "wide_decode_lds_kernel<2500, 25"),
