@@ -378,7 +378,8 @@ def main():
         pass
     out["roofline"] = {
         "bound": "mfma",
-        "kernel": "bamd_fwd_bwd = train_dec_kernel + train_enc_kernel + partial-gradient reduction",
+        "kernel": ("bamd_fwd_bwd = train_dec_kernel + train_enc_kernel + partial-gradient reduction" if a.mode == "fp32" else
+                   "bamd_fwd_bwd, BAMD_MODE_F64 = chain64r_kernel + dw64m_kernel per 262,144-row chunk + one finishing dw64_kernel"),
         "achieved": achieved, "peak": PEAK_TFLOPS[a.mode], "unit": "TFLOP/s",
         "frac": achieved / PEAK_TFLOPS[a.mode], "traffic": traffic,
         "launch_ms": k_ms, "algorithmic_flop_per_row": FLOP_TRAIN_ROW, "rows_per_launch": a.rows,
