@@ -169,3 +169,36 @@ def test_decode_fused_renormalise_nan_latent():
     cols = mask == 0
     assert rel(out[ok][:, cols], want[ok][:, cols]) < 1e-5
     assert np.mean(out[ok][:, ~cols] == want[ok][:, ~cols]) > 0.99
+
+
+@pytest.mark.parametrize("shape", [(2500, 25), (512, 6)])
+def test_wide_bf16_loader_kernels_keep_a_nan_in_its_row(shape):
+    """The bf16 encode of the wide models streams rows through an LDS ring shared by four compute waves and two loader waves, the
+    decode stores 256-byte windows assembled from an 8-tile ring: a NaN / inf cell must poison exactly its own row (latent /
+    reconstruction), whichever ring slot, row tile or window it travels through, and every other row must equal the clean run's."""
+    F, Z = shape
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 3)
+    h = native.Handle(dims, "bf16")
+    h.load_params(dev(np.concatenate([flat, [0.0]]), torch.float32))
+    n = 777                                              # six full 128-row groups + a ragged one
+    rng = np.random.default_rng(9)
+    x = rng.random((n, F)).astype(np.float32)
+    clean = h.encode(dev(x), out_dtype=torch.float32).cpu().numpy()
+    bad_rows = [0, 127, 128, 300, 776]
+    xb = x.copy()
+    for k, r in enumerate(bad_rows):
+        xb[r, (37 * k + 5) % F] = np.nan if k % 2 == 0 else np.inf
+    z = h.encode(dev(xb), out_dtype=torch.float32).cpu().numpy()
+    ok = np.ones(n, dtype=bool)
+    ok[bad_rows] = False
+    assert not np.isfinite(z[bad_rows]).all(axis=1).any(), "a poisoned row came out finite"
+    assert np.isfinite(z[ok]).all() and np.array_equal(z[ok], clean[ok])
+    zc = rng.normal(size=(n, Z)).astype(np.float32)
+    dclean = h.decode(dev(zc)).cpu().numpy()
+    zb = zc.copy()
+    for r in bad_rows:
+        zb[r, r % Z] = np.nan
+    d = h.decode(dev(zb)).cpu().numpy()
+    assert np.isnan(d[bad_rows]).all(), "a NaN latent must reach every column of its row"
+    assert np.isfinite(d[ok]).all() and np.array_equal(d[ok], dclean[ok])
