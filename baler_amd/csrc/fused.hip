@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(256) infer_kernel(const v4 *packed, const void
         asm volatile("" : "+v"(ws.voff));
         if (KIND == K_ENCODE || KIND == K_FORWARD) {
             v4 a0[tiles(F)], a1[13], a2[7], a3[4], a4[tiles(Z)];
-            if (F > 64) load_rows_wide<F>(a0, xin, in_f64, row, valid, lane, feats);
+            if (F > 64 && !RT) load_rows_wide<F>(a0, xin, in_f64, row, valid, lane, feats);
             else load_rows<F, RT>(a0, xin, in_f64, row, valid, lane, feats, fr);
             fwd_layer<N, S, 0>(a0, a1, ring, ws, bias_lds, lane);
             fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
@@ -3595,8 +3595,8 @@ template <int F, int Z, bool RT = false> struct Impl {
     }
     static int decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features, const uint8_t *int_mask,
                       void *out, int out_dtype, hipStream_t s) {
-        if (infer_pair()) {
-            hipLaunchKernelGGL((infer2_kernel<F, Z, K_DECODE, RT>), dim3(infer_grid((n + 1) / 2)), dim3(256), 0, s,
+        if (F <= 64 && infer_pair()) {
+            hipLaunchKernelGGL((infer2_kernel<F <= 64 ? F : 24, Z, K_DECODE, RT>), dim3(infer_grid((n + 1) / 2)), dim3(256), 0, s,
                                (const v4 *)h->packed.p, z, z_dtype == BAMD_F64, n, features, out, out_dtype == BAMD_F64, int_mask, fr(h), zr(h));
             BAMD_HIP(hipGetLastError());
             return BAMD_OK;
@@ -3725,18 +3725,20 @@ template <int F, int Z, bool RT = false> struct Impl {
 // are the register-chained kernels above (they have no images), training steps of up to 12288 rows run on the small-batch kernels
 // (their images live in global memory) -- the reference's 512-row steps -- and larger batches on the layer-wise kernels
 // (generic_fwd_bwd below; bamd_train_step falls through on BAMD_ERR_UNSUPPORTED).  bamd_path_of() = BAMD_PATH_FUSED_INFER.
-template <int F, int Z> struct ImplInferClass {
+template <int F, int Z, bool SMALL = true> struct ImplInferClass {
     using B = Impl<F, Z, true>;
-    static_assert(F <= 63 && F % 16 == 15 && Z % 16 == 15, "class widths are 16 T - 1; the two-tile inference kernels take up to 4 input tiles");
+    static_assert(F % 16 == 15 && Z % 16 == 15 && (F <= 63 || !SMALL), "class widths are 16 T - 1; the small-batch chain takes up to 4 input tiles");
     static bool matches(const bamd_handle *h) { return B::matches(h); }
-    static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, true>(h, st); }
+    static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, SMALL>(h, st); }
     static int fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, hipStream_t s) {
-        if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
+        if constexpr (SMALL)
+            if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
         return generic_fwd_bwd(h, x, x_dtype, n, features, grads, s);
     }
     static int train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
                           const AdamArgs &ad, hipStream_t s) {
-        if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, &ad, s);
+        if constexpr (SMALL)
+            if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, &ad, s);
         return BAMD_ERR_UNSUPPORTED;
     }
     static const FusedOps *ops() {
@@ -4141,6 +4143,7 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     if (Impl<47, 31, true>::matches(h)) return Impl<47, 31, true>::ops();
     if (ImplInferClass<63, 15>::matches(h)) return ImplInferClass<63, 15>::ops();
     if (ImplInferClass<63, 31>::matches(h)) return ImplInferClass<63, 31>::ops();
+    if (ImplInferClass<79, 31, false>::matches(h)) return ImplInferClass<79, 31, false>::ops();      // 64..79 columns: inference only (one tile per wave)
     if (ImplWide<512, 6>::matches(h)) return ImplWide<512, 6>::ops();
     if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();
     if (ImplWide<625, 7>::matches(h)) return ImplWide<625, 7>::ops();

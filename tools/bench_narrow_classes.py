@@ -18,7 +18,7 @@ def ms(fn, reps=5):
         best = min(best, e0.elapsed_time(e1) / reps)
     return best
 n = 1_000_000
-for F, Z in ((24, 15), (25, 10), (31, 15), (16, 4), (33, 8), (47, 15), (24, 16), (47, 31), (48, 12), (63, 31), (64, 16)):
+for F, Z in ((24, 15), (25, 10), (31, 15), (16, 4), (33, 8), (47, 15), (24, 16), (47, 31), (48, 12), (63, 31), (64, 16), (79, 31), (80, 16)):
     dims = orc.ae_dims(F, Z)
     h = native.Handle(dims, "fp32")
     p = torch.from_numpy(np.concatenate([orc.formula_params(dims, 1), [0.0]]).astype(np.float32)).cuda()
