@@ -124,7 +124,7 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
             for (int l = 0; l <= n_layers; ++l) d += (l ? "-" : "") + std::to_string(dims[l]);
             fprintf(stderr, "[baler_amd] model %s (%s) has no fused %s: %s run layer by layer (generic.hip, activations through HBM)\n",
                     d.c_str(), mode == BAMD_MODE_F64 ? "fp64" : mode == BAMD_MODE_BF16 ? "bf16" : "fp32",
-                    path == BAMD_PATH_GENERIC ? "kernel instantiation" : "throughput training kernels (encode / decode / validation are fused; up to 63 columns also training steps of up to 12288 rows)",
+                    path == BAMD_PATH_GENERIC ? "kernel instantiation" : "throughput training kernels (encode / decode / validation and training steps of up to 12288 rows are fused)",
                     path == BAMD_PATH_GENERIC ? "encode / decode / training" : "larger training batches");
         }
     }

@@ -2717,7 +2717,7 @@ __global__ void __launch_bounds__(64 * W) lat2_chain_kernel(const v4 *packed, co
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
     WStream ws = make_stream(packed, N::packed_f4() * 16, lane);
     constexpr int TF = tiles(F), TZ = tiles(Z);
-    static_assert(TF <= 4 && TZ <= 2, "input / latent tiles");
+    static_assert(TF <= 8 && TZ <= 2, "input / latent tiles");
     LAT_T(0);
     // the rows first (layer 0 waits for them), then the ring's first D fragments queue up behind them
     const int64_t row = (int64_t)blockIdx.x * 16 + (lane & 15);
@@ -2811,16 +2811,21 @@ __global__ void __launch_bounds__(64 * W) lat2_chain_kernel(const v4 *packed, co
     }
     // ---------------- loss, dL/drecon ----------------
     double lacc = 0.0;
-    {
-        const int t = wave;                       // LF == 1: at most one recon tile per wave
-        static_assert(LF == 1, "recon tiles per wave");
-        const v4 x0 = a0[t < TF ? t : TF - 1];
+#pragma unroll
+    for (int i = 0; i < LF; ++i) {                // this wave's recon tiles wave, wave + W, ... (one up to 63 columns, two in the 79-column class)
+        const int t = wave + W * i, tc = t < TF ? t : TF - 1;
+        v4 x0 = a0[0];
+#pragma unroll
+        for (int u = 1; u < TF; ++u) x0 = tc == u ? a0[u] : x0;       // (register select: a run-time index would put a0 in scratch)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float d = o8[0][r] - x0[r];
-            const bool live = valid && t < TF && slot_feature(F, t < TF ? t : TF - 1, g, r) >= 0;
+            float d = o8[i][r] - x0[r];
+            bool live = false;
+#pragma unroll
+            for (int u = 0; u < TF; ++u) live = live || (tc == u && slot_feature(F, u, g, r) >= 0);
+            live = live && valid && t < TF;
             if (live) lacc += (double)d * (double)d;
-            o8[0][r] = live ? d * (2.0f / (float)(RT ? fr : F)) : 0.f;
+            o8[i][r] = live ? d * (2.0f / (float)(RT ? fr : F)) : 0.f;
         }
     }
     // ---------------- backward chain (input gradients), publishing dZ images ----------------
@@ -3721,13 +3726,13 @@ template <int F, int Z, bool RT = false> struct Impl {
     }
 };
 
-// Classes beyond what the throughput training pair's LDS images hold (48..63 columns: 164 KB): encode / decode / forward + loss
+// Classes beyond what the throughput training pair's LDS images hold (48..79 columns: 164 KB and more): encode / decode / forward + loss
 // are the register-chained kernels above (they have no images), training steps of up to 12288 rows run on the small-batch kernels
 // (their images live in global memory) -- the reference's 512-row steps -- and larger batches on the layer-wise kernels
 // (generic_fwd_bwd below; bamd_train_step falls through on BAMD_ERR_UNSUPPORTED).  bamd_path_of() = BAMD_PATH_FUSED_INFER.
 template <int F, int Z, bool SMALL = true> struct ImplInferClass {
     using B = Impl<F, Z, true>;
-    static_assert(F % 16 == 15 && Z % 16 == 15 && (F <= 63 || !SMALL), "class widths are 16 T - 1; the small-batch chain takes up to 4 input tiles");
+    static_assert(F % 16 == 15 && Z % 16 == 15 && (F <= 79 || !SMALL), "class widths are 16 T - 1; the small-batch chain takes up to 5 input tiles");
     static bool matches(const bamd_handle *h) { return B::matches(h); }
     static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, SMALL>(h, st); }
     static int fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, hipStream_t s) {
@@ -4143,7 +4148,7 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     if (Impl<47, 31, true>::matches(h)) return Impl<47, 31, true>::ops();
     if (ImplInferClass<63, 15>::matches(h)) return ImplInferClass<63, 15>::ops();
     if (ImplInferClass<63, 31>::matches(h)) return ImplInferClass<63, 31>::ops();
-    if (ImplInferClass<79, 31, false>::matches(h)) return ImplInferClass<79, 31, false>::ops();      // 64..79 columns: inference only (one tile per wave)
+    if (ImplInferClass<79, 31, true>::matches(h)) return ImplInferClass<79, 31, true>::ops();      // 64..79 columns: one-tile inference kernels, small-batch training
     if (ImplWide<512, 6>::matches(h)) return ImplWide<512, 6>::ops();
     if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();
     if (ImplWide<625, 7>::matches(h)) return ImplWide<625, 7>::ops();

@@ -828,9 +828,9 @@ def test_any_narrow_table_runs_fused(F, Z):
 def test_wider_narrow_tables_say_where_they_run(F, Z, path):
     """Up to 47 columns with a latent of up to 31: full class instantiations (every kernel).  48..63 columns: encode / decode /
     forward + loss on the fused kernels, training on the small-batch kernels up to 12288 rows and layer by layer beyond (the
-    throughput pair's images of a 63-column class need 164 KB of LDS); 64..79 columns: the fused inference kernels only (one row
-    tile per wave), training layer by layer; wider still, or a latent above 31, everything layer by layer.  Correct either way,
-    and bamd_path_of says which."""
+    throughput pair's images of a 63-column class need 164 KB of LDS); 64..79 columns the same on the one-tile inference kernels
+    (two recon tiles per wave in the small-batch chain); wider still, or a latent above 31, everything layer by layer.  Correct
+    either way, and bamd_path_of says which."""
     dims = orc.ae_dims(F, Z)
     flat = orc.formula_params(dims, 7)
     h, p = make_handle(dims, flat, "fp32")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep of the class instantiations: random (columns, latent) pairs up to 63 x 31 and random row counts;
+"""Randomised parity sweep of the class instantiations: random (columns, latent) pairs up to 79 x 31 and random row counts;
 encode / decode / forward + loss / fwd_bwd (small-batch and throughput sizes) of the fp32 kernels against the fp64 oracle.
 python tools/fuzz_narrow_classes.py [shapes] [seed]      (GPU box; the oracle is the checker here, as in tests/)"""
 import os, sys
@@ -17,7 +17,7 @@ rng = np.random.default_rng(seed)
 worst, fails = 0.0, 0
 os.environ["BALER_AMD_QUIET"] = "1"
 for k in range(count):
-    F, Z = int(rng.integers(1, 64)), int(rng.integers(1, 32))
+    F, Z = int(rng.integers(1, 80)), int(rng.integers(1, 32))
     dims = orc.ae_dims(F, Z)
     flat = orc.formula_params(dims, 1000 + k)
     h = native.Handle(dims, "fp32")
