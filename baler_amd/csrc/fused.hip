@@ -2308,6 +2308,11 @@ __device__ __forceinline__ void dw_flush(v4 *__restrict__ slab, const v4 (&acc)[
 // Image buffers alternate between two LDS regions (A: 240 slot rows, B: 320 slot rows) so that the next
 // layer's image writes never touch what a slower wave is still reading: ONE barrier per layer.
 constexpr int kImgB = 320;
+template <class N> constexpr int img_a_rows();
+// the bias fragments sit in LDS behind the images when both fit the 160 KB; the 63-column class reads them from the packed copy (L2)
+template <class N> constexpr bool train_bias_in_lds() {
+    return (img_a_rows<N>() + 320) * 68 * 4 + (N::bf_off(8) - N::bf_off(0)) * 16 <= 160 * 1024;
+}
 template <class N> constexpr int img_a_rows() {     // 240 up to 31 columns, 256 for the 47-column class (its [X_7 | dZ_7] and [X_0 | dZ_0] images)
     int m = 240;
     const int need[] = {DW<N, 7>::rows_x + DW<N, 7>::rows_dz, DW<N, 5>::rows_x + DW<N, 5>::rows_dz, DW<N, 2>::rows_x + DW<N, 2>::rows_dz,
@@ -2327,8 +2332,12 @@ __global__ void __launch_bounds__(256) train_dec_kernel(const v4 *packed, const 
                   DW<N, 5>::rows_x + DW<N, 5>::rows_dz <= kImgA && DW<N, 4>::rows_x + DW<N, 4>::rows_dz <= kImgB, "image buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *imgA = lds, *imgB = lds + kImgA * kQS;
-    v4 *bias_lds = (v4 *)(lds + (kImgA + kImgB) * kQS);
-    stage_bias<N>(bias_lds, packed);
+    const v4 *bias_lds = packed + N::bf_off(0);
+    if constexpr (train_bias_in_lds<N>()) {
+        v4 *stage = (v4 *)(lds + (kImgA + kImgB) * kQS);
+        stage_bias<N>(stage, packed);
+        bias_lds = stage;
+    }
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     v4 *slab = slabs + (int64_t)blockIdx.x * 64;   // column of this workgroup in the [tile][workgroup][lane] buffer
     const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
@@ -2460,8 +2469,12 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
     static_assert(DW<N, 1>::rows_x + DW<N, 1>::rows_dz <= kImgB && DW<N, 0>::rows_x + DW<N, 0>::rows_dz <= kImgA, "image buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *imgA = lds, *imgB = lds + kImgA * kQS;
-    v4 *bias_lds = (v4 *)(lds + (kImgA + kImgB) * kQS);
-    stage_bias<N>(bias_lds, packed);
+    const v4 *bias_lds = packed + N::bf_off(0);
+    if constexpr (train_bias_in_lds<N>()) {
+        v4 *stage = (v4 *)(lds + (kImgA + kImgB) * kQS);
+        stage_bias<N>(stage, packed);
+        bias_lds = stage;
+    }
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     v4 *slab = slabs + (int64_t)blockIdx.x * 64;   // column of this workgroup in the [tile][workgroup][lane] buffer
     const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
@@ -2519,8 +2532,12 @@ __global__ void __launch_bounds__(256) train_enc_kernel(const v4 *packed, const 
                   DW<N, 1>::rows_x + DW<N, 1>::rows_dz <= kImgB && DW<N, 0>::rows_x + DW<N, 0>::rows_dz <= kImgA, "image buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *imgA = lds, *imgB = lds + kImgA * kQS;   // layers 3,1 -> B ; layers 2,0 -> A : one barrier per layer
-    v4 *bias_lds = (v4 *)(lds + (kImgA + kImgB) * kQS);
-    stage_bias<N>(bias_lds, packed);
+    const v4 *bias_lds = packed + N::bf_off(0);
+    if constexpr (train_bias_in_lds<N>()) {
+        v4 *stage = (v4 *)(lds + (kImgA + kImgB) * kQS);
+        stage_bias<N>(stage, packed);
+        bias_lds = stage;
+    }
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     v4 *slab = slabs + (int64_t)blockIdx.x * 64;   // column of this workgroup in the [tile][workgroup][lane] buffer
     const int64_t ngroups = (n + kRowsPerWG - 1) / kRowsPerWG;
@@ -3571,7 +3588,7 @@ template <int F, int Z, bool RT = false> struct Impl {
             if (h->dims[i] != N::dim(i)) return false;
         return true;
     }
-    static constexpr int train_lds = (img_a_rows<N>() + kImgB) * kQS * (int)sizeof(float) + (N::bf_off(8) - N::bf_off(0)) * 16;      // images + bias fragments
+    static constexpr int train_lds = (img_a_rows<N>() + kImgB) * kQS * (int)sizeof(float) + (train_bias_in_lds<N>() ? (N::bf_off(8) - N::bf_off(0)) * 16 : 0);      // images (+ bias fragments)
     static int fr(const bamd_handle *h) { return h->dims[0]; }
     static int zr(const bamd_handle *h) { return h->dims[4]; }
     static int setup(bamd_handle *h, FusedState *st) {
@@ -3726,7 +3743,7 @@ template <int F, int Z, bool RT = false> struct Impl {
     }
 };
 
-// Classes beyond what the throughput training pair's LDS images hold (48..79 columns: 164 KB and more): encode / decode / forward + loss
+// Classes beyond what the throughput training pair's LDS images hold (64..79 columns: 165 KB): encode / decode / forward + loss
 // are the register-chained kernels above (they have no images), training steps of up to 12288 rows run on the small-batch kernels
 // (their images live in global memory) -- the reference's 512-row steps -- and larger batches on the layer-wise kernels
 // (generic_fwd_bwd below; bamd_train_step falls through on BAMD_ERR_UNSUPPORTED).  bamd_path_of() = BAMD_PATH_FUSED_INFER.
@@ -4138,16 +4155,15 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     }
     if (h->mode != BAMD_MODE_F32) return nullptr;
     BAMD_AE24_ALL
-    // any other narrow table: the class instantiations (run-time widths; Impl<F, Z, true>): up to 47 columns with a latent of up to
-    // 31 on every kernel, 48..63 columns on the inference and small-batch kernels (ImplInferClass).  64 columns and more, or a
-    // latent above 31, run on generic.hip (the two-tile inference kernels take 4 input tiles, the small-batch chain 2 latent
-    // tiles) -- DESIGN.md section 8
+    // any other narrow table: the class instantiations (run-time widths; Impl<F, Z, true>): up to 63 columns with a latent of up to
+    // 31 on every kernel, 64..79 columns on the one-tile inference and the small-batch kernels (ImplInferClass).  80 columns and
+    // more, or a latent above 31, run on generic.hip -- DESIGN.md section 8
     if (Impl<31, 15, true>::matches(h)) return Impl<31, 15, true>::ops();
     if (Impl<47, 15, true>::matches(h)) return Impl<47, 15, true>::ops();
     if (Impl<31, 31, true>::matches(h)) return Impl<31, 31, true>::ops();
     if (Impl<47, 31, true>::matches(h)) return Impl<47, 31, true>::ops();
-    if (ImplInferClass<63, 15>::matches(h)) return ImplInferClass<63, 15>::ops();
-    if (ImplInferClass<63, 31>::matches(h)) return ImplInferClass<63, 31>::ops();
+    if (Impl<63, 15, true>::matches(h)) return Impl<63, 15, true>::ops();
+    if (Impl<63, 31, true>::matches(h)) return Impl<63, 31, true>::ops();
     if (ImplInferClass<79, 31, true>::matches(h)) return ImplInferClass<79, 31, true>::ops();      // 64..79 columns: one-tile inference kernels, small-batch training
     if (ImplWide<512, 6>::matches(h)) return ImplWide<512, 6>::ops();
     if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();

@@ -741,7 +741,7 @@ def other_configs(dev):
     hw_.close()
     del xw
     # narrow tables other than the 24-column one (models.py:122-139 builds AE(n_features, z_dim) for any width): class instantiations
-    # with run-time widths up to 47 columns / a latent of 31; 48..63 columns fused for inference and small batches, 64..79 for inference; beyond: layer-wise
+    # with run-time widths up to 63 columns / a latent of 31; 64..79 columns fused for inference and small batches; beyond: layer-wise
     n = 1_000_000
     res["narrow_tables"] = {}
     for F, Z in ((30, 8), (47, 31), (63, 31), (64, 16), (80, 16)):

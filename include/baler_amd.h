@@ -98,7 +98,7 @@ void bamd_destroy(bamd_handle *h);
  * CFD_dense_AE(625, 7) (exafel1_config.py:14-15,33: 25 x 25 blocks) and the 512-column model; an F64 handle of the 24-column AE
  * has fused fp64 kernels for inference and for training steps of any size (chunks of 262144 rows over one image buffer).
  * Any other narrow table of the reference's AE (hidden widths 200-100-50) is served by a CLASS instantiation with run-time widths:
- * up to 47 columns with a latent of up to 31 by all kernels (BAMD_PATH_FUSED); 48..79 columns by the fused inference kernels and,
+ * up to 63 columns with a latent of up to 31 by all kernels (BAMD_PATH_FUSED); 64..79 columns by the fused inference kernels and,
  * for training steps of up to 12288 rows, the small-batch kernels (BAMD_PATH_FUSED_INFER: larger training batches of such a
  * handle run layer by layer).
  * Any other shape runs on the layer-wise kernels (activations through HBM, 2-7x slower):
@@ -108,7 +108,7 @@ typedef enum bamd_path {
     BAMD_PATH_GENERIC = 0,   /* generic.hip: LDS-tiled MFMA GEMM per layer */
     BAMD_PATH_FUSED = 1,     /* fused.hip: register chain (24-column AE) or streamed wide layers + chain */
     BAMD_PATH_BF16 = 2,      /* bf16.hip / bf16_train.hip (24-column AE, BAMD_MODE_BF16); its small batches use the fused fp32 step */
-    BAMD_PATH_FUSED_INFER = 3 /* 48..79 columns: fused.hip for encode / decode / forward + loss and for training steps of up to 12288 rows,
+    BAMD_PATH_FUSED_INFER = 3 /* 64..79 columns: fused.hip for encode / decode / forward + loss and for training steps of up to 12288 rows,
                               * generic.hip for larger training batches */
 } bamd_path;
 int bamd_path_of(const bamd_handle *h);   /* a bamd_path, or BAMD_ERR_INVALID for a null handle */

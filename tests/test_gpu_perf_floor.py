@@ -138,7 +138,7 @@ def test_round4_kernel_floors():
     """Round 4: class instantiations for other narrow tables (AE(30, 8): every kernel; AE(48, 12): inference + small-batch training),
     the fp64 fused training step with per-layer tile blocks at 262,144 rows, bf16 encode of the 512-column model."""
     n = 1_000_000
-    for (F, Z), path, lim_e, lim_t, lim_s in (((30, 8), "fused", 0.635, 3.99, 27.6), ((48, 12), "fused-infer", 0.86, None, 30.0)):
+    for (F, Z), path, lim_e, lim_t, lim_s in (((30, 8), "fused", 0.635, 3.99, 27.6), ((48, 12), "fused", 0.86, 4.9, 30.0)):
         dims = orc.ae_dims(F, Z)
         h = native.Handle(dims, "fp32")
         assert h.path == path
