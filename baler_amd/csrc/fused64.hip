@@ -157,10 +157,10 @@ __device__ __forceinline__ void publish(d4 *xch, double *img, int slot0, const d
     }
 }
 
-template <int F, int Z, int W>
+template <int F, int Z, int W, bool RT = false>
 __global__ void __launch_bounds__(64 * W) chain64_kernel(const d4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
                                                          const double *__restrict__ feats, double *__restrict__ imgs,
-                                                         double *__restrict__ loss_part) {
+                                                         double *__restrict__ loss_part, int fr) {
     using N = Net64<F, Z>;
     constexpr int TF = tiles(F), TZ = tiles(Z);
     static_assert(TF <= W && TZ == 1 && F % 16 != 0, "input / latent tiles");
@@ -175,17 +175,19 @@ __global__ void __launch_bounds__(64 * W) chain64_kernel(const d4 *packed, const
     // rows first (layer 0 waits for them), then the ring's first fragments queue up behind them
     const int64_t row = (int64_t)blockIdx.x * 16 + (lane & 15);
     const bool valid = row < n;
-    const int64_t rbase = (valid ? row : 0) * F;
+    const int fw = RT ? fr : F;                                    // the table's real width (row stride, valid features, loss scale)
+    const int64_t rbase = (valid ? row : 0) * fw;
     d4 a0[TF];
 #pragma unroll
     for (int t = 0; t < TF; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = creg_feature(F, t, g, r);
-            const int fc = f >= 0 ? f : 0;                        // padding slots read feature 0 (finite, meets zero weights)
+            const bool live = f >= 0 && (!RT || f < fr);
+            const int fc = live ? f : 0;                          // padding slots read feature 0 (finite, meets zero weights)
             double v = in_f64 ? ((const double *)xin)[rbase + fc] : (double)((const float *)xin)[rbase + fc];
-            if (feats) v = (v - feats[fc]) / feats[F + fc];
-            a0[t][r] = f >= 0 ? v : 0.0;
+            if (feats) v = (v - feats[fc]) / feats[fw + fc];
+            a0[t][r] = live ? v : 0.0;
         }
     using SQ = Seq<N, W, 12>;
     d4 ring[SQ::D];
@@ -238,9 +240,9 @@ __global__ void __launch_bounds__(64 * W) chain64_kernel(const d4 *packed, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double d = o8[0][r] - x0[r];
-            const bool live = valid && wave < TF && creg_feature(F, t, g, r) >= 0;
+            const bool live = valid && wave < TF && creg_feature(F, t, g, r) >= 0 && (!RT || creg_feature(F, t, g, r) < fr);
             if (live) lacc += d * d;
-            o8[0][r] = live ? d * (2.0 / (double)F) : 0.0;
+            o8[0][r] = live ? d * (2.0 / (double)fw) : 0.0;
         }
     }
     // ---------------- backward chain (input gradients), publishing dZ images ----------------
@@ -305,10 +307,10 @@ template <int NL> __device__ __forceinline__ void lrelu_bwd_mask(d4 (&d)[NL], un
 #pragma unroll
         for (int r = 0; r < 4; ++r) d[i][r] = ((mask >> (4 * i + r)) & 1ull) ? d[i][r] : d[i][r] * kSlope;
 }
-template <int F, int Z>
+template <int F, int Z, bool RT = false>
 __global__ void __launch_bounds__(256) chain64r_kernel(const d4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
                                                        const double *__restrict__ feats, double *__restrict__ imgs,
-                                                       double *__restrict__ loss_part, int nblk) {
+                                                       double *__restrict__ loss_part, int nblk, int fr) {
     using N = Net64<F, Z>;
     constexpr int TF = tiles(F), TZ = tiles(Z);
     static_assert(TZ == 1 && F % 16 != 0, "input / latent tiles");
@@ -325,17 +327,19 @@ __global__ void __launch_bounds__(256) chain64r_kernel(const d4 *packed, const v
     ws.voff = lane * 32;
     const int64_t row = (int64_t)blk * 16 + (lane & 15);
     const bool valid = row < n;
-    const int64_t rbase = (valid ? row : 0) * F;
+    const int fw = RT ? fr : F;                                    // the table's real width (row stride, valid features, loss scale)
+    const int64_t rbase = (valid ? row : 0) * fw;
     d4 a0[TF];
 #pragma unroll
     for (int t = 0; t < TF; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = creg_feature(F, t, g, r);
-            const int fc = f >= 0 ? f : 0;                        // padding slots read feature 0 (finite, meets zero weights)
+            const bool live = f >= 0 && (!RT || f < fr);
+            const int fc = live ? f : 0;                          // padding slots read feature 0 (finite, meets zero weights)
             double v = in_f64 ? ((const double *)xin)[rbase + fc] : (double)((const float *)xin)[rbase + fc];
-            if (feats) v = (v - feats[fc]) / feats[F + fc];
-            a0[t][r] = f >= 0 ? v : 0.0;
+            if (feats) v = (v - feats[fc]) / feats[fw + fc];
+            a0[t][r] = live ? v : 0.0;
         }
     using SQ = Seq<N, 1, 8>;
     d4 ring[SQ::D];
@@ -390,9 +394,9 @@ __global__ void __launch_bounds__(256) chain64r_kernel(const d4 *packed, const v
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double d = o8[t][r] - a0[t][r];
-            const bool live = valid && creg_feature(F, t, g, r) >= 0;
+            const bool live = valid && creg_feature(F, t, g, r) >= 0 && (!RT || creg_feature(F, t, g, r) < fr);
             if (live) lacc += d * d;
-            o8[t][r] = live ? d * (2.0 / (double)F) : 0.0;
+            o8[t][r] = live ? d * (2.0 / (double)fw) : 0.0;
         }
     publish<F, false, 1>(nullptr, img, N::z_off(7), o8, lane, 0);
     // ---------------- backward chain (input gradients), publishing the dZ images ----------------
@@ -497,45 +501,50 @@ __device__ __forceinline__ void ilayer(const d4 (&in)[tiles(SQ::kd(g))], d4 (&ou
     if (N::act(G0 + g)) lrelu(out);
 }
 // rows of width D_ -> register tiles in the f64 accumulator layout (register r of tile t on lane group g = feature 16 t + 4 r + g)
-template <int D_>
+// RT: the instantiation serves a CLASS of narrow tables (D_ = 16 T - 1 is the class width, `dr` the table's real width: row stride,
+// valid features and the min / range pairs come from it; the class's slots beyond it are zeros that meet zero weights) -- as in fused.hip
+template <int D_, bool RT = false>
 __device__ __forceinline__ void load_rows64(d4 (&a)[tiles(D_)], const void *xin, int in_f64, int64_t row, bool valid, int lg,
-                                            const double *__restrict__ feats) {
-    const int64_t rbase = (valid ? row : 0) * D_;
+                                            const double *__restrict__ feats, int dr = D_) {
+    const int dw = RT ? dr : D_;
+    const int64_t rbase = (valid ? row : 0) * dw;
 #pragma unroll
     for (int t = 0; t < tiles(D_); ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = creg_feature(D_, t, lg, r);
-            const int fc = f >= 0 ? f : 0;                        // padding slots read feature 0 (finite, meets zero weights)
+            const bool live = f >= 0 && (!RT || f < dr);
+            const int fc = live ? f : 0;                          // padding slots read feature 0 (finite, meets zero weights)
             double v = in_f64 ? ((const double *)xin)[rbase + fc] : (double)((const float *)xin)[rbase + fc];
-            if (feats) v = (v - feats[fc]) / feats[D_ + fc];
-            a[t][r] = f >= 0 ? v : 0.0;
+            if (feats) v = (v - feats[fc]) / feats[dw + fc];
+            a[t][r] = live ? v : 0.0;
         }
 }
-template <int D_>
+template <int D_, bool RT = false>
 __device__ __forceinline__ void store_rows64(const d4 (&a)[tiles(D_)], void *out, int out_f64, int64_t row, bool valid, int lg,
-                                             const double *__restrict__ renorm, const uint8_t *__restrict__ imask) {
+                                             const double *__restrict__ renorm, const uint8_t *__restrict__ imask, int dr = D_) {
     if (!valid) return;
+    const int dw = RT ? dr : D_;
 #pragma unroll
     for (int t = 0; t < tiles(D_); ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = creg_feature(D_, t, lg, r);
-            if (f < 0) continue;
+            if (f < 0 || (RT && f >= dr)) continue;
             double v = a[t][r];
             if (renorm) {      // norm * range + min with two roundings, then the int-column truncation (elementwise.hip renormalize_k)
-                v = __dadd_rn(__dmul_rn(v, renorm[D_ + f]), renorm[f]);
+                v = __dadd_rn(__dmul_rn(v, renorm[dw + f]), renorm[f]);
                 if (imask && imask[f]) v = trunc(v);
             }
-            if (out_f64) ((double *)out)[row * D_ + f] = v;
-            else ((float *)out)[row * D_ + f] = (float)v;
+            if (out_f64) ((double *)out)[row * dw + f] = v;
+            else ((float *)out)[row * dw + f] = (float)v;
         }
 }
-template <int F, int Z, int KIND>
+template <int F, int Z, int KIND, bool RT = false>
 __global__ void __launch_bounds__(256) infer64_kernel(const d4 *packed, const void *__restrict__ xin, int in_f64, int64_t n,
                                                       const double *__restrict__ feats, void *__restrict__ out, int out_f64,
                                                       const double *__restrict__ renorm, const uint8_t *__restrict__ imask,
-                                                      double *__restrict__ loss_part) {
+                                                      double *__restrict__ loss_part, int fr, int zr) {
     using N = Net64<F, Z>;
     constexpr int G0 = KIND == I_DECODE ? 4 : 0, NGM = KIND == I_FORWARD ? 8 : 4;
     using SQ = ISeq<N, G0, NGM, 8>;
@@ -559,21 +568,21 @@ __global__ void __launch_bounds__(256) infer64_kernel(const d4 *packed, const vo
         const bool valid = row < n;
         if constexpr (KIND == I_DECODE) {
             d4 a4[tiles(Z)], s5[4], s6[7], s7[13], o8[tiles(F)];
-            load_rows64<Z>(a4, xin, in_f64, row, valid, lg, feats);
+            load_rows64<Z, RT>(a4, xin, in_f64, row, valid, lg, feats, zr);
             ilayer<N, SQ, 0, G0>(a4, s5, ring, ws, bias_lds, lg);
             ilayer<N, SQ, 1, G0>(s5, s6, ring, ws, bias_lds, lg);
             ilayer<N, SQ, 2, G0>(s6, s7, ring, ws, bias_lds, lg);
             ilayer<N, SQ, 3, G0>(s7, o8, ring, ws, bias_lds, lg);
-            store_rows64<F>(o8, out, out_f64, row, valid, lg, renorm, imask);
+            store_rows64<F, RT>(o8, out, out_f64, row, valid, lg, renorm, imask, fr);
         } else {
             d4 a0[tiles(F)], s1[13], s2[7], s3[4], s4[tiles(Z)];
-            load_rows64<F>(a0, xin, in_f64, row, valid, lg, feats);
+            load_rows64<F, RT>(a0, xin, in_f64, row, valid, lg, feats, fr);
             ilayer<N, SQ, 0, G0>(a0, s1, ring, ws, bias_lds, lg);
             ilayer<N, SQ, 1, G0>(s1, s2, ring, ws, bias_lds, lg);
             ilayer<N, SQ, 2, G0>(s2, s3, ring, ws, bias_lds, lg);
             ilayer<N, SQ, 3, G0>(s3, s4, ring, ws, bias_lds, lg);
             if constexpr (KIND == I_ENCODE) {
-                store_rows64<Z>(s4, out, out_f64, row, valid, lg, nullptr, nullptr);
+                store_rows64<Z, RT>(s4, out, out_f64, row, valid, lg, nullptr, nullptr, zr);
             } else {
                 d4 s5[4], s6[7], s7[13], o8[tiles(F)];
                 ilayer<N, SQ, 4, G0>(s4, s5, ring, ws, bias_lds, lg);
@@ -585,9 +594,9 @@ __global__ void __launch_bounds__(256) infer64_kernel(const d4 *packed, const vo
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double d = o8[t][r] - a0[t][r];
-                        if (valid && creg_feature(F, t, lg, r) >= 0) lacc += d * d;
+                        if (valid && creg_feature(F, t, lg, r) >= 0 && (!RT || creg_feature(F, t, lg, r) < fr)) lacc += d * d;
                     }
-                if (out) store_rows64<F>(o8, out, out_f64, row, valid, lg, nullptr, nullptr);
+                if (out) store_rows64<F, RT>(o8, out, out_f64, row, valid, lg, nullptr, nullptr, fr);
             }
         }
         iseq_tail<SQ, SQ::real>(ring, ws, std::make_integer_sequence<int, SQ::total - SQ::real>{});      // step over the padding
@@ -621,10 +630,10 @@ enum { DW_WRITE = 0, DW_ADAM = 1 };
 template <class N, int MODE>
 __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ imgs, int nblk, const double *__restrict__ loss_part,
                                                    const int *__restrict__ inv_map, double *__restrict__ grads, Adam64 ad,
-                                                   const double *__restrict__ part, int nsplit) {
+                                                   const double *__restrict__ part, int nsplit, int np, double inv_c) {
     // nsplit == 0: the whole job.  nsplit > 0: the tiles' partial sums over `nsplit` block ranges are in `part` (dw64m_kernel); this
     // launch adds them in range order and finishes (store / Adam).
-    constexpr int T = N::slab_off(N::L), np = N::nparams();
+    constexpr int T = N::slab_off(N::L);       // (np, inv_c: the handle's real parameter count and 1 / columns -- class instantiations)
     constexpr int kPerXcd = (T + 1 + 7) / 8;
     __shared__ __attribute__((aligned(32))) d4 red[4 * 64];
     const int tile = (blockIdx.x & 7) * kPerXcd + (blockIdx.x >> 3);       // XCD c takes a contiguous tile range (see fused.hip)
@@ -632,7 +641,7 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     if (tile == T) {   // loss: fixed-order sum of the per-block partials, / C
         const double s = block_sum_fixed(loss_part, nblk, (double *)red);
         if (threadIdx.x == 0) {
-            const double gl = s * (1.0 / N::dim(0));
+            const double gl = s * inv_c;
             if (grads) grads[np] = gl;
             if (MODE == DW_ADAM && ad.loss_accum) *ad.loss_accum += gl;
         }
@@ -841,27 +850,42 @@ struct Ops64 {
 };
 State64 *st64(bamd_handle *h) { return (State64 *)h->fused64_state; }
 
-template <int F, int Z> struct Impl64 {
+// RT: the instantiation serves every AE(f <= F, z <= Z) with the reference's hidden widths (as Impl<F, Z, true> in fused.hip): the
+// geometry is the class's, the maps and the row I/O follow the handle's real dimensions
+template <int F, int Z, bool RT = false> struct Impl64 {
     using N = Net64<F, Z>;
+    static int fr(const bamd_handle *h) { return h->dims[0]; }
+    static int zr(const bamd_handle *h) { return h->dims[4]; }
     static constexpr int kLds = (2 * 13 * 64 + (N::bf_off(N::L) - N::bf_off(0))) * 32;
     static constexpr int kLdsR = (N::bf_off(N::L) - N::bf_off(0)) * 32;       // chain64r_kernel: the bias fragments only
     static bool matches(const bamd_handle *h) {
         if (h->L != 8) return false;
+        if (RT) {
+            for (int i = 1; i <= 7; ++i)
+                if (i != 4 && h->dims[i] != N::dim(i)) return false;
+            return h->dims[0] == h->dims[8] && h->dims[0] >= 1 && h->dims[0] <= F && h->dims[4] >= 1 && h->dims[4] <= Z;
+        }
         for (int i = 0; i <= 8; ++i)
             if (h->dims[i] != N::dim(i)) return false;
         return true;
     }
-    static int setup(bamd_handle *, State64 *st) {
+    static int setup(bamd_handle *h, State64 *st) {
+        // geometry (tiles, fragment order, slot -> feature) from the instantiated Net64; which slots hold a parameter, and its canonical
+        // index, from the handle's real dimensions (identical for an exact instantiation)
+        const int nparams = (int)h->nparams;
+        auto dimr = [&](int i) { return h->dims[i]; };
+        auto woff = [&](int l) { return (int)h->w_off[l]; };
+        auto boff = [&](int l) { return (int)h->b_off[l]; };
         std::vector<int> src((size_t)N::packed_d4() * 4, -1);
         for (int l = 0; l < N::L; ++l) {
-            const int K = N::dim(l), NN = N::dim(l + 1), KT = tiles(K), NT = tiles(NN);
+            const int K = N::dim(l), NN = N::dim(l + 1), KT = tiles(K), NT = tiles(NN), Kr = dimr(l), NNr = dimr(l + 1);
             // forward fragment (q, t): lane (i, g) component r = W[16 t + i][16 q + 4 r + g]
             for (int q = 0; q < KT; ++q)
                 for (int t = 0; t < NT; ++t)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int r = 0; r < 4; ++r) {
                             const int n = 16 * t + (lane & 15), k = creg_feature(K, q, lane >> 4, r);
-                            if (n < NN && k >= 0) src[((size_t)N::wf_off(l) + (q * NT + t) * 64 + lane) * 4 + r] = N::w_off(l) + n * K + k;
+                            if (n < NNr && k >= 0 && k < Kr) src[((size_t)N::wf_off(l) + (q * NT + t) * 64 + lane) * 4 + r] = woff(l) + n * Kr + k;
                         }
             // backward fragment (tq, tk), l >= 1: lane (i, g) component r = W[16 tq + 4 r + g][16 tk + i]
             for (int tq = 0; tq < NT && l >= 1; ++tq)
@@ -869,41 +893,41 @@ template <int F, int Z> struct Impl64 {
                     for (int lane = 0; lane < 64; ++lane)
                         for (int r = 0; r < 4; ++r) {
                             const int n = creg_feature(NN, tq, lane >> 4, r), k = 16 * tk + (lane & 15);
-                            if (n >= 0 && k < K) src[((size_t)N::wb_off(l) + (tq * KT + tk) * 64 + lane) * 4 + r] = N::w_off(l) + n * K + k;
+                            if (n >= 0 && n < NNr && k < Kr) src[((size_t)N::wb_off(l) + (tq * KT + tk) * 64 + lane) * 4 + r] = woff(l) + n * Kr + k;
                         }
             // bias fragment (t, g) component r = b[16 t + 4 r + g]
             for (int t = 0; t < NT; ++t)
                 for (int g = 0; g < 4; ++g)
                     for (int r = 0; r < 4; ++r) {
                         const int n = creg_feature(NN, t, g, r);
-                        if (n >= 0) src[((size_t)N::bf_off(l) + t * 4 + g) * 4 + r] = N::b_off(l) + n;
+                        if (n >= 0 && n < NNr) src[((size_t)N::bf_off(l) + t * 4 + g) * 4 + r] = boff(l) + n;
                     }
         }
         // weight-gradient tile (kt, nt) of layer l: thread e = 4 lane + r holds dW[16 nt + g + 4 r][16 kt + (lane & 15)]; column K = db
         const int ntiles = N::slab_off(N::L);
         std::vector<int> inv((size_t)ntiles * 256, -1);
         for (int l = 0; l < N::L; ++l) {
-            const int K = N::dim(l), NN = N::dim(l + 1), NT = tiles(NN);
+            const int K = N::dim(l), NN = N::dim(l + 1), NT = tiles(NN), Kr = dimr(l), NNr = dimr(l + 1);
             for (int kt = 0; kt < tiles(K + 1); ++kt)
                 for (int nt = 0; nt < NT; ++nt)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int r = 0; r < 4; ++r) {
                             const int n = creg_feature(NN, nt, lane >> 4, r), kc = 16 * kt + (lane & 15);
-                            if (n < 0) continue;
+                            if (n < 0 || n >= NNr) continue;
                             const size_t o = ((size_t)(N::slab_off(l) + kt * NT + nt) * 64 + lane) * 4 + r;
-                            if (kc < K) inv[o] = N::w_off(l) + n * K + kc;
-                            else if (kc == K) inv[o] = N::b_off(l) + n;
+                            if (kc < K) { if (kc < Kr) inv[o] = woff(l) + n * Kr + kc; }
+                            else if (kc == K) inv[o] = boff(l) + n;      // (the ones slot sits at the CLASS width)
                         }
         }
         {
-            std::vector<char> seen(N::nparams(), 0);
+            std::vector<char> seen(nparams, 0);
             for (int v : inv) if (v >= 0) seen[v]++;
             for (char c : seen) if (c != 1) { set_error("fp64 fused step: incomplete gradient map"); return BAMD_ERR_INVALID; }
         }
-        std::vector<int> off((size_t)N::nparams() + 1, 0), idx;
+        std::vector<int> off((size_t)nparams + 1, 0), idx;
         for (int v : src) if (v >= 0) off[v + 1]++;
-        for (int p = 0; p < N::nparams(); ++p) off[p + 1] += off[p];
-        idx.resize(off[N::nparams()]);
+        for (int p = 0; p < nparams; ++p) off[p + 1] += off[p];
+        idx.resize(off[nparams]);
         std::vector<int> cur(off.begin(), off.end() - 1);
         for (size_t i = 0; i < src.size(); ++i) if (src[i] >= 0) idx[cur[src[i]]++] = (int)i;
         st->packed_doubles = (int)src.size();
@@ -917,7 +941,7 @@ template <int F, int Z> struct Impl64 {
         BAMD_HIP(hipMemcpy(st->inv_map.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice));
         BAMD_HIP(hipMemcpy(st->sc_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
         BAMD_HIP(hipMemcpy(st->sc_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
-        BAMD_HIP(hipFuncSetAttribute((const void *)chain64_kernel<F, Z, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        BAMD_HIP(hipFuncSetAttribute((const void *)chain64_kernel<F, Z, 4, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
         return BAMD_OK;
     }
     static int step(bamd_handle *h, State64 *st, const void *x, int x_dtype, int64_t n, const double *features, double *grads,
@@ -959,13 +983,13 @@ template <int F, int Z> struct Impl64 {
             const char *re = getenv("BALER_AMD_F64_REGCHAIN_BLKS");
             const int64_t rmin = re ? atoll(re) : 1024;
             if (nblk_all >= rmin)
-                hipLaunchKernelGGL((chain64r_kernel<F, Z>), dim3((nblk + 3) / 4), dim3(256), kLdsR, s, (const d4 *)st->packed.p,
-                                   (const void *)((const char *)x + (size_t)r0 * F * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
-                                   (double *)h->lossp.p + r0 / 16, nblk);
+                hipLaunchKernelGGL((chain64r_kernel<F, Z, RT>), dim3((nblk + 3) / 4), dim3(256), kLdsR, s, (const d4 *)st->packed.p,
+                                   (const void *)((const char *)x + (size_t)r0 * fr(h) * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
+                                   (double *)h->lossp.p + r0 / 16, nblk, fr(h));
             else
-                hipLaunchKernelGGL((chain64_kernel<F, Z, 4>), dim3(nblk), dim3(256), kLds, s, (const d4 *)st->packed.p,
-                                   (const void *)((const char *)x + (size_t)r0 * F * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
-                                   (double *)h->lossp.p + r0 / 16);
+                hipLaunchKernelGGL((chain64_kernel<F, Z, 4, RT>), dim3(nblk), dim3(256), kLds, s, (const d4 *)st->packed.p,
+                                   (const void *)((const char *)x + (size_t)r0 * fr(h) * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
+                                   (double *)h->lossp.p + r0 / 16, fr(h));
             if (macro) {
                 const int ns = splits_of(nblk);
                 if (big)
@@ -983,10 +1007,10 @@ template <int F, int Z> struct Impl64 {
         const int nblk_fin = (int)nblk_all;
         if (ad)
             hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
-                               (const int *)st->inv_map.p, grads, *ad, part, nsplit);
+                               (const int *)st->inv_map.p, grads, *ad, part, nsplit, (int)h->nparams, 1.0 / fr(h));
         else
             hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
-                               (const int *)st->inv_map.p, grads, Adam64{}, part, nsplit);
+                               (const int *)st->inv_map.p, grads, Adam64{}, part, nsplit, (int)h->nparams, 1.0 / fr(h));
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
@@ -1002,15 +1026,15 @@ template <int F, int Z> struct Impl64 {
             if (rc) return rc;
         }
         if (kind == I_ENCODE)
-            hipLaunchKernelGGL((infer64_kernel<F, Z, I_ENCODE>), dim3(grid), dim3(256), lds, s, (const d4 *)st->packed.p, x, in64, n, features,
-                               out, out64, renorm, imask, (double *)nullptr);
+            hipLaunchKernelGGL((infer64_kernel<F, Z, I_ENCODE, RT>), dim3(grid), dim3(256), lds, s, (const d4 *)st->packed.p, x, in64, n, features,
+                               out, out64, renorm, imask, (double *)nullptr, fr(h), zr(h));
         else if (kind == I_DECODE)
-            hipLaunchKernelGGL((infer64_kernel<F, Z, I_DECODE>), dim3(grid), dim3(256), lds, s, (const d4 *)st->packed.p, x, in64, n, features,
-                               out, out64, renorm, imask, (double *)nullptr);
+            hipLaunchKernelGGL((infer64_kernel<F, Z, I_DECODE, RT>), dim3(grid), dim3(256), lds, s, (const d4 *)st->packed.p, x, in64, n, features,
+                               out, out64, renorm, imask, (double *)nullptr, fr(h), zr(h));
         else {
-            hipLaunchKernelGGL((infer64_kernel<F, Z, I_FORWARD>), dim3(grid), dim3(256), lds, s, (const d4 *)st->packed.p, x, in64, n, features,
-                               out, out64, renorm, imask, (double *)h->lossp.p);
-            hipLaunchKernelGGL(sum_loss64_k, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, grid, 1.0 / F, loss_sum);
+            hipLaunchKernelGGL((infer64_kernel<F, Z, I_FORWARD, RT>), dim3(grid), dim3(256), lds, s, (const d4 *)st->packed.p, x, in64, n, features,
+                               out, out64, renorm, imask, (double *)h->lossp.p, fr(h), zr(h));
+            hipLaunchKernelGGL(sum_loss64_k, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, grid, 1.0 / fr(h), loss_sum);
         }
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
@@ -1032,6 +1056,11 @@ const Ops64 *find64(const bamd_handle *h) {
     if (Impl64<24, 4>::matches(h)) return Impl64<24, 4>::ops();
     if (Impl64<24, 3>::matches(h)) return Impl64<24, 3>::ops();
     if (Impl64<24, 2>::matches(h)) return Impl64<24, 2>::ops();
+    // any other narrow table with a latent of at most 15: class instantiations with run-time widths (the exchange chain gives one
+    // input tile to a wave: up to 63 columns; a latent tile pair is not plumbed through the fp64 chains)
+    if (Impl64<31, 15, true>::matches(h)) return Impl64<31, 15, true>::ops();
+    if (Impl64<47, 15, true>::matches(h)) return Impl64<47, 15, true>::ops();
+    if (Impl64<63, 15, true>::matches(h)) return Impl64<63, 15, true>::ops();
     return nullptr;
 }
 

@@ -287,6 +287,67 @@ def test_fp64_fused_step_ragged(n, data10k):
     assert rel(g4.cpu().numpy()[:-1], go2) < TOL64
 
 
+@pytest.mark.parametrize("F,Z", [(30, 8), (25, 10), (47, 12), (63, 15), (16, 4), (1, 1), (33, 15)])
+def test_fp64_any_narrow_table_runs_fused(F, Z):
+    """The fp64 mode -- the reference's own dtype (models.py:128-136) -- for tables other than the 24-column one: class instantiations
+    of the fp64 kernels with run-time widths (Impl64<31|47|63, 15, true>: register-chained inference, both training chains, the
+    weight-gradient tile blocks, the fused Adam step), against the scalar fp64 oracle at 1e-11: encode / decode (+ fused
+    un-normalisation and int truncation) / forward + loss, gradients at 1 .. 20,001 rows (exchange chain, register chain, tile blocks),
+    float32 and float64 rows, normalise-on-load, the one-call step == fwd_bwd + adam_step bit for bit."""
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 300 + F)
+    h, p = make_handle(dims, flat, "fp64")
+    assert h.path == "fused"
+    rng = np.random.default_rng(F * 10 + Z)
+    for n in (1, 17, 333, 4099):
+        x = rng.random((n, F))
+        z_ref = orc.encode(dims, flat, x)
+        assert rel(h.encode(dev(x)).cpu().numpy(), z_ref) < TOL64, n
+        x32 = x.astype(np.float32)
+        assert rel(h.encode(dev(x32)).cpu().numpy(), orc.encode(dims, flat, x32.astype(np.float64))) < 1e-6      # float32 output of float32 rows
+        assert rel(h.decode(dev(z_ref)).cpu().numpy(), orc.decode(dims, flat, z_ref)) < TOL64
+        recon, loss = h.forward_loss(dev(x))
+        fw = orc.forward(dims, flat, x)
+        assert rel(recon.cpu().numpy(), fw) < TOL64 and abs(loss.item() - orc.loss(x, fw)) < TOL64 * loss.item()
+    raw = rng.normal(size=(777, F)) * 50 + 7
+    mn, rg = raw.min(0), raw.max(0) - raw.min(0)
+    feats = dev(np.stack([mn, rg]))
+    xn = (raw - mn) / rg
+    zn = orc.encode(dims, flat, xn)
+    assert rel(h.encode(dev(raw), features=feats).cpu().numpy(), zn) < TOL64
+    mask = np.zeros(F, dtype=np.uint8)
+    mask[::3] = 1
+    out = h.decode(dev(zn), features=feats, int_mask=dev(mask)).cpu().numpy()
+    want = orc.cast_int_cols(orc.renormalize(orc.decode(dims, flat, zn), mn, rg), mask)
+    edge = np.abs(want - np.round(want)) < 1e-9
+    assert np.array_equal(np.isnan(out), np.isnan(want)) and rel(out[~edge], want[~edge]) < TOL64
+    for n in (1, 100, 513, 20001):
+        x = rng.random((n, F))
+        lo, go = orc.fwd_bwd(dims, flat, x)
+        grads = torch.full_like(p, 3.0)
+        h.fwd_bwd(dev(x), grads)
+        gh = grads.cpu().numpy()
+        assert rel(gh[:-1], go) < TOL64 and abs(gh[-1] - lo) < TOL64 * lo, n
+    lo2, go2 = orc.fwd_bwd(dims, flat, xn)
+    g2 = torch.zeros_like(p)
+    h.fwd_bwd(dev(raw), g2, features=feats)
+    assert rel(g2.cpu().numpy()[:-1], go2) < TOL64
+    x = rng.random((512, F))
+    m1, v1, m2, v2 = (torch.zeros_like(p) for _ in range(4))
+    p1, p2 = p.clone(), p.clone()
+    h1, _ = make_handle(dims, flat, "fp64")
+    h1.train_step(dev(x), p1, m1, v1, 1, 1e-3)
+    g = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), g)
+    h.adam_step(p2, g, m2, v2, 1, 1e-3)
+    assert torch.equal(p1[:-1], p2[:-1]) and torch.equal(m1[:-1], m2[:-1]) and torch.equal(v1[:-1], v2[:-1])
+    st = orc.FitState(dims, flat)
+    _, g_o = orc.fwd_bwd(dims, flat, x)
+    orc.adam_step(st.params, g_o, st.m, st.v, 1, 1e-3)
+    assert rel_l2(p1.cpu().numpy()[:-1], st.params) < 1e-9
+    assert rel(h1.encode(dev(x)).cpu().numpy(), orc.encode(dims, st.params, x)) < 1e-9
+
+
 @pytest.mark.parametrize("n", [1, 33, 1000, 16385, 70001])
 def test_fp64_register_chain_equals_exchange_chain(n, monkeypatch):
     """The two fp64 training chains -- one workgroup per 16-row block exchanging every layer through LDS (chain64_kernel: the 512-row
