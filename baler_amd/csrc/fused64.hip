@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(64 * W) chain64_kernel(const d4 *packed, const
                                                          double *__restrict__ loss_part, int fr) {
     using N = Net64<F, Z>;
     constexpr int TF = tiles(F), TZ = tiles(Z);
-    static_assert(TF <= W && TZ == 1 && F % 16 != 0, "input / latent tiles");
+    static_assert(TF <= W && TZ <= W && F % 16 != 0, "input / latent tiles");
     constexpr int kNB = N::bf_off(N::L) - N::bf_off(0);
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     d4 *xchA = (d4 *)lds_raw, *xchB = xchA + 13 * 64, *bias_lds = xchB + 13 * 64;
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) chain64r_kernel(const d4 *packed, const v
                                                        double *__restrict__ loss_part, int nblk, int fr) {
     using N = Net64<F, Z>;
     constexpr int TF = tiles(F), TZ = tiles(Z);
-    static_assert(TZ == 1 && F % 16 != 0, "input / latent tiles");
+    static_assert(TZ <= 2 && F % 16 != 0, "input / latent tiles");
     constexpr int kNB = N::bf_off(N::L) - N::bf_off(0);
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     d4 *bias_lds = (d4 *)lds_raw;
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) chain64r_kernel(const d4 *packed, const v
             {
                 d4 s5[4];
                 {
-                    d4 s4[1];
+                    d4 s4[TZ];
                     {
                         d4 s3[4];
                         {
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(256) chain64r_kernel(const d4 *packed, const v
             {
                 d4 d3[4];
                 {
-                    d4 d4_[1];
+                    d4 d4_[TZ];
                     {
                         d4 d5[4];
                         {
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) chain64r_kernel(const d4 *packed, const v
                             ZERO64(d5, 4) seq_mm<SQ, 10>(d6, d5, ring, ws, 0); lrelu_bwd_mask(d5, m5);
                         }
                         publish<50, false, 1>(nullptr, img, N::z_off(4), d5, lane, 0);
-                        ZERO64(d4_, 1) seq_mm<SQ, 11>(d5, d4_, ring, ws, 0);                                     // dL/dz: en4 has no activation
+                        ZERO64(d4_, TZ) seq_mm<SQ, 11>(d5, d4_, ring, ws, 0);                                     // dL/dz: en4 has no activation
                     }
                     publish<Z, false, 1>(nullptr, img, N::z_off(3), d4_, lane, 0);
                     ZERO64(d3, 4) seq_mm<SQ, 12>(d4_, d3, ring, ws, 0); lrelu_bwd_mask(d3, m3);
@@ -1056,11 +1056,13 @@ const Ops64 *find64(const bamd_handle *h) {
     if (Impl64<24, 4>::matches(h)) return Impl64<24, 4>::ops();
     if (Impl64<24, 3>::matches(h)) return Impl64<24, 3>::ops();
     if (Impl64<24, 2>::matches(h)) return Impl64<24, 2>::ops();
-    // any other narrow table with a latent of at most 15: class instantiations with run-time widths (the exchange chain gives one
-    // input tile to a wave: up to 63 columns; a latent tile pair is not plumbed through the fp64 chains)
+    // any other narrow table: class instantiations with run-time widths (the exchange chain gives one input tile to a wave: up to
+    // 63 columns; a latent of up to 31)
     if (Impl64<31, 15, true>::matches(h)) return Impl64<31, 15, true>::ops();
     if (Impl64<47, 15, true>::matches(h)) return Impl64<47, 15, true>::ops();
     if (Impl64<63, 15, true>::matches(h)) return Impl64<63, 15, true>::ops();
+    if (Impl64<31, 31, true>::matches(h)) return Impl64<31, 31, true>::ops();
+    if (Impl64<63, 31, true>::matches(h)) return Impl64<63, 31, true>::ops();
     return nullptr;
 }
 

@@ -100,7 +100,7 @@ void bamd_destroy(bamd_handle *h);
  * Any other narrow table of the reference's AE (hidden widths 200-100-50) is served by a CLASS instantiation with run-time widths:
  * up to 63 columns with a latent of up to 31 by all kernels (BAMD_PATH_FUSED); 64..79 columns by the fused inference kernels and,
  * for training steps of up to 12288 rows, the small-batch kernels (BAMD_PATH_FUSED_INFER: larger training batches of such a
- * handle run layer by layer).  An F64 handle has class instantiations of the fp64 kernels for up to 63 columns with a latent of up to 15.
+ * handle run layer by layer).  An F64 handle has class instantiations of the fp64 kernels for up to 63 columns with a latent of up to 31.
  * Any other shape runs on the layer-wise kernels (activations through HBM, 2-7x slower):
  * bamd_create prints one line to stderr for such a handle unless BALER_AMD_QUIET=1.  There is no model object in the
  * reference to query (models.py builds nn.Linear layers of any width); this call exists so that callers and tests can tell. */

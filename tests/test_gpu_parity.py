@@ -287,10 +287,10 @@ def test_fp64_fused_step_ragged(n, data10k):
     assert rel(g4.cpu().numpy()[:-1], go2) < TOL64
 
 
-@pytest.mark.parametrize("F,Z", [(30, 8), (25, 10), (47, 12), (63, 15), (16, 4), (1, 1), (33, 15)])
+@pytest.mark.parametrize("F,Z", [(30, 8), (25, 10), (47, 12), (63, 15), (16, 4), (1, 1), (33, 15), (24, 16), (40, 20), (63, 31), (31, 17)])
 def test_fp64_any_narrow_table_runs_fused(F, Z):
     """The fp64 mode -- the reference's own dtype (models.py:128-136) -- for tables other than the 24-column one: class instantiations
-    of the fp64 kernels with run-time widths (Impl64<31|47|63, 15, true>: register-chained inference, both training chains, the
+    of the fp64 kernels with run-time widths (Impl64<31|47|63, 15|31, true>: register-chained inference, both training chains, the
     weight-gradient tile blocks, the fused Adam step), against the scalar fp64 oracle at 1e-11: encode / decode (+ fused
     un-normalisation and int truncation) / forward + loss, gradients at 1 .. 20,001 rows (exchange chain, register chain, tile blocks),
     float32 and float64 rows, normalise-on-load, the one-call step == fwd_bwd + adam_step bit for bit."""
