@@ -122,9 +122,11 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
         if (!(q && q[0] == '1')) {
             std::string d;
             for (int l = 0; l <= n_layers; ++l) d += (l ? "-" : "") + std::to_string(dims[l]);
+            const std::string infer_only = "throughput training kernels (encode / decode / validation and training steps of up to " +
+                                           std::to_string((long long)fused_latency_rows(h)) + " rows are fused)";
             fprintf(stderr, "[baler_amd] model %s (%s) has no fused %s: %s run layer by layer (generic.hip, activations through HBM)\n",
                     d.c_str(), mode == BAMD_MODE_F64 ? "fp64" : mode == BAMD_MODE_BF16 ? "bf16" : "fp32",
-                    path == BAMD_PATH_GENERIC ? "kernel instantiation" : "throughput training kernels (encode / decode / validation and training steps of up to 12288 rows are fused)",
+                    path == BAMD_PATH_GENERIC ? "kernel instantiation" : infer_only.c_str(),
                     path == BAMD_PATH_GENERIC ? "encode / decode / training" : "larger training batches");
         }
     }
@@ -352,6 +354,25 @@ int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, 
     int rc = bamd_fwd_bwd(h, x, x_dtype, n_rows, features, grads, stream);
     if (rc) return rc;
     return bamd_adam_step(h, params, grads, m, v, hp, loss_accum, stream);
+}
+
+int bamd_train_epoch(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, int64_t batch_size, const double *features, void *params,
+                     void *grads, void *m, void *v, const bamd_adam *hp, double *loss_accum, int64_t *steps_out, void *stream) {
+    BAMD_REQUIRE(h && hp, "null argument");
+    BAMD_REQUIRE(batch_size > 0 && n_rows >= 0 && (x || n_rows == 0), "bad arguments");
+    BAMD_REQUIRE(x_dtype == BAMD_F32 || x_dtype == BAMD_F64, "bad dtype");
+    const size_t row_bytes = (size_t)h->dims[0] * (x_dtype == BAMD_F64 ? 8 : 4);
+    bamd_adam step_hp = *hp;
+    int64_t steps = 0;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += batch_size, ++steps) {
+        const int64_t rows = n_rows - r0 < batch_size ? n_rows - r0 : batch_size;
+        step_hp.step = hp->step + steps;
+        const int rc = bamd_train_step(h, (const char *)x + (size_t)r0 * row_bytes, x_dtype, rows, features, params, grads, m, v, &step_hp,
+                                       loss_accum, stream);
+        if (rc) return rc;
+    }
+    if (steps_out) *steps_out = steps;
+    return BAMD_OK;
 }
 
 int bamd_emd_rows(const void *x, const void *recon, int dtype, int64_t n_rows, int n_cols, double *out,

@@ -2311,7 +2311,7 @@ constexpr int kImgB = 320;
 template <class N> constexpr int img_a_rows();
 // the bias fragments sit in LDS behind the images when both fit the 160 KB; the 63-column class reads them from the packed copy (L2)
 template <class N> constexpr bool train_bias_in_lds() {
-    return (img_a_rows<N>() + 320) * 68 * 4 + (N::bf_off(8) - N::bf_off(0)) * 16 <= 160 * 1024;
+    return (size_t)(img_a_rows<N>() + kImgB) * kQS * sizeof(float) + (size_t)(N::bf_off(8) - N::bf_off(0)) * 16 <= 160 * 1024;
 }
 template <class N> constexpr int img_a_rows() {     // 240 up to 31 columns, 256 for the 47-column class (its [X_7 | dZ_7] and [X_0 | dZ_0] images)
     int m = 240;
@@ -3684,8 +3684,6 @@ template <int F, int Z, bool RT = false> struct Impl {
         constexpr size_t img_bytes = (size_t)Lat<N>::z_off(N::L) * kImgStride * sizeof(float);
         int rc = st->imgs.ensure(img_bytes * (size_t)nblk);
         if (rc) return rc;
-        rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk > 1024 ? nblk : 1024));
-        if (rc) return rc;
         rc = h->lossp.ensure(sizeof(double) * (size_t)(4 * nblk > 1024 ? 4 * nblk : 1024));
         if (rc) return rc;
         int nloss = nblk;
@@ -4245,6 +4243,9 @@ int fused_pack(bamd_handle *h, hipStream_t s) {
 bool fused_trains(const bamd_handle *h) {   // false: large-batch training of this handle runs layer by layer
     if (!h->fused_ok) return false;
     return ((const FusedState *)h->fused_state)->ops->throughput_training;
+}
+int64_t fused_latency_rows(const bamd_handle *h) {   // the handle's small-batch limit (default 12288; BALER_AMD_LATENCY_ROWS)
+    return h->fused_ok ? ((const FusedState *)h->fused_state)->latency_max_rows : 0;
 }
 bool fused_serves_bf16_inference(const bamd_handle *h) {   // wide models in the bf16 mode: encode / decode live in fused.hip
     return h->fused_ok && ((const FusedState *)h->fused_state)->ops->pack_extra != nullptr;

@@ -7,6 +7,7 @@ int fused_setup(bamd_handle *h);                 // decides h->fused_ok, allocat
 int fused_pack(bamd_handle *h, hipStream_t s);   // h->params -> h->packed (no-op when !fused_ok)
 void fused_teardown(bamd_handle *h);
 bool fused_trains(const bamd_handle *h);                   // false: inference-only class, training runs on generic.hip
+int64_t fused_latency_rows(const bamd_handle *h);          // rows up to which training steps run on the small-batch kernels (0: no fused path)
 bool fused_serves_bf16_inference(const bamd_handle *h);   // BF16 handle of a wide model (no bf16.hip state)
 void fused_params_changed(bamd_handle *h);       // an optimiser step changed h->params / h->packed: lazily refreshed copies are stale
 // scatter lists (CSR over parameters) into h->packed for the fused Adam+pack kernel; all null when !fused_ok

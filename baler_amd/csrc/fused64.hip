@@ -738,7 +738,7 @@ template <class N, bool BIG> struct Dwm64 {      // BIG: batches of >= 16,384 ro
 // one tile block of layer l (compile-time shape): accumulate over this workgroup's block range, sum the four waves' accumulators
 // through LDS in a fixed order, store the range partial
 template <class N, bool BIG, int l>
-__device__ __forceinline__ void dw64m_block(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total, int split0,
+__device__ __forceinline__ void dw64m_block(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total, int accumulate,
                                             int idx, d4 *red) {
     using D = Dwm64<N, BIG>;
     constexpr int MN = D::shape(l).mn, MK = D::shape(l).mk, NA = MN * MK, U = NA >= 16 ? 1 : 2, HALF = NA / 2;
@@ -800,22 +800,26 @@ __device__ __forceinline__ void dw64m_block(const double *__restrict__ imgs, int
             const double *q = rf + t * 1024;
             const double gsum = ((q[e] + q[256 + e]) + q[512 + e]) + q[768 + e];
             const int tile = soff + kt[c] * ntc + nt[a];
-            part[((int64_t)tile * nsplit_total + split0 + blockIdx.y) * 256 + e] = gsum;
+            double *dst = part + ((int64_t)tile * nsplit_total + blockIdx.y) * 256 + e;
+            *dst = accumulate ? *dst + gsum : gsum;      // chunks after the first add to the range's running sum (chunk order: one stream)
         }
     }
 }
 template <class N, bool BIG>
 __global__ void __launch_bounds__(256) dw64m_kernel(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total,
-                                                    int split0) {
-    // this launch covers block ranges split0 .. split0 + gridDim.y - 1 of the nsplit_total ranges the finishing launch adds up (a batch
-    // beyond State64::chunk_rows runs chunk after chunk over the same image buffer: one launch of this kernel per chunk)
+                                                    int accumulate) {
+    // this launch covers block ranges 0 .. gridDim.y - 1 of the nsplit_total ranges the finishing launch adds up.  A batch beyond
+    // State64::chunk_rows runs chunk after chunk over the same image buffer, one launch of this kernel per chunk: every chunk after
+    // the first ADDS its range partials to the first chunk's (`accumulate`; the launches are ordered on one stream, so the sum has
+    // a fixed order: chunk after chunk per range, then range after range in dw64_kernel) -- the partial buffer and the finishing
+    // launch do not grow with the batch
     using D = Dwm64<N, BIG>;
     __shared__ __attribute__((aligned(32))) d4 red[(BIG ? 8 : 4) * 4 * 64];      // half of a block's accumulators from four waves: 64 / 32 KB
     const int mac = (blockIdx.x & 7) * D::per_xcd + (blockIdx.x >> 3);
     if (mac >= D::total) return;
     static_assert(N::L == 8, "one case per layer below");
 #define BAMD_DW64M_CASE(l_) \
-    if (mac >= D::off(l_) && mac < D::off(l_ + 1)) { dw64m_block<N, BIG, l_>(imgs, nblk, part, nsplit_total, split0, mac - D::off(l_), red); return; }
+    if (mac >= D::off(l_) && mac < D::off(l_ + 1)) { dw64m_block<N, BIG, l_>(imgs, nblk, part, nsplit_total, accumulate, mac - D::off(l_), red); return; }
     BAMD_DW64M_CASE(0) BAMD_DW64M_CASE(1) BAMD_DW64M_CASE(2) BAMD_DW64M_CASE(3)
     BAMD_DW64M_CASE(4) BAMD_DW64M_CASE(5) BAMD_DW64M_CASE(6) BAMD_DW64M_CASE(7)
 #undef BAMD_DW64M_CASE
@@ -968,12 +972,13 @@ template <int F, int Z, bool RT = false> struct Impl64 {
         auto splits_of = [big](int64_t blks) { return (int)std::min<int64_t>(big ? (blks >= 4096 ? 32 : 16) : 8, std::max<int64_t>(1, blks / 4)); };
         int nsplit = 0;
         if (macro) {
-            for (int k = 0; k < nchunk; ++k) nsplit += splits_of((std::min(n - k * chunk, chunk) + 15) / 16);
+            // the first chunk is the largest (every chunk but the last is a full one): its range count is the buffer's; 32 ranges at most,
+            // i.e. (tiles + 1) x 32 x 2 KB = 19.6 MB whatever the batch
+            nsplit = splits_of((std::min(n, chunk) + 15) / 16);
             rc = st->dwpart.ensure((size_t)(N::slab_off(N::L) + 1) * nsplit * 256 * sizeof(double));
             if (rc) return rc;
         }
         const size_t xes = x_dtype == BAMD_F64 ? 8 : 4;
-        int split0 = 0;
         for (int k = 0; k < nchunk; ++k) {
             const int64_t r0 = k * chunk, rows = std::min(n - r0, chunk);
             const int nblk = (int)((rows + 15) / 16);
@@ -994,11 +999,10 @@ template <int F, int Z, bool RT = false> struct Impl64 {
                 const int ns = splits_of(nblk);
                 if (big)
                     hipLaunchKernelGGL((dw64m_kernel<N, true>), dim3(8 * Dwm64<N, true>::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
-                                       (double *)st->dwpart.p, nsplit, split0);
+                                       (double *)st->dwpart.p, nsplit, k > 0);
                 else
                     hipLaunchKernelGGL((dw64m_kernel<N, false>), dim3(8 * Dwm64<N, false>::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
-                                       (double *)st->dwpart.p, nsplit, split0);
-                split0 += ns;
+                                       (double *)st->dwpart.p, nsplit, k > 0);
             }
         }
         const double *part = macro ? (const double *)st->dwpart.p : nullptr;

@@ -29,9 +29,23 @@ def rank_world():
     return 0, 1
 
 
+def force_pg():
+    """BALER_AMD_FORCE_PG=1: build the process group and keep every collective of the data-parallel step even at world size 1
+    (one GPU): RCCL's library load, communicator set-up, its stream hand-off around bamd_fwd_bwd / bamd_adam_step and the
+    dmabuf IPC mode are then exercised on a single-GPU box exactly as an 8-GPU run exercises them."""
+    return os.environ.get("BALER_AMD_FORCE_PG") == "1"
+
+
+def collectives_on():
+    """Does a training step run the data-parallel sequence (bamd_fwd_bwd -> all-reduce -> bamd_adam_step)?  With more than one
+    rank always; with ONE rank only when BALER_AMD_FORCE_PG=1 built a group (a sum over one rank is the identity: results are
+    bit-identical to the single-process step, tests/test_gpu_dp.py::test_rccl_world1_*)."""
+    return is_dist() and (td.get_world_size() > 1 or force_pg())
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from torchrun's environment (RANK/WORLD_SIZE/MASTER_*).
-    Returns (rank, world, local_rank).  No-op for single-process runs."""
+    Returns (rank, world, local_rank).  No-op for single-process runs unless BALER_AMD_FORCE_PG=1 (then a one-rank group)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -40,7 +54,7 @@ def init_from_env(backend=None):
     if "BALER_AMD_FORCE_DEVICE" in os.environ:
         local = int(os.environ["BALER_AMD_FORCE_DEVICE"])
     backend = backend or os.environ.get("BALER_AMD_DIST_BACKEND")
-    if world > 1 and not is_dist():
+    if (world > 1 or force_pg()) and not is_dist():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -58,14 +72,14 @@ def init_from_env(backend=None):
 
 def allreduce_sum(t):
     """In-place SUM all-reduce on the current stream (RCCL: one ncclAllReduce(ncclSum))."""
-    if is_dist() and td.get_world_size() > 1:
+    if collectives_on():
         td.all_reduce(t, op=td.ReduceOp.SUM)
     return t
 
 
 def broadcast(t, src=0):
     """Broadcast a tensor from `src` (initial parameters: every rank constructs its own randomly initialised model)."""
-    if is_dist() and td.get_world_size() > 1:
+    if collectives_on():
         td.broadcast(t, src=src)
     return t
 

@@ -63,7 +63,7 @@ class Adam:
             handle.adam_step(self.model.flat, self.grads, self.m, self.v, self.step_count, g["lr"], g["betas"][0],
                              g["betas"][1], g["eps"], loss_accum=self.loss_accum)
             return
-        if world == 1:
+        if world == 1 and not bdist.collectives_on():       # (BALER_AMD_FORCE_PG=1 keeps the all-reduce at one rank)
             self.step_count += 1
             handle.train_step(batch, self.model.flat, self.m, self.v, self.step_count, g["lr"], g["betas"][0],
                               g["betas"][1], g["eps"], loss_accum=self.loss_accum, grads=self.grads)
@@ -73,6 +73,28 @@ class Adam:
         self.step_count += 1
         handle.adam_step(self.model.flat, self.grads, self.m, self.v, self.step_count, g["lr"],
                          g["betas"][0], g["betas"][1], g["eps"], loss_accum=self.loss_accum)
+
+
+def _epoch_in_one_call(world, swae_latent_dim):
+    """A single process without the sliced-Wasserstein loss runs an epoch as ONE native call (bamd_train_epoch: the batch loop of
+    training.py:64-97 inside the library; bit-identical to one bamd_train_step per batch).  BALER_AMD_EPOCH_CALL=0: per-step calls."""
+    return (world == 1 and not bdist.collectives_on() and swae_latent_dim is None
+            and os.environ.get("BALER_AMD_EPOCH_CALL", "1") != "0")
+
+
+def _run_batches(optimizer, h, rows, spans, bs, world, swae_latent_dim):
+    """The optimiser steps of the batches `spans` (consecutive local row ranges of `rows`)."""
+    if not spans:
+        return
+    if _epoch_in_one_call(world, swae_latent_dim):
+        a, b = spans[0][0], spans[-1][1]
+        g = optimizer.param_groups[0]
+        optimizer.step_count += h.train_epoch(rows[a:b], bs, optimizer.model.flat, optimizer.m, optimizer.v,
+                                              optimizer.step_count + 1, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                              loss_accum=optimizer.loss_accum, grads=optimizer.grads)
+        return
+    for a, b in spans:
+        optimizer.train_step(h, rows[a:b], world, swae_latent_dim=swae_latent_dim)
 
 
 def _swae_dim(config, model):
@@ -134,8 +156,7 @@ def fit(config, model, train_dl, model_children, regular_param, optimizer, laten
     h = model.handle()
     optimizer.loss_accum.zero_()
     rows, spans = _local_batches(data, bs, rank, world)
-    for a, b in spans:
-        optimizer.train_step(h, rows[a:b], world, swae_latent_dim=_swae_dim(config, model))
+    _run_batches(optimizer, h, rows, spans, bs, world, _swae_dim(config, model))
     # one device->host read per epoch (the reference does one per step)
     last = float(optimizer.grads[model.nparams].item())
     epoch_loss = float(optimizer.loss_accum.item()) / len(spans)
@@ -302,11 +323,10 @@ def _fit_with_capture(config, model, train_dl, model_children, optimizer, want_a
     model.train()
     h = model.handle()
     optimizer.loss_accum.zero_()
-    for i, (a, b) in enumerate(spans):
-        if i == len(spans) - 1:
-            model._dirty = False      # the native Adam kept the handle's packed weights in step with model.flat
-            _capture(model, rows, (a, b), world)
-        optimizer.train_step(h, rows[a:b], world, swae_latent_dim=_swae_dim(config, model))
+    _run_batches(optimizer, h, rows, spans[:-1], bs, world, _swae_dim(config, model))
+    model._dirty = False      # the native Adam kept the handle's packed weights in step with model.flat
+    _capture(model, rows, spans[-1], world)
+    _run_batches(optimizer, h, rows, spans[-1:], bs, world, _swae_dim(config, model))
     last = float(optimizer.grads[model.nparams].item())
     epoch_loss = float(optimizer.loss_accum.item()) / len(spans)
     model._dirty = False

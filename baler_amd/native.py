@@ -24,6 +24,7 @@ SYMBOLS = (
     "bamd_renormalize", "bamd_encode", "bamd_decode", "bamd_forward_loss", "bamd_fwd_bwd",
     "bamd_adam_step", "bamd_train_step", "bamd_emd_rows", "bamd_activation_means",
     "bamd_error_deltas", "bamd_apply_deltas", "bamd_fwd_bwd_latent", "bamd_swd", "bamd_col_minmax", "bamd_path_of",
+    "bamd_train_epoch",
 )
 
 
@@ -73,6 +74,7 @@ def lib():
     L.bamd_fwd_bwd.argtypes = [vp, vp, ci, i64, vp, vp, vp]
     L.bamd_adam_step.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, vp]
     L.bamd_train_step.argtypes = [vp, vp, ci, i64, vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, vp]
+    L.bamd_train_epoch.argtypes = [vp, vp, ci, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, ctypes.POINTER(i64), vp]
     L.bamd_emd_rows.argtypes = [vp, vp, ci, i64, ci, vp, vp]
     L.bamd_activation_means.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp]
     L.bamd_error_deltas.argtypes = [vp, vp, ci, i64, dbl, vp, vp, vp]
@@ -369,6 +371,25 @@ class Handle:
         hp = AdamHP(int(step), float(lr), float(beta1), float(beta2), float(eps))
         _check(lib().bamd_train_step(self._h, _ptr(x), _dt(x), x.shape[0], _ptr(features), _ptr(params), _ptr(grads),
                                      _ptr(m), _ptr(v), ctypes.byref(hp), _ptr(loss_accum), self._s()), "bamd_train_step")
+
+    def train_epoch(self, x, batch_size, params, m, v, first_step, lr, beta1=0.9, beta2=0.999, eps=1e-8, loss_accum=None,
+                    grads=None, features=None):
+        """One epoch of sequential batches over the resident rows `x` in ONE native call (bamd_train_epoch: the batch loop runs
+        inside the library, every batch as train_step).  `first_step` = Adam's t of the first batch.  Returns the number of steps."""
+        x = _dev_tensor(x)
+        self._mine(x, params, m, v, grads, loss_accum, features)
+        for t in (params, m, v):
+            _dev_tensor(t)
+            if t.dtype != self.param_dtype:
+                raise NativeError("optimizer tensors must have the handle's parameter type")
+        if grads is not None and (grads.dtype != self.param_dtype or grads.numel() < self.nparams + 1):
+            raise NativeError("grads must hold param_count+1 elements of the handle's parameter type")
+        hp = AdamHP(int(first_step), float(lr), float(beta1), float(beta2), float(eps))
+        steps = ctypes.c_int64(0)
+        _check(lib().bamd_train_epoch(self._h, _ptr(x), _dt(x), x.shape[0], int(batch_size), _ptr(features), _ptr(params),
+                                      _ptr(grads), _ptr(m), _ptr(v), ctypes.byref(hp), _ptr(loss_accum), ctypes.byref(steps),
+                                      self._s()), "bamd_train_epoch")
+        return int(steps.value)
 
     def activation_means(self, x, features=None, max_nodes=200):
         x = _dev_tensor(x)

@@ -261,7 +261,13 @@ def main():
               file=sys.stderr, flush=True)
         sys.exit(3)
     rank_diag("process group up", local)
-    if world > 1:
+    coll = bdist.collectives_on()      # world > 1, or a one-rank group forced with BALER_AMD_FORCE_PG=1 (RCCL's first run on one GPU)
+    if rank == 0 and torch.cuda.is_available():        # (the library version is readable without a communicator)
+        try:
+            log("RCCL version " + ".".join(str(v) for v in torch.cuda.nccl.version()))
+        except Exception as e:
+            log(f"RCCL version unavailable: {type(e).__name__}: {e}")
+    if coll:
         # the FIRST collective of the run, on its own, so that a hang or an IPC failure is attributable from the log tail
         import torch.distributed as td
         try:
@@ -304,7 +310,7 @@ def main():
         if record:
             e1.record()
             ev.append((e0, e1))
-        if world > 1:
+        if coll:
             bdist.allreduce_sum(grads)
         state["t"] += 1
         h.adam_step(flat, grads, m, v, state["t"], 1e-3, loss_accum=loss_acc)
@@ -335,6 +341,10 @@ def main():
     k_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
     log(f"train: {value:.4g} rows/s, {1e3 * dt / a.steps:.3f} ms/step, fwd_bwd {k_ms:.3f} ms")
     final_loss = float(grads[-1].item())
+    wsum = torch.arange(1, flat.numel() + 1, dtype=torch.float64, device=dev)
+    param_checksum = [float(flat.double().sum().item()), float((flat.double() * wsum).sum().item())]
+    grad_checksum = [float(grads.double().sum().item()), float((grads.double() * wsum).sum().item())]
+    del wsum
 
     out = {
         "metric": "rows/sec (train) + rows/sec (encode), CMS 24-col AE at 1/2/4/8 GPUs",
@@ -350,11 +360,12 @@ def main():
         },
         "train_rows_per_s": value, "last_batch_loss": final_loss,
         "rccl_ranks": bdist.rank_world()[1],
-        "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
+        "dist_backend": (torch.distributed.get_backend() if coll else None),
         "replicas_identical": replicas_identical,
+        "param_checksum": param_checksum, "grad_checksum": grad_checksum,   # after the K timed steps (float64 sums: bit-exact run to run)
         "source_hash": source_hash(),
     }
-    if world > 1:
+    if coll:
         # the 247 KB [grads | loss] all-reduce alone (latency-bound on xGMI), 200 back-to-back calls
         for _ in range(10):
             bdist.allreduce_sum(grads)

@@ -99,7 +99,7 @@ void bamd_destroy(bamd_handle *h);
  * has fused fp64 kernels for inference and for training steps of any size (chunks of 262144 rows over one image buffer).
  * Any other narrow table of the reference's AE (hidden widths 200-100-50) is served by a CLASS instantiation with run-time widths:
  * up to 63 columns with a latent of up to 31 by all kernels (BAMD_PATH_FUSED); 64..79 columns by the fused inference kernels and,
- * for training steps of up to 12288 rows, the small-batch kernels (BAMD_PATH_FUSED_INFER: larger training batches of such a
+ * for training steps of up to the small-batch limit (default 12288 rows; BALER_AMD_LATENCY_ROWS at bamd_create), the small-batch kernels (BAMD_PATH_FUSED_INFER: larger training batches of such a
  * handle run layer by layer).  An F64 handle has class instantiations of the fp64 kernels for up to 63 columns with a latent of up to 31.
  * Any other shape runs on the layer-wise kernels (activations through HBM, 2-7x slower):
  * bamd_create prints one line to stderr for such a handle unless BALER_AMD_QUIET=1.  There is no model object in the
@@ -108,7 +108,7 @@ typedef enum bamd_path {
     BAMD_PATH_GENERIC = 0,   /* generic.hip: LDS-tiled MFMA GEMM per layer */
     BAMD_PATH_FUSED = 1,     /* fused.hip: register chain (24-column AE) or streamed wide layers + chain */
     BAMD_PATH_BF16 = 2,      /* bf16.hip / bf16_train.hip (24-column AE, BAMD_MODE_BF16); its small batches use the fused fp32 step */
-    BAMD_PATH_FUSED_INFER = 3 /* 64..79 columns: fused.hip for encode / decode / forward + loss and for training steps of up to 12288 rows,
+    BAMD_PATH_FUSED_INFER = 3 /* 64..79 columns: fused.hip for encode / decode / forward + loss and for training steps of up to the small-batch limit (default 12288 rows),
                               * generic.hip for larger training batches */
 } bamd_path;
 int bamd_path_of(const bamd_handle *h);   /* a bamd_path, or BAMD_ERR_INVALID for a null handle */
@@ -203,6 +203,19 @@ int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, voi
 int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features,
                     void *params, void *grads, void *m, void *v, const bamd_adam *hp,
                     double *loss_accum, void *stream);
+
+/* Replaces: ONE EPOCH of training.fit's batch loop (training.py:64-97) -- `for idx, inputs in enumerate(train_dl)`: sequential
+ * batches of `batch_size` rows of the resident table, no shuffling, the partial last batch kept (training.py:237-263) -- in ONE
+ * call: the loop runs inside the library, every batch exactly as bamd_train_step() (same kernels, same arguments, hp->step for the
+ * first batch and +1 for every following one, one learning rate for the epoch as the reference's per-epoch scheduler gives it),
+ * enqueued back to back on `stream` with no host synchronisation and no host round trip per step.  Bit-identical to the loop of
+ * bamd_train_step() calls it replaces.  x: (n_rows, n_features) row-major, x_dtype.  *loss_accum += every batch's loss
+ * (running_loss of training.py:97); grads (may be NULL) holds the LAST batch's gradient and loss afterwards (the "Training Loss"
+ * training.py:100 prints).  *steps_out (host, may be NULL) receives the number of optimiser steps taken = ceil(n_rows / batch_size).
+ * For single-process training; data-parallel runs keep the per-step sequence (the all-reduce sits between the two halves). */
+int bamd_train_epoch(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, int64_t batch_size, const double *features,
+                     void *params, void *grads, void *m, void *v, const bamd_adam *hp, double *loss_accum, int64_t *steps_out,
+                     void *stream);
 
 /* ---- diagnostics -------------------------------------------------------------------------------
  * Replaces: the EMD term of utils.mse_loss_emd_l1 (utils.py:112-119): sum over rows of the 1-D

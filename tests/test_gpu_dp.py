@@ -291,3 +291,67 @@ def test_dp_validation_split_equals_single_process(tmp_path):
     assert np.allclose(l2, l1, rtol=1e-10, atol=0)
     assert np.array_equal(np.isnan(a1), np.isnan(a2)) and np.allclose(np.nan_to_num(a2), np.nan_to_num(a1), rtol=1e-9, atol=1e-12)
     assert np.linalg.norm(p2 - p1) / np.linalg.norm(p1) < 1e-10
+
+
+# ---- RCCL itself, on the one GPU of the box: a ONE-rank "nccl" process group (BALER_AMD_FORCE_PG=1) -----------------------
+# Every multi-rank test above runs over gloo (RCCL needs one GPU per rank).  A world-1 RCCL group is legal on one GPU and runs
+# everything of the data-parallel step except the wire: init_process_group("nccl", device_id=...), RCCL's library load and
+# communicator, dmabuf IPC mode, and the stream hand-off between RCCL's stream and the launch stream around bamd_fwd_bwd /
+# bamd_adam_step (a sum over one rank is the identity, so any mis-ordering shows as a changed bit).
+
+def _bench_json(r):
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_rccl_world1_bench_step_is_bit_identical():
+    args = [os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--rows", "65536", "--no-extras",
+            "--no-cpu-baseline"]
+    env = dict(os.environ, BALER_AMD_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BALER_AMD_DIST_BACKEND", None)
+    env.pop("BALER_AMD_FORCE_DEVICE", None)
+    # the child is started before anything in IT touches the GPU (torchrun forks the rank); nothing is re-exec'd
+    d = _bench_json(_torchrun(1, args, env, free_port()))
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["dist_backend"] == "nccl"
+    assert d["allreduce_us"] > 0 and d["allreduce_bytes"] == 4 * 61840 and d["value"] > 0
+    # the same steps without any process group: gradients and parameters must agree to the last bit
+    env0 = dict(os.environ)
+    for k in ("BALER_AMD_FORCE_PG", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "BALER_AMD_DIST_BACKEND"):
+        env0.pop(k, None)
+    r0 = subprocess.run([sys.executable] + args, env=env0, capture_output=True, text=True, timeout=900)
+    d0 = _bench_json(r0)
+    assert d0["dist_backend"] is None and "allreduce_us" not in d0
+    assert d["param_checksum"] == d0["param_checksum"] and d["grad_checksum"] == d0["grad_checksum"]
+    assert d["last_batch_loss"] == d0["last_batch_loss"]
+    assert "RCCL version" in r0.stderr          # printed on every run: bench.py --gpus 1 names the library it would use
+
+
+def test_rccl_world1_cli_train_is_bit_identical(tmp_path):
+    """`python -m baler_amd --mode train` under a one-rank RCCL group (fwd_bwd -> ncclAllReduce -> adam_step per batch) writes the
+    same loss curve and model as the plain single-process run (one fused bamd_train_step per batch)."""
+    import torch
+    outs = {}
+    for tag in ("plain", "rccl"):
+        base = tmp_path / tag
+        os.makedirs(base)
+        out = _dp_workspace(base, epochs=3)
+        script = base / "w.py"
+        script.write_text(_SPLIT_WORKER)
+        env = dict(os.environ, REPO=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BALER_AMD_DIST_BACKEND", "BALER_AMD_FORCE_DEVICE", "BALER_AMD_FORCE_PG"):
+            env.pop(k, None)
+        if tag == "plain":
+            cmd = [sys.executable, str(script)]
+        else:
+            env["BALER_AMD_FORCE_PG"] = "1"
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                   "--master-port", str(free_port()), str(script)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(base))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        sd = torch.load(out / "compressed_output" / "model.pt")
+        outs[tag] = (np.load(out / "training" / "loss_data.npy"), np.concatenate([v.numpy().ravel() for v in sd.values()]))
+    assert outs["plain"][0].shape == (2, 3)
+    assert np.array_equal(outs["plain"][0], outs["rccl"][0])          # bamd_train_step == bamd_fwd_bwd + identity + bamd_adam_step
+    assert np.array_equal(outs["plain"][1], outs["rccl"][1])

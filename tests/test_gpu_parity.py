@@ -1416,3 +1416,33 @@ def test_hostio_round_trip_with_block_events():
     back = hostio.download_rows(out, ready=ready, chunk_bytes=3 << 20)
     assert np.array_equal(back, src * 2.0)
     assert np.array_equal(hostio.download_rows(out[:0]), src[:0] * 2.0)
+
+
+@pytest.mark.parametrize("mode,n,bs", [("fp32", 3000, 512), ("fp64", 1300, 512), ("fp32", 40000, 16384), ("bf16", 9000, 4096)])
+def test_train_epoch_equals_the_per_step_loop(mode, n, bs, data10k):
+    """bamd_train_epoch (the batch loop of training.fit, training.py:64-97, inside the library: ONE host call per epoch) is
+    bit-identical to one bamd_train_step per batch: parameters, Adam moments, the running loss, the last batch's gradient and
+    the step count -- over small-batch steps (4-row chain / fp64 chain), the throughput pair and the bf16 kernels, with the
+    partial last batch the reference keeps (training.py:237-263)."""
+    dims = orc.ae_dims(24, 15)
+    flat = orc.formula_params(dims, 21)
+    x = dev(np.concatenate([data10k] * 4)[:n])
+    res = []
+    for one_call in (False, True):
+        h, p = make_handle(dims, flat, mode)
+        m, v, g = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+        acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+        t = 4                                           # Adam's step counter does not have to start at 1
+        for _ in range(2):                              # two epochs: the second starts from the first's state
+            if one_call:
+                t += h.train_epoch(x, bs, p, m, v, t + 1, 1e-3, loss_accum=acc, grads=g)
+            else:
+                for a in range(0, n, bs):
+                    t += 1
+                    h.train_step(x[a:a + bs], p, m, v, t, 1e-3, loss_accum=acc, grads=g)
+        res.append((t, p.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy(), g.cpu().numpy(), acc.item()))
+        h.close()
+    (t0, p0, m0, v0, g0, a0), (t1, p1, m1, v1, g1, a1) = res
+    assert t0 == t1 == 4 + 2 * ((n + bs - 1) // bs)
+    assert np.array_equal(p0, p1) and np.array_equal(m0, m1) and np.array_equal(v0, v1) and np.array_equal(g0, g1) and a0 == a1
+    assert np.isfinite(a1) and a1 > 0

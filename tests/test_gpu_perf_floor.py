@@ -1,8 +1,10 @@
-"""Throughput floors on MI355X: at most 15 % above the steady-state times of the last committed bench (profiles/r3_bench.json,
-the numbers quoted next to every assertion), so a change that drops a kernel off its fast path -- spills, a lost fragment ring,
-a fallback to the layer-wise kernels -- or a 20 % regression fails a test instead of only showing up in the next bench line.
-Timing as bench.py does it: ~30 ms of the same call first (the first ~20 launches of a kernel mix run 10-13 % slow, DESIGN.md
-section 5), then the best of five event-timed samples on the launch stream.  Synthetic uniform rows."""
+"""Throughput floors on MI355X: SLACK (30 %) above the steady-state times of the committed bench lines (profiles/r*_bench.json, the
+numbers quoted next to every assertion), so a change that drops a kernel off its fast path -- spills, a lost fragment ring, a
+fallback to the layer-wise kernels (2-7x) -- fails a test instead of only showing up in the next bench line.  The margin is wider
+than the 10-13 % clock-ramp / lease-to-lease variation DESIGN.md section 5 documents: another box, power cap or a busy node must
+not fail these without a code regression; the tight numbers are PRINTED for the reader.
+Timing as bench.py does it: ~30 ms of the same call first, then the MEDIAN of five event-timed samples on the launch stream.
+Synthetic uniform rows."""
 import numpy as np
 import pytest
 import torch
@@ -11,6 +13,13 @@ from baler_amd import native
 from oracle import c_oracle as orc
 
 pytestmark = pytest.mark.gpu
+
+SLACK = 1.30
+
+
+def lim(baseline):
+    """Upper bound of a time whose committed steady-state value is `baseline`."""
+    return baseline * SLACK
 
 
 def _handle(mode="fp32"):
@@ -31,15 +40,15 @@ def _ms(fn, reps, warm_ms=30.0, samples=5):
     torch.cuda.synchronize()
     for _ in range(min(200, int(warm_ms / max(e0.elapsed_time(e1), 1e-3)))):
         fn()
-    best = float("inf")
+    got = []
     for _ in range(samples):
         e0.record()
         for _ in range(reps):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / reps)
-    return best
+        got.append(e0.elapsed_time(e1) / reps)
+    return sorted(got)[len(got) // 2]
 
 
 def test_throughput_floors():
@@ -63,10 +72,10 @@ def test_throughput_floors():
     t_benc = _ms(lambda: hb.encode(x), 5)
     print(f"fwd_bwd {t_train:.3f} ms, encode {t_enc:.3f} ms, decode {t_dec:.3f} ms, bs512 step {1e3 * t_512:.1f} us, "
           f"bf16 encode {t_benc:.3f} ms per 1M rows")
-    assert t_train < 3.85, "training pair (r3 bench: 3.35 ms per 1M rows)"
-    assert t_enc < 0.615 and t_dec < 0.59, "fp32 encode / decode (r3 bench: 0.535 / 0.513 ms per 1M rows)"
-    assert 1e3 * t_512 < 21.0, "small-batch step (r3 bench: 18.2 us)"
-    assert t_benc < 0.112, "bf16 encode (r3 bench: 0.098 ms per 1M rows)"
+    assert t_train < lim(3.35), "training pair (bench: 3.35 ms per 1M rows)"
+    assert t_enc < lim(0.535) and t_dec < lim(0.513), "fp32 encode / decode (bench: 0.535 / 0.513 ms per 1M rows)"
+    assert 1e3 * t_512 < lim(18.2), "small-batch step (bench: 18.2 us)"
+    assert t_benc < lim(0.098), "bf16 encode (bench: 0.098 ms per 1M rows)"
 
 
 def test_round2_kernel_floors():
@@ -99,10 +108,10 @@ def test_round2_kernel_floors():
     t_wt = _ms(lambda: hw.fwd_bwd(xw, gw), 3)
     print(f"bf16 fwd_bwd {t_b:.3f} ms per 1M rows, fp64 bs512 step {1e3 * t_64:.1f} us, CFD_dense_AE(2500,25) encode {t_we:.3f} / decode {t_wd:.3f} ms "
           f"/ fwd_bwd {t_wt:.3f} ms per 32768 frames")
-    assert t_b < 0.857, "bf16 training kernels (r3 bench: 0.745 ms per 1M rows)"
-    assert 1e3 * t_64 < 47.4, "fp64 fused small-batch step (r3 bench: 41.2 us; layer-wise: 768 us)"
-    assert t_we < 0.327 and t_wd < 0.313, "wide-layer encode / decode (r3 bench: 0.284 / 0.272 ms per 32768 frames; layer-wise 0.66)"
-    assert t_wt < 1.80, "wide-model training pass (r3 bench: 1.56 ms per 32768 frames; all layer-wise 3.3)"
+    assert t_b < lim(0.745), "bf16 training kernels (r4 bench: 0.745 ms per 1M rows)"
+    assert 1e3 * t_64 < lim(41.2), "fp64 fused small-batch step (bench: 41.2 us; layer-wise: 768 us)"
+    assert t_we < lim(0.284) and t_wd < lim(0.272), "wide-layer encode / decode (bench: 0.284 / 0.272 ms per 32768 frames; layer-wise 0.66)"
+    assert t_wt < lim(1.56), "wide-model training pass (bench: 1.56 ms per 32768 frames; all layer-wise 3.3)"
     hb = native.Handle(wd, "bf16")
     hb.load_params(torch.from_numpy(np.concatenate([orc.formula_params(wd, 1), [0.0]]).astype(np.float32)).cuda())
     xb = torch.rand((131072, 2500), dtype=torch.float32, device="cuda")
@@ -110,7 +119,7 @@ def test_round2_kernel_floors():
     t_be = _ms(lambda: hb.encode(xb, out_dtype=torch.float32), 3)
     t_bd = _ms(lambda: hb.decode(zb), 3)
     print(f"bf16 mode, 131072 frames: encode {t_be:.3f} ms, decode {t_bd:.3f} ms")
-    assert t_be < 0.367 and t_bd < 0.505, "bf16 wide-layer encode / decode (round 4: 0.319 / 0.439 ms per 131072 frames = 0.52 / 0.38 of HBM; fp32 1.13 / 1.09)"
+    assert t_be < lim(0.319) and t_bd < lim(0.439), "bf16 wide-layer encode / decode (round 4: 0.319 / 0.439 ms per 131072 frames = 0.52 / 0.38 of HBM; fp32 1.13 / 1.09)"
 
 
 def test_round3_kernel_floors():
@@ -130,15 +139,15 @@ def test_round3_kernel_floors():
     fe, ft = 300_700 * n / 1e9 / 157.3, 1_554_200 * n / 1e9 / 157.3
     print(f"CFD_dense_AE(625,7), {n} blocks: encode {t_e:.3f} ms = {fe / t_e:.2f} of peak, decode {t_d:.3f} ms = {fe / t_d:.2f}, "
           f"fwd_bwd {t_t:.3f} ms = {ft / t_t:.2f}")
-    assert fe / t_e > 0.57, "exafel blocks encode (r3 bench: 0.655 of the fp32 MFMA peak)"
-    assert fe / t_d > 0.68 and ft / t_t > 0.55, "exafel decode / training pass (r3 bench: 0.785 / 0.63)"
+    assert fe / t_e > 0.655 / SLACK, "exafel blocks encode (bench: 0.655 of the fp32 MFMA peak)"
+    assert fe / t_d > 0.785 / SLACK and ft / t_t > 0.63 / SLACK, "exafel decode / training pass (bench: 0.785 / 0.63)"
 
 
 def test_round4_kernel_floors():
     """Round 4: class instantiations for other narrow tables (AE(30, 8): every kernel; AE(48, 12): inference + small-batch training),
     the fp64 fused training step with per-layer tile blocks at 262,144 rows, bf16 encode of the 512-column model."""
     n = 1_000_000
-    for (F, Z), path, lim_e, lim_t, lim_s in (((30, 8), "fused", 0.635, 3.99, 27.6), ((48, 12), "fused", 0.86, 4.9, 30.0)):
+    for (F, Z), path, lim_e, lim_t, lim_s in (((30, 8), "fused", lim(0.55), lim(3.45), lim(24.5)), ((48, 12), "fused", lim(0.75), lim(4.24), lim(26.0))):
         dims = orc.ae_dims(F, Z)
         h = native.Handle(dims, "fp32")
         assert h.path == path
@@ -168,11 +177,11 @@ def test_round4_kernel_floors():
     g64 = torch.zeros_like(p64)
     t_64 = _ms(lambda: h64.fwd_bwd(x, g64), 3)
     print(f"fp64 fwd_bwd {t_64:.3f} ms per 262144 rows = {357000 * 262144 / t_64 / 1e9 / 78.6:.3f} of the fp64 MFMA peak")
-    assert t_64 < 2.85, "fp64 fused training step (round 4: 2.47 ms per 262144 rows = 0.48 of the fp64 MFMA peak; round 3: 3.24, layer-wise 5.9)"
+    assert t_64 < lim(2.47), "fp64 fused training step (round 4: 2.47 ms per 262144 rows = 0.48 of the fp64 MFMA peak; round 3: 3.24, layer-wise 5.9)"
     wd = orc.ae_dims(512, 6)
     hb = native.Handle(wd, "bf16")
     hb.load_params(torch.from_numpy(np.concatenate([orc.formula_params(wd, 1), [0.0]]).astype(np.float32)).cuda())
     xb = torch.rand((1 << 20, 512), dtype=torch.float32, device="cuda")
     t_b = _ms(lambda: hb.encode(xb, out_dtype=torch.float32), 3)
     print(f"512-column model, bf16 encode: {t_b:.3f} ms per 1M rows = {2048 * (1 << 20) / t_b / 1e9:.2f} TB/s of rows")
-    assert t_b < 0.613, "bf16 encode of the 512-column model (round 4: 0.533 ms per 1M rows = 4.0 TB/s of rows; round 3: 2.44 TB/s)"
+    assert t_b < lim(0.533), "bf16 encode of the 512-column model (round 4: 0.533 ms per 1M rows = 4.0 TB/s of rows; round 3: 2.44 TB/s)"

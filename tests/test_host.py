@@ -228,6 +228,31 @@ def test_data_parallel_world2_gloo(tmp_path):
     assert "DP-OK" in out.stdout
 
 
+def test_forced_one_rank_process_group_gloo(tmp_path):
+    """BALER_AMD_FORCE_PG=1: init_from_env builds a ONE-rank group and the data-parallel step keeps its collectives (what the
+    GPU box runs over RCCL, tests/test_gpu_dp.py::test_rccl_world1_*); without the switch a single process has no group."""
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, os.environ['REPO'])\n"
+        "import torch\n"
+        "from baler_amd import dist as bdist\n"
+        "assert not bdist.collectives_on()\n"
+        "rank, world, local = bdist.init_from_env('gloo')\n"
+        "forced = os.environ.get('BALER_AMD_FORCE_PG') == '1'\n"
+        "assert (rank, world) == (0, 1) and bdist.is_dist() == forced and bdist.collectives_on() == forced\n"
+        "t = torch.arange(5.0)\n"
+        "assert torch.equal(bdist.allreduce_sum(t.clone()), t) and torch.equal(bdist.broadcast(t.clone()), t)\n"
+        "bdist.barrier()\n"
+        "print('PG-OK', forced)\n")
+    for forced in ("1", "0"):
+        env = dict(os.environ, REPO=REPO, BALER_AMD_FORCE_PG=forced, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert f"PG-OK {forced == '1'}" in out.stdout
+
+
 def test_delta_side_channel_files_roundtrip(tmp_path):
     """split_deltas -> save_deltas -> load_deltas (host logic of helper.py:589-606, baler.py:316-338,
     helper.py:655-665), and the list-of-float16 form the reference's own writer produced loads the same way."""

@@ -184,21 +184,36 @@ def test_bench_spawns_its_own_ranks(tmp_path):
 
 
 def test_prefault_jobs_hold_the_array_and_wait_by_span_start():
-    """hostio.prefault: every background memset keeps its array alive, and wait_prefault(stop) waits for every span that
-    STARTS below `stop` (a span overlapping the rows about to be drained must be mapped before they are copied in)."""
+    """hostio.prefault: every PENDING or RUNNING background memset keeps its array alive (a finished job has dropped its
+    reference), and wait_prefault(stop) waits for every span that STARTS below `stop` (a span overlapping the rows about to be
+    drained must be mapped before they are copied in).  Deterministic: the pool is blocked behind gate jobs while the array's
+    liveness is checked, so nothing depends on how fast the memsets run."""
     import gc
+    import threading
     import weakref
-    n = (3 * hostio.PREFAULT_SPAN + 12345) // 8
-    arr = np.empty(n, dtype=np.float64)
-    ref = weakref.ref(arr)
-    futs = hostio.prefault(arr)
-    assert [(a, e) for a, e, _ in futs] == [(a, min(a + hostio.PREFAULT_SPAN, arr.nbytes))
-                                            for a in range(0, arr.nbytes, hostio.PREFAULT_SPAN)]
-    del arr
-    gc.collect()
-    assert ref() is not None                      # the pending / finished jobs still reference it
+    from concurrent.futures import ThreadPoolExecutor
+    if hostio._FAULT_POOL is None:
+        hostio._FAULT_POOL = ThreadPoolExecutor(max_workers=hostio.PREFAULT_THREADS)
+    gate = threading.Event()
+    gates = [hostio._FAULT_POOL.submit(gate.wait) for _ in range(hostio.PREFAULT_THREADS)]      # every worker is parked
+    try:
+        n = (3 * hostio.PREFAULT_SPAN + 12345) // 8
+        arr = np.empty(n, dtype=np.float64)
+        ref = weakref.ref(arr)
+        futs = hostio.prefault(arr)
+        assert [(a, e) for a, e, _ in futs] == [(a, min(a + hostio.PREFAULT_SPAN, arr.nbytes))
+                                                for a in range(0, arr.nbytes, hostio.PREFAULT_SPAN)]
+        del arr
+        gc.collect()
+        assert ref() is not None and not any(f.done() for _, _, f in futs)      # pending jobs hold the array
+    finally:
+        gate.set()
+    for g in gates:
+        g.result()
     hostio.wait_prefault(futs, hostio.PREFAULT_SPAN + 1)
     assert len(futs) == 2                         # spans starting at 0 and at PREFAULT_SPAN are done and popped
     hostio.wait_prefault(futs)
     assert futs == []
+    gc.collect()
+    assert ref() is None                          # every job has finished and dropped its reference: the array is gone
     assert hostio.prefault(np.empty(1024)) == []  # small arrays are not worth a thread hop
