@@ -899,6 +899,444 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     }
 }
 
+// =====================================================================================================================
+// Round 5 -- the training pair re-written: a per-wave REGISTER CHAIN through ALL layers, weight fragments through an LDS ring.
+//
+// What bounded the kernels above: four lock-stepped waves exchanging every wide layer through LDS -- a
+// barrier, an LDS round trip and a serial VALU epilogue per layer on ONE in-order wave per SIMD (MFMA busy 27 %).  The narrow
+// layers already ran as a per-wave register chain ("M-split": a wave computes ALL output tiles of ITS 16 rows, a packed C tile
+// pair IS the next product's B operand); what kept the wide layers from it is the fragment stream: one 1-KiB fragment per
+// 16-cycle MFMA and wave = 64 B/clk per wave, four times what a CU's vector-memory path delivers.  Here every fragment is
+// fetched ONCE per workgroup, by direct-to-LDS loads (buffer_load ... lds: no registers, asynchronous), into a ring of kR
+// slots of kG KiB that all four waves read (ds_read_b128, kPF reads ahead of the MFMAs) -- the L1 path carries 1 KiB per kG / 4
+// ... per 4 MFMAs of the CU, the LDS one KiB per MFMA and wave.  The chain itself then has NO barrier and no LDS round trip between
+// layers; the ring is kept in step by ONE workgroup barrier per kG MFMAs (all four waves run the same instruction stream on
+// different rows, so they arrive together): before barrier s a wave waits (counted vmcnt, asm) for ITS quarter of slot s + 1,
+// after it slot s + 1 is complete and slot s - 1 is free, and the wave requests its quarter of slot s + 3 into that place.
+// Images are written (own rows, no barrier) only for what the weight-gradient phases and the LeakyReLU masks read back.
+// The cut between the two launches moves to the BOTTLENECK: PART 0 = forward 0..7, loss, input-gradient products 7..4, weight
+// gradients of the decoder (7..4: 149 tiles); PART 1 = forward 0..2 recomputed, dZ_3 handed over (ONE tile: 32 B per row instead
+// of 224), input-gradient products 3..1, weight gradients of the encoder (3..0: 149 tiles).  Each launch then keeps only its own
+// half of the images (108 / 100 KB instead of 132), which is what makes room for the 48-KB ring.
+constexpr int kG = 12;        // fragments (KiB) per ring slot = MFMAs per wave between two ring barriers; a multiple of 4
+constexpr int kR = 4;         // ring slots (a power of two): one being read, one complete, one in flight, one being requested
+constexpr int kPF = 12;       // fragment reads ahead of the MFMAs (4 registers each); <= kG
+static_assert(kG % 4 == 0 && (kR & (kR - 1)) == 0 && kPF <= kG, "ring geometry");
+
+template <int PART> struct Cut {
+    static constexpr int fwd_end = PART == 0 ? 8 : 3;        // forward layers [0, fwd_end)
+    static constexpr int bwd_hi = PART == 0 ? 7 : 3;         // weight gradients of layers bwd_hi .. bwd_lo
+    static constexpr int bwd_lo = PART == 0 ? 4 : 0;
+    static constexpr int chain_lo = PART == 0 ? 4 : 1;       // input-gradient products of layers bwd_hi .. chain_lo
+    __host__ __device__ static constexpr bool has(int l) { return l <= bwd_hi && l >= bwd_lo; }
+};
+// the launch's fragment stream in consumption order: forward products [q][t] of layers 0 .. fwd_end - 1, then the input-gradient
+// products [q][t] of layers bwd_hi .. chain_lo
+template <class N, int PART> struct Stream2 {
+    using C = Cut<PART>;
+    __host__ __device__ static constexpr int fo_f(int l) { int s = 0; for (int j = 0; j < l; ++j) s += N::kb(j) * N::nt(j); return s; }
+    __host__ __device__ static constexpr int fo_b(int l) { int s = fo_f(C::fwd_end); for (int j = C::bwd_hi; j > l; --j) s += N::kbb(j) * N::ntb(j); return s; }
+    static constexpr int nfrag = fo_b(C::chain_lo) + N::kbb(C::chain_lo) * N::ntb(C::chain_lo);
+    static constexpr int nslot = cdiv(nfrag, kG);
+    static_assert(nslot >= kR, "a launch's stream fills the ring");
+};
+// LDS image regions of a launch ([64 rows][stride] each; strides and swizzle as above).  dZ_l has the shape of X_{l+1}.
+//   PART 0:  X_7 | dZ_6 | X_6 | X_5 | X_4 | dZ_7 | dZ_4 ;  dZ_5 -> X_7's region (dead after dW_7)
+//   PART 1:  X_1 | X_2 | dZ_1 | X_0 | [X_3 | dZ_3 | dZ_2] ;  dZ_0 -> the bracket (448 B per row: dead after dW_3 and dW_2)
+template <class N, int PART> struct Plan2 {
+    __host__ __device__ static constexpr int S(int i) { return N::istride(i); }
+    __host__ __device__ static constexpr int xoff(int l) {
+        if (PART == 0) return 64 * (l == 7 ? 0 : l == 6 ? 2 * S(7) : l == 5 ? 2 * S(7) + S(6) : 2 * S(7) + S(6) + S(5));
+        return 64 * (l == 1 ? 0 : l == 2 ? S(1) : l == 0 ? S(1) + 2 * S(2) : S(1) + 2 * S(2) + S(0));
+    }
+    __host__ __device__ static constexpr int zoff(int l) {
+        if (PART == 0) return l == 7 ? xoff(4) + 64 * S(4) : l == 6 ? 64 * S(7) : l == 5 ? xoff(7) : xoff(4) + 64 * (S(4) + S(8));
+        return l == 1 ? 64 * (S(1) + S(2)) : l == 3 ? xoff(3) + 64 * S(3) : l == 2 ? xoff(3) + 64 * (S(3) + S(4)) : xoff(3);
+    }
+    static constexpr int img_bytes = PART == 0 ? zoff(4) + 64 * S(5) : zoff(2) + 64 * S(3);
+    static_assert(PART == 0 || S(1) <= S(3) + S(4) + S(3), "dZ_0 fits the region of X_3 | dZ_3 | dZ_2");
+    static_assert(S(6) <= S(7) && S(5) <= S(6), "a region is reused with a stride that is not larger");
+    static constexpr int fl_off = img_bytes;                               // 64 doubles: min | range
+    static constexpr int ring_off = (img_bytes + 512 + 1023) & ~1023;
+    static constexpr int lds_bytes = ring_off + kR * kG * 1024;
+    static_assert(lds_bytes <= 160 * 1024, "images + ring exceed one CU's LDS");
+};
+
+// one direct-to-LDS load: 64 lanes x 16 bytes = one fragment.  M0 (the LDS base) is not preserved by hipcc around asm: set and restored here
+__device__ __forceinline__ void dma_1k(unsigned lds_addr, int voff, __amdgpu_buffer_rsrc_t rs, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+struct Ring2 {
+    __amdgpu_buffer_rsrc_t rs;      // the launch's fragment stream
+    unsigned lds0;                  // LDS byte address of the ring
+    unsigned rot;                   // (slots requested before this iteration) mod kR
+    int lane16, wave;
+    lds_p rd[kR];                   // read base of the slot at stream position i mod kR of THIS iteration (+ lane * 16)
+};
+// this wave's quarter of slot NS of the stream into ring position `pos`
+template <class ST, int NS> __device__ __forceinline__ void ring_request(const Ring2 &rg, unsigned pos) {
+#ifdef BAMD_ABL_NODMA       // timing-only: no direct-to-LDS loads
+    return;
+#endif
+#pragma unroll
+    for (int k = 0; k < kG / 4; ++k) {
+        int fi = NS * kG + rg.wave * (kG / 4) + k;
+        fi = fi < ST::nfrag ? fi : ST::nfrag - 1;                          // the tail of the last slot: a valid fragment, never read
+        const unsigned dst = rg.lds0 + pos * (kG * 1024u) + (unsigned)(rg.wave * (kG / 4) + k) * 1024u;
+        dma_1k(__builtin_amdgcn_readfirstlane(dst), rg.lane16, rg.rs, __builtin_amdgcn_readfirstlane(fi * 1024));
+    }
+}
+// ring barrier S (in front of the first MFMA of slot S): afterwards slot S + 1 is complete and slot S - 1 free
+template <class ST, int S> __device__ __forceinline__ void ring_barrier(const Ring2 &rg) {
+    // all but my youngest requests (slot S + 2): my quarter of slot S + 1 has landed.  A bare s_barrier, not __syncthreads(): that one
+    // drains lgkmcnt(0), i.e. the kPF fragment reads in flight, at every ring barrier; nothing this barrier orders needs it (the slot
+    // whose place is requested next was consumed by MFMAs that have issued; image traffic has its own barriers A .. E).  The asm
+    // statements keep hipcc from moving LDS reads across it.
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(kG / 4) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ring_request<ST, (S + kR - 1) % ST::nslot>(rg, (rg.rot + S + kR - 1) & (kR - 1));
+}
+template <int GI> __device__ __forceinline__ bf8 ring_read(const Ring2 &rg) {
+#ifdef BAMD_ABL_NOFRAG      // timing-only: no fragment reads (stale operands)
+    bf8 z; asm volatile("" : "=v"(z)); return z;
+#else
+    return lds_b128(rg.rd[(GI / kG) & (kR - 1)] + (GI % kG) * 1024);
+#endif
+}
+// product with all NT output tiles of this wave's 16 rows: fragment GI0 + q NT + t feeds MFMA (k block q, tile t)
+template <class ST, int GI0, int KB, int NT, int F_>
+__device__ __forceinline__ void mstep2(v4 (&acc)[NT], const bf8 (&b)[KB], const Ring2 &rg, bf8 (&fr)[kPF]) {
+    constexpr int q = F_ / NT, t = F_ % NT, GI = GI0 + F_;
+    if constexpr (GI % kG == 0) ring_barrier<ST, GI / kG>(rg);
+    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+    acc[t] = mfma(fr[GI % kPF], b[q], q == 0 ? zero : acc[t]);
+    if constexpr (GI + kPF < ST::nfrag) fr[GI % kPF] = ring_read<GI + kPF>(rg);
+    if constexpr (F_ % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+}
+template <class ST, int GI0, int KB, int NT, int... F_>
+__device__ __forceinline__ void mchain2_impl(v4 (&acc)[NT], const bf8 (&b)[KB], const Ring2 &rg, bf8 (&fr)[kPF], std::integer_sequence<int, F_...>) {
+    (mstep2<ST, GI0, KB, NT, F_>(acc, b, rg, fr), ...);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class ST, int GI0, int KB, int NT>
+__device__ __forceinline__ void mchain2(v4 (&acc)[NT], const bf8 (&b)[KB], const Ring2 &rg, bf8 (&fr)[kPF]) {
+    mchain2_impl<ST, GI0, KB, NT>(acc, b, rg, fr, std::make_integer_sequence<int, KB * NT>{});
+}
+
+// input rows in C-TILE layout: lane (j, g) holds features 16 t + 4 g + r (t = 0, 1; r = 0..3) of row j of its wave's 16 rows --
+// the registers of two C tiles, i.e. (after the conversion) the B operand of layer 0 in the register chain's k order AND the
+// values the loss compares the reconstruction with: no LDS copy of x
+struct RawX2 { double d[8]; };
+template <int F>
+__device__ __forceinline__ void x_issue2(RawX2 &raw, const void *x, int is_f64, int64_t row, int64_t n, int g) {
+    const int64_t r = row < n ? row : 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int f0 = 16 * t + 4 * g;
+        const int64_t base = r * F + (f0 < F ? f0 : 0);
+        if (is_f64) {
+            const double2 *p = (const double2 *)((const double *)x + base);
+            const double2 a = p[0], b = p[1];
+            raw.d[4 * t] = a.x; raw.d[4 * t + 1] = a.y; raw.d[4 * t + 2] = b.x; raw.d[4 * t + 3] = b.y;
+        } else {
+            const float4 a = *(const float4 *)((const float *)x + base);
+            raw.d[4 * t] = a.x; raw.d[4 * t + 1] = a.y; raw.d[4 * t + 2] = a.z; raw.d[4 * t + 3] = a.w;
+        }
+    }
+}
+
+template <int F, int Z, int PART>
+__global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restrict__ wfrags, const void *__restrict__ xin, int in_f64, int64_t n,
+                                                          const double *__restrict__ feats, v4 *__restrict__ slabs,
+                                                          u2 *__restrict__ dz, int loss_tile) {
+    using N = TNet<F, Z>;
+    using C = Cut<PART>;
+    using ST = Stream2<N, PART>;
+    using PL = Plan2<N, PART>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+    const lds_p img = (lds_p)lds_raw;
+    double *fl = (double *)(lds_raw + PL::fl_off);              // [0..31] min, [32..63] range
+#ifdef BAMD_BF16_TRACE
+    unsigned long long *bt_lds = (unsigned long long *)(lds_raw + PL::lds_bytes);      // 4 waves x 64 stamps
+#define BT2(i) do { if ((threadIdx.x & 63) == 0) bt_lds[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BT2(i) do {} while (0)
+#endif
+    for (int i = threadIdx.x; i < PL::img_bytes / 16; i += 256) ((uint4 *)lds_raw)[i] = make_uint4(0, 0, 0, 0);   // finite padding slots
+    if (threadIdx.x < 64) {
+        const int f = threadIdx.x & 31, which = threadIdx.x >> 5;
+        fl[threadIdx.x] = (feats && f < F) ? feats[which * F + f] : (which ? 1.0 : 0.0);
+    }
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ngroups = (n + kRows - 1) / kRows;
+    Ring2 rg;
+    rg.rs = __builtin_amdgcn_make_buffer_rsrc((void *)wfrags, 0, ST::nfrag * 1024, 0x00020000);
+    rg.lds0 = (unsigned)(size_t)(img + PL::ring_off);
+    rg.rot = 0;
+    rg.lane16 = lane * 16;
+    rg.wave = wave;
+    v4 *slab = slabs + (int64_t)blockIdx.x * 64;
+
+    v4 g7[C::has(7) ? N::dwn(7) : 1], g6[C::has(6) ? N::dwn(6) : 1], g5[C::has(5) ? N::dwn(5) : 1], g4[C::has(4) ? N::dwn(4) : 1];
+    v4 g3[C::has(3) ? N::dwn(3) : 1], g2[C::has(2) ? N::dwn(2) : 1], g1[C::has(1) ? N::dwn(1) : 1], g0[C::has(0) ? N::dwn(0) : 1];
+    zero_acc(g7); zero_acc(g6); zero_acc(g5); zero_acc(g4); zero_acc(g3); zero_acc(g2); zero_acc(g1); zero_acc(g0);
+    double lacc = 0.0;
+    // the ring's first slots; slot 0 (and the images' zeros) must be there before the first fragment reads
+#pragma unroll
+    for (int s = 0; s < kR - 1; ++s) {
+        if (s == 0) ring_request<ST, 0>(rg, 0);
+        if (s == 1) ring_request<ST, 1 % ST::nslot>(rg, 1);
+        if (s == 2) ring_request<ST, 2 % ST::nslot>(rg, 2);
+    }
+    static_assert(kR == 4, "prologue requests slots 0 .. 2");
+    RawX2 xraw;
+    x_issue2<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15), n, lane >> 4);
+    u2 hand = (u2){0u, 0u};
+    if constexpr (PART == 1) hand = dz[((int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15)) * 4 + (lane >> 4)];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        // keep the LDS address arithmetic inside the loop (LICM would hoist hundreds of registers)
+        asm volatile("" : "+v"(rg.lane16), "+s"(wave), "+v"(lane));
+        BT2(0);
+        const int j = lane & 15, g = lane >> 4;
+        Lays ls;
+        ls.s1 = make_lay<64>(lane); ls.s3 = make_lay<192>(lane); ls.s5 = make_lay<320>(lane); ls.s7 = make_lay<448>(lane);
+#pragma unroll
+        for (int i = 0; i < kR; ++i) rg.rd[i] = img + PL::ring_off + ((rg.rot + i) & (kR - 1)) * (kG * 1024) + 16 * lane;
+        const int64_t row = grp * kRows + 16 * wave + j;
+        const bool valid = row < n;
+        bf8 fr[kPF];
+#pragma unroll
+        for (int i = 0; i < kPF; ++i) fr[i] = lds_b128(rg.rd[0] + i * 1024);       // slot 0: complete since the last ring barrier of the previous iteration
+        // ---- input rows: normalise, fp32 values in C-tile layout (kept for the loss), bf16 B operand of layer 0 ------------------
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int f = 16 * (e >> 2) + 4 * g + (e & 3);
+            double d = xraw.d[e];
+            if (feats) d = (d - fl[f & 31]) / fl[32 + (f & 31)];
+            v[e] = f < F ? (float)d : (f == F ? 1.0f : 0.f);                     // slot F = the ones column
+        }
+        bf8 b0[1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b0[0][e] = (__bf16)v[e];
+        if constexpr (C::has(0)) {
+            const Lay &l0 = lay_of<N::istride(0)>(ls);
+            const lds_p ob = img + PL::xoff(0) + 16 * wave * N::istride(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) lds_w64(ob + l0.wr(t & 1) + 32 * (t & ~1), pack4((v4){v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]}));
+        }
+
+        // ---- forward product of layer l: B operands `bin` -> packed output tiles `pk` (stored into image l + 1, own rows, when this
+        //      launch reads it back: weight gradient of layer l + 1, LeakyReLU mask of the input-gradient product of layer l + 1) -------
+#define BAMD2_FWD(l, bin, pk)                                                                                                \
+        u2 pk[N::nt(l)];                                                                                                     \
+        {                                                                                                                    \
+            v4 acc[N::nt(l)];                                                                                                \
+            mchain2<ST, ST::fo_f(l), N::kb(l), N::nt(l)>(acc, bin, rg, fr);                                                  \
+            const Lay &lo = lay_of<N::istride((l) + 1)>(ls);                                                                 \
+            const lds_p ob = img + PL::xoff((l) + 1) + 16 * wave * N::istride((l) + 1);                                      \
+            _Pragma("unroll") for (int t = 0; t < N::nt(l); ++t) {                                                           \
+                if (N::act(l)) lrelu4(acc[t]);                                                                               \
+                pk[t] = pack4(acc[t]);                                                                                       \
+                if constexpr (C::has((l) + 1)) lds_w64(ob + lo.wr(t & 1) + 32 * (t & ~1), pk[t]);                            \
+            }                                                                                                                \
+        }
+        // ---- input-gradient product of layer l: B operands `bin` (dZ_l) -> packed dZ_{l-1} tiles `pk`, masked with the sign of X_l (own
+        //      rows, read back from the image) where layer l - 1 has an activation; stored into dZ_{l-1}'s region when this launch
+        //      computes that layer's weight gradient
+#define BAMD2_BWD(l, bin, pk)                                                                                                \
+        u2 pk[N::ntb(l)];                                                                                                    \
+        {                                                                                                                    \
+            const Lay &lo = lay_of<N::istride(l)>(ls);                                                                       \
+            const lds_p xb = img + PL::xoff(l) + 16 * wave * N::istride(l);                                                  \
+            u2 y[N::ntb(l)];                                                                                                 \
+            if constexpr (N::act((l) - 1)) {                                                                                 \
+                _Pragma("unroll") for (int t = 0; t < N::ntb(l); ++t) y[t] = lds_b64(xb + lo.wr(t & 1) + 32 * (t & ~1));     \
+            }                                                                                                                \
+            v4 acc[N::ntb(l)];                                                                                               \
+            mchain2<ST, ST::fo_b(l), N::kbb(l), N::ntb(l)>(acc, bin, rg, fr);                                                \
+            const lds_p zb = img + PL::zoff(((l) - 1) >= C::bwd_lo ? (l) - 1 : C::bwd_lo) + 16 * wave * N::istride(l);        \
+            _Pragma("unroll") for (int t = 0; t < N::ntb(l); ++t) {                                                          \
+                if constexpr (N::act((l) - 1)) pk[t] = lrelu_bwd_pack4(acc[t], y[t]);                                        \
+                else pk[t] = pack4(acc[t]);                                                                                  \
+                if constexpr ((l) - 1 >= C::bwd_lo) lds_w64(zb + lo.wr(t & 1) + 32 * (t & ~1), pk[t]);                       \
+            }                                                                                                                \
+        }
+#define BAMD2_DW(l, G) dw_phase<N, l, N::istride((l) + 1), N::istride(l)>(G, img + PL::zoff(l), img + PL::xoff(l), lay_of<N::istride((l) + 1)>(ls), \
+                                                                         lay_of<N::istride(l)>(ls), wave);
+        BT2(1);
+        BAMD2_FWD(0, b0, p1)
+        BT2(2);
+        bf8 b1[N::kb(1)];
+        regfeed<N::kb(1), N::nt(0)>(b1, p1);
+        BAMD2_FWD(1, b1, p2)
+        BT2(3);
+        bf8 b2[N::kb(2)];
+        regfeed<N::kb(2), N::nt(1)>(b2, p2);
+        BAMD2_FWD(2, b2, p3)
+        BT2(4);
+        if constexpr (PART == 0) {
+            bf8 b3[N::kb(3)];
+            regfeed<N::kb(3), N::nt(2)>(b3, p3);
+            BAMD2_FWD(3, b3, p4)
+            BT2(5);
+            bf8 b4[N::kb(4)];
+            regfeed<N::kb(4), N::nt(3)>(b4, p4);
+            BAMD2_FWD(4, b4, p5)
+            BT2(6);
+            bf8 b5[N::kb(5)];
+            regfeed<N::kb(5), N::nt(4)>(b5, p5);
+            BAMD2_FWD(5, b5, p6)
+            BT2(7);
+            bf8 b6[N::kb(6)];
+            regfeed<N::kb(6), N::nt(5)>(b6, p6);
+            BAMD2_FWD(6, b6, p7)
+            BT2(8);
+            bf8 b7[N::kb(7)];
+            regfeed<N::kb(7), N::nt(6)>(b7, p7);
+            // layer 7 + loss: both output tiles of this wave's 16 rows against the fp32 input values it kept
+            static_assert(N::nt(7) == 2, "the reconstruction is two tiles");
+            v4 rec[2];
+            mchain2<ST, ST::fo_f(7), N::kb(7), 2>(rec, b7, rg, fr);
+            BT2(9);
+            u2 d7[2];
+            const Lay &l8 = lay_of<N::istride(8)>(ls);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                v4 d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = rec[t][r] - v[4 * t + r];
+                    const bool live = valid && 16 * t + 4 * g + r < F;
+                    if (live) lacc += (double)e * (double)e;
+                    d[r] = live ? e * (2.0f / (float)F) : 0.f;                  // dL/drecon = 2 (r - x) / C  (utils.py:195-199)
+                }
+                d7[t] = pack4(d);
+                lds_w64(img + PL::zoff(7) + 16 * wave * N::istride(8) + l8.wr(t & 1) + 32 * (t & ~1), d7[t]);
+            }
+            BT2(10);
+            __syncthreads();                                                    // A: dZ_7 and X_4 .. X_7 of all 64 rows
+            BT2(11);
+            bf8 c7[N::kbb(7)];
+            regfeed<N::kbb(7), 2>(c7, d7);
+            BAMD2_BWD(7, c7, q6)
+            BT2(12);
+            BAMD2_DW(7, g7)
+            BT2(13);
+            __syncthreads();                                                    // B: dZ_6 complete; X_7 dead (dZ_5 goes there)
+            BT2(14);
+            bf8 c6[N::kbb(6)];
+            regfeed<N::kbb(6), N::ntb(7)>(c6, q6);
+            BAMD2_BWD(6, c6, q5)
+            BT2(15);
+            bf8 c5[N::kbb(5)];
+            regfeed<N::kbb(5), N::ntb(6)>(c5, q5);
+            BAMD2_BWD(5, c5, q4)
+            BT2(16);
+            bf8 c4[N::kbb(4)];
+            regfeed<N::kbb(4), N::ntb(5)>(c4, q4);
+            BAMD2_BWD(4, c4, q3)
+            // hand-off to the second launch: dZ_3 (ONE tile), 8 bytes per lane: [row][g]; rows beyond n carry zeros
+            static_assert(N::ntb(4) == 1, "the latent is one tile");
+            dz[row * 4 + g] = q3[0];
+            // the NEXT iteration's rows, requested behind the last ring wait of this one: the weight-gradient phases below give the
+            // HBM fetch its time (loads of a wave retire in order: requested at the top it would stand in front of every ring wait)
+            x_issue2<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);
+            BT2(17);
+            BAMD2_DW(6, g6)
+            BT2(18);
+            __syncthreads();                                                    // D: dZ_5, dZ_4 complete
+            BT2(19);
+            BAMD2_DW(5, g5)
+            BT2(20);
+            BAMD2_DW(4, g4)
+            BT2(21);
+            __syncthreads();                                                    // E: the next forward overwrites X_4 .. X_7
+            BT2(22);
+        } else {
+            static_assert(N::ntb(4) == 1 && N::nt(3) == 1, "the latent is one tile");
+            // dZ_3 of these rows from the first launch -> its image (own rows) and the B operand of the first input-gradient product
+            u2 q3[1] = {hand};
+            {
+                const Lay &l4 = lay_of<N::istride(4)>(ls);
+                lds_w64(img + PL::zoff(3) + 16 * wave * N::istride(4) + l4.wr(0), q3[0]);
+            }
+            BT2(5);
+            __syncthreads();                                                    // A: X_0 .. X_3 and dZ_3 of all 64 rows
+            BT2(6);
+            bf8 c3[N::kbb(3)];
+            regfeed<N::kbb(3), 1>(c3, q3);
+            BAMD2_BWD(3, c3, q2)
+            BT2(7);
+            BAMD2_DW(3, g3)
+            BT2(8);
+            __syncthreads();                                                    // B: dZ_2
+            BT2(9);
+            bf8 c2[N::kbb(2)];
+            regfeed<N::kbb(2), N::ntb(3)>(c2, q2);
+            BAMD2_BWD(2, c2, q1)
+            BT2(10);
+            BAMD2_DW(2, g2)
+            BT2(11);
+            __syncthreads();                                                    // C: dZ_1; X_3 | dZ_3 | dZ_2 dead (dZ_0 goes there)
+            BT2(12);
+            bf8 c1[N::kbb(1)];
+            regfeed<N::kbb(1), N::ntb(2)>(c1, q1);
+            BAMD2_BWD(1, c1, q0)
+            (void)q0;
+            BT2(13);
+            x_issue2<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);
+            {
+                const int64_t nr = row + (int64_t)gridDim.x * kRows;
+                hand = dz[(nr < ngroups * kRows ? nr : row) * 4 + g];
+            }
+            BAMD2_DW(1, g1)
+            BT2(14);
+            __syncthreads();                                                    // D: dZ_0
+            BT2(15);
+            BAMD2_DW(0, g0)
+            BT2(16);
+            __syncthreads();                                                    // E
+            BT2(17);
+        }
+#undef BAMD2_FWD
+#undef BAMD2_BWD
+#undef BAMD2_DW
+        rg.rot = (rg.rot + ST::nslot) & (kR - 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // nothing may land in LDS after the workgroup has gone
+#ifdef BAMD_BF16_TRACE
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 256) g_bf16_trace[PART][threadIdx.x >> 6][threadIdx.x & 63] = bt_lds[threadIdx.x];
+#endif
+#undef BT2
+    if constexpr (C::has(7)) dw_flush<N, 7>(slab, g7, lane, wave);
+    if constexpr (C::has(6)) dw_flush<N, 6>(slab, g6, lane, wave);
+    if constexpr (C::has(5)) dw_flush<N, 5>(slab, g5, lane, wave);
+    if constexpr (C::has(4)) dw_flush<N, 4>(slab, g4, lane, wave);
+    if constexpr (C::has(3)) dw_flush<N, 3>(slab, g3, lane, wave);
+    if constexpr (C::has(2)) dw_flush<N, 2>(slab, g2, lane, wave);
+    if constexpr (C::has(1)) dw_flush<N, 1>(slab, g1, lane, wave);
+    if constexpr (C::has(0)) dw_flush<N, 0>(slab, g0, lane, wave);
+    if constexpr (PART == 0) {   // per-workgroup loss partial (fixed-order tree), stored after the tiles
+        __syncthreads();
+        double *sh = (double *)lds_raw;
+        sh[threadIdx.x] = lacc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) ((double *)(slabs + (int64_t)loss_tile * gridDim.x * 64))[blockIdx.x] = sh[0];
+    }
+}
+
 // Fixed-order reduction of the per-workgroup partial gradients ([tile][workgroup][64 lanes] float4) into the canonical
 // (state-dict) layout; block `ntiles`: grads[np] = sum of the loss partials / C.  One wave per tile (see fused.hip).
 __global__ void __launch_bounds__(256) reduce_tiles_k(const v4 *__restrict__ slabs, int nslab, int ntiles, const int *__restrict__ inv_map,
@@ -948,12 +1386,15 @@ struct TrainOps;
 struct TrainState {
     const TrainOps *ops = nullptr;
     DevBuf src, w, inv, dz;
+    DevBuf src2[2], w2[2];          // the register-chain pair: one fragment stream per launch
     int wcount = 0, ntiles = 0, nparams = 0, n_features = 0;
+    int wcount2[2] = {0, 0};
     int nwg_max = 256;
 };
 struct TrainOps {
     int (*setup)(bamd_handle *, TrainState *);
     int (*fwd_bwd)(bamd_handle *, TrainState *, const void *, int, int64_t, const double *, float *, hipStream_t);
+    int (*pack)(bamd_handle *, TrainState *, hipStream_t);
 };
 TrainState *tstate(bamd_handle *h) { return (TrainState *)h->bf16_train_state; }
 
@@ -970,6 +1411,35 @@ template <int F, int Z> struct TImpl {
         for (int i = 0; i <= 8; ++i)
             if (h->dims[i] != N::dim(i)) return false;
         return true;
+    }
+    // gradient map (accumulator tile slot -> canonical parameter), tile count, parameter count
+    static int setup_maps(bamd_handle *h, TrainState *st) {
+        // accumulator tile (kt, nt) of layer l, lane (j, g), register r = dW[16 nt + 4 g + r][16 kt + j]; column K = db
+        const int ntiles = N::slab_off(N::L);
+        std::vector<int> inv((size_t)ntiles * 256, -1);
+        for (int l = 0; l < N::L; ++l) {
+            const int K = N::dim(l), NN = N::dim(l + 1);
+            for (int k = 0; k < N::kt(l); ++k)
+                for (int t = 0; t < N::nt(l); ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = 16 * t + 4 * (lane >> 4) + r, kc = 16 * k + (lane & 15);
+                            if (n >= NN) continue;
+                            const size_t o = ((size_t)(N::slab_off(l) + k * N::nt(l) + t) * 64 + lane) * 4 + r;
+                            if (kc < K) inv[o] = N::w_off(l) + n * K + kc;
+                            else if (kc == K) inv[o] = N::b_off(l) + n;
+                        }
+        }
+        {   // every parameter must be produced exactly once
+            std::vector<char> seen(N::nparams(), 0);
+            for (int v : inv) if (v >= 0) seen[v]++;
+            for (char c : seen) if (c != 1) { set_error("bf16 training: incomplete gradient map"); return BAMD_ERR_INVALID; }
+        }
+        st->ntiles = ntiles; st->nparams = N::nparams(); st->n_features = F;
+        int rc = st->inv.ensure(inv.size() * sizeof(int));
+        if (rc) return rc;
+        BAMD_HIP(hipMemcpy(st->inv.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice));
+        return BAMD_OK;
     }
     static int setup(bamd_handle *h, TrainState *st) {
         const size_t wcount = (size_t)N::nfrag() * 512;
@@ -1004,36 +1474,14 @@ template <int F, int Z> struct TImpl {
             static_assert(N::dim(1) % 16 && N::dim(2) % 16 && N::dim(3) % 16 && N::dim(4) % 16,
                           "every layer output needs a padding slot for the ones column");
         }
-        // accumulator tile (kt, nt) of layer l, lane (j, g), register r = dW[16 nt + 4 g + r][16 kt + j]; column K = db
-        const int ntiles = N::slab_off(N::L);
-        std::vector<int> inv((size_t)ntiles * 256, -1);
-        for (int l = 0; l < N::L; ++l) {
-            const int K = N::dim(l), NN = N::dim(l + 1);
-            for (int k = 0; k < N::kt(l); ++k)
-                for (int t = 0; t < N::nt(l); ++t)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = 16 * t + 4 * (lane >> 4) + r, kc = 16 * k + (lane & 15);
-                            if (n >= NN) continue;
-                            const size_t o = ((size_t)(N::slab_off(l) + k * N::nt(l) + t) * 64 + lane) * 4 + r;
-                            if (kc < K) inv[o] = N::w_off(l) + n * K + kc;
-                            else if (kc == K) inv[o] = N::b_off(l) + n;
-                        }
-        }
-        {   // every parameter must be produced exactly once
-            std::vector<char> seen(N::nparams(), 0);
-            for (int v : inv) if (v >= 0) seen[v]++;
-            for (char c : seen) if (c != 1) { set_error("bf16 training: incomplete gradient map"); return BAMD_ERR_INVALID; }
-        }
-        st->wcount = (int)wcount; st->ntiles = ntiles; st->nparams = N::nparams(); st->n_features = F;
-        int rc = st->src.ensure(src.size() * sizeof(int));
+        int rc = setup_maps(h, st);
         if (rc) return rc;
-        rc = st->inv.ensure(inv.size() * sizeof(int));
+        st->wcount = (int)wcount;
+        rc = st->src.ensure(src.size() * sizeof(int));
         if (rc) return rc;
         rc = st->w.ensure(wcount * sizeof(__bf16) + 4096);
         if (rc) return rc;
         BAMD_HIP(hipMemcpy(st->src.p, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
-        BAMD_HIP(hipMemcpy(st->inv.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice));
         BAMD_HIP(hipFuncSetAttribute((const void *)bf16_train_kernel<F, Z, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes()));
         BAMD_HIP(hipFuncSetAttribute((const void *)bf16_train_kernel<F, Z, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes()));
         return BAMD_OK;
@@ -1054,22 +1502,135 @@ template <int F, int Z> struct TImpl {
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
+    static int pack(bamd_handle *h, TrainState *st, hipStream_t s) {
+        hipLaunchKernelGGL(pack_train_k, dim3((st->wcount + 255) / 256), dim3(256), 0, s, (const float *)h->params.p,
+                           (const int *)st->src.p, st->wcount, (__bf16 *)st->w.p);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
     static const TrainOps *ops() {
-        static const TrainOps o = {setup, fwd_bwd};
+        static const TrainOps o = {setup, fwd_bwd, pack};
         return &o;
     }
 };
 
+// ---- host side of the round-5 pair -------------------------------------------------------------------------------------------
+template <int F, int Z> struct TImpl2 {
+    using N = TNet<F, Z>;
+    static bool matches(const bamd_handle *h) { return TImpl<F, Z>::matches(h); }
+    static constexpr int lds2(int part) {
+#ifdef BAMD_BF16_TRACE
+        return (part ? Plan2<N, 1>::lds_bytes : Plan2<N, 0>::lds_bytes) + 2048;      // + the stamps
+#else
+        return part ? Plan2<N, 1>::lds_bytes : Plan2<N, 0>::lds_bytes;
+#endif
+    }
+    // fragment source map of one launch's stream.  EVERY product is fed from packed C tiles (or, layer 0, from rows loaded in that
+    // layout): k slot (g, e) of k block q <-> feature 32 q + 16 (e >> 2) + 4 g + (e & 3)
+    template <int PART> static void stream_map(std::vector<int> &src) {
+        using C = Cut<PART>;
+        using ST = Stream2<N, PART>;
+        src.assign((size_t)ST::nfrag * 512, -1);
+        auto kperm = [](int q, int g, int e) { return 32 * q + 16 * (e >> 2) + 4 * g + (e & 3); };
+        for (int l = 0; l < C::fwd_end; ++l) {
+            const int K = N::dim(l), NN = N::dim(l + 1);
+            // forward fragment (q, t): lane (i, g) element e = [W | b | .][16 t + i][k]: input column K (the ones slot) holds the
+            // bias, and padding output NN has a 1 there: it becomes the next layer's ones slot
+            for (int q = 0; q < N::kb(l); ++q)
+                for (int t = 0; t < N::nt(l); ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int n = 16 * t + (lane & 15), k = kperm(q, lane >> 4, e);
+                            int v = -1;
+                            if (n < NN && k < K) v = N::w_off(l) + n * K + k;
+                            else if (n < NN && k == K) v = N::b_off(l) + n;
+                            else if (n == NN && k == K) v = -2;
+                            src[((size_t)(ST::fo_f(l) + q * N::nt(l) + t) * 64 + lane) * 8 + e] = v;
+                        }
+        }
+        for (int l = C::bwd_hi; l >= C::chain_lo; --l) {
+            const int K = N::dim(l), NN = N::dim(l + 1);
+            // input-gradient fragment (q, t): lane (i, g) element e = W[n][16 t + i], n = the permuted k slot (an output feature)
+            for (int q = 0; q < N::kbb(l); ++q)
+                for (int t = 0; t < N::ntb(l); ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int n = kperm(q, lane >> 4, e), k = 16 * t + (lane & 15);
+                            if (n < NN && k < K) src[((size_t)(ST::fo_b(l) + q * N::ntb(l) + t) * 64 + lane) * 8 + e] = N::w_off(l) + n * K + k;
+                        }
+        }
+    }
+    static int setup(bamd_handle *h, TrainState *st) {
+        // the gradient map, the tile count and the checks are the first version's (same weight-gradient phases, same tile layout)
+        int rc = TImpl<F, Z>::setup_maps(h, st);
+        if (rc) return rc;
+        std::vector<int> src;
+        stream_map<0>(src);
+        st->wcount2[0] = (int)src.size();
+        rc = st->src2[0].ensure(src.size() * sizeof(int));
+        if (!rc) rc = st->w2[0].ensure(src.size() * sizeof(__bf16) + 4096);
+        if (rc) return rc;
+        BAMD_HIP(hipMemcpy(st->src2[0].p, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
+        stream_map<1>(src);
+        st->wcount2[1] = (int)src.size();
+        rc = st->src2[1].ensure(src.size() * sizeof(int));
+        if (!rc) rc = st->w2[1].ensure(src.size() * sizeof(__bf16) + 4096);
+        if (rc) return rc;
+        BAMD_HIP(hipMemcpy(st->src2[1].p, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
+        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_train2_kernel<F, Z, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2(0)));
+        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_train2_kernel<F, Z, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2(1)));
+        return BAMD_OK;
+    }
+    static int pack(bamd_handle *h, TrainState *st, hipStream_t s) {
+        for (int p = 0; p < 2; ++p)
+            hipLaunchKernelGGL(pack_train_k, dim3((st->wcount2[p] + 255) / 256), dim3(256), 0, s, (const float *)h->params.p,
+                               (const int *)st->src2[p].p, st->wcount2[p], (__bf16 *)st->w2[p].p);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int fwd_bwd(bamd_handle *h, TrainState *st, const void *x, int x_dtype, int64_t n, const double *features, float *grads,
+                       hipStream_t s) {
+        const int64_t ngroups = (n + kRows - 1) / kRows;
+        const int grid = (int)(ngroups < st->nwg_max ? ngroups : st->nwg_max);
+        int rc = h->slabs.ensure(((size_t)st->ntiles * 1024 + 16) * (size_t)grid);      // tiles + one double per workgroup for the loss
+        if (rc) return rc;
+        rc = st->dz.ensure((size_t)ngroups * kRows * 32);                               // dZ_3: one tile = 32 bytes per row
+        if (rc) return rc;
+        hipLaunchKernelGGL((bf16_train2_kernel<F, Z, 0>), dim3(grid), dim3(256), (lds2(0)), s, (const uint4 *)st->w2[0].p, x,
+                           x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
+        hipLaunchKernelGGL((bf16_train2_kernel<F, Z, 1>), dim3(grid), dim3(256), (lds2(1)), s, (const uint4 *)st->w2[1].p, x,
+                           x_dtype == BAMD_F64, n, features, (v4 *)h->slabs.p, (u2 *)st->dz.p, st->ntiles);
+        hipLaunchKernelGGL(reduce_tiles_k, dim3(st->ntiles + 1), dim3(256), 0, s, (const v4 *)h->slabs.p, grid, st->ntiles,
+                           (const int *)st->inv.p, st->nparams, 1.0 / F, grads);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static const TrainOps *ops() {
+        static const TrainOps o = {setup, fwd_bwd, pack};
+        return &o;
+    }
+};
+
+// BALER_AMD_BF16_TRAIN_V1=1: the round-2..4 pair (N-split wide layers, cut below layer 1) instead of the register-chain pair
+static bool train_v1() {
+    const char *e = getenv("BALER_AMD_BF16_TRAIN_V1");
+    return e && e[0] == '1';
+}
+template <int F, int Z> const TrainOps *pick_train(const bamd_handle *h) {
+    if (!TImpl<F, Z>::matches(h)) return nullptr;
+    return train_v1() ? TImpl<F, Z>::ops() : TImpl2<F, Z>::ops();
+}
 const TrainOps *find_train(const bamd_handle *h) {
-    if (TImpl<24, 15>::matches(h)) return TImpl<24, 15>::ops();
-    if (TImpl<24, 12>::matches(h)) return TImpl<24, 12>::ops();
-    if (TImpl<24, 8>::matches(h)) return TImpl<24, 8>::ops();
-    if (TImpl<24, 6>::matches(h)) return TImpl<24, 6>::ops();
-    if (TImpl<24, 10>::matches(h)) return TImpl<24, 10>::ops();
-    if (TImpl<24, 5>::matches(h)) return TImpl<24, 5>::ops();
-    if (TImpl<24, 4>::matches(h)) return TImpl<24, 4>::ops();
-    if (TImpl<24, 3>::matches(h)) return TImpl<24, 3>::ops();
-    if (TImpl<24, 2>::matches(h)) return TImpl<24, 2>::ops();
+    const TrainOps *o = nullptr;
+    if ((o = pick_train<24, 15>(h))) return o;
+    if ((o = pick_train<24, 12>(h))) return o;
+    if ((o = pick_train<24, 8>(h))) return o;
+    if ((o = pick_train<24, 6>(h))) return o;
+    if ((o = pick_train<24, 10>(h))) return o;
+    if ((o = pick_train<24, 5>(h))) return o;
+    if ((o = pick_train<24, 4>(h))) return o;
+    if ((o = pick_train<24, 3>(h))) return o;
+    if ((o = pick_train<24, 2>(h))) return o;
     return nullptr;
 }
 
@@ -1096,6 +1657,7 @@ void bf16_train_teardown(bamd_handle *h) {
     TrainState *st = tstate(h);
     if (!st) return;
     st->src.release(); st->w.release(); st->inv.release(); st->dz.release();
+    for (int p = 0; p < 2; ++p) { st->src2[p].release(); st->w2[p].release(); }
     delete st;
     h->bf16_train_state = nullptr;
 }
@@ -1105,10 +1667,7 @@ bool bf16_train_ok(const bamd_handle *h) { return h->bf16_train_state != nullptr
 int bf16_train_pack(bamd_handle *h, hipStream_t s) {
     TrainState *st = tstate(h);
     if (!st) return BAMD_OK;
-    hipLaunchKernelGGL(pack_train_k, dim3((st->wcount + 255) / 256), dim3(256), 0, s, (const float *)h->params.p,
-                       (const int *)st->src.p, st->wcount, (__bf16 *)st->w.p);
-    BAMD_HIP(hipGetLastError());
-    return BAMD_OK;
+    return st->ops->pack(h, st, s);
 }
 
 int bf16_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, hipStream_t s) {
