@@ -941,23 +941,23 @@ template <class N, int PART> struct Stream2 {
     static_assert(nslot >= kR, "a launch's stream fills the ring");
 };
 // LDS image regions of a launch ([64 rows][stride] each; strides and swizzle as above).  dZ_l has the shape of X_{l+1}.
-//   PART 0:  X_7 | dZ_6 | X_6 | X_5 | X_4 | dZ_7 | dZ_4 ;  dZ_5 -> X_7's region (dead after dW_7)
-//   PART 1:  X_1 | X_2 | dZ_1 | X_0 | [X_3 | dZ_3 | dZ_2] ;  dZ_0 -> the bracket (448 B per row: dead after dW_3 and dW_2)
+//   PART 0:  [X_7 | dZ_7] | dZ_6 | X_6 | X_5 | X_4 ;  dZ_5 and dZ_4 -> the bracket (dead after dW_7): 96 KB
+//   PART 1:  X_1 | X_0 | [X_3 | dZ_3 | pad] | X_2 | dZ_2 | dZ_0 ;  dZ_1 -> the bracket (dead after dW_3): 112 KB
+// Together with the 48-KB ring that is PART 1's LDS to the last byte (the per-feature min / range of normalise-on-load sit in registers).
 template <class N, int PART> struct Plan2 {
     __host__ __device__ static constexpr int S(int i) { return N::istride(i); }
     __host__ __device__ static constexpr int xoff(int l) {
-        if (PART == 0) return 64 * (l == 7 ? 0 : l == 6 ? 2 * S(7) : l == 5 ? 2 * S(7) + S(6) : 2 * S(7) + S(6) + S(5));
-        return 64 * (l == 1 ? 0 : l == 2 ? S(1) : l == 0 ? S(1) + 2 * S(2) : S(1) + 2 * S(2) + S(0));
+        if (PART == 0) return 64 * (l == 7 ? 0 : l == 6 ? 2 * S(7) + S(8) : l == 5 ? 2 * S(7) + S(8) + S(6) : 2 * S(7) + S(8) + S(6) + S(5));
+        return 64 * (l == 1 ? 0 : l == 0 ? S(1) : l == 3 ? S(1) + S(0) : S(1) + S(0) + S(2));
     }
     __host__ __device__ static constexpr int zoff(int l) {
-        if (PART == 0) return l == 7 ? xoff(4) + 64 * S(4) : l == 6 ? 64 * S(7) : l == 5 ? xoff(7) : xoff(4) + 64 * (S(4) + S(8));
-        return l == 1 ? 64 * (S(1) + S(2)) : l == 3 ? xoff(3) + 64 * S(3) : l == 2 ? xoff(3) + 64 * (S(3) + S(4)) : xoff(3);
+        if (PART == 0) return 64 * (l == 7 ? S(7) : l == 6 ? S(7) + S(8) : l == 5 ? 0 : S(6));
+        return l == 3 ? xoff(3) + 64 * S(3) : l == 1 ? xoff(3) : l == 2 ? xoff(2) + 64 * S(2) : xoff(2) + 64 * (S(2) + S(3));
     }
-    static constexpr int img_bytes = PART == 0 ? zoff(4) + 64 * S(5) : zoff(2) + 64 * S(3);
-    static_assert(PART == 0 || S(1) <= S(3) + S(4) + S(3), "dZ_0 fits the region of X_3 | dZ_3 | dZ_2");
-    static_assert(S(6) <= S(7) && S(5) <= S(6), "a region is reused with a stride that is not larger");
-    static constexpr int fl_off = img_bytes;                               // 64 doubles: min | range
-    static constexpr int ring_off = (img_bytes + 512 + 1023) & ~1023;
+    static constexpr int img_bytes = PART == 0 ? xoff(4) + 64 * S(4) : zoff(0) + 64 * S(1);
+    static_assert(S(6) + S(5) <= S(7) + S(8), "dZ_5 | dZ_4 fit the region of X_7 | dZ_7");
+    static_assert(S(3) + S(4) <= S(2), "X_3 | dZ_3 fit the region dZ_1 takes over");
+    static constexpr int ring_off = (img_bytes + 1023) & ~1023;
     static constexpr int lds_bytes = ring_off + kR * kG * 1024;
     static_assert(lds_bytes <= 160 * 1024, "images + ring exceed one CU's LDS");
 };
@@ -1006,24 +1006,85 @@ template <int GI> __device__ __forceinline__ bf8 ring_read(const Ring2 &rg) {
     return lds_b128(rg.rd[(GI / kG) & (kR - 1)] + (GI % kG) * 1024);
 #endif
 }
-// product with all NT output tiles of this wave's 16 rows: fragment GI0 + q NT + t feeds MFMA (k block q, tile t)
-template <class ST, int GI0, int KB, int NT, int F_>
-__device__ __forceinline__ void mstep2(v4 (&acc)[NT], const bf8 (&b)[KB], const Ring2 &rg, bf8 (&fr)[kPF]) {
-    constexpr int q = F_ / NT, t = F_ % NT, GI = GI0 + F_;
-    if constexpr (GI % kG == 0) ring_barrier<ST, GI / kG>(rg);
-    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
-    acc[t] = mfma(fr[GI % kPF], b[q], q == 0 ? zero : acc[t]);
-    if constexpr (GI + kPF < ST::nfrag) fr[GI % kPF] = ring_read<GI + kPF>(rg);
-    if constexpr (F_ % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+// LeakyReLU / its derivative for the register-chain pair: SCALAR v_mul_f32.  A v_pk_mul_f32 next to v_mfma_f32_16x16x32_bf16 cannot hide
+// behind the MFMA at all (tools/probe/valu_beside_mfma_probe.hip, one wave per SIMD: MFMA slot 16.5 cycles, + one v_pk_mul_f32 = 33.3,
+// + two independent v_mul_f32 = 17.3): the packed form that wins in the serial epilogues of the first pair costs 17 cycles per
+// instruction here.
+__device__ __forceinline__ void lrelu4s(v4 &a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = __builtin_elementwise_maximum(a[r], a[r] * 0.01f);
 }
-template <class ST, int GI0, int KB, int NT, int... F_>
-__device__ __forceinline__ void mchain2_impl(v4 (&acc)[NT], const bf8 (&b)[KB], const Ring2 &rg, bf8 (&fr)[kPF], std::integer_sequence<int, F_...>) {
-    (mstep2<ST, GI0, KB, NT, F_>(acc, b, rg, fr), ...);
+__device__ __forceinline__ u2 lrelu_bwd_pack4s(const v4 &d, u2 y) {
+    v4 m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[r] = d[r] * 0.01f;
+    const u2 p1 = pack4(d), p2 = pack4(m);
+    unsigned sh = 0x000F000Fu;
+    u2 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned mask;
+        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(mask) : "v"(sh), "v"(y[h]));      // (through asm: see lrelu_bwd_pack4)
+        o[h] = (p2[h] & mask) | (p1[h] & ~mask);
+    }
+    return o;
+}
+// ---- a product of the register chain, software-pipelined -------------------------------------------------------------------------
+// The B operand of k block q is two tiles of the PREVIOUS product's raw accumulators after their epilogue (`fin(tile)`: activation or
+// mask, conversion, the image store where this launch reads the tile back).  A product does not finish its own outputs: the NEXT
+// product finishes them k block by k block, one k block ahead of its MFMAs, and the scheduler is told to deal that VALU work between
+// the MFMAs (sched_group_barrier: 1 MFMA, VPM VALU, 1 LDS read, ...): an epilogue placed behind its own product left the MFMA pipe
+// idle for ~75 cycles per tile and the VALU idle during the MFMAs (measured: tools/bf16_trace2.py).  `post(tile)` runs right after
+// MFMA `tile` of the LAST k block: the hook in which the caller finishes tiles 0, 1 for the next product's first B operand (or, for
+// the last product of a chain, every tile with a lag of two).
+template <int V> using IC = std::integral_constant<int, V>;
+template <int Q, int NTP, class Fin> __device__ __forceinline__ bf8 bop(Fin &fin) {
+    typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+    u2 lo = (u2){0u, 0u}, hi = (u2){0u, 0u};
+    if constexpr (2 * Q < NTP) lo = fin(IC<2 * Q>{});
+    if constexpr (2 * Q + 1 < NTP) hi = fin(IC<2 * Q + 1>{});
+    return __builtin_bit_cast(bf8, (u4_){lo[0], lo[1], hi[0], hi[1]});
+}
+template <class ST, int GI, int VPM, bool FIRST>
+__device__ __forceinline__ void mfma_one(v4 &acc, const bf8 &b, const Ring2 &rg, bf8 (&fr)[kPF]) {
+    if constexpr (GI % kG == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        ring_barrier<ST, GI / kG>(rg);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+    acc = mfma(fr[GI % kPF], b, FIRST ? zero : acc);
+    if constexpr (GI + kPF < ST::nfrag) fr[GI % kPF] = ring_read<GI + kPF>(rg);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // this MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);        // its share of the VALU work of the region
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // its fragment read
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // an image store, if one is ready
+}
+template <class ST, int GI0, int KB, int NT, int NTP, int VPM, int Q, class Fin, class Post, int... T>
+__device__ __forceinline__ void pstep(v4 (&acc)[NT], bf8 (&bq)[2], Fin &fin, Post &post, const Ring2 &rg, bf8 (&fr)[kPF],
+                                      std::integer_sequence<int, T...>) {
+    if constexpr (Q + 1 < KB) bq[(Q + 1) & 1] = bop<Q + 1, NTP>(fin);
+    auto one = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        mfma_one<ST, GI0 + Q * NT + t, VPM, Q == 0>(acc[t], bq[Q & 1], rg, fr);
+        if constexpr (Q == KB - 1) post(tc);
+    };
+    (one(IC<T>{}), ...);
     __builtin_amdgcn_sched_barrier(0);
 }
-template <class ST, int GI0, int KB, int NT>
-__device__ __forceinline__ void mchain2(v4 (&acc)[NT], const bf8 (&b)[KB], const Ring2 &rg, bf8 (&fr)[kPF]) {
-    mchain2_impl<ST, GI0, KB, NT>(acc, b, rg, fr, std::make_integer_sequence<int, KB * NT>{});
+template <class ST, int GI0, int KB, int NT, int NTP, int VPM, class Fin, class Post, int... Q>
+__device__ __forceinline__ void mprod_impl(v4 (&acc)[NT], const bf8 &b0, Fin &fin, Post &post, const Ring2 &rg, bf8 (&fr)[kPF],
+                                           std::integer_sequence<int, Q...>) {
+    bf8 bq[2];
+    bq[0] = b0;
+    (pstep<ST, GI0, KB, NT, NTP, VPM, Q>(acc, bq, fin, post, rg, fr, std::make_integer_sequence<int, NT>{}), ...);
+}
+// acc[NT] = product over KB k blocks; b0 = B operand of k block 0 (finished by the caller), fin = epilogue of the previous product's
+// tiles (NTP of them) for k blocks 1 .. KB - 1
+template <class ST, int GI0, int KB, int NT, int NTP, class Fin, class Post>
+__device__ __forceinline__ void mprod(v4 (&acc)[NT], const bf8 &b0, Fin &fin, Post &post, const Ring2 &rg, bf8 (&fr)[kPF]) {
+    constexpr int VPM = (22 + NT - 1) / NT;            // ~22 VALU per k block of epilogue work (two tiles), dealt over its NT MFMAs
+    mprod_impl<ST, GI0, KB, NT, NTP, VPM>(acc, b0, fin, post, rg, fr, std::make_integer_sequence<int, KB>{});
 }
 
 // input rows in C-TILE layout: lane (j, g) holds features 16 t + 4 g + r (t = 0, 1; r = 0..3) of row j of its wave's 16 rows --
@@ -1058,20 +1119,23 @@ __global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restric
     using PL = Plan2<N, PART>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
     const lds_p img = (lds_p)lds_raw;
-    double *fl = (double *)(lds_raw + PL::fl_off);              // [0..31] min, [32..63] range
-#ifdef BAMD_BF16_TRACE
-    unsigned long long *bt_lds = (unsigned long long *)(lds_raw + PL::lds_bytes);      // 4 waves x 64 stamps
-#define BT2(i) do { if ((threadIdx.x & 63) == 0) bt_lds[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef BAMD_BF16_TRACE      // PART 0: stamps in LDS behind the ring (copied out at the end); PART 1 has no LDS left: straight to global memory
+    unsigned long long *bt_lds = PART == 0 ? (unsigned long long *)(lds_raw + PL::lds_bytes) : &g_bf16_trace[1][0][0];
+#define BT2(i) do { if ((threadIdx.x & 63) == 0 && (PART == 0 || blockIdx.x == 0)) bt_lds[(threadIdx.x >> 6) * (PART == 0 ? 64 : 128) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define BT2(i) do {} while (0)
 #endif
     for (int i = threadIdx.x; i < PL::img_bytes / 16; i += 256) ((uint4 *)lds_raw)[i] = make_uint4(0, 0, 0, 0);   // finite padding slots
-    if (threadIdx.x < 64) {
-        const int f = threadIdx.x & 31, which = threadIdx.x >> 5;
-        fl[threadIdx.x] = (feats && f < F) ? feats[which * F + f] : (which ? 1.0 : 0.0);
-    }
     int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ngroups = (n + kRows - 1) / kRows;
+    // min / range of this lane's eight features (normalise-on-load), in registers: the launches' LDS is images + ring to the last byte
+    double fmn[8], frg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int f = 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
+        fmn[e] = (feats && f < F) ? feats[f] : 0.0;
+        frg[e] = (feats && f < F) ? feats[F + f] : 1.0;
+    }
     Ring2 rg;
     rg.rs = __builtin_amdgcn_make_buffer_rsrc((void *)wfrags, 0, ST::nfrag * 1024, 0x00020000);
     rg.lds0 = (unsigned)(size_t)(img + PL::ring_off);
@@ -1085,13 +1149,10 @@ __global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restric
     zero_acc(g7); zero_acc(g6); zero_acc(g5); zero_acc(g4); zero_acc(g3); zero_acc(g2); zero_acc(g1); zero_acc(g0);
     double lacc = 0.0;
     // the ring's first slots; slot 0 (and the images' zeros) must be there before the first fragment reads
-#pragma unroll
-    for (int s = 0; s < kR - 1; ++s) {
-        if (s == 0) ring_request<ST, 0>(rg, 0);
-        if (s == 1) ring_request<ST, 1 % ST::nslot>(rg, 1);
-        if (s == 2) ring_request<ST, 2 % ST::nslot>(rg, 2);
-    }
     static_assert(kR == 4, "prologue requests slots 0 .. 2");
+    ring_request<ST, 0>(rg, 0);
+    ring_request<ST, 1 % ST::nslot>(rg, 1);
+    ring_request<ST, 2 % ST::nslot>(rg, 2);
     RawX2 xraw;
     x_issue2<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows + 16 * wave + (lane & 15), n, lane >> 4);
     u2 hand = (u2){0u, 0u};
@@ -1119,140 +1180,146 @@ __global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restric
         for (int e = 0; e < 8; ++e) {
             const int f = 16 * (e >> 2) + 4 * g + (e & 3);
             double d = xraw.d[e];
-            if (feats) d = (d - fl[f & 31]) / fl[32 + (f & 31)];
+            if (feats) d = (d - fmn[e]) / frg[e];
             v[e] = f < F ? (float)d : (f == F ? 1.0f : 0.f);                     // slot F = the ones column
         }
-        bf8 b0[1];
+        bf8 b0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) b0[0][e] = (__bf16)v[e];
+        for (int e = 0; e < 8; ++e) b0[e] = (__bf16)v[e];
         if constexpr (C::has(0)) {
             const Lay &l0 = lay_of<N::istride(0)>(ls);
             const lds_p ob = img + PL::xoff(0) + 16 * wave * N::istride(0);
 #pragma unroll
             for (int t = 0; t < 2; ++t) lds_w64(ob + l0.wr(t & 1) + 32 * (t & ~1), pack4((v4){v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]}));
         }
+        BT2(1);
 
-        // ---- forward product of layer l: B operands `bin` -> packed output tiles `pk` (stored into image l + 1, own rows, when this
-        //      launch reads it back: weight gradient of layer l + 1, LeakyReLU mask of the input-gradient product of layer l + 1) -------
-#define BAMD2_FWD(l, bin, pk)                                                                                                \
-        u2 pk[N::nt(l)];                                                                                                     \
-        {                                                                                                                    \
-            v4 acc[N::nt(l)];                                                                                                \
-            mchain2<ST, ST::fo_f(l), N::kb(l), N::nt(l)>(acc, bin, rg, fr);                                                  \
-            const Lay &lo = lay_of<N::istride((l) + 1)>(ls);                                                                 \
-            const lds_p ob = img + PL::xoff((l) + 1) + 16 * wave * N::istride((l) + 1);                                      \
-            _Pragma("unroll") for (int t = 0; t < N::nt(l); ++t) {                                                           \
-                if (N::act(l)) lrelu4(acc[t]);                                                                               \
-                pk[t] = pack4(acc[t]);                                                                                       \
-                if constexpr (C::has((l) + 1)) lds_w64(ob + lo.wr(t & 1) + 32 * (t & ~1), pk[t]);                            \
-            }                                                                                                                \
+        // epilogue of forward tile t of layer l: [LeakyReLU] -> bf16 (-> image l + 1, own rows, when this launch reads it back)
+#define BAMD3_FIN_F(l, accv)                                                                                                 \
+        [&](auto tc) -> u2 {                                                                                                 \
+            constexpr int t = decltype(tc)::value;                                                                           \
+            v4 a = accv[t];                                                                                                  \
+            if (N::act(l)) lrelu4s(a);                                                                                        \
+            const u2 p = pack4(a);                                                                                           \
+            if constexpr (C::has((l) + 1))                                                                                   \
+                lds_w64(img + PL::xoff((l) + 1) + 16 * wave * N::istride((l) + 1) + lay_of<N::istride((l) + 1)>(ls).wr(t & 1) + 32 * (t & ~1), p); \
+            return p;                                                                                                        \
         }
-        // ---- input-gradient product of layer l: B operands `bin` (dZ_l) -> packed dZ_{l-1} tiles `pk`, masked with the sign of X_l (own
-        //      rows, read back from the image) where layer l - 1 has an activation; stored into dZ_{l-1}'s region when this launch
-        //      computes that layer's weight gradient
-#define BAMD2_BWD(l, bin, pk)                                                                                                \
-        u2 pk[N::ntb(l)];                                                                                                    \
-        {                                                                                                                    \
-            const Lay &lo = lay_of<N::istride(l)>(ls);                                                                       \
+        // epilogue of tile t of the input-gradient product of layer l (= dZ_{l-1}): mask with the sign of X_l (own rows, read ahead
+        // into `yv`) where layer l - 1 has an activation -> bf16 (-> dZ_{l-1}'s region when this launch computes that weight gradient)
+#define BAMD3_FIN_B(l, accv, yv)                                                                                             \
+        [&](auto tc) -> u2 {                                                                                                 \
+            constexpr int t = decltype(tc)::value;                                                                           \
+            u2 p;                                                                                                            \
+            if constexpr (N::act((l) - 1)) p = lrelu_bwd_pack4s(accv[t], yv[t]);                                              \
+            else p = pack4(accv[t]);                                                                                         \
+            if constexpr ((l) - 1 >= C::bwd_lo)                                                                              \
+                lds_w64(img + PL::zoff((l) - 1 >= C::bwd_lo ? (l) - 1 : C::bwd_lo) + 16 * wave * N::istride(l) + lay_of<N::istride(l)>(ls).wr(t & 1) + 32 * (t & ~1), p); \
+            return p;                                                                                                        \
+        }
+        // sign masks of X_l (own rows) for the input-gradient product of layer l, read ahead of that product
+#define BAMD3_MASKS(l, yv)                                                                                                   \
+        u2 yv[N::ntb(l)];                                                                                                    \
+        if constexpr (N::act((l) - 1)) {                                                                                     \
             const lds_p xb = img + PL::xoff(l) + 16 * wave * N::istride(l);                                                  \
-            u2 y[N::ntb(l)];                                                                                                 \
-            if constexpr (N::act((l) - 1)) {                                                                                 \
-                _Pragma("unroll") for (int t = 0; t < N::ntb(l); ++t) y[t] = lds_b64(xb + lo.wr(t & 1) + 32 * (t & ~1));     \
-            }                                                                                                                \
-            v4 acc[N::ntb(l)];                                                                                               \
-            mchain2<ST, ST::fo_b(l), N::kbb(l), N::ntb(l)>(acc, bin, rg, fr);                                                \
-            const lds_p zb = img + PL::zoff(((l) - 1) >= C::bwd_lo ? (l) - 1 : C::bwd_lo) + 16 * wave * N::istride(l);        \
-            _Pragma("unroll") for (int t = 0; t < N::ntb(l); ++t) {                                                          \
-                if constexpr (N::act((l) - 1)) pk[t] = lrelu_bwd_pack4(acc[t], y[t]);                                        \
-                else pk[t] = pack4(acc[t]);                                                                                  \
-                if constexpr ((l) - 1 >= C::bwd_lo) lds_w64(zb + lo.wr(t & 1) + 32 * (t & ~1), pk[t]);                       \
-            }                                                                                                                \
+            _Pragma("unroll") for (int t = 0; t < N::ntb(l); ++t) yv[t] = lds_b64(xb + lay_of<N::istride(l)>(ls).wr(t & 1) + 32 * (t & ~1)); \
         }
 #define BAMD2_DW(l, G) dw_phase<N, l, N::istride((l) + 1), N::istride(l)>(G, img + PL::zoff(l), img + PL::xoff(l), lay_of<N::istride((l) + 1)>(ls), \
                                                                          lay_of<N::istride(l)>(ls), wave);
-        BT2(1);
-        BAMD2_FWD(0, b0, p1)
+        auto nofin = [&](auto) -> u2 { return (u2){0u, 0u}; };
+        // forward 0 .. 2 (both launches): each product finishes its predecessor's tiles; post(1) of a product's last k block finishes
+        // ITS tiles 0, 1 = the first B operand of the next product
+        v4 a1[N::nt(0)], a2[N::nt(1)], a3[N::nt(2)];
+        auto fin0 = BAMD3_FIN_F(0, a1);
+        auto fin1 = BAMD3_FIN_F(1, a2);
+        auto fin2 = BAMD3_FIN_F(2, a3);
+        bf8 b1, b2, b3;
+        auto post0 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b1 = bop<0, N::nt(0)>(fin0); };
+        auto post1 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b2 = bop<0, N::nt(1)>(fin1); };
+        mprod<ST, ST::fo_f(0), N::kb(0), N::nt(0), 2>(a1, b0, nofin, post0, rg, fr);
         BT2(2);
-        bf8 b1[N::kb(1)];
-        regfeed<N::kb(1), N::nt(0)>(b1, p1);
-        BAMD2_FWD(1, b1, p2)
+        mprod<ST, ST::fo_f(1), N::kb(1), N::nt(1), N::nt(0)>(a2, b1, fin0, post1, rg, fr);
         BT2(3);
-        bf8 b2[N::kb(2)];
-        regfeed<N::kb(2), N::nt(1)>(b2, p2);
-        BAMD2_FWD(2, b2, p3)
-        BT2(4);
         if constexpr (PART == 0) {
-            bf8 b3[N::kb(3)];
-            regfeed<N::kb(3), N::nt(2)>(b3, p3);
-            BAMD2_FWD(3, b3, p4)
-            BT2(5);
-            bf8 b4[N::kb(4)];
-            regfeed<N::kb(4), N::nt(3)>(b4, p4);
-            BAMD2_FWD(4, b4, p5)
-            BT2(6);
-            bf8 b5[N::kb(5)];
-            regfeed<N::kb(5), N::nt(4)>(b5, p5);
-            BAMD2_FWD(5, b5, p6)
-            BT2(7);
-            bf8 b6[N::kb(6)];
-            regfeed<N::kb(6), N::nt(5)>(b6, p6);
-            BAMD2_FWD(6, b6, p7)
-            BT2(8);
-            bf8 b7[N::kb(7)];
-            regfeed<N::kb(7), N::nt(6)>(b7, p7);
-            // layer 7 + loss: both output tiles of this wave's 16 rows against the fp32 input values it kept
-            static_assert(N::nt(7) == 2, "the reconstruction is two tiles");
-            v4 rec[2];
-            mchain2<ST, ST::fo_f(7), N::kb(7), 2>(rec, b7, rg, fr);
-            BT2(9);
-            u2 d7[2];
-            const Lay &l8 = lay_of<N::istride(8)>(ls);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            v4 a4[N::nt(3)], a5[N::nt(4)], a6[N::nt(5)], a7[N::nt(6)], rec[2];
+            static_assert(N::nt(7) == 2 && N::nt(3) == 1 && N::ntb(4) == 1, "the reconstruction is two tiles, the latent one");
+            auto fin3 = BAMD3_FIN_F(3, a4);
+            auto fin4 = BAMD3_FIN_F(4, a5);
+            auto fin5 = BAMD3_FIN_F(5, a6);
+            auto fin6 = BAMD3_FIN_F(6, a7);
+            // loss: both output tiles of this wave's 16 rows against the fp32 input values it kept; dL/drecon = 2 (r - x) / C (utils.py:195-199)
+            auto fin7 = [&](auto tc) -> u2 {
+                constexpr int t = decltype(tc)::value;
                 v4 d;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float e = rec[t][r] - v[4 * t + r];
                     const bool live = valid && 16 * t + 4 * g + r < F;
                     if (live) lacc += (double)e * (double)e;
-                    d[r] = live ? e * (2.0f / (float)F) : 0.f;                  // dL/drecon = 2 (r - x) / C  (utils.py:195-199)
+                    d[r] = live ? e * (2.0f / (float)F) : 0.f;
                 }
-                d7[t] = pack4(d);
-                lds_w64(img + PL::zoff(7) + 16 * wave * N::istride(8) + l8.wr(t & 1) + 32 * (t & ~1), d7[t]);
-            }
+                const u2 p = pack4(d);
+                lds_w64(img + PL::zoff(7) + 16 * wave * N::istride(8) + lay_of<N::istride(8)>(ls).wr(t & 1) + 32 * (t & ~1), p);
+                return p;
+            };
+            bf8 b4, b5, b6, b7, c7;
+            auto post2 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b3 = bop<0, N::nt(2)>(fin2); };
+            auto post3 = [&](auto tc) { if constexpr (decltype(tc)::value == 0) b4 = bop<0, N::nt(3)>(fin3); };
+            auto post4 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b5 = bop<0, N::nt(4)>(fin4); };
+            auto post5 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b6 = bop<0, N::nt(5)>(fin5); };
+            auto post6 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b7 = bop<0, N::nt(6)>(fin6); };
+            auto post7 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c7 = bop<0, 2>(fin7); };
+            mprod<ST, ST::fo_f(2), N::kb(2), N::nt(2), N::nt(1)>(a3, b2, fin1, post2, rg, fr);
+            BT2(4);
+            mprod<ST, ST::fo_f(3), N::kb(3), N::nt(3), N::nt(2)>(a4, b3, fin2, post3, rg, fr);
+            BT2(5);
+            mprod<ST, ST::fo_f(4), N::kb(4), N::nt(4), N::nt(3)>(a5, b4, fin3, post4, rg, fr);
+            BT2(6);
+            mprod<ST, ST::fo_f(5), N::kb(5), N::nt(5), N::nt(4)>(a6, b5, fin4, post5, rg, fr);
+            BT2(7);
+            mprod<ST, ST::fo_f(6), N::kb(6), N::nt(6), N::nt(5)>(a7, b6, fin5, post6, rg, fr);
+            BT2(8);
+            mprod<ST, ST::fo_f(7), N::kb(7), 2, N::nt(6)>(rec, b7, fin6, post7, rg, fr);
             BT2(10);
             __syncthreads();                                                    // A: dZ_7 and X_4 .. X_7 of all 64 rows
             BT2(11);
-            bf8 c7[N::kbb(7)];
-            regfeed<N::kbb(7), 2>(c7, d7);
-            BAMD2_BWD(7, c7, q6)
+            // input-gradient products 7 .. 4: dZ_6 .. dZ_3, finished by the next product each
+            v4 d6[N::ntb(7)], d5[N::ntb(6)], d4[N::ntb(5)], d3[1];
+            BAMD3_MASKS(7, y7)
+            auto finb7 = BAMD3_FIN_B(7, d6, y7);
+            bf8 c6, c5, c4;
+            auto postb7 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c6 = bop<0, N::ntb(7)>(finb7); };
+            mprod<ST, ST::fo_b(7), N::kbb(7), N::ntb(7), 2>(d6, c7, nofin, postb7, rg, fr);
             BT2(12);
             BAMD2_DW(7, g7)
             BT2(13);
-            __syncthreads();                                                    // B: dZ_6 complete; X_7 dead (dZ_5 goes there)
+            __syncthreads();                                                    // B: X_7 | dZ_7 dead (dZ_5, dZ_4 go there)
             BT2(14);
-            bf8 c6[N::kbb(6)];
-            regfeed<N::kbb(6), N::ntb(7)>(c6, q6);
-            BAMD2_BWD(6, c6, q5)
+            BAMD3_MASKS(6, y6)
+            auto finb6 = BAMD3_FIN_B(6, d5, y6);
+            auto postb6 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c5 = bop<0, N::ntb(6)>(finb6); };
+            mprod<ST, ST::fo_b(6), N::kbb(6), N::ntb(6), N::ntb(7)>(d5, c6, finb7, postb6, rg, fr);
             BT2(15);
-            bf8 c5[N::kbb(5)];
-            regfeed<N::kbb(5), N::ntb(6)>(c5, q5);
-            BAMD2_BWD(5, c5, q4)
+            BAMD3_MASKS(5, y5)
+            auto finb5 = BAMD3_FIN_B(5, d4, y5);
+            auto postb5 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c4 = bop<0, N::ntb(5)>(finb5); };
+            mprod<ST, ST::fo_b(5), N::kbb(5), N::ntb(5), N::ntb(6)>(d4, c5, finb6, postb5, rg, fr);
             BT2(16);
-            bf8 c4[N::kbb(4)];
-            regfeed<N::kbb(4), N::ntb(5)>(c4, q4);
-            BAMD2_BWD(4, c4, q3)
+            u2 yz[1];
+            auto finb4 = BAMD3_FIN_B(4, d3, yz);
+            u2 q3 = (u2){0u, 0u};
+            auto postb4 = [&](auto tc) { if constexpr (decltype(tc)::value == 0) q3 = finb4(IC<0>{}); };
+            mprod<ST, ST::fo_b(4), N::kbb(4), 1, N::ntb(5)>(d3, c4, finb5, postb4, rg, fr);
             // hand-off to the second launch: dZ_3 (ONE tile), 8 bytes per lane: [row][g]; rows beyond n carry zeros
-            static_assert(N::ntb(4) == 1, "the latent is one tile");
-            dz[row * 4 + g] = q3[0];
+            dz[row * 4 + g] = q3;
             // the NEXT iteration's rows, requested behind the last ring wait of this one: the weight-gradient phases below give the
             // HBM fetch its time (loads of a wave retire in order: requested at the top it would stand in front of every ring wait)
             x_issue2<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);
             BT2(17);
+            __syncthreads();                                                    // D: dZ_6, dZ_5, dZ_4 of all 64 rows
+            BT2(19);
             BAMD2_DW(6, g6)
             BT2(18);
-            __syncthreads();                                                    // D: dZ_5, dZ_4 complete
-            BT2(19);
             BAMD2_DW(5, g5)
             BT2(20);
             BAMD2_DW(4, g4)
@@ -1260,60 +1327,80 @@ __global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restric
             __syncthreads();                                                    // E: the next forward overwrites X_4 .. X_7
             BT2(22);
         } else {
+            // forward 2 is the last forward product here: its tiles (X_3) are finished right behind their last MFMAs, with a lag of two
+            u2 x3p[N::nt(2)];
+            auto post2 = [&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (t >= 2) x3p[t - 2] = fin2(IC<t - 2>{});
+            };
+            mprod<ST, ST::fo_f(2), N::kb(2), N::nt(2), N::nt(1)>(a3, b2, fin1, post2, rg, fr);
+            static_assert(N::nt(2) >= 2, "lagged finish");
+            x3p[N::nt(2) - 2] = fin2(IC<N::nt(2) - 2>{});
+            x3p[N::nt(2) - 1] = fin2(IC<N::nt(2) - 1>{});
+            (void)x3p;
+            BT2(4);
             static_assert(N::ntb(4) == 1 && N::nt(3) == 1, "the latent is one tile");
             // dZ_3 of these rows from the first launch -> its image (own rows) and the B operand of the first input-gradient product
-            u2 q3[1] = {hand};
-            {
-                const Lay &l4 = lay_of<N::istride(4)>(ls);
-                lds_w64(img + PL::zoff(3) + 16 * wave * N::istride(4) + l4.wr(0), q3[0]);
-            }
+            lds_w64(img + PL::zoff(3) + 16 * wave * N::istride(4) + lay_of<N::istride(4)>(ls).wr(0), hand);
+            typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+            const bf8 c3 = __builtin_bit_cast(bf8, (u4_){hand[0], hand[1], 0u, 0u});
             BT2(5);
             __syncthreads();                                                    // A: X_0 .. X_3 and dZ_3 of all 64 rows
             BT2(6);
-            bf8 c3[N::kbb(3)];
-            regfeed<N::kbb(3), 1>(c3, q3);
-            BAMD2_BWD(3, c3, q2)
+            v4 d2[N::ntb(3)], d1[N::ntb(2)], d0[N::ntb(1)];
+            BAMD3_MASKS(3, y3)
+            auto finb3 = BAMD3_FIN_B(3, d2, y3);
+            bf8 c2, c1;
+            auto postb3 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c2 = bop<0, N::ntb(3)>(finb3); };
+            mprod<ST, ST::fo_b(3), N::kbb(3), N::ntb(3), 1>(d2, c3, nofin, postb3, rg, fr);
             BT2(7);
             BAMD2_DW(3, g3)
             BT2(8);
-            __syncthreads();                                                    // B: dZ_2
+            __syncthreads();                                                    // B: X_3 | dZ_3 dead (dZ_1 goes there)
             BT2(9);
-            bf8 c2[N::kbb(2)];
-            regfeed<N::kbb(2), N::ntb(3)>(c2, q2);
-            BAMD2_BWD(2, c2, q1)
+            BAMD3_MASKS(2, y2)
+            auto finb2 = BAMD3_FIN_B(2, d1, y2);
+            auto postb2 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c1 = bop<0, N::ntb(2)>(finb2); };
+            mprod<ST, ST::fo_b(2), N::kbb(2), N::ntb(2), N::ntb(3)>(d1, c2, finb3, postb2, rg, fr);
             BT2(10);
-            BAMD2_DW(2, g2)
-            BT2(11);
-            __syncthreads();                                                    // C: dZ_1; X_3 | dZ_3 | dZ_2 dead (dZ_0 goes there)
-            BT2(12);
-            bf8 c1[N::kbb(1)];
-            regfeed<N::kbb(1), N::ntb(2)>(c1, q1);
-            BAMD2_BWD(1, c1, q0)
-            (void)q0;
-            BT2(13);
+            BAMD3_MASKS(1, y1)
+            auto finb1 = BAMD3_FIN_B(1, d0, y1);
+            u2 z0p[N::ntb(1)];
+            auto postb1 = [&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (t >= 2) z0p[t - 2] = finb1(IC<t - 2>{});
+            };
+            mprod<ST, ST::fo_b(1), N::kbb(1), N::ntb(1), N::ntb(2)>(d0, c1, finb2, postb1, rg, fr);
+            z0p[N::ntb(1) - 2] = finb1(IC<N::ntb(1) - 2>{});
+            z0p[N::ntb(1) - 1] = finb1(IC<N::ntb(1) - 1>{});
+            (void)z0p;
             x_issue2<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);
             {
                 const int64_t nr = row + (int64_t)gridDim.x * kRows;
                 hand = dz[(nr < ngroups * kRows ? nr : row) * 4 + g];
             }
+            BT2(13);
+            __syncthreads();                                                    // D: dZ_2, dZ_1, dZ_0 of all 64 rows
+            BT2(15);
+            BAMD2_DW(2, g2)
+            BT2(11);
             BAMD2_DW(1, g1)
             BT2(14);
-            __syncthreads();                                                    // D: dZ_0
-            BT2(15);
             BAMD2_DW(0, g0)
             BT2(16);
             __syncthreads();                                                    // E
             BT2(17);
         }
-#undef BAMD2_FWD
-#undef BAMD2_BWD
+#undef BAMD3_FIN_F
+#undef BAMD3_FIN_B
+#undef BAMD3_MASKS
 #undef BAMD2_DW
         rg.rot = (rg.rot + ST::nslot) & (kR - 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // nothing may land in LDS after the workgroup has gone
 #ifdef BAMD_BF16_TRACE
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x < 256) g_bf16_trace[PART][threadIdx.x >> 6][threadIdx.x & 63] = bt_lds[threadIdx.x];
+    if (PART == 0 && blockIdx.x == 0 && threadIdx.x < 256) g_bf16_trace[0][threadIdx.x >> 6][threadIdx.x & 63] = bt_lds[threadIdx.x];
 #endif
 #undef BT2
     if constexpr (C::has(7)) dw_flush<N, 7>(slab, g7, lane, wave);
@@ -1520,7 +1607,7 @@ template <int F, int Z> struct TImpl2 {
     static bool matches(const bamd_handle *h) { return TImpl<F, Z>::matches(h); }
     static constexpr int lds2(int part) {
 #ifdef BAMD_BF16_TRACE
-        return (part ? Plan2<N, 1>::lds_bytes : Plan2<N, 0>::lds_bytes) + 2048;      // + the stamps
+        return part ? Plan2<N, 1>::lds_bytes : Plan2<N, 0>::lds_bytes + 2048;        // + the stamps (PART 1 stamps go to global memory)
 #else
         return part ? Plan2<N, 1>::lds_bytes : Plan2<N, 0>::lds_bytes;
 #endif
