@@ -1030,21 +1030,23 @@ __device__ __forceinline__ u2 lrelu_bwd_pack4s(const v4 &d, u2 y) {
     return o;
 }
 // ---- a product of the register chain, software-pipelined -------------------------------------------------------------------------
-// The B operand of k block q is two tiles of the PREVIOUS product's raw accumulators after their epilogue (`fin(tile)`: activation or
-// mask, conversion, the image store where this launch reads the tile back).  A product does not finish its own outputs: the NEXT
-// product finishes them k block by k block, one k block ahead of its MFMAs, and the scheduler is told to deal that VALU work between
-// the MFMAs (sched_group_barrier: 1 MFMA, VPM VALU, 1 LDS read, ...): an epilogue placed behind its own product left the MFMA pipe
-// idle for ~75 cycles per tile and the VALU idle during the MFMAs (measured: tools/bf16_trace2.py).  `post(tile)` runs right after
-// MFMA `tile` of the LAST k block: the hook in which the caller finishes tiles 0, 1 for the next product's first B operand (or, for
-// the last product of a chain, every tile with a lag of two).
+// Measured on gfx950, ONE wave per SIMD (tools/probe/valu_beside_mfma_probe.hip): a v_mfma_f32_16x16x32_bf16 slot is 16.5 cycles; up
+// to two INDEPENDENT VALU instructions issue beside it for free (17.3), further ones cost 4.4 cycles each, a DEPENDENT one ~8, a
+// v_pk_mul_f32 17 (it does not overlap the MFMA at all), a ds_write_b64 ~20.  An epilogue placed BEHIND its product (the first
+// version of this pair, and the first pair's N-split phases) therefore ADDS its ~10 VALU per tile to the MFMA time: 75 cycles per tile,
+// more than the whole product of a narrow layer.  Here the output tiles of a product are computed GROUP BY GROUP (kGS tiles, all k
+// blocks of a group before the next group: fragment order [group][k block][tile]), so that a group's tiles are final while the next
+// group's MFMAs issue, and the scheduler is told to deal the finished group's epilogue between those MFMAs (sched_group_barrier:
+// 1 MFMA, VPM VALU, LDS reads / writes).  The LAST group of a product is finished beside the first MFMAs of the next product
+// (`carry`), or in front of a workgroup barrier where one separates the two.
+constexpr int kGS = 4;        // output tiles per group
 template <int V> using IC = std::integral_constant<int, V>;
-template <int Q, int NTP, class Fin> __device__ __forceinline__ bf8 bop(Fin &fin) {
-    typedef unsigned u4_ __attribute__((ext_vector_type(4)));
-    u2 lo = (u2){0u, 0u}, hi = (u2){0u, 0u};
-    if constexpr (2 * Q < NTP) lo = fin(IC<2 * Q>{});
-    if constexpr (2 * Q + 1 < NTP) hi = fin(IC<2 * Q + 1>{});
-    return __builtin_bit_cast(bf8, (u4_){lo[0], lo[1], hi[0], hi[1]});
-}
+template <int NT> struct Grp {
+    static constexpr int NG = cdiv(NT, kGS);
+    __host__ __device__ static constexpr int size(int g) { return g < NG - 1 ? kGS : NT - kGS * (NG - 1); }
+    // fragment (group g, k block q, tile j of the group) of a product with KB k blocks: KB kGS g + q size(g) + j
+    __host__ __device__ static constexpr int frag(int KB, int g, int q, int j) { return KB * kGS * g + q * size(g) + j; }
+};
 template <class ST, int GI, int VPM, bool FIRST>
 __device__ __forceinline__ void mfma_one(v4 &acc, const bf8 &b, const Ring2 &rg, bf8 (&fr)[kPF]) {
     if constexpr (GI % kG == 0) {
@@ -1057,35 +1059,51 @@ __device__ __forceinline__ void mfma_one(v4 &acc, const bf8 &b, const Ring2 &rg,
     if constexpr (GI + kPF < ST::nfrag) fr[GI % kPF] = ring_read<GI + kPF>(rg);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // this MFMA
     __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);        // its share of the VALU work of the region
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // its fragment read
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // its fragment read (+ a mask read)
     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // an image store, if one is ready
 }
-template <class ST, int GI0, int KB, int NT, int NTP, int VPM, int Q, class Fin, class Post, int... T>
-__device__ __forceinline__ void pstep(v4 (&acc)[NT], bf8 (&bq)[2], Fin &fin, Post &post, const Ring2 &rg, bf8 (&fr)[kPF],
-                                      std::integer_sequence<int, T...>) {
-    if constexpr (Q + 1 < KB) bq[(Q + 1) & 1] = bop<Q + 1, NTP>(fin);
-    auto one = [&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        mfma_one<ST, GI0 + Q * NT + t, VPM, Q == 0>(acc[t], bq[Q & 1], rg, fr);
-        if constexpr (Q == KB - 1) post(tc);
-    };
-    (one(IC<T>{}), ...);
+template <class ST, int GI0, int KB, int NT, int VPM, int TG, int Q, int... J>
+__device__ __forceinline__ void pstepq(v4 (&acc)[NT], const bf8 (&b)[KB], const Ring2 &rg, bf8 (&fr)[kPF], std::integer_sequence<int, J...>) {
+    (mfma_one<ST, GI0 + Grp<NT>::frag(KB, TG, Q, J), VPM, Q == 0>(acc[kGS * TG + J], b[Q], rg, fr), ...);
+}
+template <class ST, int GI0, int KB, int NT, int VPM, int TG, int... Q>
+__device__ __forceinline__ void pallq(v4 (&acc)[NT], const bf8 (&b)[KB], const Ring2 &rg, bf8 (&fr)[kPF], std::integer_sequence<int, Q...>) {
+    (pstepq<ST, GI0, KB, NT, VPM, TG, Q>(acc, b, rg, fr, std::make_integer_sequence<int, Grp<NT>::size(TG)>{}), ...);
+}
+template <int NT, int G_, class Fn> __device__ __forceinline__ void for_group(Fn &fn) {      // fn(tile) for the tiles of group G_
+    auto f = [&](auto jc) { if constexpr (decltype(jc)::value < Grp<NT>::size(G_)) fn(IC<kGS * G_ + decltype(jc)::value>{}); };
+    f(IC<0>{}); f(IC<1>{}); f(IC<2>{}); f(IC<3>{});
+    static_assert(kGS == 4, "group size");
+}
+// region TG of a product: request what the epilogue of group TG will read (pre), finish group TG - 1 (VT VALU per tile), MFMAs of group TG
+template <class ST, int GI0, int KB, int NT, int VT, int TG, int CV, class Fin, class Pre>
+__device__ __forceinline__ void pregion(v4 (&acc)[NT], const bf8 (&b)[KB], Fin &fin, Pre &pre, const Ring2 &rg, bf8 (&fr)[kPF]) {
+    using G = Grp<NT>;
+    constexpr int SZ = G::size(TG);
+    constexpr int work = TG > 0 ? VT * G::size(TG > 0 ? TG - 1 : 0) : CV;         // VALU instructions to hide in this region
+    constexpr int VPM = (work + KB * SZ - 1) / (KB * SZ) > 0 ? (work + KB * SZ - 1) / (KB * SZ) : 1;
+    for_group<NT, TG>(pre);
+    if constexpr (TG > 0) for_group<NT, (TG > 0 ? TG - 1 : 0)>(fin);
+    pallq<ST, GI0, KB, NT, VPM, TG>(acc, b, rg, fr, std::make_integer_sequence<int, KB>{});
     __builtin_amdgcn_sched_barrier(0);
 }
-template <class ST, int GI0, int KB, int NT, int NTP, int VPM, class Fin, class Post, int... Q>
-__device__ __forceinline__ void mprod_impl(v4 (&acc)[NT], const bf8 &b0, Fin &fin, Post &post, const Ring2 &rg, bf8 (&fr)[kPF],
-                                           std::integer_sequence<int, Q...>) {
-    bf8 bq[2];
-    bq[0] = b0;
-    (pstep<ST, GI0, KB, NT, NTP, VPM, Q>(acc, bq, fin, post, rg, fr, std::make_integer_sequence<int, NT>{}), ...);
+template <class ST, int GI0, int KB, int NT, int VT, int CV, class Fin, class Pre, int... TG>
+__device__ __forceinline__ void pregions(v4 (&acc)[NT], const bf8 (&b)[KB], Fin &fin, Pre &pre, const Ring2 &rg, bf8 (&fr)[kPF],
+                                         std::integer_sequence<int, TG...>) {
+    (pregion<ST, GI0, KB, NT, VT, TG, CV>(acc, b, fin, pre, rg, fr), ...);
 }
-// acc[NT] = product over KB k blocks; b0 = B operand of k block 0 (finished by the caller), fin = epilogue of the previous product's
-// tiles (NTP of them) for k blocks 1 .. KB - 1
-template <class ST, int GI0, int KB, int NT, int NTP, class Fin, class Post>
-__device__ __forceinline__ void mprod(v4 (&acc)[NT], const bf8 &b0, Fin &fin, Post &post, const Ring2 &rg, bf8 (&fr)[kPF]) {
-    constexpr int VPM = (22 + NT - 1) / NT;            // ~22 VALU per k block of epilogue work (two tiles), dealt over its NT MFMAs
-    mprod_impl<ST, GI0, KB, NT, NTP, VPM>(acc, b0, fin, post, rg, fr, std::make_integer_sequence<int, KB>{});
+// acc[NT] = product over KB k blocks of the B operands made of the previous product's packed tiles pkp[NTP]; `carry` finishes what
+// is still unfinished of pkp (CV VALU instructions, hidden beside the first group's MFMAs); fin(tile) finishes a tile of THIS product
+// (all groups but the last: the caller's next carry does that one); pre(tile) requests what fin(tile) will need from LDS
+template <class ST, int GI0, int KB, int NT, int NTP, int VT, int CV, class Fin, class Pre, class Carry>
+__device__ __forceinline__ void mprod(v4 (&acc)[NT], const u2 (&pkp)[NTP], Fin &fin, Pre &pre, Carry &carry, const Ring2 &rg, bf8 (&fr)[kPF]) {
+    carry();
+    bf8 b[KB];
+    regfeed<KB, NTP>(b, pkp);
+    pregions<ST, GI0, KB, NT, VT, CV>(acc, b, fin, pre, rg, fr, std::make_integer_sequence<int, Grp<NT>::NG>{});
 }
+// the tiles of the LAST group of a product with NT tiles: what the next carry (or the code in front of a barrier) finishes
+template <int NT, class Fin> __device__ __forceinline__ void finish_last(Fin &fin) { for_group<NT, Grp<NT>::NG - 1>(fin); }
 
 // input rows in C-TILE layout: lane (j, g) holds features 16 t + 4 g + r (t = 0, 1; r = 0..3) of row j of its wave's 16 rows --
 // the registers of two C tiles, i.e. (after the conversion) the B operand of layer 0 in the register chain's k order AND the
@@ -1183,9 +1201,6 @@ __global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restric
             if (feats) d = (d - fmn[e]) / frg[e];
             v[e] = f < F ? (float)d : (f == F ? 1.0f : 0.f);                     // slot F = the ones column
         }
-        bf8 b0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) b0[e] = (__bf16)v[e];
         if constexpr (C::has(0)) {
             const Lay &l0 = lay_of<N::istride(0)>(ls);
             const lds_p ob = img + PL::xoff(0) + 16 * wave * N::istride(0);
@@ -1194,61 +1209,66 @@ __global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restric
         }
         BT2(1);
 
-        // epilogue of forward tile t of layer l: [LeakyReLU] -> bf16 (-> image l + 1, own rows, when this launch reads it back)
-#define BAMD3_FIN_F(l, accv)                                                                                                 \
-        [&](auto tc) -> u2 {                                                                                                 \
+        // epilogue of forward tile t of layer l into pkv[t]: [LeakyReLU] -> bf16 (-> image l + 1, own rows, when this launch reads it back)
+#define BAMD3_FIN_F(l, accv, pkv)                                                                                            \
+        [&](auto tc) {                                                                                                       \
             constexpr int t = decltype(tc)::value;                                                                           \
             v4 a = accv[t];                                                                                                  \
-            if (N::act(l)) lrelu4s(a);                                                                                        \
-            const u2 p = pack4(a);                                                                                           \
+            if (N::act(l)) lrelu4s(a);                                                                                       \
+            pkv[t] = pack4(a);                                                                                               \
             if constexpr (C::has((l) + 1))                                                                                   \
-                lds_w64(img + PL::xoff((l) + 1) + 16 * wave * N::istride((l) + 1) + lay_of<N::istride((l) + 1)>(ls).wr(t & 1) + 32 * (t & ~1), p); \
-            return p;                                                                                                        \
+                lds_w64(img + PL::xoff((l) + 1) + 16 * wave * N::istride((l) + 1) + lay_of<N::istride((l) + 1)>(ls).wr(t & 1) + 32 * (t & ~1), pkv[t]); \
         }
-        // epilogue of tile t of the input-gradient product of layer l (= dZ_{l-1}): mask with the sign of X_l (own rows, read ahead
-        // into `yv`) where layer l - 1 has an activation -> bf16 (-> dZ_{l-1}'s region when this launch computes that weight gradient)
-#define BAMD3_FIN_B(l, accv, yv)                                                                                             \
-        [&](auto tc) -> u2 {                                                                                                 \
+        // epilogue of tile t of the input-gradient product of layer l (= dZ_{l-1}) into pkv[t]: mask with the sign of X_l (own rows,
+        // requested a region ahead into yv[t]) where layer l - 1 has an activation -> bf16 (-> dZ_{l-1}'s region when this launch
+        // computes that weight gradient)
+#define BAMD3_FIN_B(l, accv, yv, pkv)                                                                                        \
+        [&](auto tc) {                                                                                                       \
             constexpr int t = decltype(tc)::value;                                                                           \
-            u2 p;                                                                                                            \
-            if constexpr (N::act((l) - 1)) p = lrelu_bwd_pack4s(accv[t], yv[t]);                                              \
-            else p = pack4(accv[t]);                                                                                         \
+            if constexpr (N::act((l) - 1)) pkv[t] = lrelu_bwd_pack4s(accv[t], yv[t]);                                        \
+            else pkv[t] = pack4(accv[t]);                                                                                    \
             if constexpr ((l) - 1 >= C::bwd_lo)                                                                              \
-                lds_w64(img + PL::zoff((l) - 1 >= C::bwd_lo ? (l) - 1 : C::bwd_lo) + 16 * wave * N::istride(l) + lay_of<N::istride(l)>(ls).wr(t & 1) + 32 * (t & ~1), p); \
-            return p;                                                                                                        \
+                lds_w64(img + PL::zoff((l) - 1 >= C::bwd_lo ? (l) - 1 : C::bwd_lo) + 16 * wave * N::istride(l) + lay_of<N::istride(l)>(ls).wr(t & 1) + 32 * (t & ~1), pkv[t]); \
         }
-        // sign masks of X_l (own rows) for the input-gradient product of layer l, read ahead of that product
-#define BAMD3_MASKS(l, yv)                                                                                                   \
-        u2 yv[N::ntb(l)];                                                                                                    \
-        if constexpr (N::act((l) - 1)) {                                                                                     \
-            const lds_p xb = img + PL::xoff(l) + 16 * wave * N::istride(l);                                                  \
-            _Pragma("unroll") for (int t = 0; t < N::ntb(l); ++t) yv[t] = lds_b64(xb + lay_of<N::istride(l)>(ls).wr(t & 1) + 32 * (t & ~1)); \
+        // sign mask of tile t of X_l (own rows) for the input-gradient product of layer l
+#define BAMD3_PRE_B(l, yv)                                                                                                   \
+        [&](auto tc) {                                                                                                       \
+            constexpr int t = decltype(tc)::value;                                                                           \
+            if constexpr (N::act((l) - 1))                                                                                   \
+                yv[t] = lds_b64(img + PL::xoff(l) + 16 * wave * N::istride(l) + lay_of<N::istride(l)>(ls).wr(t & 1) + 32 * (t & ~1)); \
         }
 #define BAMD2_DW(l, G) dw_phase<N, l, N::istride((l) + 1), N::istride(l)>(G, img + PL::zoff(l), img + PL::xoff(l), lay_of<N::istride((l) + 1)>(ls), \
                                                                          lay_of<N::istride(l)>(ls), wave);
-        auto nofin = [&](auto) -> u2 { return (u2){0u, 0u}; };
-        // forward 0 .. 2 (both launches): each product finishes its predecessor's tiles; post(1) of a product's last k block finishes
-        // ITS tiles 0, 1 = the first B operand of the next product
+        constexpr int VF = 10, VB = 12, VN = 2;          // VALU instructions per tile: forward epilogue, masked backward epilogue, conversion only
+        auto nopre = [&](auto) {};
+        auto nocarry = [&]() {};
+        u2 pk0[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) pk0[t] = pack4((v4){v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]});
+        // forward 0 .. 2 (both launches)
         v4 a1[N::nt(0)], a2[N::nt(1)], a3[N::nt(2)];
-        auto fin0 = BAMD3_FIN_F(0, a1);
-        auto fin1 = BAMD3_FIN_F(1, a2);
-        auto fin2 = BAMD3_FIN_F(2, a3);
-        bf8 b1, b2, b3;
-        auto post0 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b1 = bop<0, N::nt(0)>(fin0); };
-        auto post1 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b2 = bop<0, N::nt(1)>(fin1); };
-        mprod<ST, ST::fo_f(0), N::kb(0), N::nt(0), 2>(a1, b0, nofin, post0, rg, fr);
+        u2 p1[N::nt(0)], p2[N::nt(1)], p3[N::nt(2)];
+        auto fin0 = BAMD3_FIN_F(0, a1, p1);
+        auto fin1 = BAMD3_FIN_F(1, a2, p2);
+        auto fin2 = BAMD3_FIN_F(2, a3, p3);
+        auto carry1 = [&]() { finish_last<N::nt(0)>(fin0); };
+        auto carry2 = [&]() { finish_last<N::nt(1)>(fin1); };
+        mprod<ST, ST::fo_f(0), N::kb(0), N::nt(0), 2, VF, 0>(a1, pk0, fin0, nopre, nocarry, rg, fr);
         BT2(2);
-        mprod<ST, ST::fo_f(1), N::kb(1), N::nt(1), N::nt(0)>(a2, b1, fin0, post1, rg, fr);
+        mprod<ST, ST::fo_f(1), N::kb(1), N::nt(1), N::nt(0), VF, VF * Grp<N::nt(0)>::size(Grp<N::nt(0)>::NG - 1)>(a2, p1, fin1, nopre, carry1, rg, fr);
         BT2(3);
+        mprod<ST, ST::fo_f(2), N::kb(2), N::nt(2), N::nt(1), VF, VF * Grp<N::nt(1)>::size(Grp<N::nt(1)>::NG - 1)>(a3, p2, fin2, nopre, carry2, rg, fr);
+        BT2(4);
         if constexpr (PART == 0) {
-            v4 a4[N::nt(3)], a5[N::nt(4)], a6[N::nt(5)], a7[N::nt(6)], rec[2];
             static_assert(N::nt(7) == 2 && N::nt(3) == 1 && N::ntb(4) == 1, "the reconstruction is two tiles, the latent one");
-            auto fin3 = BAMD3_FIN_F(3, a4);
-            auto fin4 = BAMD3_FIN_F(4, a5);
-            auto fin5 = BAMD3_FIN_F(5, a6);
-            auto fin6 = BAMD3_FIN_F(6, a7);
+            v4 a4[N::nt(3)], a5[N::nt(4)], a6[N::nt(5)], a7[N::nt(6)], rec[2];
+            u2 p4[N::nt(3)], p5[N::nt(4)], p6[N::nt(5)], p7[N::nt(6)], d7[2];
+            auto fin3 = BAMD3_FIN_F(3, a4, p4);
+            auto fin4 = BAMD3_FIN_F(4, a5, p5);
+            auto fin5 = BAMD3_FIN_F(5, a6, p6);
+            auto fin6 = BAMD3_FIN_F(6, a7, p7);
             // loss: both output tiles of this wave's 16 rows against the fp32 input values it kept; dL/drecon = 2 (r - x) / C (utils.py:195-199)
-            auto fin7 = [&](auto tc) -> u2 {
+            auto fin7 = [&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 v4 d;
 #pragma unroll
@@ -1258,68 +1278,64 @@ __global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restric
                     if (live) lacc += (double)e * (double)e;
                     d[r] = live ? e * (2.0f / (float)F) : 0.f;
                 }
-                const u2 p = pack4(d);
-                lds_w64(img + PL::zoff(7) + 16 * wave * N::istride(8) + lay_of<N::istride(8)>(ls).wr(t & 1) + 32 * (t & ~1), p);
-                return p;
+                d7[t] = pack4(d);
+                lds_w64(img + PL::zoff(7) + 16 * wave * N::istride(8) + lay_of<N::istride(8)>(ls).wr(t & 1) + 32 * (t & ~1), d7[t]);
             };
-            bf8 b4, b5, b6, b7, c7;
-            auto post2 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b3 = bop<0, N::nt(2)>(fin2); };
-            auto post3 = [&](auto tc) { if constexpr (decltype(tc)::value == 0) b4 = bop<0, N::nt(3)>(fin3); };
-            auto post4 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b5 = bop<0, N::nt(4)>(fin4); };
-            auto post5 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b6 = bop<0, N::nt(5)>(fin5); };
-            auto post6 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) b7 = bop<0, N::nt(6)>(fin6); };
-            auto post7 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c7 = bop<0, 2>(fin7); };
-            mprod<ST, ST::fo_f(2), N::kb(2), N::nt(2), N::nt(1)>(a3, b2, fin1, post2, rg, fr);
-            BT2(4);
-            mprod<ST, ST::fo_f(3), N::kb(3), N::nt(3), N::nt(2)>(a4, b3, fin2, post3, rg, fr);
+            auto carry3 = [&]() { finish_last<N::nt(2)>(fin2); };
+            auto carry4 = [&]() { finish_last<N::nt(3)>(fin3); };
+            auto carry5 = [&]() { finish_last<N::nt(4)>(fin4); };
+            auto carry6 = [&]() { finish_last<N::nt(5)>(fin5); };
+            auto carry7 = [&]() { finish_last<N::nt(6)>(fin6); };
+#define BAMD3_LASTV(nt_, vt) ((vt) * Grp<nt_>::size(Grp<nt_>::NG - 1))
+            mprod<ST, ST::fo_f(3), N::kb(3), N::nt(3), N::nt(2), VN, BAMD3_LASTV(N::nt(2), VF)>(a4, p3, fin3, nopre, carry3, rg, fr);
             BT2(5);
-            mprod<ST, ST::fo_f(4), N::kb(4), N::nt(4), N::nt(3)>(a5, b4, fin3, post4, rg, fr);
+            mprod<ST, ST::fo_f(4), N::kb(4), N::nt(4), N::nt(3), VF, BAMD3_LASTV(N::nt(3), VN)>(a5, p4, fin4, nopre, carry4, rg, fr);
             BT2(6);
-            mprod<ST, ST::fo_f(5), N::kb(5), N::nt(5), N::nt(4)>(a6, b5, fin4, post5, rg, fr);
+            mprod<ST, ST::fo_f(5), N::kb(5), N::nt(5), N::nt(4), VF, BAMD3_LASTV(N::nt(4), VF)>(a6, p5, fin5, nopre, carry5, rg, fr);
             BT2(7);
-            mprod<ST, ST::fo_f(6), N::kb(6), N::nt(6), N::nt(5)>(a7, b6, fin5, post6, rg, fr);
+            mprod<ST, ST::fo_f(6), N::kb(6), N::nt(6), N::nt(5), VF, BAMD3_LASTV(N::nt(5), VF)>(a7, p6, fin6, nopre, carry6, rg, fr);
             BT2(8);
-            mprod<ST, ST::fo_f(7), N::kb(7), 2, N::nt(6)>(rec, b7, fin6, post7, rg, fr);
+            mprod<ST, ST::fo_f(7), N::kb(7), 2, N::nt(6), 30, BAMD3_LASTV(N::nt(6), VF)>(rec, p7, fin7, nopre, carry7, rg, fr);
+            BT2(9);
+            finish_last<2>(fin7);
             BT2(10);
             __syncthreads();                                                    // A: dZ_7 and X_4 .. X_7 of all 64 rows
             BT2(11);
-            // input-gradient products 7 .. 4: dZ_6 .. dZ_3, finished by the next product each
-            v4 d6[N::ntb(7)], d5[N::ntb(6)], d4[N::ntb(5)], d3[1];
-            BAMD3_MASKS(7, y7)
-            auto finb7 = BAMD3_FIN_B(7, d6, y7);
-            bf8 c6, c5, c4;
-            auto postb7 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c6 = bop<0, N::ntb(7)>(finb7); };
-            mprod<ST, ST::fo_b(7), N::kbb(7), N::ntb(7), 2>(d6, c7, nofin, postb7, rg, fr);
+            // input-gradient products 7 .. 4: dZ_6 .. dZ_3
+            v4 e6[N::ntb(7)], e5[N::ntb(6)], e4[N::ntb(5)], e3[1];
+            u2 q6[N::ntb(7)], q5[N::ntb(6)], q4[N::ntb(5)], q3[1], y7[N::ntb(7)], y6[N::ntb(6)], y5[N::ntb(5)], yz[1];
+            auto finb7 = BAMD3_FIN_B(7, e6, y7, q6);
+            auto finb6 = BAMD3_FIN_B(6, e5, y6, q5);
+            auto finb5 = BAMD3_FIN_B(5, e4, y5, q4);
+            auto finb4 = BAMD3_FIN_B(4, e3, yz, q3);
+            auto pre7 = BAMD3_PRE_B(7, y7);
+            auto pre6 = BAMD3_PRE_B(6, y6);
+            auto pre5 = BAMD3_PRE_B(5, y5);
+            auto carryb6 = [&]() { finish_last<N::ntb(7)>(finb7); };
+            auto carryb5 = [&]() { finish_last<N::ntb(6)>(finb6); };
+            auto carryb4 = [&]() { finish_last<N::ntb(5)>(finb5); };
+            mprod<ST, ST::fo_b(7), N::kbb(7), N::ntb(7), 2, VB, 0>(e6, d7, finb7, pre7, nocarry, rg, fr);
             BT2(12);
             BAMD2_DW(7, g7)
             BT2(13);
             __syncthreads();                                                    // B: X_7 | dZ_7 dead (dZ_5, dZ_4 go there)
             BT2(14);
-            BAMD3_MASKS(6, y6)
-            auto finb6 = BAMD3_FIN_B(6, d5, y6);
-            auto postb6 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c5 = bop<0, N::ntb(6)>(finb6); };
-            mprod<ST, ST::fo_b(6), N::kbb(6), N::ntb(6), N::ntb(7)>(d5, c6, finb7, postb6, rg, fr);
+            mprod<ST, ST::fo_b(6), N::kbb(6), N::ntb(6), N::ntb(7), VB, BAMD3_LASTV(N::ntb(7), VB)>(e5, q6, finb6, pre6, carryb6, rg, fr);
             BT2(15);
-            BAMD3_MASKS(5, y5)
-            auto finb5 = BAMD3_FIN_B(5, d4, y5);
-            auto postb5 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c4 = bop<0, N::ntb(5)>(finb5); };
-            mprod<ST, ST::fo_b(5), N::kbb(5), N::ntb(5), N::ntb(6)>(d4, c5, finb6, postb5, rg, fr);
+            mprod<ST, ST::fo_b(5), N::kbb(5), N::ntb(5), N::ntb(6), VB, BAMD3_LASTV(N::ntb(6), VB)>(e4, q5, finb5, pre5, carryb5, rg, fr);
             BT2(16);
-            u2 yz[1];
-            auto finb4 = BAMD3_FIN_B(4, d3, yz);
-            u2 q3 = (u2){0u, 0u};
-            auto postb4 = [&](auto tc) { if constexpr (decltype(tc)::value == 0) q3 = finb4(IC<0>{}); };
-            mprod<ST, ST::fo_b(4), N::kbb(4), 1, N::ntb(5)>(d3, c4, finb5, postb4, rg, fr);
+            mprod<ST, ST::fo_b(4), N::kbb(4), 1, N::ntb(5), VN, BAMD3_LASTV(N::ntb(5), VB)>(e3, q4, finb4, nopre, carryb4, rg, fr);
+            finish_last<1>(finb4);
             // hand-off to the second launch: dZ_3 (ONE tile), 8 bytes per lane: [row][g]; rows beyond n carry zeros
-            dz[row * 4 + g] = q3;
+            dz[row * 4 + g] = q3[0];
             // the NEXT iteration's rows, requested behind the last ring wait of this one: the weight-gradient phases below give the
             // HBM fetch its time (loads of a wave retire in order: requested at the top it would stand in front of every ring wait)
             x_issue2<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);
             BT2(17);
             __syncthreads();                                                    // D: dZ_6, dZ_5, dZ_4 of all 64 rows
-            BT2(19);
-            BAMD2_DW(6, g6)
             BT2(18);
+            BAMD2_DW(6, g6)
+            BT2(19);
             BAMD2_DW(5, g5)
             BT2(20);
             BAMD2_DW(4, g4)
@@ -1327,73 +1343,58 @@ __global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restric
             __syncthreads();                                                    // E: the next forward overwrites X_4 .. X_7
             BT2(22);
         } else {
-            // forward 2 is the last forward product here: its tiles (X_3) are finished right behind their last MFMAs, with a lag of two
-            u2 x3p[N::nt(2)];
-            auto post2 = [&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                if constexpr (t >= 2) x3p[t - 2] = fin2(IC<t - 2>{});
-            };
-            mprod<ST, ST::fo_f(2), N::kb(2), N::nt(2), N::nt(1)>(a3, b2, fin1, post2, rg, fr);
-            static_assert(N::nt(2) >= 2, "lagged finish");
-            x3p[N::nt(2) - 2] = fin2(IC<N::nt(2) - 2>{});
-            x3p[N::nt(2) - 1] = fin2(IC<N::nt(2) - 1>{});
-            (void)x3p;
-            BT2(4);
             static_assert(N::ntb(4) == 1 && N::nt(3) == 1, "the latent is one tile");
+            finish_last<N::nt(2)>(fin2);                                        // X_3 (a single group: nothing of it is finished yet)
+            static_assert(Grp<N::nt(2)>::NG == 1, "forward 2 is one group");
             // dZ_3 of these rows from the first launch -> its image (own rows) and the B operand of the first input-gradient product
             lds_w64(img + PL::zoff(3) + 16 * wave * N::istride(4) + lay_of<N::istride(4)>(ls).wr(0), hand);
-            typedef unsigned u4_ __attribute__((ext_vector_type(4)));
-            const bf8 c3 = __builtin_bit_cast(bf8, (u4_){hand[0], hand[1], 0u, 0u});
+            u2 q3[1] = {hand};
             BT2(5);
             __syncthreads();                                                    // A: X_0 .. X_3 and dZ_3 of all 64 rows
             BT2(6);
-            v4 d2[N::ntb(3)], d1[N::ntb(2)], d0[N::ntb(1)];
-            BAMD3_MASKS(3, y3)
-            auto finb3 = BAMD3_FIN_B(3, d2, y3);
-            bf8 c2, c1;
-            auto postb3 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c2 = bop<0, N::ntb(3)>(finb3); };
-            mprod<ST, ST::fo_b(3), N::kbb(3), N::ntb(3), 1>(d2, c3, nofin, postb3, rg, fr);
+            v4 e2[N::ntb(3)], e1[N::ntb(2)], e0[N::ntb(1)];
+            u2 q2[N::ntb(3)], q1[N::ntb(2)], q0[N::ntb(1)], y3[N::ntb(3)], y2[N::ntb(2)], y1[N::ntb(1)];
+            auto finb3 = BAMD3_FIN_B(3, e2, y3, q2);
+            auto finb2 = BAMD3_FIN_B(2, e1, y2, q1);
+            auto finb1 = BAMD3_FIN_B(1, e0, y1, q0);
+            auto pre3 = BAMD3_PRE_B(3, y3);
+            auto pre2 = BAMD3_PRE_B(2, y2);
+            auto pre1 = BAMD3_PRE_B(1, y1);
+            auto carryb2 = [&]() { finish_last<N::ntb(3)>(finb3); };
+            auto carryb1 = [&]() { finish_last<N::ntb(2)>(finb2); };
+#define BAMD3_LASTV(nt_, vt) ((vt) * Grp<nt_>::size(Grp<nt_>::NG - 1))
+            mprod<ST, ST::fo_b(3), N::kbb(3), N::ntb(3), 1, VB, 0>(e2, q3, finb3, pre3, nocarry, rg, fr);
             BT2(7);
             BAMD2_DW(3, g3)
             BT2(8);
             __syncthreads();                                                    // B: X_3 | dZ_3 dead (dZ_1 goes there)
             BT2(9);
-            BAMD3_MASKS(2, y2)
-            auto finb2 = BAMD3_FIN_B(2, d1, y2);
-            auto postb2 = [&](auto tc) { if constexpr (decltype(tc)::value == 1) c1 = bop<0, N::ntb(2)>(finb2); };
-            mprod<ST, ST::fo_b(2), N::kbb(2), N::ntb(2), N::ntb(3)>(d1, c2, finb3, postb2, rg, fr);
+            mprod<ST, ST::fo_b(2), N::kbb(2), N::ntb(2), N::ntb(3), VB, BAMD3_LASTV(N::ntb(3), VB)>(e1, q2, finb2, pre2, carryb2, rg, fr);
             BT2(10);
-            BAMD3_MASKS(1, y1)
-            auto finb1 = BAMD3_FIN_B(1, d0, y1);
-            u2 z0p[N::ntb(1)];
-            auto postb1 = [&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                if constexpr (t >= 2) z0p[t - 2] = finb1(IC<t - 2>{});
-            };
-            mprod<ST, ST::fo_b(1), N::kbb(1), N::ntb(1), N::ntb(2)>(d0, c1, finb2, postb1, rg, fr);
-            z0p[N::ntb(1) - 2] = finb1(IC<N::ntb(1) - 2>{});
-            z0p[N::ntb(1) - 1] = finb1(IC<N::ntb(1) - 1>{});
-            (void)z0p;
+            mprod<ST, ST::fo_b(1), N::kbb(1), N::ntb(1), N::ntb(2), VB, BAMD3_LASTV(N::ntb(2), VB)>(e0, q1, finb1, pre1, carryb1, rg, fr);
+            finish_last<N::ntb(1)>(finb1);
+            (void)q0;
             x_issue2<F>(xraw, xin, in_f64, row + (int64_t)gridDim.x * kRows, n, g);
             {
                 const int64_t nr = row + (int64_t)gridDim.x * kRows;
                 hand = dz[(nr < ngroups * kRows ? nr : row) * 4 + g];
             }
-            BT2(13);
-            __syncthreads();                                                    // D: dZ_2, dZ_1, dZ_0 of all 64 rows
-            BT2(15);
-            BAMD2_DW(2, g2)
             BT2(11);
+            __syncthreads();                                                    // D: dZ_2, dZ_1, dZ_0 of all 64 rows
+            BT2(12);
+            BAMD2_DW(2, g2)
+            BT2(13);
             BAMD2_DW(1, g1)
             BT2(14);
             BAMD2_DW(0, g0)
-            BT2(16);
+            BT2(15);
             __syncthreads();                                                    // E
-            BT2(17);
+            BT2(16);
         }
+#undef BAMD3_LASTV
 #undef BAMD3_FIN_F
 #undef BAMD3_FIN_B
-#undef BAMD3_MASKS
+#undef BAMD3_PRE_B
 #undef BAMD2_DW
         rg.rot = (rg.rot + ST::nslot) & (kR - 1);
     }
@@ -1619,6 +1620,11 @@ template <int F, int Z> struct TImpl2 {
         using ST = Stream2<N, PART>;
         src.assign((size_t)ST::nfrag * 512, -1);
         auto kperm = [](int q, int g, int e) { return 32 * q + 16 * (e >> 2) + 4 * g + (e & 3); };
+        // position of fragment (k block q, tile t) in its product's stream: tiles in groups of kGS, [group][k block][tile of the group]
+        auto gfrag = [](int KB, int NT, int q, int t) {
+            const int NG = (NT + kGS - 1) / kGS, gidx = t / kGS, size = gidx < NG - 1 ? kGS : NT - kGS * (NG - 1);
+            return KB * kGS * gidx + q * size + (t - kGS * gidx);
+        };
         for (int l = 0; l < C::fwd_end; ++l) {
             const int K = N::dim(l), NN = N::dim(l + 1);
             // forward fragment (q, t): lane (i, g) element e = [W | b | .][16 t + i][k]: input column K (the ones slot) holds the
@@ -1632,7 +1638,7 @@ template <int F, int Z> struct TImpl2 {
                             if (n < NN && k < K) v = N::w_off(l) + n * K + k;
                             else if (n < NN && k == K) v = N::b_off(l) + n;
                             else if (n == NN && k == K) v = -2;
-                            src[((size_t)(ST::fo_f(l) + q * N::nt(l) + t) * 64 + lane) * 8 + e] = v;
+                            src[((size_t)(ST::fo_f(l) + gfrag(N::kb(l), N::nt(l), q, t)) * 64 + lane) * 8 + e] = v;
                         }
         }
         for (int l = C::bwd_hi; l >= C::chain_lo; --l) {
@@ -1643,7 +1649,7 @@ template <int F, int Z> struct TImpl2 {
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
                             const int n = kperm(q, lane >> 4, e), k = 16 * t + (lane & 15);
-                            if (n < NN && k < K) src[((size_t)(ST::fo_b(l) + q * N::ntb(l) + t) * 64 + lane) * 8 + e] = N::w_off(l) + n * K + k;
+                            if (n < NN && k < K) src[((size_t)(ST::fo_b(l) + gfrag(N::kbb(l), N::ntb(l), q, t)) * 64 + lane) * 8 + e] = N::w_off(l) + n * K + k;
                         }
         }
     }
@@ -1698,10 +1704,10 @@ template <int F, int Z> struct TImpl2 {
     }
 };
 
-// BALER_AMD_BF16_TRAIN_V1=1: the round-2..4 pair (N-split wide layers, cut below layer 1) instead of the register-chain pair
+// BALER_AMD_BF16_TRAIN_V2=1: the round-5 register-chain pair instead of the N-split pair (measured slower: DESIGN.md section 4.6)
 static bool train_v1() {
-    const char *e = getenv("BALER_AMD_BF16_TRAIN_V1");
-    return e && e[0] == '1';
+    const char *e = getenv("BALER_AMD_BF16_TRAIN_V2");
+    return !(e && e[0] == '1');
 }
 template <int F, int Z> const TrainOps *pick_train(const bamd_handle *h) {
     if (!TImpl<F, Z>::matches(h)) return nullptr;

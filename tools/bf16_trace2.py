@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import torch
 
+os.environ["BALER_AMD_BF16_TRAIN_V2"] = "1"
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from baler_amd import native, synth                               # noqa: E402
 from baler_amd.modules import models                              # noqa: E402
@@ -28,9 +30,9 @@ T = np.array(buf[:], dtype=np.uint64).astype(np.int64).reshape(2, 4, 128)
 
 P0 = ["top", "rows->regs", "fwd 0 (13)", "fwd 1 (49)", "fwd 2 (16)", "fwd 3 (2)", "fwd 4 (4)", "fwd 5 (14)", "fwd 6 (52)", "fwd 7 (14)",
       "loss + dZ_7", "barrier A", "bwd 7 (13)", "dW 7", "barrier B", "bwd 6 (49)", "bwd 5 (16)", "bwd 4 (2) + hand-off + next rows",
-      "dW 6", "barrier D", "dW 5", "dW 4", "barrier E"]
-P1 = ["top", "rows->regs + X_0", "fwd 0 (13)", "fwd 1 (49)", "fwd 2 (16)", "dZ_3 -> image", "barrier A", "bwd 3 (4)", "dW 3", "barrier B",
-      "bwd 2 (14)", "dW 2", "barrier C", "bwd 1 (52) + next rows", "dW 1", "barrier D", "dW 0", "barrier E"]
+      "barrier D", "dW 6", "dW 5", "dW 4", "barrier E"]
+P1 = ["top", "rows->regs + X_0", "fwd 0 (13)", "fwd 1 (49)", "fwd 2 (16)", "X_3, dZ_3 -> images", "barrier A", "bwd 3 (4)", "dW 3", "barrier B",
+      "bwd 2 (14)", "bwd 1 (52) + next rows", "barrier D", "dW 2", "dW 1", "dW 0", "barrier E"]
 for part, names in ((0, P0), (1, P1)):
     print(f"PART {part}: iteration total (wave 0) {T[part, 0, len(names) - 1] - T[part, 0, 0]} cycles; per phase, waves 0..3")
     for i in range(1, len(names)):
