@@ -643,13 +643,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // FULL: the caller guarantees a full chunk (kc < F / 16).  The streamed loops only ever load full chunks and treat the
 // remainder of the wide dimension as an epilogue: with the "full chunk?" test inside the loop every row load sat behind a branch
 // whose other side is a different load sequence, and hipcc joins such paths with conservative waits.
-template <int F, bool FULL = false>
-__device__ __forceinline__ v4 wide_x_chunk(const void *x, int in_f64, int64_t row, int kc, int g) {
+// WRT ("run-time width"): the kernel serves a CLASS of wide models -- F is the class width (a multiple of 16: the geometry of the
+// packed weights, where every chunk is a full one), `fr` <= F the model's real column count, a kernel argument: rows are fr values
+// long, the loops over the wide dimension run tiles(fr) chunks, and the one chunk that reaches beyond fr reads / stores its
+// features one by one (natural order: a full class tile), the rest zero -- they meet the zero weights the pack map gives them.
+template <int F, bool FULL = false, bool WRT = false>
+__device__ __forceinline__ v4 wide_x_chunk(const void *x, int in_f64, int64_t row, int kc, int g, int fr = F) {
     // features 16 kc + 4 g .. + 3 of `row` (register r = MFMA step r, k = 4 g + r: the packed weights' order for full tiles);
     // the partial last chunk is r-major (slot_feature): register 0 of lane group g = feature 16 kc + g, the rest padding
     v4 v = (v4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (WRT && !FULL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * kc + 4 * g + r;
+            if (f < fr) v[r] = in_f64 ? (float)((const double *)x)[row * fr + f] : ((const float *)x)[row * fr + f];
+        }
+        return v;
+    }
     if (FULL || 16 * kc + 16 <= F) {
-        const int64_t i = row * F + 16 * kc + 4 * g;
+        const int64_t i = row * (WRT ? fr : F) + 16 * kc + 4 * g;
         if (in_f64) {
             const double2 lo = *(const double2 *)((const double *)x + i), hi = *(const double2 *)((const double *)x + i + 2);
             v = (v4){(float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y};
@@ -667,10 +679,20 @@ __device__ __forceinline__ v4 wide_x_chunk(const void *x, int in_f64, int64_t ro
 }
 
 // store tile t of a wide row (C layout) as float / double
-template <int F, bool FULL = false>
-__device__ __forceinline__ void wide_store_tile(const v4 &o, void *out, int out_f64, int64_t row, int t, int g) {
+template <int F, bool FULL = false, bool WRT = false>
+__device__ __forceinline__ void wide_store_tile(const v4 &o, void *out, int out_f64, int64_t row, int t, int g, int fr = F) {
+    if constexpr (WRT && !FULL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * t + 4 * g + r;
+            if (f < fr) {
+                if (out_f64) ((double *)out)[row * fr + f] = (double)o[r]; else ((float *)out)[row * fr + f] = o[r];
+            }
+        }
+        return;
+    }
     if (FULL || 16 * t + 16 <= F) {      // full tile: the lane's 4 consecutive features as one vector store
-        const int64_t i = row * F + 16 * t + 4 * g;
+        const int64_t i = row * (WRT ? fr : F) + 16 * t + 4 * g;
         if (out_f64) {
             *(double2 *)((double *)out + i) = make_double2((double)o[0], (double)o[1]);
             *(double2 *)((double *)out + i + 2) = make_double2((double)o[2], (double)o[3]);
@@ -1379,11 +1401,11 @@ __global__ void __launch_bounds__(256) pack_wide_bf16_k(const float *__restrict_
 // double-buffered LDS stage (see wide_bf16_encode_kernel: every load of a wave then has the same lead -- fragments and rows three
 // chunks ahead -- so the in-order vmcnt never makes an L2 hit wait for an HBM miss; fragment traffic through the L1 drops 4x;
 // 32 + 32 fragment registers instead of 104).  All four waves must call it together (one barrier per chunk).
-template <int F, bool IN64, int RT = 1>
+template <int F, bool IN64, int RT = 1, bool WRT = false>
 __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13], v4 (*wst)[13][64], const WStream &ww, const void *xin,
-                                                    int64_t rrow, int64_t rrow1, int g, int lane, int wave) {
-    constexpr int KC = F / 16;            // FULL chunks: the loop; the remainder F % 16 is the epilogue below
-    static_assert(KC >= 3, "at least three full chunks");
+                                                    int64_t rrow, int64_t rrow1, int g, int lane, int wave, int fr = F) {
+    const int KC = (WRT ? fr : F) / 16;   // FULL chunks: the loop; the remainder is the epilogue below
+    static_assert(F / 16 >= 3, "at least three full chunks");
     v4 wq[2][4], xr[3], xs[3];            // xs / acc1: the second row tile (RT == 2)
     auto wload = [&](v4 (&w)[4], int kc) {
         kc = kc < KC ? kc : KC - 1;
@@ -1400,8 +1422,8 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
             if (t < 13) wst[slot][t][lane] = w[k];
         }
     };
-    auto lx = [&](int kc) { return wide_x_chunk<F, true>(xin, IN64 ? 1 : 0, rrow, kc < KC ? kc : 0, g); };
-    auto ly = [&](int kc) { return RT == 2 ? wide_x_chunk<F, true>(xin, IN64 ? 1 : 0, rrow1, kc < KC ? kc : 0, g) : (v4){0.f, 0.f, 0.f, 0.f}; };
+    auto lx = [&](int kc) { return wide_x_chunk<F, true, WRT>(xin, IN64 ? 1 : 0, rrow, kc < KC ? kc : 0, g, fr); };
+    auto ly = [&](int kc) { return RT == 2 ? wide_x_chunk<F, true, WRT>(xin, IN64 ? 1 : 0, rrow1, kc < KC ? kc : 0, g, fr) : (v4){0.f, 0.f, 0.f, 0.f}; };
     wload(wq[0], 0);
     wload(wq[1], 1);
 #pragma unroll
@@ -1457,10 +1479,11 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
     if (kc + 2 < KC) iter(kc + 2, I0(), I2());
     if (kc + 3 < KC) iter(kc + 3, I1(), I0());
     if (kc + 4 < KC) iter(kc + 4, I0(), I1());
-    if (F % 16 != 0) {                    // the remaining F % 16 features: one partial chunk, fragments straight from L2
-        constexpr int KL = F / 16, ST = tile_steps(F, KL);
-        const v4 xv = wide_x_chunk<F>(xin, IN64 ? 1 : 0, rrow, KL, g);
-        const v4 yv = RT == 2 ? wide_x_chunk<F>(xin, IN64 ? 1 : 0, rrow1, KL, g) : xv;
+    if ((WRT ? fr : F) % 16 != 0) {       // the remaining features: one partial chunk, fragments straight from L2
+        const int KL = KC;
+        constexpr int ST = WRT ? 4 : tile_steps(F, F / 16);      // (a class chunk is a full tile: padding meets zero weights and a zero x)
+        const v4 xv = wide_x_chunk<F, false, WRT>(xin, IN64 ? 1 : 0, rrow, KL, g, fr);
+        const v4 yv = RT == 2 ? wide_x_chunk<F, false, WRT>(xin, IN64 ? 1 : 0, rrow1, KL, g, fr) : xv;
         v4 wt[13];
 #pragma unroll
         for (int t = 0; t < 13; ++t) wt[t] = frag_rt(ww, KL * 13 + t);
@@ -1479,18 +1502,19 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
 // `emit(o, t, slot, full)` consumes output tile t; full = std::true_type in the main loop, where every tile touched is a full one
 // (no "partial tile?" test in front of the loads and stores), std::false_type for the last tiles.  All four waves together; one
 // barrier per tile.
-template <int F, class Pre, class Emit>
+template <int F, bool WRT = false, class Pre, class Emit>
 __device__ __forceinline__ void wide_out_product_lds(const v4 (&a7)[13], v4 (*wst)[13][64], const WStream &ww, const v4 *bias7, int g,
-                                                     int lane, int wave, Pre pre, Emit emit) {
-    constexpr int KC = tiles(F), KF = F / 16;      // all / full output tiles
-    static_assert(KF >= 3, "at least three full tiles");
+                                                     int lane, int wave, Pre pre, Emit emit, int fr = F) {
+    constexpr int KCS = tiles(F);                  // stride of the fragment array [k tile of the 200 side][output tile]
+    const int KC = WRT ? (fr + 15) / 16 : tiles(F), KF = (WRT ? fr : F) / 16;      // all / full output tiles
+    static_assert(F / 16 >= 3, "at least three full tiles");
     v4 wq[2][4];
     auto wload = [&](v4 (&w)[4], int t) {
         t = t < KC ? t : KC - 1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int q = wave + 4 * k;
-            w[k] = frag_rt(ww, (q < 13 ? q : 12) * KC + t);
+            w[k] = frag_rt(ww, (q < 13 ? q : 12) * KCS + t);
         }
     };
     auto wstore = [&](const v4 (&w)[4], int slot) {
@@ -1558,9 +1582,9 @@ __device__ __forceinline__ void wide_out_product_lds(const v4 (&a7)[13], v4 (*ws
     tail(12, I0(), I0()); tail(13, I1(), I1());
 }
 
-template <int F, int Z, bool IN64>
+template <int F, int Z, bool IN64, bool WRT = false>
 __global__ void __launch_bounds__(256) wide_encode_lds_kernel(const v4 *packed, const void *__restrict__ xin, int64_t n,
-                                                              void *__restrict__ out, int out_f64) {
+                                                              void *__restrict__ out, int out_f64, int fr = F, int zr = Z) {
     using N = Net<F, Z>;
     using S = StreamWideEnc<N>;
     __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
@@ -1576,7 +1600,7 @@ __global__ void __launch_bounds__(256) wide_encode_lds_kernel(const v4 *packed, 
         asm volatile("" : "+v"(ws.voff), "+v"(ww.voff));
         v4 a1[13];
         init_bias(a1, bias_lds, lane);
-        wide_in_product_lds<F, IN64, 1>(a1, a1, wst, ww, xin, valid ? row : 0, 0, g, lane, wave);
+        wide_in_product_lds<F, IN64, 1, WRT>(a1, a1, wst, ww, xin, valid ? row : 0, 0, g, lane, wave, fr);
         lrelu(a1);
         Ring ring;
         ring_prime<S::total>(ring, ws);
@@ -1584,13 +1608,13 @@ __global__ void __launch_bounds__(256) wide_encode_lds_kernel(const v4 *packed, 
         fwd_layer<N, S, 1>(a1, a2, ring, ws, bias_lds, lane);
         fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
         fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
-        store_rows<Z>(a4, out, out_f64, row, valid, lane, nullptr, nullptr);
+        store_rows<Z, WRT>(a4, out, out_f64, row, valid, lane, nullptr, nullptr, zr);
     }
 }
 
-template <int F, int Z, bool OUT64>
+template <int F, int Z, bool OUT64, bool WRT = false>
 __global__ void __launch_bounds__(256) wide_decode_lds_kernel(const v4 *packed, const void *__restrict__ zin, int in_f64, int64_t n,
-                                                              void *__restrict__ out) {
+                                                              void *__restrict__ out, int fr = F, int zr = Z) {
     using N = Net<F, Z>;
     using S = StreamWideDec<N>;
     __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
@@ -1607,14 +1631,14 @@ __global__ void __launch_bounds__(256) wide_decode_lds_kernel(const v4 *packed, 
         Ring ring;
         ring_prime<S::total>(ring, ws);
         v4 a4[tiles(Z)], a5[4], a6[7], a7[13];
-        load_rows<Z>(a4, zin, in_f64, row, valid, lane, nullptr);
+        load_rows<Z, WRT>(a4, zin, in_f64, row, valid, lane, nullptr, zr);
         fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
         fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
         fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
-        wide_out_product_lds<F>(a7, wst, ww, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, lane, wave, [&](int, auto, auto) {},
+        wide_out_product_lds<F, WRT>(a7, wst, ww, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, lane, wave, [&](int, auto, auto) {},
                                 [&](const v4 &o, int t, auto, auto full) {
-                                    if (valid) wide_store_tile<F, decltype(full)::value>(o, out, OUT64 ? 1 : 0, row, t, g);
-                                });
+                                    if (valid) wide_store_tile<F, decltype(full)::value, WRT>(o, out, OUT64 ? 1 : 0, row, t, g, fr);
+                                }, fr);
     }
 }
 
@@ -1633,10 +1657,17 @@ template <class N> struct StreamWideMidBwd {   // transposed fragments of layers
     static constexpr int start_f4 = N::wb_off(6);
 };
 // one activation / gradient row block in C layout from / to a row-major float32 matrix [rows][D]
-template <int D>
-__device__ __forceinline__ void load_act(v4 (&a)[tiles(D)], const float *__restrict__ y, int64_t rrow, int g) {
+template <int D, bool WRT = false>
+__device__ __forceinline__ void load_act(v4 (&a)[tiles(D)], const float *__restrict__ y, int64_t rrow, int g, int dr = D) {
 #pragma unroll
     for (int t = 0; t < tiles(D); ++t) {
+        if constexpr (WRT) {      // a class width: rows of dr values, slots beyond dr are zero
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = slot_feature(D, t, g, r);
+                a[t][r] = (f >= 0 && f < dr) ? y[rrow * dr + f] : 0.f;
+            }
+        } else
         if (D - 16 * t >= 16 && D % 4 == 0) {
             a[t] = *(const v4 *)(y + rrow * D + 16 * t + 4 * g);
         } else {
@@ -1654,14 +1685,15 @@ __device__ __forceinline__ void load_act(v4 (&a)[tiles(D)], const float *__restr
 // dz8 = 2 (recon - x) / F, loss_part[workgroup] = sum of squared errors (double, fixed order).
 // TRAIN = false is the validation pass (training.py:104-137): no activation stores, `dz8` (may be null) receives the
 // reconstruction itself as float32 / float64.
-template <int F, int Z, bool TRAIN>
+template <int F, int Z, bool TRAIN, bool WRT = false>
 __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, const float *__restrict__ x, int64_t n, float *__restrict__ y1,
                                                              float *__restrict__ y2, float *__restrict__ y3, float *__restrict__ y4,
                                                              float *__restrict__ y5, float *__restrict__ y6, float *__restrict__ y7,
-                                                             void *__restrict__ dz8, int out_f64, double *__restrict__ loss_part) {
+                                                             void *__restrict__ dz8, int out_f64, double *__restrict__ loss_part,
+                                                             int fr = F, int zr = Z) {
     using N = Net<F, Z>;
     using S = StreamWideMid<N>;
-    constexpr int KC = tiles(F);
+    const int KC = WRT ? (fr + 15) / 16 : tiles(F);
     __shared__ __attribute__((aligned(16))) v4 bias_lds[N::bf_off(N::L) - N::bf_off(0)];
     __shared__ double sh[256];
     stage_bias<N>(bias_lds, packed);
@@ -1671,7 +1703,7 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
     WStream ws = make_stream(packed + S::start_f4, (N::packed_f4() - S::start_f4) * 16, lane);
     WStream w0 = make_stream(packed + N::wf_off(0), N::wcount(0) * 16, lane);
     WStream w7 = make_stream(packed + N::wf_off(7), N::wcount(7) * 16, lane);
-    const float gscale = 2.0f / F;
+    const float gscale = 2.0f / (float)(WRT ? fr : F);
     double lacc = 0.0;
     for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {      // workgroup-uniform trip count: the product has barriers
         const int64_t row = (grp * 4 + wave) * 16 + (lane & 15);
@@ -1682,7 +1714,7 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
         {
             v4 a1[13];
             init_bias(a1, bias_lds, lane);
-            wide_in_product_lds<F, false, 1>(a1, a1, wst, w0, x, rrow, 0, g, lane, wave);
+            wide_in_product_lds<F, false, 1, WRT>(a1, a1, wst, w0, x, rrow, 0, g, lane, wave, fr);
             lrelu(a1);
             if (TRAIN) store_rows<200>(a1, y1, 0, row, valid, lane, nullptr, nullptr);
             Ring ring;
@@ -1693,7 +1725,7 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
             fwd_layer<N, S, 2>(a2, a3, ring, ws, bias_lds, lane);
             if (TRAIN) store_rows<50>(a3, y3, 0, row, valid, lane, nullptr, nullptr);
             fwd_layer<N, S, 3>(a3, a4, ring, ws, bias_lds, lane);
-            if (TRAIN) store_rows<Z>(a4, y4, 0, row, valid, lane, nullptr, nullptr);
+            if (TRAIN) store_rows<Z, WRT>(a4, y4, 0, row, valid, lane, nullptr, nullptr, zr);
             fwd_layer<N, S, 4>(a4, a5, ring, ws, bias_lds, lane);
             if (TRAIN) store_rows<50>(a5, y5, 0, row, valid, lane, nullptr, nullptr);
             fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
@@ -1704,11 +1736,11 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
         // de4 + loss: the x tiles are re-read three tiles ahead of the tile being multiplied, like the fragments (HBM again:
         // 327 MB of rows do not stay in the 256-MB MALL between the two passes)
         v4 xr[3];
-        wide_out_product_lds<F>(a7, wst, w7, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, lane, wave,
+        wide_out_product_lds<F, WRT>(a7, wst, w7, bias_lds + (N::bf_off(7) - N::bf_off(0)), g, lane, wave,
             [&](int t, auto slot, auto full) {
                 constexpr int SL = decltype(slot)::value;
-                if (decltype(full)::value) xr[SL] = wide_x_chunk<F, true>(x, 0, rrow, t, g);
-                else xr[SL] = wide_x_chunk<F>(x, 0, rrow, t < KC ? t : 0, g);
+                if (decltype(full)::value) xr[SL] = wide_x_chunk<F, true, WRT>(x, 0, rrow, t, g, fr);
+                else xr[SL] = wide_x_chunk<F, false, WRT>(x, 0, rrow, t < KC ? t : 0, g, fr);
             },
             [&](const v4 &o, int t, auto slot, auto full) {
                 constexpr int SL = decltype(slot)::value;
@@ -1716,10 +1748,10 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
                 const v4 d = o - xr[SL];     // padding slots: zero weights and bias against a zero x
                 if (valid) {
                     lacc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
-                    if (TRAIN) wide_store_tile<F, FL>(d * gscale, dz8, 0, row, t, g);
-                    else if (dz8) wide_store_tile<F, FL>(o, dz8, out_f64, row, t, g);
+                    if (TRAIN) wide_store_tile<F, FL, WRT>(d * gscale, dz8, 0, row, t, g, fr);
+                    else if (dz8) wide_store_tile<F, FL, WRT>(o, dz8, out_f64, row, t, g, fr);
                 }
-            });
+            }, fr);
     }
     sh[threadIdx.x] = lacc;
     __syncthreads();
@@ -1732,14 +1764,15 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
 
 // the input-gradient chain of 16 rows per wave: dZ_6 = (dZ_7 W_7) * lrelu'(y7) streamed over the wide dimension, then layers 6..1
 // chained in registers; every dZ_l (dL/d pre-activation of layer l) is stored for the weight-gradient GEMMs.
-template <int F, int Z>
+template <int F, int Z, bool WRT = false>
 __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, const float *__restrict__ dz7, int64_t n,
                                                              const float *__restrict__ y1, const float *__restrict__ y2,
                                                              const float *__restrict__ y3, const float *__restrict__ y5,
                                                              const float *__restrict__ y6, const float *__restrict__ y7,
                                                              float *__restrict__ dz0, float *__restrict__ dz1, float *__restrict__ dz2,
                                                              float *__restrict__ dz3, float *__restrict__ dz4, float *__restrict__ dz5,
-                                                             float *__restrict__ dz6, const float *__restrict__ dz_latent) {
+                                                             float *__restrict__ dz6, const float *__restrict__ dz_latent,
+                                                             int fr = F, int zr = Z) {
     using N = Net<F, Z>;
     using S = StreamWideMidBwd<N>;
     __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
@@ -1754,7 +1787,7 @@ __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, c
         asm volatile("" : "+v"(ws.voff), "+v"(w7.voff));
         v4 d6[13];
         zero_tiles(d6);
-        wide_in_product_lds<F, false, 1>(d6, d6, wst, w7, dz7, rrow, 0, g, lane, wave);
+        wide_in_product_lds<F, false, 1, WRT>(d6, d6, wst, w7, dz7, rrow, 0, g, lane, wave, fr);
         Ring ring;
         ring_prime<S::total>(ring, ws);
         {
@@ -1773,11 +1806,11 @@ __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, c
         bwd_layer<N, S, 4>(d4, d3, ring, ws);                      // the latent layer has no activation
         if (dz_latent) {      // dL/dz of the caller's regulariser (bamd_fwd_bwd_latent: the sliced-Wasserstein term), added at the bottleneck
             v4 e[tiles(Z)];
-            load_act<Z>(e, dz_latent, rrow, g);
+            load_act<Z, WRT>(e, dz_latent, rrow, g, zr);
 #pragma unroll
             for (int t = 0; t < tiles(Z); ++t) d3[t] += e[t];
         }
-        store_rows<Z>(d3, dz3, 0, row, valid, lane, nullptr, nullptr);
+        store_rows<Z, WRT>(d3, dz3, 0, row, valid, lane, nullptr, nullptr, zr);
         bwd_layer<N, S, 3>(d3, d2, ring, ws);
         { v4 a[4]; load_act<50>(a, y3, rrow, g); lrelu_bwd(d2, a); }
         store_rows<50>(d2, dz2, 0, row, valid, lane, nullptr, nullptr);
@@ -3747,7 +3780,7 @@ template <int F, int Z, bool RT = false> struct Impl {
 // (generic_fwd_bwd below; bamd_train_step falls through on BAMD_ERR_UNSUPPORTED).  bamd_path_of() = BAMD_PATH_FUSED_INFER.
 template <int F, int Z, bool SMALL = true> struct ImplInferClass {
     using B = Impl<F, Z, true>;
-    static_assert(F % 16 == 15 && Z % 16 == 15 && (F <= 79 || !SMALL), "class widths are 16 T - 1; the small-batch chain takes up to 5 input tiles");
+    static_assert(F % 16 == 15 && Z % 16 == 15 && (F <= 127 || !SMALL), "class widths are 16 T - 1; the small-batch chain takes up to 8 input tiles");
     static bool matches(const bamd_handle *h) { return B::matches(h); }
     static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, SMALL>(h, st); }
     static int fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, hipStream_t s) {
@@ -3772,15 +3805,27 @@ template <int F, int Z, bool SMALL = true> struct ImplInferClass {
 // 2500 x 200 layer is 2 MB of accumulators per workgroup: it has to be a split-K product, generic.hip's dw_wide_k); forward_loss
 // layer-wise.  Normalise-on-load / un-normalise-on-store go through a float32 staging buffer
 // (the per-feature min / range of 2500 features do not fit next to the chain's registers).
-template <int F, int Z> struct ImplWide {
+// WRT = true: a CLASS instantiation with run-time widths (models.py:192-209 builds CFD_dense_AE(n_features, z_dim) for ANY flattened
+// field, baler.py:117-123 derives any latent): F = the class width (a multiple of 16; geometry of the packed weights), Z = the class
+// latent; the handle's real column count (48 .. F) and latent (<= Z) are kernel arguments (wide_x_chunk).  The one-tile kernels
+// with LDS-shared fragments serve every size of such a handle.
+template <int F, int Z, bool WRT = false> struct ImplWide {
     using N = Net<F, Z>;
     static constexpr int64_t kChunkRows = 1 << 18;     // staging chunk: 2.6 GB of float32 rows
+    static int Fr(const bamd_handle *h) { return WRT ? h->dims[0] : F; }
+    static int Zr(const bamd_handle *h) { return WRT ? h->dims[4] : Z; }
     static bool matches(const bamd_handle *h) {
         if (h->L != 8) return false;
+        if (WRT) {
+            for (int i = 1; i <= 7; ++i)
+                if (i != 4 && h->dims[i] != N::dim(i)) return false;
+            return h->dims[0] == h->dims[8] && h->dims[0] >= 48 && h->dims[0] <= F && h->dims[4] <= Z;
+        }
         for (int i = 0; i <= 8; ++i)
             if (h->dims[i] != N::dim(i)) return false;
         return true;
     }
+    static_assert(!WRT || F % 16 == 0, "a wide class width is a multiple of 16 (every class chunk a full tile)");
     static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, false>(h, st); }
     static int grid_for(int64_t n) {
         const int64_t wg = ((n + 15) / 16 + 3) / 4;
@@ -3789,14 +3834,15 @@ template <int F, int Z> struct ImplWide {
     static int encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
                       hipStream_t s) {
         const size_t xes = x_dtype == BAMD_F64 ? 8 : 4, zes = z_dtype == BAMD_F64 ? 8 : 4;
+        const int fr = Fr(h), zr = Zr(h);
         for (int64_t r0 = 0; r0 < n; r0 += kChunkRows) {
             const int64_t rows = n - r0 < kChunkRows ? n - r0 : kChunkRows;
-            const void *src = (const char *)x + (size_t)r0 * F * xes;
+            const void *src = (const char *)x + (size_t)r0 * fr * xes;
             int src_f64 = x_dtype == BAMD_F64;
             if (features) {
-                int rc = h->work.ensure((size_t)rows * F * sizeof(float));
+                int rc = h->work.ensure((size_t)rows * fr * sizeof(float));
                 if (rc) return rc;
-                rc = launch_normalize(src, x_dtype, rows, F, features, h->work.p, BAMD_F32, s);
+                rc = launch_normalize(src, x_dtype, rows, fr, features, h->work.p, BAMD_F32, s);
                 if (rc) return rc;
                 src = h->work.p;
                 src_f64 = 0;
@@ -3805,19 +3851,21 @@ template <int F, int Z> struct ImplWide {
             // 384 -> 419 M rows/s; C4 131072 frames 87.6 -> 91.8 M, but 32768 frames 96 -> 72 M: half the chip's wave slots empty);
             // BALER_AMD_WIDE2=0 / 1 forces one / two tiles
             const char *e2 = getenv("BALER_AMD_WIDE2");
-            const bool two = e2 ? e2[0] == '1' : rows >= 32 * 4 * 512;
-            void *zo = (void *)((char *)z + (size_t)r0 * Z * zes);
+            const bool two = !WRT && (e2 ? e2[0] == '1' : rows >= 32 * 4 * 512);
+            void *zo = (void *)((char *)z + (size_t)r0 * zr * zes);
             const int z64 = z_dtype == BAMD_F64;
-            if (two && src_f64)
-                hipLaunchKernelGGL((wide_encode2_kernel<F, Z, true>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
-            else if (two)
-                hipLaunchKernelGGL((wide_encode2_kernel<F, Z, false>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
-            else {
+            if constexpr (!WRT) {
+                if (two && src_f64)
+                    hipLaunchKernelGGL((wide_encode2_kernel<F, Z, true>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
+                else if (two)
+                    hipLaunchKernelGGL((wide_encode2_kernel<F, Z, false>), dim3(grid_for((rows + 1) / 2)), dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
+            }
+            if (!two) {
                 // fragments shared through LDS (C4, 32768 frames: 92.5 -> 98.5 M rows/s against per-wave fragments)
                 const int64_t ng = (rows + 63) / 64;
                 const dim3 gl((unsigned)(ng > 2048 ? 2048 : ng));
-                if (src_f64) hipLaunchKernelGGL((wide_encode_lds_kernel<F, Z, true>), gl, dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
-                else hipLaunchKernelGGL((wide_encode_lds_kernel<F, Z, false>), gl, dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64);
+                if (src_f64) hipLaunchKernelGGL((wide_encode_lds_kernel<F, Z, true, WRT>), gl, dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64, fr, zr);
+                else hipLaunchKernelGGL((wide_encode_lds_kernel<F, Z, false, WRT>), gl, dim3(256), 0, s, (const v4 *)h->packed.p, src, rows, zo, z64, fr, zr);
             }
         }
         BAMD_HIP(hipGetLastError());
@@ -3827,26 +3875,27 @@ template <int F, int Z> struct ImplWide {
                       void *out, int out_dtype, hipStream_t s) {
         const size_t zes = z_dtype == BAMD_F64 ? 8 : 4, oes = out_dtype == BAMD_F64 ? 8 : 4;
         if (features && out_dtype != BAMD_F64) { set_error("decode with features needs a float64 output"); return BAMD_ERR_INVALID; }
+        const int fr = Fr(h), zr = Zr(h);
         for (int64_t r0 = 0; r0 < n; r0 += kChunkRows) {
             const int64_t rows = n - r0 < kChunkRows ? n - r0 : kChunkRows;
-            void *dst = (char *)out + (size_t)r0 * F * oes;
+            void *dst = (char *)out + (size_t)r0 * fr * oes;
             void *kout = dst;
             int kout_f64 = out_dtype == BAMD_F64;
             if (features) {
-                int rc = h->work.ensure((size_t)rows * F * sizeof(float));
+                int rc = h->work.ensure((size_t)rows * fr * sizeof(float));
                 if (rc) return rc;
                 kout = h->work.p;
                 kout_f64 = 0;
             }
-            const void *zi = (const void *)((const char *)z + (size_t)r0 * Z * zes);
+            const void *zi = (const void *)((const char *)z + (size_t)r0 * zr * zes);
             if (kout_f64)
-                hipLaunchKernelGGL((wide_decode_lds_kernel<F, Z, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, zi,
-                                   z_dtype == BAMD_F64, rows, kout);
+                hipLaunchKernelGGL((wide_decode_lds_kernel<F, Z, true, WRT>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, zi,
+                                   z_dtype == BAMD_F64, rows, kout, fr, zr);
             else
-                hipLaunchKernelGGL((wide_decode_lds_kernel<F, Z, false>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, zi,
-                                   z_dtype == BAMD_F64, rows, kout);
+                hipLaunchKernelGGL((wide_decode_lds_kernel<F, Z, false, WRT>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p, zi,
+                                   z_dtype == BAMD_F64, rows, kout, fr, zr);
             if (features) {
-                int rc = launch_renormalize(kout, BAMD_F32, rows, F, features, int_mask, (double *)dst, s);
+                int rc = launch_renormalize(kout, BAMD_F32, rows, fr, features, int_mask, (double *)dst, s);
                 if (rc) return rc;
             }
         }
@@ -3857,8 +3906,8 @@ template <int F, int Z> struct ImplWide {
     static int wide_fwd(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
                         hipStream_t s) {
         const int grid = grid_for(rows);
-        hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, true>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, y[1], y[2], y[3],
-                           y[4], y[5], y[6], y[7], (void *)dz_last, 0, loss_part);
+        hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, true, WRT>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, y[1], y[2], y[3],
+                           y[4], y[5], y[6], y[7], (void *)dz_last, 0, loss_part, Fr(h), Zr(h));
         *nblk = grid;
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
@@ -3868,36 +3917,37 @@ template <int F, int Z> struct ImplWide {
     static int forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *recon, int recon_dtype,
                             double *loss_sum, hipStream_t s) {
         const size_t xes = x_dtype == BAMD_F64 ? 8 : 4, oes = recon_dtype == BAMD_F64 ? 8 : 4;
+        const int fr = Fr(h), zr = Zr(h);
         const int64_t chunk = 1 << 16;
         int rc = h->lossp.ensure(sizeof(double) * 4096 * ((n + chunk - 1) / chunk > 0 ? (n + chunk - 1) / chunk : 1));
         if (rc) return rc;
         int nblk = 0;
         for (int64_t r0 = 0; r0 < n; r0 += chunk) {
             const int64_t rows = n - r0 < chunk ? n - r0 : chunk;
-            const void *src = (const char *)x + (size_t)r0 * F * xes;
+            const void *src = (const char *)x + (size_t)r0 * fr * xes;
             if (features || x_dtype != BAMD_F32) {
-                rc = h->work.ensure((size_t)rows * F * sizeof(float));
+                rc = h->work.ensure((size_t)rows * fr * sizeof(float));
                 if (rc) return rc;
-                rc = features ? launch_normalize(src, x_dtype, rows, F, features, h->work.p, BAMD_F32, s)
-                              : launch_convert(src, x_dtype, h->work.p, BAMD_F32, rows * F, s);
+                rc = features ? launch_normalize(src, x_dtype, rows, fr, features, h->work.p, BAMD_F32, s)
+                              : launch_convert(src, x_dtype, h->work.p, BAMD_F32, rows * fr, s);
                 if (rc) return rc;
                 src = h->work.p;
             }
             const int grid = grid_for(rows);
-            hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, false>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
+            hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, false, WRT>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
                                rows, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr,
-                               (float *)nullptr, (float *)nullptr, recon ? (void *)((char *)recon + (size_t)r0 * F * oes) : nullptr,
-                               recon_dtype == BAMD_F64, (double *)h->lossp.p + nblk);
+                               (float *)nullptr, (float *)nullptr, recon ? (void *)((char *)recon + (size_t)r0 * fr * oes) : nullptr,
+                               recon_dtype == BAMD_F64, (double *)h->lossp.p + nblk, fr, zr);
             nblk += grid;
         }
-        hipLaunchKernelGGL(sum_loss_wide_k, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk, 1.0 / F, loss_sum);
+        hipLaunchKernelGGL(sum_loss_wide_k, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk, 1.0 / fr, loss_sum);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
     static int wide_bwd(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, const float *dz_latent, hipStream_t s) {
-        hipLaunchKernelGGL((wide_train_bwd_kernel<F, Z>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+        hipLaunchKernelGGL((wide_train_bwd_kernel<F, Z, WRT>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
                            (const float *)dz[7], rows, (const float *)y[1], (const float *)y[2], (const float *)y[3], (const float *)y[5],
-                           (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz_latent);
+                           (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz_latent, Fr(h), Zr(h));
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
@@ -4141,6 +4191,10 @@ template <int F, int Z> struct ImplWideBf16 {
 // generic.hip, and bamd_create says so once (bamd_path_of() = BAMD_PATH_GENERIC).
 #define BAMD_AE24(Z_) if (Impl<24, Z_>::matches(h)) return Impl<24, Z_>::ops();
 #define BAMD_AE24_ALL BAMD_AE24(15) BAMD_AE24(12) BAMD_AE24(10) BAMD_AE24(8) BAMD_AE24(6) BAMD_AE24(5) BAMD_AE24(4) BAMD_AE24(3) BAMD_AE24(2)
+// BALER_AMD_WIDE_CLASS: 0 = no run-time-width wide class (such shapes run layer by layer); "force" = the class also for the shapes
+// that have an exact instantiation (tests: class vs exact on the same model)
+static bool wide_class_on() { const char *e = getenv("BALER_AMD_WIDE_CLASS"); return !(e && e[0] == '0'); }
+static bool wide_class_forced() { const char *e = getenv("BALER_AMD_WIDE_CLASS"); return e && e[0] == 'f'; }
 static const FusedOps *find_ops(const bamd_handle *h) {
     if (h->mode == BAMD_MODE_BF16) {
         if (ImplWide<2500, 25>::matches(h)) return ImplWideBf16<2500, 25>::ops();
@@ -4162,10 +4216,23 @@ static const FusedOps *find_ops(const bamd_handle *h) {
     if (Impl<47, 31, true>::matches(h)) return Impl<47, 31, true>::ops();
     if (Impl<63, 15, true>::matches(h)) return Impl<63, 15, true>::ops();
     if (Impl<63, 31, true>::matches(h)) return Impl<63, 31, true>::ops();
-    if (ImplInferClass<79, 31, true>::matches(h)) return ImplInferClass<79, 31, true>::ops();      // 64..79 columns: one-tile inference kernels, small-batch training
-    if (ImplWide<512, 6>::matches(h)) return ImplWide<512, 6>::ops();
-    if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();
-    if (ImplWide<625, 7>::matches(h)) return ImplWide<625, 7>::ops();
+    if (!wide_class_forced()) {
+        if (ImplWide<512, 6>::matches(h)) return ImplWide<512, 6>::ops();
+        if (ImplWide<2500, 25>::matches(h)) return ImplWide<2500, 25>::ops();
+        if (ImplWide<625, 7>::matches(h)) return ImplWide<625, 7>::ops();
+    }
+    // 64..127 columns: one-tile inference kernels and small-batch training (two reconstruction tiles per wave); large batches layer-wise
+    if (ImplInferClass<79, 31, true>::matches(h)) return ImplInferClass<79, 31, true>::ops();
+    if (ImplInferClass<95, 31, true>::matches(h)) return ImplInferClass<95, 31, true>::ops();
+    if (ImplInferClass<111, 31, true>::matches(h)) return ImplInferClass<111, 31, true>::ops();
+    if (ImplInferClass<127, 31, true>::matches(h)) return ImplInferClass<127, 31, true>::ops();
+    // any other wide model with the reference's hidden widths (CFD_dense_AE(n_features, z_dim), models.py:192-209): class instantiations
+    // of the wide-layer kernels with run-time widths: up to 4096 columns, a latent of up to 15 / 31 / 63
+    if (wide_class_on()) {
+        if (ImplWide<4096, 15, true>::matches(h)) return ImplWide<4096, 15, true>::ops();
+        if (ImplWide<4096, 31, true>::matches(h)) return ImplWide<4096, 31, true>::ops();
+        if (ImplWide<4096, 63, true>::matches(h)) return ImplWide<4096, 63, true>::ops();
+    }
     return nullptr;
 }
 #undef BAMD_AE24

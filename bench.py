@@ -517,6 +517,23 @@ def main():
                 by_global[str(bs)] = {"rows_per_s": bs * nb / tg_, "us_per_step": 1e6 * tg_ / nb, "rows_per_gpu_per_step": per,
                                       "steps_timed": nb}
             out["train_rows_per_s_by_global_batch"] = by_global
+        if world == 1 and not coll and a.rows >= 2 * 512:
+            # ---- the reference's epoch (training.fit, training.py:64-97: sequential batches of 512 rows) as ONE host call: bamd_train_epoch,
+            # the batch loop inside the library.  host_us_per_step = the host thread's time inside the call (the enqueue of two
+            # launches per step); us_per_step = epoch wall time / steps with the stream drained (GPU-bound when larger than the host's)
+            nb = a.rows // 512
+
+            def epoch():
+                state["t"] += h.train_epoch(x[:nb * 512], 512, flat, m, v, state["t"] + 1, 1e-3, loss_accum=loss_acc)
+            epoch()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            epoch()
+            t_host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            out["train_bs512_epoch_call"] = {"steps": nb, "host_calls": 1, "us_per_step": 1e6 * t_all / nb, "host_us_per_step": 1e6 * t_host / nb,
+                                             "rows_per_s": nb * 512 / t_all}
         if "512" in by_batch:
             out["train_bs512_rows_per_s"] = by_batch["512"]["rows_per_s"]
             out["train_bs512_us_per_step"] = by_batch["512"]["us_per_step"]
@@ -774,6 +791,31 @@ def other_configs(dev):
                                                "train_bs512_us_per_step": ms_s * 1e3}
         hn.close()
         del xn, gn, mo, vo
+    # wide models other than the compiled-in shapes (models.py:192-209 builds CFD_dense_AE(n_features, z_dim) for any flattened field):
+    # the run-time-width class ImplWide<4096, ZC, true>; on (625, 7) also forced (BALER_AMD_WIDE_CLASS=force at bamd_create) next to
+    # the exact instantiation
+    res["wide_class"] = {}
+    for (F, Z), rows, forced in (((900, 9), 131072, False), ((1024, 11), 131072, False), ((4096, 41), 32768, False), ((128, 13), 524288, False),
+                                 ((625, 7), 131072, False), ((625, 7), 131072, True), ((2500, 25), 32768, False), ((2500, 25), 32768, True)):
+        if forced:
+            os.environ["BALER_AMD_WIDE_CLASS"] = "force"
+        try:
+            mw = models.CFD_dense_AE(F, Z, mode="fp32").to(dev)
+            hw = mw.handle()
+        finally:
+            os.environ.pop("BALER_AMD_WIDE_CLASS", None)
+        xw = torch.rand((rows, F), dtype=torch.float32, device=dev)
+        zw = hw.encode(xw)
+        gw = torch.zeros_like(mw.flat)
+        ms_e, ms_d, ms_t = event_ms(lambda: hw.encode(xw), 3), event_ms(lambda: hw.decode(zw), 3), event_ms(lambda: hw.fwd_bwd(xw, gw), 2)
+        enc_macs = F * 200 + 200 * 100 + 100 * 50 + 50 * Z
+        flop_e, flop_t = 2 * enc_macs, 2 * (3 * 2 * enc_macs - F * 200)      # train: fwd + dW + dX (no dX for en1)
+        res["wide_class"][f"ae_{F}_{Z}" + ("_class_forced" if forced else "")] = {
+            "path": hw.path, "rows": rows, "encode_rows_per_s": rows / ms_e * 1e3, "decode_rows_per_s": rows / ms_d * 1e3,
+            "train_fwd_bwd_rows_per_s": rows / ms_t * 1e3, "encode_frac_of_fp32_mfma_peak": flop_e * rows / ms_e / 1e9 / PEAK_TFLOPS["fp32"],
+            "train_frac_of_fp32_mfma_peak": flop_t * rows / ms_t / 1e9 / PEAK_TFLOPS["fp32"]}
+        hw.close()
+        del xw, zw, gw
     return res
 
 

@@ -1,0 +1,154 @@
+"""Run-time-width classes for models other than the compiled-in shapes (reference models.py:122-139, 192-209 build
+AE / CFD_dense_AE(n_features, z_dim) for ANY width, baler.py:117-123 derives any latent, and three shipped configs feed un-blocked
+2-D data of whatever size the file has):
+
+  64 .. 127 columns, latent <= 31   ImplInferClass<79|95|111|127, 31>: fused one-tile inference kernels + the small-batch training
+                                    step (chain + weight-gradient tiles + fused Adam); large training batches layer-wise;
+  48 .. 4096 columns, latent <= 63  ImplWide<4096, 15|31|63, true>: the wide-layer kernels (en1 / de4 streamed around the register
+                                    chain, LDS-shared fragments) with the column count, the chunk count and the latent as kernel
+                                    arguments: encode / decode / forward + loss and the two row-local launches of a training pass
+                                    (the weight gradients are the layer-wise split-K kernels, as for the exact wide shapes).
+
+Every call against the scalar fp64 oracle at ragged row counts with `rel()` (max of rel-L2 and max-norm, 1e-5), and the class
+forced onto shapes that have an exact instantiation (BALER_AMD_WIDE_CLASS=force at bamd_create) against that instantiation.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from baler_amd import native
+from oracle import c_oracle as orc
+from test_gpu_parity import TOL32, dev, make_handle, off_the_kink, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(dims, flat, h, p, sizes, seed, per_tensor=True):
+    F = dims[0]
+    for n in sizes:
+        x = off_the_kink(dims, flat, n, seed + n)
+        z_ref = orc.encode(dims, flat, x)
+        for xin in (dev(x), dev(x, torch.float32)):
+            want = z_ref if xin.dtype == torch.float64 else orc.encode(dims, flat, x.astype(np.float32).astype(np.float64))
+            assert rel(h.encode(xin, out_dtype=torch.float32).cpu().numpy(), want) < TOL32, ("encode", dims[0], dims[4], n, xin.dtype)
+        rec_ref = orc.decode(dims, flat, z_ref)
+        assert rel(h.decode(dev(z_ref, torch.float32)).cpu().numpy(), rec_ref) < TOL32, ("decode", F, n)
+        assert rel(h.decode(dev(z_ref), out_dtype=torch.float64).cpu().numpy(), rec_ref) < TOL32, ("decode64", F, n)
+        recon, loss = h.forward_loss(dev(x, torch.float32))
+        fw = orc.forward(dims, flat, x.astype(np.float32).astype(np.float64))
+        assert rel(recon.cpu().numpy(), fw) < TOL32, ("forward", F, n)
+        assert abs(loss.item() - orc.loss(x.astype(np.float32).astype(np.float64), fw)) < TOL32 * loss.item()
+        lo, go = orc.fwd_bwd(dims, flat, x.astype(np.float32).astype(np.float64))
+        g = torch.full_like(p, 3.0)
+        h.fwd_bwd(dev(x, torch.float32), g)
+        gh = g.cpu().numpy().astype(np.float64)
+        assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo, ("fwd_bwd", F, dims[4], n, rel(gh[:-1], go))
+        if per_tensor:
+            off = 0
+            for l in range(8):
+                for cnt in (dims[l + 1] * dims[l], dims[l + 1]):
+                    assert rel(gh[off:off + cnt], go[off:off + cnt]) < 2 * TOL32, ("tensor", F, n, l, cnt)
+                    off += cnt
+
+
+@pytest.mark.parametrize("F,Z", [(80, 16), (100, 1), (127, 31), (96, 20)])
+def test_mid_width_tables_fused_inference_and_small_batch_step(F, Z):
+    """80 .. 127 columns: fused inference and the 512-row optimiser step (reference batch_size = 512, training.py:64-97) on the class
+    kernels; the 512-row step must not fall back to the layer-wise path (a 16x cliff in round 4: 420 us vs 26 us)."""
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 300 + F)
+    h, p = make_handle(dims, flat, "fp32")
+    assert h.path == "fused-infer"
+    _check(dims, flat, h, p, (1, 17, 333, 513), F * 10)
+    # the one-call step == fwd_bwd + adam_step bit for bit (both on the small-batch kernels)
+    x = dev(off_the_kink(dims, flat, 512, 5))
+    p1, p2 = p.clone(), p.clone()
+    m1, v1, m2, v2 = (torch.zeros_like(p) for _ in range(4))
+    h1, _ = make_handle(dims, flat, "fp32")
+    h1.train_step(x, p1, m1, v1, 1, 1e-3)
+    g = torch.zeros_like(p)
+    h.fwd_bwd(x, g)
+    h.adam_step(p2, g, m2, v2, 1, 1e-3)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+    lo, go = orc.fwd_bwd(dims, flat, x.cpu().numpy())
+    pn, mm, vv = flat.copy(), np.zeros_like(flat), np.zeros_like(flat)
+    orc.adam_step(pn, go, mm, vv, 1, 1e-3)
+    live = np.abs(go) > 1e-6 * np.abs(go).max()
+    assert rel((p1.cpu().numpy().astype(np.float64)[:-1] - flat)[live], (pn - flat)[live]) < 1e-3
+
+
+@pytest.mark.parametrize("F,Z", [(128, 13), (900, 9), (1024, 11), (4096, 41), (161, 2), (100, 40), (3999, 63)])
+def test_wide_class_vs_oracle(F, Z):
+    """ImplWide<4096, ZC, true>: any wide model with the reference's hidden widths (48 .. 4096 columns, a latent of up to 63)."""
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 400 + F)
+    h, p = make_handle(dims, flat, "fp32")
+    assert h.path == "fused"
+    sizes = (1, 65, 300) if F <= 1024 else (1, 67)
+    _check(dims, flat, h, p, sizes, F, per_tensor=F <= 1024)
+    # normalise-on-load / un-normalise + truncation on store (float32 staging pass, as for the exact wide shapes)
+    rng = np.random.default_rng(F)
+    raw = rng.normal(size=(77, F)) * 5 + 2
+    mn, rg = raw.min(0), raw.max(0) - raw.min(0)
+    feats = dev(np.stack([mn, rg]))
+    zn = orc.encode(dims, flat, (raw - mn) / rg)
+    assert rel(h.encode(dev(raw), features=feats, out_dtype=torch.float32).cpu().numpy(), zn) < TOL32
+    mask = np.zeros(F, dtype=np.uint8)
+    mask[::5] = 1
+    out = h.decode(dev(zn, torch.float32), features=feats, int_mask=dev(mask), out_dtype=torch.float64).cpu().numpy()
+    pre = orc.decode(dims, flat, zn) * rg + mn
+    m1 = mask == 1
+    assert rel(out[:, ~m1], pre[:, ~m1]) < TOL32
+    edge = np.abs(pre[:, m1] - np.round(pre[:, m1])) < 1e-4 * np.maximum(1.0, np.abs(pre[:, m1]))
+    assert np.array_equal(out[:, m1][~edge], np.trunc(pre[:, m1])[~edge])
+
+
+@pytest.mark.parametrize("shape", [(625, 7), (2500, 25), (512, 6)])
+def test_wide_class_forced_onto_exact_shapes(shape, monkeypatch):
+    """The class kernels on the shapes that also have an exact instantiation: same results to float32 rounding (the class chunk that
+    reaches beyond the row is a full tile with zero weights where the exact kernel runs a short r-major tile: different summation
+    order in that one chunk), both within 1e-5 of the oracle."""
+    dims = orc.ae_dims(*shape)
+    flat = orc.formula_params(dims, 77)
+    he, p = make_handle(dims, flat, "fp32")
+    monkeypatch.setenv("BALER_AMD_WIDE_CLASS", "force")
+    hc, _ = make_handle(dims, flat, "fp32")
+    assert he.path == "fused" and hc.path == "fused"
+    n = 200
+    x = off_the_kink(dims, flat, n, 9)
+    xd = dev(x, torch.float32)
+    ze, zc = he.encode(xd, out_dtype=torch.float32), hc.encode(xd, out_dtype=torch.float32)
+    z_ref = orc.encode(dims, flat, x.astype(np.float32).astype(np.float64))
+    assert rel(zc.cpu().numpy(), z_ref) < TOL32 and rel(zc.cpu().numpy(), ze.cpu().numpy()) < TOL32
+    de, dc = he.decode(ze), hc.decode(ze)
+    assert rel(dc.cpu().numpy(), de.cpu().numpy()) < TOL32
+    ge, gc = torch.zeros_like(p), torch.zeros_like(p)
+    he.fwd_bwd(xd, ge)
+    hc.fwd_bwd(xd, gc)
+    lo, go = orc.fwd_bwd(dims, flat, x.astype(np.float32).astype(np.float64))
+    assert rel(gc.cpu().numpy().astype(np.float64)[:-1], go) < TOL32 and rel(gc.cpu().numpy(), ge.cpu().numpy()) < TOL32
+
+
+def test_wide_class_off_switch_and_bounds(monkeypatch):
+    """BALER_AMD_WIDE_CLASS=0: such shapes run layer by layer (the independent cross-check); beyond 4096 columns or a latent above
+    63 there is no class."""
+    dims = orc.ae_dims(900, 9)
+    flat = orc.formula_params(dims, 3)
+    h, p = make_handle(dims, flat, "fp32")
+    monkeypatch.setenv("BALER_AMD_WIDE_CLASS", "0")
+    monkeypatch.setenv("BALER_AMD_QUIET", "1")
+    hg, _ = make_handle(dims, flat, "fp32")
+    assert h.path == "fused" and hg.path == "generic"
+    x = dev(off_the_kink(dims, flat, 150, 4), torch.float32)
+    assert rel(h.encode(x, out_dtype=torch.float32).cpu().numpy(), hg.encode(x, out_dtype=torch.float32).cpu().numpy()) < 2e-5
+    g1, g2 = torch.zeros_like(p), torch.zeros_like(p)
+    h.fwd_bwd(x, g1)
+    hg.fwd_bwd(x, g2)
+    assert rel(g1.cpu().numpy(), g2.cpu().numpy()) < 2e-5
+    monkeypatch.delenv("BALER_AMD_WIDE_CLASS")
+    for F, Z in ((4097, 10), (500, 64)):
+        hh = native.Handle(orc.ae_dims(F, Z), "fp32")
+        assert hh.path == "generic"
+        hh.close()
