@@ -59,14 +59,12 @@ template <int F, int Z> struct BNet {
 
 __device__ __forceinline__ v4 mfma_bf16(bf8 a, bf8 b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
+// LeakyReLU as max(x, 0.01 x) with FOUR v_mul_f32, not two v_pk_mul_f32: a packed fp32 multiply does not overlap the bf16 MFMA of its
+// own wave at all (tools/probe/valu_beside_mfma_probe.hip: + 17 cycles for the first one in an MFMA slot, a plain VALU instruction
+// + 0.5); measured on this kernel: float32 rows 11.7 -> 12.5 G rows/s encode, float64 rows unchanged (bound by their conversions)
 __device__ __forceinline__ void lrelu4(v4 &a) {
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f k2 = (v2f){0.01f, 0.01f};
-    asm("" : "+v"(k2));                       // register pair, vector product: v_pk_mul_f32 (see fused.hip lrelu)
-    v4 m = a * (v4){k2[0], k2[1], k2[0], k2[1]};
-    asm("" : "+v"(m));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = __builtin_elementwise_maximum(a[r], m[r]);
+    for (int r = 0; r < 4; ++r) a[r] = __builtin_elementwise_maximum(a[r], a[r] * 0.01f);
 }
 __device__ __forceinline__ bf8 pack8(const v4 &lo, const v4 &hi) {
     bf8 o;

@@ -977,9 +977,6 @@ struct Ring2 {
 };
 // this wave's quarter of slot NS of the stream into ring position `pos`
 template <class ST, int NS> __device__ __forceinline__ void ring_request(const Ring2 &rg, unsigned pos) {
-#ifdef BAMD_ABL_NODMA       // timing-only: no direct-to-LDS loads
-    return;
-#endif
 #pragma unroll
     for (int k = 0; k < kG / 4; ++k) {
         int fi = NS * kG + rg.wave * (kG / 4) + k;
@@ -1000,11 +997,7 @@ template <class ST, int S> __device__ __forceinline__ void ring_barrier(const Ri
     ring_request<ST, (S + kR - 1) % ST::nslot>(rg, (rg.rot + S + kR - 1) & (kR - 1));
 }
 template <int GI> __device__ __forceinline__ bf8 ring_read(const Ring2 &rg) {
-#ifdef BAMD_ABL_NOFRAG      // timing-only: no fragment reads (stale operands)
-    bf8 z; asm volatile("" : "=v"(z)); return z;
-#else
     return lds_b128(rg.rd[(GI / kG) & (kR - 1)] + (GI % kG) * 1024);
-#endif
 }
 // LeakyReLU / its derivative for the register-chain pair: SCALAR v_mul_f32.  A v_pk_mul_f32 next to v_mfma_f32_16x16x32_bf16 cannot hide
 // behind the MFMA at all (tools/probe/valu_beside_mfma_probe.hip, one wave per SIMD: MFMA slot 16.5 cycles, + one v_pk_mul_f32 = 33.3,

@@ -3784,8 +3784,25 @@ template <int F, int Z, bool SMALL = true> struct ImplInferClass {
     static bool matches(const bamd_handle *h) { return B::matches(h); }
     static int setup(bamd_handle *h, FusedState *st) { return build_maps<F, Z, SMALL>(h, st); }
     static int fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, hipStream_t s) {
-        if constexpr (SMALL)
+        if constexpr (SMALL) {
             if (n <= state_of(h)->latency_max_rows) return B::small_batch(h, x, x_dtype, n, features, grads, nullptr, s);
+            // Larger batches: the same two kernels chunk after chunk over one image buffer, every chunk after the first ADDING to the
+            // gradient and the loss (lat2_dw_kernel<DW_ACCUM>; one stream: a fixed order).  Measured against the layer-wise pass at
+            // 1M rows (tools/bench_mid_width_train.py): AE(80, 16) 78 -> 101 M rows/s, AE(64, 16) 85 -> 105, AE(127, 31) 76 -> 95.
+            // BALER_AMD_CLASS_CHUNK_ROWS sets the chunk (tests: several chunks at small sizes); 0 = the layer-wise pass.
+            const char *ce = getenv("BALER_AMD_CLASS_CHUNK_ROWS");      // (read per call: a training pass is milliseconds; tests toggle it)
+            const int64_t chunk = ce ? atoll(ce) : 65536;
+            if (chunk >= 16) {
+                const size_t row_bytes = (size_t)B::fr(h) * (x_dtype == BAMD_F64 ? 8 : 4);
+                const int64_t ck = chunk & ~(int64_t)15;
+                for (int64_t r0 = 0; r0 < n; r0 += ck) {
+                    const int rc = B::small_batch(h, (const char *)x + (size_t)r0 * row_bytes, x_dtype, n - r0 < ck ? n - r0 : ck, features, grads,
+                                                  nullptr, s, r0 > 0);
+                    if (rc) return rc;
+                }
+                return BAMD_OK;
+            }
+        }
         return generic_fwd_bwd(h, x, x_dtype, n, features, grads, s);
     }
     static int train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,

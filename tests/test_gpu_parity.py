@@ -1213,7 +1213,7 @@ def test_train_step_empty_batch_and_generic_fallback():
     before = p.clone()
     h.train_step(torch.zeros((0, 24), dtype=torch.float64, device="cuda"), p, m, v, 1, 1e-3)
     assert torch.equal(p, before) and float(m.abs().max()) == 0.0       # zero gradient: Adam moves nothing
-    dims2 = orc.ae_dims(400, 9)                    # no fused instantiation: the layer-wise kernels
+    dims2 = [400, 120, 60, 30, 9, 30, 60, 120, 400]     # not the reference's hidden widths: no fused instantiation, the layer-wise kernels
     f2 = orc.formula_params(dims2, 3)
     x = synth.cfd_field(4, 40, 40).reshape(16, 400)
     ha, pa = make_handle(dims2, f2, "fp32")

@@ -152,3 +152,29 @@ def test_wide_class_off_switch_and_bounds(monkeypatch):
         hh = native.Handle(orc.ae_dims(F, Z), "fp32")
         assert hh.path == "generic"
         hh.close()
+
+
+@pytest.mark.parametrize("F,Z", [(80, 16), (64, 9)])
+def test_mid_width_large_batches_run_chunked_on_the_small_batch_kernels(F, Z, monkeypatch):
+    """Beyond the small-batch limit a 64 .. 127-column table trains chunk after chunk on the same two kernels (every chunk after the
+    first adds to the gradient and the loss): several chunks (BALER_AMD_CLASS_CHUNK_ROWS) against the oracle, against ONE chunk, and
+    against the layer-wise pass it replaced (BALER_AMD_CLASS_CHUNK_ROWS=0)."""
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 11)
+    n = 12288 + 4099                                   # beyond the default limit of 12288 rows, a ragged tail
+    x = off_the_kink(dims, flat, n, 2)
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    got = {}
+    for tag, chunk in (("many", "4096"), ("one", "1048576"), ("layerwise", "0")):
+        monkeypatch.setenv("BALER_AMD_CLASS_CHUNK_ROWS", chunk)
+        h, p = make_handle(dims, flat, "fp32")
+        g = torch.full_like(p, 7.0)
+        h.fwd_bwd(dev(x), g)
+        g2 = torch.zeros_like(p)
+        h.fwd_bwd(dev(x), g2)
+        assert torch.equal(g, g2)                      # a fixed order whatever the chunking
+        got[tag] = g.cpu().numpy().astype(np.float64)
+        h.close()
+    for tag, gh in got.items():
+        assert rel(gh[:-1], go) < 2 * TOL32 and abs(gh[-1] - lo) < TOL32 * lo, (tag, rel(gh[:-1], go))
+    assert rel(got["many"], got["one"]) < TOL32 and rel(got["many"], got["layerwise"]) < 2 * TOL32
