@@ -611,7 +611,6 @@ __global__ void __launch_bounds__(256) bf16_train_kernel(const uint4 *__restrict
     const lds_p img = (lds_p)lds_raw;
     float *xf = (float *)(lds_raw + N::img_bytes());          // fp32 copy of the normalised input rows: [64][32]
     double *fl = (double *)(xf + kRows * 32);                 // [0..31] min, [32..63] range
-    const lds_p scratch = img + (N::img_bytes() + kRows * 32 * 4 + 64 * 8) + 8 * (int)threadIdx.x;   // 512 B per wave: where the epilogue of a slot the wave does not own lands
 #ifdef BAMD_BF16_TRACE
     unsigned long long *bt_lds = (unsigned long long *)(fl + 64 + 256);
 #endif

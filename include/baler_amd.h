@@ -93,23 +93,29 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
 void bamd_destroy(bamd_handle *h);
 
 /* Which kernels serve this handle's throughput calls (bamd_encode / bamd_decode / bamd_fwd_bwd at large batches).  The fused
- * register-chained / wide-layer kernels are template instantiations for the shapes the reference ships configs for: AE(24, z) for
- * z in {15, 12, 10, 8, 6, 5, 4, 3, 2} (models.py:116-183 at the compression ratios of baler.py:117-123), CFD_dense_AE(2500, 25),
- * CFD_dense_AE(625, 7) (exafel1_config.py:14-15,33: 25 x 25 blocks) and the 512-column model; an F64 handle of the 24-column AE
- * has fused fp64 kernels for inference and for training steps of any size (chunks of 262144 rows over one image buffer).
- * Any other narrow table of the reference's AE (hidden widths 200-100-50) is served by a CLASS instantiation with run-time widths:
- * up to 63 columns with a latent of up to 31 by all kernels (BAMD_PATH_FUSED); 64..79 columns by the fused inference kernels and,
- * for training steps of up to the small-batch limit (default 12288 rows; BALER_AMD_LATENCY_ROWS at bamd_create), the small-batch kernels (BAMD_PATH_FUSED_INFER: larger training batches of such a
- * handle run layer by layer).  An F64 handle has class instantiations of the fp64 kernels for up to 63 columns with a latent of up to 31.
- * Any other shape runs on the layer-wise kernels (activations through HBM, 2-7x slower):
- * bamd_create prints one line to stderr for such a handle unless BALER_AMD_QUIET=1.  There is no model object in the
- * reference to query (models.py builds nn.Linear layers of any width); this call exists so that callers and tests can tell. */
+ * register-chained / wide-layer kernels are template instantiations.  EXACT instantiations for the shapes the reference ships configs
+ * for: AE(24, z) for z in {15, 12, 10, 8, 6, 5, 4, 3, 2} (models.py:116-183 at the compression ratios of baler.py:117-123),
+ * CFD_dense_AE(2500, 25), CFD_dense_AE(625, 7) (exafel1_config.py:14-15,33: 25 x 25 blocks) and the 512-column model; an F64 handle of
+ * the 24-column AE has fused fp64 kernels for inference and for training steps of any size.  Every OTHER model with the reference's
+ * hidden widths (200-100-50; models.py:122-139, 192-209 build them for any n_features / z_dim) is served by a CLASS instantiation with
+ * run-time widths:
+ *   - up to 63 columns, latent <= 31: every kernel (BAMD_PATH_FUSED);
+ *   - 64 .. 127 columns, latent <= 31: the fused inference kernels and the small-batch training step (reference batch_size = 512);
+ *     training batches beyond the small-batch limit (default 12288 rows; BALER_AMD_LATENCY_ROWS at bamd_create) run chunk after chunk
+ *     on the same small-batch kernels (BAMD_PATH_FUSED_INFER);
+ *   - 48 .. 4096 columns, latent <= 63, that no class above takes: the wide-layer kernels with the column count and the latent as
+ *     kernel arguments -- encode / decode / forward + loss fused, a training pass = two fused row-local launches + the layer-wise
+ *     weight-gradient kernels, as for the exact wide shapes (BAMD_PATH_FUSED; BALER_AMD_WIDE_CLASS=0 switches the class off);
+ *   - F64 handles: class instantiations of the fp64 kernels for up to 63 columns with a latent of up to 31.
+ * Any other shape (other hidden widths, more than 4096 columns, a latent above 63) runs on the layer-wise kernels (activations
+ * through HBM, 1.5-2.5x slower): bamd_create prints one line to stderr for such a handle unless BALER_AMD_QUIET=1.  There is no model
+ * object in the reference to query (models.py builds nn.Linear layers of any width); this call exists so that callers and tests can tell. */
 typedef enum bamd_path {
     BAMD_PATH_GENERIC = 0,   /* generic.hip: LDS-tiled MFMA GEMM per layer */
     BAMD_PATH_FUSED = 1,     /* fused.hip: register chain (24-column AE) or streamed wide layers + chain */
     BAMD_PATH_BF16 = 2,      /* bf16.hip / bf16_train.hip (24-column AE, BAMD_MODE_BF16); its small batches use the fused fp32 step */
-    BAMD_PATH_FUSED_INFER = 3 /* 64..79 columns: fused.hip for encode / decode / forward + loss and for training steps of up to the small-batch limit (default 12288 rows),
-                              * generic.hip for larger training batches */
+    BAMD_PATH_FUSED_INFER = 3 /* 64..127 columns: fused.hip for encode / decode / forward + loss and the small-batch training kernels (larger batches
+                              * chunk after chunk on the same kernels; no throughput training pair for these widths) */
 } bamd_path;
 int bamd_path_of(const bamd_handle *h);   /* a bamd_path, or BAMD_ERR_INVALID for a null handle */
 int64_t bamd_param_count(const bamd_handle *h);

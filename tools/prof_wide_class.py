@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""The run-time-width wide class for rocprofv3: CFD_dense_AE(900, 9), 131,072 rows: encode / decode / fwd_bwd, 10 passes."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from baler_amd import native
+from oracle import c_oracle as orc
+dims = orc.ae_dims(900, 9)
+h = native.Handle(dims, "fp32")
+p = torch.from_numpy(np.concatenate([orc.formula_params(dims, 1), [0.0]]).astype(np.float32)).cuda()
+h.load_params(p)
+assert h.path == "fused"
+x = torch.rand((131072, 900), dtype=torch.float32, device="cuda")
+g = torch.zeros_like(p)
+z = h.encode(x)
+for _ in range(10):
+    z = h.encode(x); y = h.decode(z); h.fwd_bwd(x, g)
+torch.cuda.synchronize()
+print("done")
