@@ -62,6 +62,8 @@ struct bamd_handle {
     bool params_loaded = false;
     bool fused_ok = false;          // shape is served by the fused register-chained kernels
     void *fused_state = nullptr;    // index maps of the fused path (fused.hip)
+    void *fused_small = nullptr;    // 64..127-column tables: second fused state (small-batch class kernels) beside the wide class in fused_state
+    bamd::DevBuf packed_small;      // ... and its fragment-packed weights (fused.hip: SmallScope swaps both in for a small-batch call)
     void *fused64_state = nullptr;  // maps + packed fp64 weights of the fp64 small-batch step (fused64.hip)
     void *bf16_state = nullptr;     // packed bf16 weights + maps of the bf16 inference mode (bf16.hip)
     void *bf16_train_state = nullptr;   // packed bf16 weights + maps of the bf16 training kernels (bf16_train.hip)

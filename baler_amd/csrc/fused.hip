@@ -3454,6 +3454,7 @@ struct FusedState {
                                        // k order / the narrow encoder layers 1..3 / the narrow decoder layers 4..6 (chain_bf16_pair)
     int wb_count[6] = {0, 0, 0, 0, 0, 0};
     bool wb_stale = false;             // the bf16 fragments lag the parameters (re-rounded before the next encode / decode)
+    bool packed_stale = false;         // handles with a second state (64..127 columns): an optimiser step refreshed the small-batch state's fragments only
     bool dz16 = false;                 // this pass stores dL/drecon as bfloat16 (set per pass by the layer-wise driver: fused_wide_set_dz16)
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
     DevBuf dwpart;                     // partial weight-gradient tiles of the small-batch path when a tile's blocks are split over workgroups
@@ -4212,6 +4213,19 @@ template <int F, int Z> struct ImplWideBf16 {
 // that have an exact instantiation (tests: class vs exact on the same model)
 static bool wide_class_on() { const char *e = getenv("BALER_AMD_WIDE_CLASS"); return !(e && e[0] == '0'); }
 static bool wide_class_forced() { const char *e = getenv("BALER_AMD_WIDE_CLASS"); return e && e[0] == 'f'; }
+// BALER_AMD_MID_HYBRID=0: 64..127-column tables on the small-batch class alone (large batches chunked on its kernels), as before round 5
+static bool mid_width_hybrid() {
+    const char *e = getenv("BALER_AMD_MID_HYBRID");
+    return wide_class_on() && !(e && e[0] == '0');
+}
+static const FusedOps *find_small_ops(const bamd_handle *h) {
+    if (h->mode != BAMD_MODE_F32) return nullptr;
+    if (ImplInferClass<79, 31, true>::matches(h)) return ImplInferClass<79, 31, true>::ops();
+    if (ImplInferClass<95, 31, true>::matches(h)) return ImplInferClass<95, 31, true>::ops();
+    if (ImplInferClass<111, 31, true>::matches(h)) return ImplInferClass<111, 31, true>::ops();
+    if (ImplInferClass<127, 31, true>::matches(h)) return ImplInferClass<127, 31, true>::ops();
+    return nullptr;
+}
 static const FusedOps *find_ops(const bamd_handle *h) {
     if (h->mode == BAMD_MODE_BF16) {
         if (ImplWide<2500, 25>::matches(h)) return ImplWideBf16<2500, 25>::ops();
@@ -4239,10 +4253,14 @@ static const FusedOps *find_ops(const bamd_handle *h) {
         if (ImplWide<625, 7>::matches(h)) return ImplWide<625, 7>::ops();
     }
     // 64..127 columns: one-tile inference kernels and small-batch training (two reconstruction tiles per wave); large batches layer-wise
-    if (ImplInferClass<79, 31, true>::matches(h)) return ImplInferClass<79, 31, true>::ops();
-    if (ImplInferClass<95, 31, true>::matches(h)) return ImplInferClass<95, 31, true>::ops();
-    if (ImplInferClass<111, 31, true>::matches(h)) return ImplInferClass<111, 31, true>::ops();
-    if (ImplInferClass<127, 31, true>::matches(h)) return ImplInferClass<127, 31, true>::ops();
+    // 64..127 columns: the small-batch class (one-tile inference kernels + small-batch training, two reconstruction tiles per wave).  With
+    // the wide class on it is only the SECOND state of such a handle (find_small_ops): encode / decode / forward and large training
+    // batches run on the wide class -- measured at 1M rows (tools/bench_mid_width_wide.py) fwd_bwd AE(80,16) 100.8 -> 142.3 M rows/s,
+    // AE(64,16) 104.8 -> 156.8, AE(100,1) 100.8 -> 147.7, AE(127,31) 94.7 -> 137.6, encode 0.954 -> 0.855 ms -- and the class kernels keep
+    // the small batches (512-row step 29.7 us against the wide class's 160)
+    if (!mid_width_hybrid()) {
+        if (const FusedOps *o = find_small_ops(h)) return o;
+    }
     // any other wide model with the reference's hidden widths (CFD_dense_AE(n_features, z_dim), models.py:192-209): class instantiations
     // of the wide-layer kernels with run-time widths: up to 4096 columns, a latent of up to 15 / 31 / 63
     if (wide_class_on()) {
@@ -4272,6 +4290,26 @@ extern "C" int bamd_debug_copy_imgs(bamd_handle *h, void *dst, size_t bytes) {
 }
 #endif
 
+// A handle of a 64..127-column table has TWO states: fused_state = the wide class (inference, large training batches), fused_small =
+// the small-batch class with its own packed fragments in h->packed_small.  SmallScope swaps the pair in for the duration of one host call,
+// so that the class's code sees an ordinary handle; the optimiser keeps the SMALL state's fragments current (the 512-row regime is the
+// latency-critical one) and the wide state's are re-packed before its next use (one pack_k launch of ~100 KB).
+struct SmallScope {
+    bamd_handle *h;
+    explicit SmallScope(bamd_handle *h_) : h(h_) { swap(); }
+    ~SmallScope() { swap(); }
+    void swap() { std::swap(h->fused_state, h->fused_small); std::swap(h->packed, h->packed_small); }
+    SmallScope(const SmallScope &) = delete;
+    SmallScope &operator=(const SmallScope &) = delete;
+};
+static FusedState *small_of(bamd_handle *h) { return (FusedState *)h->fused_small; }
+static bool small_takes(bamd_handle *h, int64_t n) { return h->fused_small && n <= small_of(h)->latency_max_rows; }
+
+static void state_env(FusedState *st) {
+    if (const char *lr = getenv("BALER_AMD_LATENCY_ROWS")) st->latency_max_rows = atoll(lr);
+    if (const char *l4 = getenv("BALER_AMD_LAT4_ROWS")) st->lat4_max_rows = atoll(l4);
+    if (const char *ts = getenv("BALER_AMD_TAIL_SPLIT")) st->tail_split = ts[0] != '0';
+}
 int fused_setup(bamd_handle *h) {
     h->fused_ok = false;
     const FusedOps *ops = find_ops(h);
@@ -4280,19 +4318,26 @@ int fused_setup(bamd_handle *h) {
     if (env && env[0] == '1') return BAMD_OK;
     FusedState *st = new FusedState();
     st->ops = ops;
-    if (const char *lr = getenv("BALER_AMD_LATENCY_ROWS")) st->latency_max_rows = atoll(lr);
-    if (const char *l4 = getenv("BALER_AMD_LAT4_ROWS")) st->lat4_max_rows = atoll(l4);
-    if (const char *ts = getenv("BALER_AMD_TAIL_SPLIT")) st->tail_split = ts[0] != '0';
+    state_env(st);
     h->fused_state = st;
     int rc = ops->setup(h, st);
     if (rc) return rc;
+    if (ops->wide_fwd && h->dims[0] <= 127 && mid_width_hybrid()) {
+        if (const FusedOps *so = find_small_ops(h)) {
+            FusedState *ss = new FusedState();
+            ss->ops = so;
+            state_env(ss);
+            h->fused_small = ss;
+            SmallScope sc(h);
+            rc = so->setup(h, ss);
+            if (rc) return rc;
+        }
+    }
     h->fused_ok = true;
     return BAMD_OK;
 }
 
-void fused_teardown(bamd_handle *h) {
-    FusedState *st = state_of(h);
-    if (!st) return;
+static void release_state(FusedState *st) {
     st->pack_src.release();
     st->slab_map.release();
     st->dz.release();
@@ -4302,25 +4347,55 @@ void fused_teardown(bamd_handle *h) {
     st->sc_off.release();
     st->sc_idx.release();
     delete st;
+}
+void fused_teardown(bamd_handle *h) {
+    if (FusedState *ss = small_of(h)) {
+        release_state(ss);
+        h->packed_small.release();
+        h->fused_small = nullptr;
+    }
+    FusedState *st = state_of(h);
+    if (!st) return;
+    release_state(st);
     h->fused_state = nullptr;
 }
 
 void fused_scatter(bamd_handle *h, const int **sc_off, const int **sc_idx, void **packed) {
     *sc_off = nullptr; *sc_idx = nullptr; *packed = nullptr;
     if (!h->fused_ok) return;
+    if (FusedState *ss = small_of(h)) {      // two states: Adam refreshes the small-batch state's fragments, the wide state's go stale
+        *sc_off = (const int *)ss->sc_off.p;
+        *sc_idx = (const int *)ss->sc_idx.p;
+        *packed = h->packed_small.p;
+        return;
+    }
     FusedState *st = state_of(h);
     *sc_off = (const int *)st->sc_off.p;
     *sc_idx = (const int *)st->sc_idx.p;
     *packed = h->packed.p;
 }
 
-int fused_pack(bamd_handle *h, hipStream_t s) {
-    if (!h->fused_ok) return BAMD_OK;
+static int pack_state(bamd_handle *h, hipStream_t s) {
     FusedState *st = state_of(h);
     hipLaunchKernelGGL(pack_k, dim3((st->packed_floats + 255) / 256), dim3(256), 0, s, (const float *)h->params.p,
                        (const int *)st->pack_src.p, st->packed_floats, (float *)h->packed.p);
     BAMD_HIP(hipGetLastError());
+    st->packed_stale = false;
     if (st->ops->pack_extra) return st->ops->pack_extra(h, st, s);
+    return BAMD_OK;
+}
+int fused_pack(bamd_handle *h, hipStream_t s) {
+    if (!h->fused_ok) return BAMD_OK;
+    if (h->fused_small) {
+        SmallScope sc(h);
+        const int rc = pack_state(h, s);
+        if (rc) return rc;
+    }
+    return pack_state(h, s);
+}
+// before a call on the FIRST state of a two-state handle: its fragments if an optimiser step left them behind
+static int refresh_primary(bamd_handle *h, hipStream_t s) {
+    if (h->fused_small && state_of(h)->packed_stale) return pack_state(h, s);
     return BAMD_OK;
 }
 
@@ -4329,6 +4404,7 @@ bool fused_trains(const bamd_handle *h) {   // false: large-batch training of th
     return ((const FusedState *)h->fused_state)->ops->throughput_training;
 }
 int64_t fused_latency_rows(const bamd_handle *h) {   // the handle's small-batch limit (default 12288; BALER_AMD_LATENCY_ROWS)
+    if (h->fused_ok && h->fused_small) return ((const FusedState *)h->fused_small)->latency_max_rows;
     return h->fused_ok ? ((const FusedState *)h->fused_state)->latency_max_rows : 0;
 }
 bool fused_serves_bf16_inference(const bamd_handle *h) {   // wide models in the bf16 mode: encode / decode live in fused.hip
@@ -4337,6 +4413,7 @@ bool fused_serves_bf16_inference(const bamd_handle *h) {   // wide models in the
 
 void fused_params_changed(bamd_handle *h) {   // after an optimiser step: further packed copies are refreshed on demand
     if (h->fused_ok && state_of(h)->ops->pack_extra) state_of(h)->wb_stale = true;
+    if (h->fused_ok && h->fused_small) state_of(h)->packed_stale = true;
 }
 
 static bool wide_train_on() {   // BALER_AMD_WIDE_TRAIN=0: every layer of a wide model's training pass on the layer-wise kernels
@@ -4349,6 +4426,7 @@ bool fused_wide_train(const bamd_handle *h) {
 int fused_wide_train_forward(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
                              hipStream_t s) {
     if (!fused_wide_train(h)) return BAMD_ERR_UNSUPPORTED;
+    if (const int rc = refresh_primary(h, s)) return rc;
     return state_of(h)->ops->wide_fwd(h, x, rows, y, dz_last, loss_part, nblk, s);
 }
 // BF16 handles of a wide model whose last layer's weight gradient runs on dw_wide_bf16_k: dL/drecon (the largest array of the pass)
@@ -4363,27 +4441,35 @@ int fused_wide_train_backward(bamd_handle *h, int64_t rows, float *const *y, flo
 
 int fused_encode(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *z, int z_dtype,
                  hipStream_t s) {
+    if (const int rc = refresh_primary(h, s)) return rc;
     return state_of(h)->ops->encode(h, x, x_dtype, n, features, z, z_dtype, s);
 }
 int fused_decode(bamd_handle *h, const void *z, int z_dtype, int64_t n, const double *features, const uint8_t *int_mask,
                  void *out, int out_dtype, hipStream_t s) {
     if (!state_of(h)->ops->decode)
         return generic_forward(h, z, z_dtype, n, nullptr, h->L / 2, h->L, out, out_dtype, features, int_mask, s);
+    if (const int rc = refresh_primary(h, s)) return rc;
     return state_of(h)->ops->decode(h, z, z_dtype, n, features, int_mask, out, out_dtype, s);
 }
 int fused_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *recon,
                        int recon_dtype, double *loss_sum, hipStream_t s) {
     if (!state_of(h)->ops->forward_loss) return generic_forward_loss(h, x, x_dtype, n, features, recon, recon_dtype, loss_sum, s);
+    if (const int rc = refresh_primary(h, s)) return rc;
     return state_of(h)->ops->forward_loss(h, x, x_dtype, n, features, recon, recon_dtype, loss_sum, s);
 }
 int fused_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
                   hipStream_t s) {
+    if (small_takes(h, n)) {     // (the small state's fragments are always current: fused_scatter)
+        SmallScope sc(h);
+        return state_of(h)->ops->fwd_bwd(h, x, x_dtype, n, features, grads, s);
+    }
     if (!state_of(h)->ops->fwd_bwd) return generic_fwd_bwd(h, x, x_dtype, n, features, grads, s);
+    if (const int rc = refresh_primary(h, s)) return rc;
     return state_of(h)->ops->fwd_bwd(h, x, x_dtype, n, features, grads, s);
 }
-int fused_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
-                     void *params, void *m, void *v, const bamd_adam &hp, double *loss_accum, hipStream_t s) {
-    if (!h->fused_ok || !state_of(h)->ops->train_step) return BAMD_ERR_UNSUPPORTED;
+static int train_step_on(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
+                         void *params, void *m, void *v, const bamd_adam &hp, double *loss_accum, hipStream_t s) {
+    if (!state_of(h)->ops->train_step) return BAMD_ERR_UNSUPPORTED;
     FusedState *st = state_of(h);
     AdamArgs ad;
     ad.params = (float *)params; ad.pcopy = (float *)h->params.p; ad.m = (float *)m; ad.v = (float *)v;
@@ -4394,6 +4480,17 @@ int fused_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
     ad.step_size = hp.lr / (1.0 - pow(hp.beta1, (double)hp.step));
     ad.bc2_sqrt = sqrt(1.0 - pow(hp.beta2, (double)hp.step));
     return st->ops->train_step(h, x, x_dtype, n, features, grads, ad, s);
+}
+
+int fused_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads,
+                     void *params, void *m, void *v, const bamd_adam &hp, double *loss_accum, hipStream_t s) {
+    if (!h->fused_ok) return BAMD_ERR_UNSUPPORTED;
+    if (small_takes(h, n)) {
+        state_of(h)->packed_stale = true;         // the step's fused Adam refreshes the small state's fragments only
+        SmallScope sc(h);
+        return train_step_on(h, x, x_dtype, n, features, grads, params, m, v, hp, loss_accum, s);
+    }
+    return train_step_on(h, x, x_dtype, n, features, grads, params, m, v, hp, loss_accum, s);
 }
 
 #ifdef BAMD_LAT_TRACE

@@ -100,9 +100,10 @@ void bamd_destroy(bamd_handle *h);
  * hidden widths (200-100-50; models.py:122-139, 192-209 build them for any n_features / z_dim) is served by a CLASS instantiation with
  * run-time widths:
  *   - up to 63 columns, latent <= 31: every kernel (BAMD_PATH_FUSED);
- *   - 64 .. 127 columns, latent <= 31: the fused inference kernels and the small-batch training step (reference batch_size = 512);
- *     training batches beyond the small-batch limit (default 12288 rows; BALER_AMD_LATENCY_ROWS at bamd_create) run chunk after chunk
- *     on the same small-batch kernels (BAMD_PATH_FUSED_INFER);
+ *   - 64 .. 127 columns, latent <= 31: a handle with TWO sets of packed weights -- the small-batch class for training steps up to the
+ *     small-batch limit (default 12288 rows; BALER_AMD_LATENCY_ROWS at bamd_create; reference batch_size = 512) and the wide class
+ *     below for encode / decode / forward + loss and larger training batches (BAMD_PATH_FUSED).  BALER_AMD_MID_HYBRID=0: the
+ *     small-batch class alone, larger batches chunk after chunk on its kernels (BAMD_PATH_FUSED_INFER);
  *   - 48 .. 4096 columns, latent <= 63, that no class above takes: the wide-layer kernels with the column count and the latent as
  *     kernel arguments -- encode / decode / forward + loss fused, a training pass = two fused row-local launches + the layer-wise
  *     weight-gradient kernels, as for the exact wide shapes (BAMD_PATH_FUSED; BALER_AMD_WIDE_CLASS=0 switches the class off);
@@ -114,8 +115,8 @@ typedef enum bamd_path {
     BAMD_PATH_GENERIC = 0,   /* generic.hip: LDS-tiled MFMA GEMM per layer */
     BAMD_PATH_FUSED = 1,     /* fused.hip: register chain (24-column AE) or streamed wide layers + chain */
     BAMD_PATH_BF16 = 2,      /* bf16.hip / bf16_train.hip (24-column AE, BAMD_MODE_BF16); its small batches use the fused fp32 step */
-    BAMD_PATH_FUSED_INFER = 3 /* 64..127 columns: fused.hip for encode / decode / forward + loss and the small-batch training kernels (larger batches
-                              * chunk after chunk on the same kernels; no throughput training pair for these widths) */
+    BAMD_PATH_FUSED_INFER = 3 /* 64..127 columns with BALER_AMD_MID_HYBRID=0 or BALER_AMD_WIDE_CLASS=0: fused.hip for encode / decode / forward + loss and
+                              * the small-batch training kernels (larger batches chunk after chunk on the same kernels) */
 } bamd_path;
 int bamd_path_of(const bamd_handle *h);   /* a bamd_path, or BAMD_ERR_INVALID for a null handle */
 int64_t bamd_param_count(const bamd_handle *h);

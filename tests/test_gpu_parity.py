@@ -885,13 +885,14 @@ def test_any_narrow_table_runs_fused(F, Z):
 
 @pytest.mark.parametrize("F,Z,path", [(48, 12, "fused"), (33, 8, "fused"), (24, 16, "fused"), (63, 31, "fused"), (31, 31, "fused"),
                                       (32, 1, "fused"), (47, 15, "fused"), (47, 31, "fused"), (40, 20, "fused"), (63, 15, "fused"),
-                                      (64, 16, "fused-infer"), (79, 31, "fused-infer"), (80, 8, "fused-infer"), (63, 32, "fused"), (40, 40, "generic")])
+                                      (64, 16, "fused"), (79, 31, "fused"), (80, 8, "fused"), (63, 32, "fused"), (40, 40, "generic")])
 def test_wider_narrow_tables_say_where_they_run(F, Z, path):
     """Up to 63 columns with a latent of up to 31: full class instantiations (every kernel; the 63-column class reads its bias
     fragments from L2 because images + biases would need 164 KB of LDS).  64..79 columns: encode / decode / forward + loss on the
     one-tile fused kernels, training on the small-batch kernels up to 12288 rows (two recon tiles per wave in the chain) and
-    layer by layer beyond -- round 5: the same up to 127 columns; 48 .. 4096 columns with a latent of up to 63 that no narrow class takes:
-    the run-time-width wide class (tests/test_gpu_wide_class.py); anything else layer by layer.  Correct either way, and
+    layer by layer beyond -- round 5: the same up to 127 columns for the small batches, with the run-time-width wide class as the handle's
+    first state for inference and larger batches ("fused"); 48 .. 4096 columns with a latent of up to 63 that no narrow class takes:
+    the wide class alone (tests/test_gpu_wide_class.py); anything else layer by layer.  Correct either way, and
     bamd_path_of says which."""
     dims = orc.ae_dims(F, Z)
     flat = orc.formula_params(dims, 7)

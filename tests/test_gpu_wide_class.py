@@ -56,11 +56,12 @@ def _check(dims, flat, h, p, sizes, seed, per_tensor=True):
 @pytest.mark.parametrize("F,Z", [(80, 16), (100, 1), (127, 31), (96, 20)])
 def test_mid_width_tables_fused_inference_and_small_batch_step(F, Z):
     """80 .. 127 columns: fused inference and the 512-row optimiser step (reference batch_size = 512, training.py:64-97) on the class
-    kernels; the 512-row step must not fall back to the layer-wise path (a 16x cliff in round 4: 420 us vs 26 us)."""
+    kernels; the 512-row step must not fall back to the layer-wise path (a 16x cliff in round 4: 420 us vs 26 us).  Such a handle has
+    two states: the wide class (inference, batches beyond the small-batch limit) and the small-batch class."""
     dims = orc.ae_dims(F, Z)
     flat = orc.formula_params(dims, 300 + F)
     h, p = make_handle(dims, flat, "fp32")
-    assert h.path == "fused-infer"
+    assert h.path == "fused"
     _check(dims, flat, h, p, (1, 17, 333, 513), F * 10)
     # the one-call step == fwd_bwd + adam_step bit for bit (both on the small-batch kernels)
     x = dev(off_the_kink(dims, flat, 512, 5))
@@ -159,6 +160,7 @@ def test_mid_width_large_batches_run_chunked_on_the_small_batch_kernels(F, Z, mo
     """Beyond the small-batch limit a 64 .. 127-column table trains chunk after chunk on the same two kernels (every chunk after the
     first adds to the gradient and the loss): several chunks (BALER_AMD_CLASS_CHUNK_ROWS) against the oracle, against ONE chunk, and
     against the layer-wise pass it replaced (BALER_AMD_CLASS_CHUNK_ROWS=0)."""
+    monkeypatch.setenv("BALER_AMD_MID_HYBRID", "0")     # the small-batch class alone (by default the wide class takes the large batches)
     dims = orc.ae_dims(F, Z)
     flat = orc.formula_params(dims, 11)
     n = 12288 + 4099                                   # beyond the default limit of 12288 rows, a ragged tail
@@ -178,3 +180,50 @@ def test_mid_width_large_batches_run_chunked_on_the_small_batch_kernels(F, Z, mo
     for tag, gh in got.items():
         assert rel(gh[:-1], go) < 2 * TOL32 and abs(gh[-1] - lo) < TOL32 * lo, (tag, rel(gh[:-1], go))
     assert rel(got["many"], got["one"]) < TOL32 and rel(got["many"], got["layerwise"]) < 2 * TOL32
+
+
+@pytest.mark.parametrize("F,Z", [(80, 16), (64, 9), (127, 31), (100, 1)])
+def test_mid_width_two_state_handle_follows_the_optimiser(F, Z, monkeypatch):
+    """A 64 .. 127-column handle keeps two packed copies of its weights (small-batch class + wide class).  Whatever the order of small
+    steps, large passes and inference calls, every call must see the CURRENT parameters: compared with a handle of the small-batch
+    class alone (BALER_AMD_MID_HYBRID=0, one state) driven through the same sequence, and with the oracle."""
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 21 + F)
+    xs = dev(off_the_kink(dims, flat, 512, 3))
+    xl = dev(off_the_kink(dims, flat, 12288 + 1040, 4))
+
+    def drive():
+        h, p = make_handle(dims, flat, "fp32")
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        out = []
+        h.train_step(xs, p, m, v, 1, 1e-3)                      # small: the class kernels, Adam fused
+        out.append(h.encode(xl[:777]).cpu().numpy())            # inference right after a fused small step
+        g = torch.zeros_like(p)
+        h.fwd_bwd(xl, g)                                        # large pass on the parameters of step 1
+        out.append(g.cpu().numpy().astype(np.float64))
+        h.adam_step(p, g, m, v, 2, 1e-3)
+        g2 = torch.zeros_like(p)
+        h.fwd_bwd(xs, g2)                                       # small pass on the parameters of step 2
+        out.append(g2.cpu().numpy().astype(np.float64))
+        rec, loss = h.forward_loss(xl[:300])
+        out.append(rec.cpu().numpy())
+        h.train_step(xl, p, m, v, 3, 1e-3)                      # a large one-call step (fwd_bwd + Adam inside the library)
+        out.append(h.decode(h.encode(xs)).cpu().numpy())
+        out.append(p.cpu().numpy().astype(np.float64))
+        path = h.path
+        h.close()
+        return path, out
+
+    path2, two = drive()
+    monkeypatch.setenv("BALER_AMD_MID_HYBRID", "0")
+    path1, one = drive()
+    assert path2 == "fused" and path1 == "fused-infer"
+    for k, (a, b) in enumerate(zip(two, one)):
+        assert rel(a, b) < 2 * TOL32, (k, rel(a, b))
+    # ... and the oracle on the same sequence (first three products)
+    st = orc.FitState(dims, flat)
+    _, g0 = orc.fwd_bwd(dims, st.params, xs.cpu().numpy())
+    orc.adam_step(st.params, g0, st.m, st.v, 1, 1e-3)
+    assert rel(two[0], orc.encode(dims, st.params, xl[:777].cpu().numpy())) < 2 * TOL32
+    lo, g1 = orc.fwd_bwd(dims, st.params, xl.cpu().numpy())
+    assert rel(two[1][:-1], g1) < 2 * TOL32 and abs(two[1][-1] - lo) < TOL32 * lo
