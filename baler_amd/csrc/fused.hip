@@ -3003,7 +3003,8 @@ template <class N> struct L4 {
     __host__ __device__ static constexpr int zo(int l) { int s = xo(8); for (int j = 0; j < l; ++j) s += 4 * zs(j); return s; }
     static constexpr int ps = 132;                                   // partial sums: [part][row][<= 128 features + 4]
     static constexpr int po = zo(8);
-    static constexpr int lds_floats = po + 4 * 4 * ps;
+    static constexpr int bo = po + 4 * 4 * ps;                       // biases of the 8 layers, 256 slots each (zeros beyond the layer's width)
+    static constexpr int lds_floats = bo + 8 * 256;
     static_assert(groups(0) == 4 && groups(1) == 2 && groups(6) == 4 && groups(14) == 4, "K is split only for GEMMs of 1 or 2 groups");
 };
 __device__ __forceinline__ v4 mfma4(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
@@ -3108,45 +3109,60 @@ __global__ void __launch_bounds__(256) lat4_chain_kernel(const v4 *__restrict__ 
         const int f = 64 * grp[g] + lane;
         voff[g] = f < N::l4_gemm_n(g) ? f * 16 : 0x7F000000;
     }
+    // Request order = order of use (loads of a wave retire in order): the 4 input rows (HBM), the biases, then the fragment ring.
+    // (Before: ring, then 24 individually predicated bias loads with 64-bit address arithmetic, then the rows -- 2,460 + 1,000 cycles
+    // in front of the first GEMM, tools/lat_trace.py.)
+    // the 4 input rows: lane (b, j), b < F / 4, of wave 0 reads features 4 b .. 4 b + 3 of row j (rows beyond n: row 0, never used)
+    static_assert(F % 4 == 0 && F <= 32, "input rows as 4-feature pieces of one 32-slot row");
+    double xd[4] = {0.0, 0.0, 0.0, 0.0}, xmn[4] = {0.0, 0.0, 0.0, 0.0}, xrg[4] = {1.0, 1.0, 1.0, 1.0};
+    if (wave == 0) {
+        const int fb0 = 4 * b < F ? 4 * b : 0;
+        const int64_t base = (valid ? row : 0) * F + fb0;
+        if (in_f64) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xd[r] = ((const double *)xin)[base + r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xd[r] = (double)((const float *)xin)[base + r];
+        }
+        if (feats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { xmn[r] = feats[fb0 + r]; xrg[r] = feats[F + fb0 + r]; }
+        }
+    }
+    // biases -> LDS, 256 slots per layer: thread t brings bias t of every layer through a buffer resource (beyond the layer's width: an
+    // out-of-range offset = 0.0, no branch)
+    {
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void *)params, 0, N::w_off(N::L) * 4, 0x00020000);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const int vo = (int)threadIdx.x < N::dim(l + 1) ? (int)threadIdx.x * 4 : 0x7F000000;
+            lds[T::bo + 256 * l + threadIdx.x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, vo, N::b_off(l) * 4, 0));
+        }
+    }
     v4 ring[T::D];
     l4_prologue<N>(ring, ws, voff, k0, std::make_integer_sequence<int, T::D>{});
-    // biases: accumulator layout for the GEMMs without a K split (layers 0 and 6), per finalising thread for the others
-    v4 bias0, bias6;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int f = 64 * wave + 4 * b + r;
-        bias0[r] = f < N::dim(1) ? params[N::b_off(0) + f] : 0.f;
-        bias6[r] = f < N::dim(7) ? params[N::b_off(6) + f] : 0.f;
-    }
     const int tf = threadIdx.x >> 2, tj = threadIdx.x & 3;         // finalising thread: feature tf (+ 64), row tj
-    float fb[8][2];
-#pragma unroll
-    for (int l = 0; l < 8; ++l)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fb[l][i] = (T::parts(l) > 1 && i < T::groups(l) && tf + 64 * i < N::dim(l + 1)) ? params[N::b_off(l) + tf + 64 * i] : 0.f;
     double lacc = 0.0;
     LAT_T(47);
     if (wave == 0) {
-        // the 4 input rows: lane (b, j), b < F / 4, reads features 4 b .. 4 b + 3 of row j (rows beyond n: row 0, never used)
-        static_assert(F % 4 == 0 && F <= 32, "input rows as 4-feature pieces of one 32-slot row");
-        const int64_t base = (valid ? row : 0) * F + (4 * b < F ? 4 * b : 0);
-        double d[4];
-        if (in_f64) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) d[r] = ((const double *)xin)[base + r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) d[r] = (double)((const float *)xin)[base + r];
-        }
         v4 x0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (feats) d[r] = (d[r] - feats[(4 * b < F ? 4 * b : 0) + r]) / feats[F + (4 * b < F ? 4 * b : 0) + r];
-            x0[r] = 4 * b < F ? (float)d[r] : 0.f;
+            double d = xd[r];
+            if (feats) d = (d - xmn[r]) / xrg[r];
+            x0[r] = 4 * b < F ? (float)d : 0.f;
         }
         if (4 * b < 32) l4_publish<F, true>(x0, lds + T::xo(0), T::xs(0), irs, LT::x_off(0), rowbytes, 0, lane);
     }
     __syncthreads();
+    // biases: accumulator layout for the GEMMs without a K split (layers 0 and 6), per finalising thread for the others
+    const v4 bias0 = *(const v4 *)(lds + T::bo + 64 * wave + 4 * b), bias6 = *(const v4 *)(lds + T::bo + 256 * 6 + 64 * wave + 4 * b);
+    float fb[8][2];
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fb[l][i] = (T::parts(l) > 1 && i < T::groups(l)) ? lds[T::bo + 256 * l + tf + 64 * i] : 0.f;
     LAT_T(48);
     float *pbuf = lds + T::po;
     // One chain GEMM.  FWD: layer l = g, input X_l, output X_{l+1} = act(W x + b).  !FWD: layer l = 15 - g, input dZ_l, output
