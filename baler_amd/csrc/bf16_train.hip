@@ -972,10 +972,12 @@ struct Ring2 {
     unsigned lds0;                  // LDS byte address of the ring
     unsigned rot;                   // (slots requested before this iteration) mod kR
     int lane16, wave;
+    bool req;                       // this wave requests fragments (the pair: every wave; the quad launches: waves 0 .. 3)
     lds_p rd[kR];                   // read base of the slot at stream position i mod kR of THIS iteration (+ lane * 16)
 };
 // this wave's quarter of slot NS of the stream into ring position `pos`
 template <class ST, int NS> __device__ __forceinline__ void ring_request(const Ring2 &rg, unsigned pos) {
+    if (!rg.req) return;            // (wave-uniform)
 #pragma unroll
     for (int k = 0; k < kG / 4; ++k) {
         int fi = NS * kG + rg.wave * (kG / 4) + k;
@@ -990,7 +992,7 @@ template <class ST, int S> __device__ __forceinline__ void ring_barrier(const Ri
     // drains lgkmcnt(0), i.e. the kPF fragment reads in flight, at every ring barrier; nothing this barrier orders needs it (the slot
     // whose place is requested next was consumed by MFMAs that have issued; image traffic has its own barriers A .. E).  The asm
     // statements keep hipcc from moving LDS reads across it.
-    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(kG / 4) : "memory");
+    if (rg.req) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(kG / 4) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     ring_request<ST, (S + kR - 1) % ST::nslot>(rg, (rg.rot + S + kR - 1) & (kR - 1));
@@ -1152,6 +1154,7 @@ __global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restric
     rg.rot = 0;
     rg.lane16 = lane * 16;
     rg.wave = wave;
+    rg.req = true;
     v4 *slab = slabs + (int64_t)blockIdx.x * 64;
 
     v4 g7[C::has(7) ? N::dwn(7) : 1], g6[C::has(6) ? N::dwn(6) : 1], g5[C::has(5) ? N::dwn(5) : 1], g4[C::has(4) ? N::dwn(4) : 1];
@@ -1417,6 +1420,369 @@ __global__ void __launch_bounds__(256) bf16_train2_kernel(const uint4 *__restric
     }
 }
 
+// =====================================================================================================================
+// Round 5, second rewrite ("quad"): FOUR launches of TWO weight-gradient layers each, EIGHT waves per workgroup (two per SIMD).
+//
+// The pair above shows what ONE in-order wave per SIMD cannot overlap (a KiB of fragment from LDS, ~2.6 VALU instructions and the MFMA
+// itself per MFMA slot); a second wave per SIMD can, but 128 rows of the pair's images do not fit the LDS and its resident
+// weight-gradient tiles not the 256 registers a wave then has.  Cutting the backward pass into four launches {7, 6} {5, 4} {3, 2} {1, 0}
+// makes both fit: a launch keeps X_hi, dZ_hi and X_lo only (dZ_lo is written IN PLACE over X_hi once dW_hi is done: the mask is read
+// from the very slot the gradient goes to) -- 832 / 576 / 576 / 832 B per row = 104 KB for 128 rows next to the 48-KB ring -- and
+// 117 / 32 / 32 / 117 tiles over eight waves (<= 17 accumulator tiles per wave).  Every launch recomputes the forward chain up to its
+// layers (8 / 5 / 3 / 1 products) from the rows and takes dZ_hi from the previous launch (224 / 32 / 224 B per row): 489 instead of
+// 327 chain MFMAs per 16 rows and four passes over the rows -- the price of the second wave.
+// Per iteration (128 rows, a wave = 16 rows through the whole chain in registers, as in the pair):
+//   rows -> forward products (X_hi, X_lo -> images, own rows) -> dZ_hi -> image (loss, or the hand-off record)
+//   barrier A -> dW_hi -> barrier B -> product hi (dZ_lo over X_hi, own rows) -> product lo (dZ_{lo-1} -> hand-off record)
+//   -> next rows / record requested -> barrier D -> dW_lo -> barrier E.
+// The ring is the pair's (kG fragments per slot, one workgroup barrier per slot), requested by waves 0..3 (a quarter each).
+constexpr int kRows3 = 128;
+template <int PART> struct Cut3 {
+    static constexpr int fwd_end = PART == 0 ? 8 : PART == 1 ? 5 : PART == 2 ? 3 : 1;     // forward layers [0, fwd_end)
+    static constexpr int bwd_hi = 7 - 2 * PART, bwd_lo = 6 - 2 * PART;                    // weight gradients of these two layers
+    static constexpr int chain_lo = PART == 3 ? 1 : bwd_lo;                               // input-gradient products of layers bwd_hi .. chain_lo
+    __host__ __device__ static constexpr bool has(int l) { return l == bwd_hi || l == bwd_lo; }
+};
+template <class N, int PART> struct Stream3 {
+    using C = Cut3<PART>;
+    __host__ __device__ static constexpr int fo_f(int l) { int s = 0; for (int j = 0; j < l; ++j) s += N::kb(j) * N::nt(j); return s; }
+    __host__ __device__ static constexpr int fo_b(int l) { int s = fo_f(C::fwd_end); for (int j = C::bwd_hi; j > l; --j) s += N::kbb(j) * N::ntb(j); return s; }
+    static constexpr int nfrag = fo_b(C::chain_lo) + N::kbb(C::chain_lo) * N::ntb(C::chain_lo);
+    static constexpr int nslot = cdiv(nfrag, kG);
+    static_assert(nslot >= kR, "a launch's stream fills the ring");
+};
+// LDS regions of a launch, 128 rows each: [X_hi, later dZ_lo] | dZ_hi | X_lo (dZ_l has the shape, hence the stride, of X_{l+1})
+template <class N, int PART> struct Plan3 {
+    using C = Cut3<PART>;
+    __host__ __device__ static constexpr int S(int i) { return N::istride(i); }
+    __host__ __device__ static constexpr int xoff(int l) { return l == C::bwd_hi ? 0 : kRows3 * (S(C::bwd_hi) + S(C::bwd_hi + 1)); }
+    __host__ __device__ static constexpr int zoff(int l) { return l == C::bwd_hi ? kRows3 * S(C::bwd_hi) : 0; }
+    static constexpr int img_bytes = kRows3 * (S(C::bwd_hi) + S(C::bwd_hi + 1) + S(C::bwd_lo));
+    static constexpr int ring_off = (img_bytes + 1023) & ~1023;
+    static constexpr int lds_bytes = ring_off + kR * kG * 1024;
+    static_assert(S(C::bwd_lo + 1) == S(C::bwd_hi), "dZ_lo takes X_hi's place");
+    static_assert(lds_bytes <= 160 * 1024, "images + ring exceed one CU's LDS");
+};
+// weight-gradient tiles of layer l over EIGHT waves and 128 rows (four 32-row contractions per tile): as DwGeo / dw_phase above
+template <class N, int l> struct DwGeo8 {
+    static constexpr int NT = N::nt(l), KT = N::kt(l);
+    static constexpr bool BYN = cdiv(NT, 8) * KT <= cdiv(KT, 8) * NT;
+    static constexpr int NO = BYN ? cdiv(NT, 8) : cdiv(KT, 8);      // owned slots
+    static constexpr int OWN = BYN ? NT : KT;                       // tiles on the owned side
+    static constexpr int NS = BYN ? KT : NT;                        // streamed tiles
+    static constexpr int NACC = NO * NS;
+};
+constexpr int kDWD8 = 1;
+template <class N, int l> using Acc8 = v4[DwGeo8<N, l>::NACC];
+template <class N, int l> using Own8 = bf8[DwGeo8<N, l>::NO][4];
+template <class N, int l, int SZ, int SX, int S>
+__device__ __forceinline__ void dw8_step(Acc8<N, l> &acc, const Own8<N, l> &own, bf8 (&ring)[kDWD8 + 1][4],
+                                         lds_p sbase0, lds_p sbase1) {
+    using G = DwGeo8<N, l>;
+    constexpr int SS = G::BYN ? SX : SZ;          // stride of the streamed image
+    if constexpr (S + kDWD8 < G::NS) {
+        constexpr int t = S + kDWD8;
+        const lds_p sb = ((t & 1) ? sbase1 : sbase0) + 32 * (t & ~1);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ring[t % (kDWD8 + 1)][h] = tr_operand<SS>(sb, h);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bf8 (&st)[4] = ring[S % (kDWD8 + 1)];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int i = 0; i < G::NO; ++i) {
+            v4 &c = acc[i * G::NS + S];
+            c = G::BYN ? mfma(own[i][h], st[h], c) : mfma(st[h], own[i][h], c);      // A = dZ^T tile, B = [X | 1] tile
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class N, int l, int SZ, int SX, int... S>
+__device__ __forceinline__ void dw8_phase_impl(Acc8<N, l> &acc, lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave,
+                                               std::integer_sequence<int, S...>) {
+    using G = DwGeo8<N, l>;
+    constexpr int SO = G::BYN ? SZ : SX, SS = G::BYN ? SX : SZ;
+    const lds_p oimg = G::BYN ? zimg : ximg, simg = G::BYN ? ximg : zimg;
+    const Lay &lo = G::BYN ? lz : lx, &lst = G::BYN ? lx : lz;
+    bf8 own[G::NO][4];
+#pragma unroll
+    for (int i = 0; i < G::NO; ++i) {
+        int t = wave + 8 * i;                                        // owned tile; a slot this wave does not have computes on the last
+        t = t < G::OWN ? t : G::OWN - 1;                             // tile (wave-uniform, never flushed)
+        const lds_p ob = oimg + lo.tr(t & 1) + 32 * (t & ~1);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) own[i][h] = tr_operand<SO>(ob, h);
+    }
+    const lds_p sb0 = simg + lst.tr0, sb1 = simg + lst.tr1;
+    bf8 ring[kDWD8 + 1][4];
+#pragma unroll
+    for (int t = 0; t < kDWD8 && t < G::NS; ++t) {
+        const lds_p sb = ((t & 1) ? sb1 : sb0) + 32 * (t & ~1);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ring[t][h] = tr_operand<SS>(sb, h);
+    }
+    (dw8_step<N, l, SZ, SX, S>(acc, own, ring, sb0, sb1), ...);
+}
+template <class N, int l, int SZ, int SX>
+__device__ __forceinline__ void dw8_phase(Acc8<N, l> &acc, lds_p zimg, lds_p ximg, const Lay &lz, const Lay &lx, int wave) {
+    dw8_phase_impl<N, l, SZ, SX>(acc, zimg, ximg, lz, lx, wave, std::make_integer_sequence<int, DwGeo8<N, l>::NS>{});
+}
+template <class N, int l>
+__device__ __forceinline__ void dw8_flush(v4 *__restrict__ slab, const Acc8<N, l> &acc, int lane, int wave) {
+    using G = DwGeo8<N, l>;
+    constexpr int NT = N::nt(l), KT = N::kt(l);
+#pragma unroll
+    for (int i = 0; i < G::NO; ++i)
+#pragma unroll
+        for (int s_ = 0; s_ < G::NS; ++s_) {
+            const int o = wave + 8 * i;
+            const int t = G::BYN ? o : s_, k = G::BYN ? s_ : o;
+            if (o < G::OWN) slab[(int64_t)(N::slab_off(l) + k * NT + t) * gridDim.x * 64 + lane] = acc[i * G::NS + s_];
+        }
+    (void)KT;
+}
+
+template <int F, int Z, int PART>
+__global__ void __launch_bounds__(512) bf16_train3_kernel(const uint4 *__restrict__ wfrags, const void *__restrict__ xin, int in_f64, int64_t n,
+                                                          const double *__restrict__ feats, v4 *__restrict__ slabs,
+                                                          const u2 *__restrict__ dz_in, u2 *__restrict__ dz_out, int loss_tile) {
+    using N = TNet<F, Z>;
+    using C = Cut3<PART>;
+    using ST = Stream3<N, PART>;
+    using PL = Plan3<N, PART>;
+    constexpr int HI = C::bwd_hi, LO = C::bwd_lo;
+    constexpr int NTH = PART == 0 ? 1 : N::nt(HI);                 // tiles of the hand-off record this launch READS (dZ_hi; launch 0: none)
+    constexpr int NTO = PART == 3 ? 1 : N::ntb(LO);                // tiles of the record it WRITES (dZ_{lo-1}; launch 3: none)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+    const lds_p img = (lds_p)lds_raw;
+    for (int i = threadIdx.x; i < PL::img_bytes / 16; i += 512) ((uint4 *)lds_raw)[i] = make_uint4(0, 0, 0, 0);   // finite padding slots
+    int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ngroups = (n + kRows3 - 1) / kRows3;
+    // min / range of this lane's eight features (normalise-on-load): a small LDS table behind the ring would do as well; registers for now
+    double fmn[8], frg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int f = 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
+        fmn[e] = (feats && f < F) ? feats[f] : 0.0;
+        frg[e] = (feats && f < F) ? feats[F + f] : 1.0;
+    }
+    Ring2 rg;
+    rg.rs = __builtin_amdgcn_make_buffer_rsrc((void *)wfrags, 0, ST::nfrag * 1024, 0x00020000);
+    rg.lds0 = (unsigned)(size_t)(img + PL::ring_off);
+    rg.rot = 0;
+    rg.lane16 = lane * 16;
+    rg.wave = wave;
+    rg.req = wave < 4;
+    v4 *slab = slabs + (int64_t)blockIdx.x * 64;
+    v4 ghi[DwGeo8<N, HI>::NACC], glo[DwGeo8<N, LO>::NACC];
+    zero_acc(ghi); zero_acc(glo);
+    double lacc = 0.0;
+    static_assert(kR == 4, "prologue requests slots 0 .. 2");
+    ring_request<ST, 0>(rg, 0);
+    ring_request<ST, 1 % ST::nslot>(rg, 1);
+    ring_request<ST, 2 % ST::nslot>(rg, 2);
+    RawX2 xraw;
+    x_issue2<F>(xraw, xin, in_f64, (int64_t)blockIdx.x * kRows3 + 16 * wave + (lane & 15), n, lane >> 4);
+    u2 hand[NTH];
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) hand[t] = (u2){0u, 0u};
+    if constexpr (PART > 0) {
+        const int64_t r0 = (int64_t)blockIdx.x * kRows3 + 16 * wave + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) hand[t] = dz_in[(r0 * NTH + t) * 4 + (lane >> 4)];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        asm volatile("" : "+v"(rg.lane16), "+s"(wave), "+v"(lane));      // (keeps the LDS address arithmetic inside the loop)
+        const int j = lane & 15, g = lane >> 4;
+        Lays ls;
+        ls.s1 = make_lay<64>(lane); ls.s3 = make_lay<192>(lane); ls.s5 = make_lay<320>(lane); ls.s7 = make_lay<448>(lane);
+#pragma unroll
+        for (int i = 0; i < kR; ++i) rg.rd[i] = img + PL::ring_off + ((rg.rot + i) & (kR - 1)) * (kG * 1024) + 16 * lane;
+        const int64_t row = grp * kRows3 + 16 * wave + j;
+        const bool valid = row < n;
+        bf8 fr[kPF];
+#pragma unroll
+        for (int i = 0; i < kPF; ++i) fr[i] = lds_b128(rg.rd[0] + i * 1024);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int f = 16 * (e >> 2) + 4 * g + (e & 3);
+            double d = xraw.d[e];
+            if (feats) d = (d - fmn[e]) / frg[e];
+            v[e] = f < F ? (float)d : (f == F ? 1.0f : 0.f);                     // slot F = the ones column
+        }
+        if constexpr (C::has(0)) {
+            const Lay &l0 = lay_of<N::istride(0)>(ls);
+            const lds_p ob = img + PL::xoff(0) + 16 * wave * N::istride(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) lds_w64(ob + l0.wr(t & 1) + 32 * (t & ~1), pack4((v4){v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]}));
+        }
+#define BAMD3_FIN_F(l, accv, pkv)                                                                                            \
+        [&](auto tc) {                                                                                                       \
+            constexpr int t = decltype(tc)::value;                                                                           \
+            v4 a = accv[t];                                                                                                  \
+            if (N::act(l)) lrelu4s(a);                                                                                       \
+            pkv[t] = pack4(a);                                                                                               \
+            if constexpr (C::has((l) + 1))                                                                                   \
+                lds_w64(img + PL::xoff((l) + 1) + 16 * wave * N::istride((l) + 1) + lay_of<N::istride((l) + 1)>(ls).wr(t & 1) + 32 * (t & ~1), pkv[t]); \
+        }
+        // epilogue of tile t of the input-gradient product of layer l (= dZ_{l-1}): mask with the sign of X_l (own rows, read a region
+        // ahead into yv[t] -- for l = hi from the very slot the result is written to) -> bf16 (-> image when this launch has dW_{l-1})
+#define BAMD3_FIN_B(l, accv, yv, pkv)                                                                                        \
+        [&](auto tc) {                                                                                                       \
+            constexpr int t = decltype(tc)::value;                                                                           \
+            if constexpr (N::act((l) - 1)) pkv[t] = lrelu_bwd_pack4s(accv[t], yv[t]);                                        \
+            else pkv[t] = pack4(accv[t]);                                                                                    \
+            if constexpr (C::has((l) - 1))                                                                                   \
+                lds_w64(img + PL::zoff((l) - 1) + 16 * wave * N::istride(l) + lay_of<N::istride(l)>(ls).wr(t & 1) + 32 * (t & ~1), pkv[t]); \
+        }
+#define BAMD3_PRE_B(l, yv)                                                                                                   \
+        [&](auto tc) {                                                                                                       \
+            constexpr int t = decltype(tc)::value;                                                                           \
+            if constexpr (N::act((l) - 1))                                                                                   \
+                yv[t] = lds_b64(img + PL::xoff(l) + 16 * wave * N::istride(l) + lay_of<N::istride(l)>(ls).wr(t & 1) + 32 * (t & ~1)); \
+        }
+#define BAMD3_LASTV(nt_, vt) ((vt) * Grp<nt_>::size(Grp<nt_>::NG - 1))
+        constexpr int VF = 10, VB = 12, VN = 2;
+        auto nopre = [&](auto) {};
+        auto nocarry = [&]() {};
+        u2 pk0[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) pk0[t] = pack4((v4){v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]});
+        // ---- forward products 0 .. fwd_end - 1 (every launch from the rows); dzh = this launch's dZ_hi as packed tiles ----------------
+        u2 dzh[N::nt(HI)];
+        {
+            v4 a1[N::nt(0)];
+            u2 p1[N::nt(0)];
+            auto fin0 = BAMD3_FIN_F(0, a1, p1);
+            mprod<ST, ST::fo_f(0), N::kb(0), N::nt(0), 2, VF, 0>(a1, pk0, fin0, nopre, nocarry, rg, fr);
+            if constexpr (C::fwd_end == 1) {
+                finish_last<N::nt(0)>(fin0);
+            } else {
+                v4 a2[N::nt(1)], a3[N::nt(2)];
+                u2 p2[N::nt(1)], p3[N::nt(2)];
+                auto fin1 = BAMD3_FIN_F(1, a2, p2);
+                auto fin2 = BAMD3_FIN_F(2, a3, p3);
+                auto carry1 = [&]() { finish_last<N::nt(0)>(fin0); };
+                auto carry2 = [&]() { finish_last<N::nt(1)>(fin1); };
+                mprod<ST, ST::fo_f(1), N::kb(1), N::nt(1), N::nt(0), VF, BAMD3_LASTV(N::nt(0), VF)>(a2, p1, fin1, nopre, carry1, rg, fr);
+                mprod<ST, ST::fo_f(2), N::kb(2), N::nt(2), N::nt(1), VF, BAMD3_LASTV(N::nt(1), VF)>(a3, p2, fin2, nopre, carry2, rg, fr);
+                if constexpr (C::fwd_end == 3) {
+                    finish_last<N::nt(2)>(fin2);
+                } else {
+                    v4 a4[N::nt(3)], a5[N::nt(4)];
+                    u2 p4[N::nt(3)], p5[N::nt(4)];
+                    auto fin3 = BAMD3_FIN_F(3, a4, p4);
+                    auto fin4 = BAMD3_FIN_F(4, a5, p5);
+                    auto carry3 = [&]() { finish_last<N::nt(2)>(fin2); };
+                    auto carry4 = [&]() { finish_last<N::nt(3)>(fin3); };
+                    mprod<ST, ST::fo_f(3), N::kb(3), N::nt(3), N::nt(2), VN, BAMD3_LASTV(N::nt(2), VF)>(a4, p3, fin3, nopre, carry3, rg, fr);
+                    mprod<ST, ST::fo_f(4), N::kb(4), N::nt(4), N::nt(3), VF, BAMD3_LASTV(N::nt(3), VN)>(a5, p4, fin4, nopre, carry4, rg, fr);
+                    if constexpr (C::fwd_end == 5) {
+                        finish_last<N::nt(4)>(fin4);
+                    } else {
+                        static_assert(C::fwd_end == 8 && N::nt(7) == 2, "launch 0: the whole forward pass; the reconstruction is two tiles");
+                        v4 a6[N::nt(5)], a7[N::nt(6)], rec[2];
+                        u2 p6[N::nt(5)], p7[N::nt(6)];
+                        auto fin5 = BAMD3_FIN_F(5, a6, p6);
+                        auto fin6 = BAMD3_FIN_F(6, a7, p7);
+                        // loss: both output tiles of this wave's 16 rows against the fp32 input values it kept; dL/drecon = 2 (r - x) / C
+                        auto fin7 = [&](auto tc) {
+                            constexpr int t = decltype(tc)::value;
+                            v4 d;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float e = rec[t][r] - v[4 * t + r];
+                                const bool live = valid && 16 * t + 4 * g + r < F;
+                                if (live) lacc += (double)e * (double)e;
+                                d[r] = live ? e * (2.0f / (float)F) : 0.f;
+                            }
+                            dzh[t] = pack4(d);
+                        };
+                        auto carry5 = [&]() { finish_last<N::nt(4)>(fin4); };
+                        auto carry6 = [&]() { finish_last<N::nt(5)>(fin5); };
+                        auto carry7 = [&]() { finish_last<N::nt(6)>(fin6); };
+                        mprod<ST, ST::fo_f(5), N::kb(5), N::nt(5), N::nt(4), VF, BAMD3_LASTV(N::nt(4), VF)>(a6, p5, fin5, nopre, carry5, rg, fr);
+                        mprod<ST, ST::fo_f(6), N::kb(6), N::nt(6), N::nt(5), VF, BAMD3_LASTV(N::nt(5), VF)>(a7, p6, fin6, nopre, carry6, rg, fr);
+                        mprod<ST, ST::fo_f(7), N::kb(7), 2, N::nt(6), 30, BAMD3_LASTV(N::nt(6), VF)>(rec, p7, fin7, nopre, carry7, rg, fr);
+                        finish_last<2>(fin7);
+                    }
+                }
+            }
+        }
+        if constexpr (PART > 0) {
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) dzh[t] = hand[t];
+        }
+        // dZ_hi of these rows -> its image (own rows)
+#pragma unroll
+        for (int t = 0; t < N::nt(HI); ++t)
+            lds_w64(img + PL::zoff(HI) + 16 * wave * N::istride(HI + 1) + lay_of<N::istride(HI + 1)>(ls).wr(t & 1) + 32 * (t & ~1), dzh[t]);
+        __syncthreads();                                                    // A: X_hi, X_lo and dZ_hi of all 128 rows
+        dw8_phase<N, HI, N::istride(HI + 1), N::istride(HI)>(ghi, img + PL::zoff(HI), img + PL::xoff(HI), lay_of<N::istride(HI + 1)>(ls),
+                                                              lay_of<N::istride(HI)>(ls), wave);
+        __syncthreads();                                                    // B: X_hi is dead (dZ_lo goes there)
+        // ---- input-gradient products hi (-> dZ_lo, in place over X_hi) and lo (-> the hand-off record; the last launch has none) ------
+        {
+            v4 eh[N::ntb(HI)];
+            u2 qh[N::ntb(HI)], yh[N::ntb(HI)];
+            auto finbh = BAMD3_FIN_B(HI, eh, yh, qh);
+            auto preh = BAMD3_PRE_B(HI, yh);
+            mprod<ST, ST::fo_b(HI), N::kbb(HI), N::ntb(HI), N::nt(HI), VB, 0>(eh, dzh, finbh, preh, nocarry, rg, fr);
+            if constexpr (PART == 3) {
+                finish_last<N::ntb(HI)>(finbh);
+            } else {
+                v4 el[N::ntb(LO)];
+                u2 ql[N::ntb(LO)], yl[N::ntb(LO)];
+                auto finbl = BAMD3_FIN_B(LO, el, yl, ql);
+                auto prel = BAMD3_PRE_B(LO, yl);
+                auto carryl = [&]() { finish_last<N::ntb(HI)>(finbh); };
+                mprod<ST, ST::fo_b(LO), N::kbb(LO), N::ntb(LO), N::ntb(HI), N::act(LO - 1) ? VB : VN, BAMD3_LASTV(N::ntb(HI), VB)>(el, qh, finbl, prel, carryl, rg, fr);
+                finish_last<N::ntb(LO)>(finbl);
+                // hand-off to the next launch: dZ_{lo-1}, [row][tile][g], 8 bytes per lane and tile; rows beyond n carry zeros
+#pragma unroll
+                for (int t = 0; t < NTO; ++t) dz_out[(row * NTO + t) * 4 + g] = ql[t];
+            }
+        }
+        // the NEXT iteration's rows (and record), requested behind the last ring wait of this one
+        {
+            const int64_t nr = row + (int64_t)gridDim.x * kRows3;
+            x_issue2<F>(xraw, xin, in_f64, nr, n, g);
+            if constexpr (PART > 0) {
+                const int64_t hr = nr < ngroups * kRows3 ? nr : row;
+#pragma unroll
+                for (int t = 0; t < NTH; ++t) hand[t] = dz_in[(hr * NTH + t) * 4 + g];
+            }
+        }
+        __syncthreads();                                                    // D: dZ_lo of all 128 rows
+        dw8_phase<N, LO, N::istride(LO + 1), N::istride(LO)>(glo, img + PL::zoff(LO), img + PL::xoff(LO), lay_of<N::istride(LO + 1)>(ls),
+                                                              lay_of<N::istride(LO)>(ls), wave);
+        __syncthreads();                                                    // E: the next forward pass overwrites the images
+#undef BAMD3_LASTV
+#undef BAMD3_FIN_F
+#undef BAMD3_FIN_B
+#undef BAMD3_PRE_B
+        rg.rot = (rg.rot + ST::nslot) & (kR - 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // nothing may land in LDS after the workgroup has gone
+    dw8_flush<N, HI>(slab, ghi, lane, wave);
+    dw8_flush<N, LO>(slab, glo, lane, wave);
+    if constexpr (PART == 0) {   // per-workgroup loss partial (fixed-order tree), stored after the tiles
+        __syncthreads();
+        double *sh = (double *)lds_raw;
+        sh[threadIdx.x] = lacc;
+        __syncthreads();
+        for (int st = 256; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) ((double *)(slabs + (int64_t)loss_tile * gridDim.x * 64))[blockIdx.x] = sh[0];
+    }
+}
+
 // Fixed-order reduction of the per-workgroup partial gradients ([tile][workgroup][64 lanes] float4) into the canonical
 // (state-dict) layout; block `ntiles`: grads[np] = sum of the loss partials / C.  One wave per tile (see fused.hip).
 __global__ void __launch_bounds__(256) reduce_tiles_k(const v4 *__restrict__ slabs, int nslab, int ntiles, const int *__restrict__ inv_map,
@@ -1467,6 +1833,8 @@ struct TrainState {
     const TrainOps *ops = nullptr;
     DevBuf src, w, inv, dz;
     DevBuf src2[2], w2[2];          // the register-chain pair: one fragment stream per launch
+    DevBuf src3[4], w3[4], dz3[3];  // the quad launches: fragment streams and the three hand-off records (dZ_5, dZ_3, dZ_1)
+    int wcount3[4] = {0, 0, 0, 0};
     int wcount = 0, ntiles = 0, nparams = 0, n_features = 0;
     int wcount2[2] = {0, 0};
     int nwg_max = 256;
@@ -1696,14 +2064,113 @@ template <int F, int Z> struct TImpl2 {
     }
 };
 
-// BALER_AMD_BF16_TRAIN_V2=1: the round-5 register-chain pair instead of the N-split pair (measured slower: DESIGN.md section 4.6)
-static bool train_v1() {
+
+// ---- host side of the quad launches -----------------------------------------------------------------------------------------
+template <int F, int Z> struct TImpl3 {
+    using N = TNet<F, Z>;
+    static bool matches(const bamd_handle *h) { return TImpl<F, Z>::matches(h); }
+    // fragment source map of one launch's stream (see TImpl2::stream_map: every product is fed from packed C tiles)
+    template <int PART> static void stream_map(std::vector<int> &src) {
+        using C = Cut3<PART>;
+        using ST = Stream3<N, PART>;
+        src.assign((size_t)ST::nfrag * 512, -1);
+        auto kperm = [](int q, int g, int e) { return 32 * q + 16 * (e >> 2) + 4 * g + (e & 3); };
+        auto gfrag = [](int KB, int NT, int q, int t) {
+            const int NG = (NT + kGS - 1) / kGS, gidx = t / kGS, size = gidx < NG - 1 ? kGS : NT - kGS * (NG - 1);
+            return KB * kGS * gidx + q * size + (t - kGS * gidx);
+        };
+        for (int l = 0; l < C::fwd_end; ++l) {
+            const int K = N::dim(l), NN = N::dim(l + 1);
+            for (int q = 0; q < N::kb(l); ++q)
+                for (int t = 0; t < N::nt(l); ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int n = 16 * t + (lane & 15), k = kperm(q, lane >> 4, e);
+                            int v = -1;
+                            if (n < NN && k < K) v = N::w_off(l) + n * K + k;
+                            else if (n < NN && k == K) v = N::b_off(l) + n;
+                            else if (n == NN && k == K) v = -2;
+                            src[((size_t)(ST::fo_f(l) + gfrag(N::kb(l), N::nt(l), q, t)) * 64 + lane) * 8 + e] = v;
+                        }
+        }
+        for (int l = C::bwd_hi; l >= C::chain_lo; --l) {
+            const int K = N::dim(l), NN = N::dim(l + 1);
+            for (int q = 0; q < N::kbb(l); ++q)
+                for (int t = 0; t < N::ntb(l); ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int n = kperm(q, lane >> 4, e), k = 16 * t + (lane & 15);
+                            if (n < NN && k < K) src[((size_t)(ST::fo_b(l) + gfrag(N::kbb(l), N::ntb(l), q, t)) * 64 + lane) * 8 + e] = N::w_off(l) + n * K + k;
+                        }
+        }
+    }
+    template <int PART> static int setup_part(TrainState *st) {
+        std::vector<int> src;
+        stream_map<PART>(src);
+        st->wcount3[PART] = (int)src.size();
+        int rc = st->src3[PART].ensure(src.size() * sizeof(int));
+        if (!rc) rc = st->w3[PART].ensure(src.size() * sizeof(__bf16) + 4096);
+        if (rc) return rc;
+        BAMD_HIP(hipMemcpy(st->src3[PART].p, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
+        BAMD_HIP(hipFuncSetAttribute((const void *)bf16_train3_kernel<F, Z, PART>, hipFuncAttributeMaxDynamicSharedMemorySize, Plan3<N, PART>::lds_bytes));
+        return BAMD_OK;
+    }
+    static int setup(bamd_handle *h, TrainState *st) {
+        int rc = TImpl<F, Z>::setup_maps(h, st);
+        if (!rc) rc = setup_part<0>(st);
+        if (!rc) rc = setup_part<1>(st);
+        if (!rc) rc = setup_part<2>(st);
+        if (!rc) rc = setup_part<3>(st);
+        return rc;
+    }
+    static int pack(bamd_handle *h, TrainState *st, hipStream_t s) {
+        for (int p = 0; p < 4; ++p)
+            hipLaunchKernelGGL(pack_train_k, dim3((st->wcount3[p] + 255) / 256), dim3(256), 0, s, (const float *)h->params.p,
+                               (const int *)st->src3[p].p, st->wcount3[p], (__bf16 *)st->w3[p].p);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int fwd_bwd(bamd_handle *h, TrainState *st, const void *x, int x_dtype, int64_t n, const double *features, float *grads,
+                       hipStream_t s) {
+        const int64_t ngroups = (n + kRows3 - 1) / kRows3;
+        const int grid = (int)(ngroups < st->nwg_max ? ngroups : st->nwg_max);
+        int rc = h->slabs.ensure(((size_t)st->ntiles * 1024 + 16) * (size_t)grid);      // tiles + one double per workgroup for the loss
+        // hand-off records: dZ_5 (7 tiles), dZ_3 (1), dZ_1 (7): 32 bytes per row and tile
+        if (!rc) rc = st->dz3[0].ensure((size_t)ngroups * kRows3 * 32 * N::ntb(6));
+        if (!rc) rc = st->dz3[1].ensure((size_t)ngroups * kRows3 * 32 * N::ntb(4));
+        if (!rc) rc = st->dz3[2].ensure((size_t)ngroups * kRows3 * 32 * N::ntb(2));
+        if (rc) return rc;
+        const int f64 = x_dtype == BAMD_F64;
+        hipLaunchKernelGGL((bf16_train3_kernel<F, Z, 0>), dim3(grid), dim3(512), (Plan3<N, 0>::lds_bytes), s, (const uint4 *)st->w3[0].p, x, f64, n,
+                           features, (v4 *)h->slabs.p, (const u2 *)nullptr, (u2 *)st->dz3[0].p, st->ntiles);
+        hipLaunchKernelGGL((bf16_train3_kernel<F, Z, 1>), dim3(grid), dim3(512), (Plan3<N, 1>::lds_bytes), s, (const uint4 *)st->w3[1].p, x, f64, n,
+                           features, (v4 *)h->slabs.p, (const u2 *)st->dz3[0].p, (u2 *)st->dz3[1].p, st->ntiles);
+        hipLaunchKernelGGL((bf16_train3_kernel<F, Z, 2>), dim3(grid), dim3(512), (Plan3<N, 2>::lds_bytes), s, (const uint4 *)st->w3[2].p, x, f64, n,
+                           features, (v4 *)h->slabs.p, (const u2 *)st->dz3[1].p, (u2 *)st->dz3[2].p, st->ntiles);
+        hipLaunchKernelGGL((bf16_train3_kernel<F, Z, 3>), dim3(grid), dim3(512), (Plan3<N, 3>::lds_bytes), s, (const uint4 *)st->w3[3].p, x, f64, n,
+                           features, (v4 *)h->slabs.p, (const u2 *)st->dz3[2].p, (u2 *)nullptr, st->ntiles);
+        hipLaunchKernelGGL(reduce_tiles_k, dim3(st->ntiles + 1), dim3(256), 0, s, (const v4 *)h->slabs.p, grid, st->ntiles,
+                           (const int *)st->inv.p, st->nparams, 1.0 / F, grads);
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static const TrainOps *ops() {
+        static const TrainOps o = {setup, fwd_bwd, pack};
+        return &o;
+    }
+};
+
+// BALER_AMD_BF16_TRAIN_V2=1: the round-5 register-chain pair instead of the N-split pair; =3: the quad launches (four launches, eight
+// waves per workgroup) -- DESIGN.md section 4.6
+static int train_version() {
     const char *e = getenv("BALER_AMD_BF16_TRAIN_V2");
-    return !(e && e[0] == '1');
+    return e && e[0] == '1' ? 2 : (e && e[0] == '3' ? 3 : 1);
 }
 template <int F, int Z> const TrainOps *pick_train(const bamd_handle *h) {
     if (!TImpl<F, Z>::matches(h)) return nullptr;
-    return train_v1() ? TImpl<F, Z>::ops() : TImpl2<F, Z>::ops();
+    const int v = train_version();
+    if (v == 3) { if constexpr (Z == 15) return TImpl3<F, Z>::ops(); }      // (built for the benchmarked shape first)
+    return v == 2 ? TImpl2<F, Z>::ops() : TImpl<F, Z>::ops();
 }
 const TrainOps *find_train(const bamd_handle *h) {
     const TrainOps *o = nullptr;
@@ -1743,6 +2210,8 @@ void bf16_train_teardown(bamd_handle *h) {
     if (!st) return;
     st->src.release(); st->w.release(); st->inv.release(); st->dz.release();
     for (int p = 0; p < 2; ++p) { st->src2[p].release(); st->w2[p].release(); }
+    for (int p = 0; p < 4; ++p) { st->src3[p].release(); st->w3[p].release(); }
+    for (int p = 0; p < 3; ++p) st->dz3[p].release();
     delete st;
     h->bf16_train_state = nullptr;
 }

@@ -291,8 +291,9 @@ def test_wide_model_large_batches(shape, n):
     assert abs(a[-1] - b[-1]) < 1e-4 * b[-1] and rel(a[:-1], b[:-1]) < 5e-3
 
 
+@pytest.mark.parametrize("version", ["1", "3"])
 @pytest.mark.parametrize("n", [1, 65, 1000, 20000])
-def test_register_chain_pair(n, data, monkeypatch):
+def test_register_chain_pair(n, version, data, monkeypatch):
     """BALER_AMD_BF16_TRAIN_V2=1 (read at handle creation): the round-5 pair -- per-wave register chain through all layers, weight
     fragments through an LDS ring fed by direct-to-LDS loads, cut at the bottleneck, epilogues dealt between the next tile group's
     MFMAs -- against the oracle at the mode's bar and against the default pair (both round every operand to bfloat16 once, in
@@ -302,7 +303,7 @@ def test_register_chain_pair(n, data, monkeypatch):
     h1, p = handle(flat)
     g1 = torch.zeros_like(p)
     h1.fwd_bwd(torch.as_tensor(x[:n]).cuda(), g1)
-    monkeypatch.setenv("BALER_AMD_BF16_TRAIN_V2", "1")
+    monkeypatch.setenv("BALER_AMD_BF16_TRAIN_V2", version)     # "3": the quad launches (four launches, eight waves per workgroup)
     h2, _ = handle(flat)
     g2, g3 = torch.zeros_like(p), torch.zeros_like(p)
     h2.fwd_bwd(torch.as_tensor(x[:n]).cuda(), g2)
