@@ -23,6 +23,8 @@ prof b python3 $R/tools/bench_bf16_train.py                      # the shipped b
 export BALER_AMD_BF16_TRAIN_V2=1                                  # (an environment variable of THIS shell: the profiled program is still python3 itself)
 prof r python3 $R/tools/bench_bf16_train.py                      # the round-5 register-chain pair
 $T rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $O/rpmc_l -o run -- python3 $R/tools/bench_bf16_train.py > $O/rpmc_l.log 2>&1
+export BALER_AMD_BF16_TRAIN_V2=3                                  # the four launches with eight waves per workgroup (two waves per SIMD)
+prof q python3 $R/tools/bench_bf16_train.py
 unset BALER_AMD_BF16_TRAIN_V2
 prof c python3 $R/tools/bench_c4.py 32768                         # CFD_dense_AE(2500, 25), exact instantiation
 prof k python3 $R/tools/prof_wide_class.py                        # the run-time-width wide class on CFD_dense_AE(900, 9)
@@ -35,5 +37,7 @@ if [ -f $R/.abl/btrace.so ]; then BALER_AMD_LIB=$R/.abl/btrace.so timeout 200 py
 if [ -x $R/tools/probe/valu_beside_mfma_probe.out ]; then timeout 120 $R/tools/probe/valu_beside_mfma_probe.out > $O/valu_probe.txt 2>&1; fi
 timeout 300 python3 $R/tools/bench_wide_class.py > $O/wide_class_bench.txt 2>&1
 timeout 200 python3 $R/tools/bench_mid_width_train.py > $O/mid_width_train.txt 2>&1
-for d in stats bstats rstats cstats kstats sstats fstats istats; do echo "== $d"; python3 $R/tools/kstats.py $O/$d 8; done
+timeout 200 python3 $R/tools/bench_mid_width_wide.py > $O/mid_width_wide.txt 2>&1
+timeout 60 $R/tools/probe/launch_gap_probe.out > $O/launch_gap_probe.txt 2>&1
+for d in stats bstats rstats qstats cstats kstats sstats fstats istats; do echo "== $d"; python3 $R/tools/kstats.py $O/$d 8; done
 tail -1 $O/bench.json | cut -c1-400

@@ -21,6 +21,8 @@ KEYS = (("train_dec_kernel", "train_dec"), ("train_enc_kernel", "train_enc"), ("
         ("bf16_train_kernel<PART 0>", "bf16_train_kernel<24, 15, 0>"), ("bf16_train_kernel<PART 1>", "bf16_train_kernel<24, 15, 1>"),
         ("reduce_tiles_k", "reduce_tiles_k"),
         ("bf16_train2_kernel<PART 0> (register chain)", "bf16_train2_kernel<24, 15, 0>"), ("bf16_train2_kernel<PART 1> (register chain)", "bf16_train2_kernel<24, 15, 1>"),
+        ("bf16_train3_kernel<PART 0> (quad, two waves per SIMD)", "bf16_train3_kernel<24, 15, 0>"), ("bf16_train3_kernel<PART 1> (quad)", "bf16_train3_kernel<24, 15, 1>"),
+        ("bf16_train3_kernel<PART 2> (quad)", "bf16_train3_kernel<24, 15, 2>"), ("bf16_train3_kernel<PART 3> (quad)", "bf16_train3_kernel<24, 15, 3>"),
         ("wide class: wide_encode_lds_kernel<4096, 15, WRT>", "wide_encode_lds_kernel<4096, 15"), ("wide class: wide_decode_lds_kernel<4096, 15, WRT>", "wide_decode_lds_kernel<4096, 15"),
         ("wide class: wide_train_fwd_kernel<4096, 15, WRT>", "wide_train_fwd_kernel<4096, 15"), ("wide class: wide_train_bwd_kernel<4096, 15, WRT>", "wide_train_bwd_kernel<4096, 15"),
         ("wide_encode_lds_kernel", "wide_encode_lds_kernel<2500, 25"), ("wide_infer_kernel<DECODE>", "wide_infer_kernel<2500, 25, 1"), ("wide_decode_lds_kernel", "wide_decode_lds_kernel<2500, 25"),
@@ -65,6 +67,7 @@ fp32 = merge("")
 bf16 = merge("b")
 c4 = merge("c")
 regchain = merge("r")
+quad = merge("q")
 wclass = merge("k")
 small = merge("s")
 infer16 = merge("i")
@@ -89,6 +92,7 @@ out = {
     "source_hash": bench.source_hash(), "rows": 1000000, "kernels": fp32, "bf16_kernels": bf16,
     "c4_note": "CFD_dense_AE(2500, 25), 32768 frames per launch, `python3 tools/bench_c4.py 32768`", "c4_kernels": c4,
     "regchain_note": "the round-5 register-chain pair (BALER_AMD_BF16_TRAIN_V2=1), `python3 tools/bench_bf16_train.py`, 1,000,000 rows per launch: measured slower than the shipped pair (DESIGN.md section 4.6)", "regchain_kernels": regchain,
+    "quad_note": "the four launches with eight waves per workgroup (BALER_AMD_BF16_TRAIN_V2=3), `python3 tools/bench_bf16_train.py`, 1,000,000 rows per launch: two waves per SIMD, measured slower than the shipped pair (DESIGN.md section 4.6)", "quad_kernels": quad,
     "wide_class_note": "the run-time-width wide class on CFD_dense_AE(900, 9), 131,072 float32 rows per launch, `python3 tools/prof_wide_class.py`", "wide_class_kernels": wclass,
     "bf16_infer_note": "bf16 encode / decode of AE(24, 15), `python3 tools/bench_bf16_infer.py` (4M rows, float64 and float32 rows)", "bf16_infer_kernels": infer16,
     "bs512_note": "512-row bamd_train_step, `python3 tools/bench_one_batch.py 512 400`", "bs512_kernels": small,
@@ -97,11 +101,12 @@ out = {
     "bf16_fwd_bwd_hbm_bytes_per_launch": sum(bf16[k]["hbm_bytes"] for k in ("bf16_train_kernel<PART 0>", "bf16_train_kernel<PART 1>", "reduce_tiles_k") if k in bf16),
 }
 json.dump(out, open(os.path.join(REPO, "profiles", "pmc_summary.json"), "w"), indent=1)
-STATS = (("stats", "r5_kernel_stats.csv"), ("bstats", "r5_bf16_kernel_stats.csv"), ("rstats", "r5_bf16_regchain_kernel_stats.csv"),
+STATS = (("stats", "r5_kernel_stats.csv"), ("bstats", "r5_bf16_kernel_stats.csv"), ("rstats", "r5_bf16_regchain_kernel_stats.csv"), ("qstats", "r5_bf16_quad_kernel_stats.csv"),
          ("cstats", "r5_c4_kernel_stats.csv"), ("kstats", "r5_wide_class_kernel_stats.csv"),
          ("sstats", "r5_bs512_kernel_stats.csv"), ("fstats", "r5_fp64_kernel_stats.csv"), ("istats", "r5_bf16_infer_kernel_stats.csv"))
 for src, dst in (("regchain_trace.txt", "r5_bf16_regchain_trace.txt"), ("valu_probe.txt", "r5_valu_beside_mfma_probe.txt"),
-                 ("wide_class_bench.txt", "r5_wide_class_bench.txt"), ("mid_width_train.txt", "r5_mid_width_train.txt")):
+                 ("wide_class_bench.txt", "r5_wide_class_bench.txt"), ("mid_width_train.txt", "r5_mid_width_train.txt"),
+                 ("mid_width_wide.txt", "r5_mid_width_two_state.txt"), ("launch_gap_probe.txt", "r5_launch_gap_probe.txt")):
     if os.path.exists(f"{R}/{src}"):
         shutil.copy(f"{R}/{src}", os.path.join(REPO, "profiles", dst))
 for d, name in STATS:
@@ -112,7 +117,7 @@ d = json.loads(open(f"{R}/bench.json").read().strip().splitlines()[-1])
 if d.get("source_hash") == out["source_hash"]:
     d["roofline"]["traffic"] = out["fwd_bwd_hbm_bytes_per_launch"]
 json.dump(d, open(os.path.join(REPO, "profiles", "r5_bench.json"), "w"), indent=1)
-for name, tab in (("fp32", fp32), ("bf16", bf16), ("bf16 register chain", regchain), ("c4", c4), ("wide class", wclass), ("bs512", small), ("fp64", f64), ("bf16 infer", infer16)):
+for name, tab in (("fp32", fp32), ("bf16", bf16), ("bf16 register chain", regchain), ("bf16 quad", quad), ("c4", c4), ("wide class", wclass), ("bs512", small), ("fp64", f64), ("bf16 infer", infer16)):
     for k, v in tab.items():
         print(f"{name} {k:28s} busy {100 * v.get('mfma_busy', 0):5.1f}%  valu/mfma {v.get('valu_per_mfma', 0):.2f}  wait_any {v.get('wait_any_frac', 0):.3f}  "
               f"hbm {v.get('hbm_bytes', 0) / 1e6:7.1f} MB  mfma {v.get('SQ_INSTS_MFMA', 0) / 1e6:.1f} M  lds_conflict {v.get('lds_conflict_frac', 0):.2f}")
