@@ -185,3 +185,55 @@ def test_round4_kernel_floors():
     t_b = _ms(lambda: hb.encode(xb, out_dtype=torch.float32), 3)
     print(f"512-column model, bf16 encode: {t_b:.3f} ms per 1M rows = {2048 * (1 << 20) / t_b / 1e9:.2f} TB/s of rows")
     assert t_b < lim(0.533), "bf16 encode of the 512-column model (round 4: 0.533 ms per 1M rows = 4.0 TB/s of rows; round 3: 2.44 TB/s)"
+
+
+def test_round5_kernel_floors():
+    """Round 5: 64 .. 127-column tables on two states per handle (the wide class for inference and large batches, the small-batch class for
+    the 512-row step), the run-time-width wide class on a 900-column model, the 512-row step of the 24-column model after the chain's new
+    prologue."""
+    n = 1_000_000
+    for (F, Z), lim_e, lim_t, lim_s in (((80, 16), lim(0.86), lim(7.0), lim(29.7)), ((127, 31), lim(1.04), lim(7.25), lim(31.0))):
+        dims = orc.ae_dims(F, Z)
+        h = native.Handle(dims, "fp32")
+        assert h.path == "fused"
+        p = torch.from_numpy(np.concatenate([orc.formula_params(dims, 1), [0.0]]).astype(np.float32)).cuda()
+        h.load_params(p)
+        x = torch.rand((n, F), dtype=torch.float64, device="cuda")
+        g, m, v = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+        st = {"t": 0}
+
+        def steps():
+            for i in range(100):
+                st["t"] += 1
+                h.train_step(x[i * 512:(i + 1) * 512], p, m, v, st["t"], 1e-3)
+        t_e = _ms(lambda: h.encode(x), 5)
+        t_t = _ms(lambda: h.fwd_bwd(x, g), 3)
+        t_s = _ms(steps, 1, samples=3) / 100
+        print(f"AE({F},{Z}) [two states]: encode {t_e:.3f} ms, fwd_bwd {t_t:.3f} ms per 1M rows, bs512 step {1e3 * t_s:.1f} us")
+        assert t_e < lim_e, "mid-width encode on the wide class (round 5: 0.86 / 1.04 ms per 1M rows; layer-wise 2.1)"
+        assert t_t < lim_t, "mid-width fwd_bwd on the wide class (round 5: 7.0 / 7.25 ms per 1M rows; chunked small-batch kernels 9.9 / 10.6, layer-wise 12.6)"
+        assert 1e3 * t_s < lim_s, "mid-width 512-row step on the small-batch class (round 5: 29.7 / 31 us; the wide class alone 160, layer-wise 418)"
+        del x
+    wd = orc.ae_dims(900, 9)
+    hw = native.Handle(wd, "fp32")
+    assert hw.path == "fused"
+    pw = torch.from_numpy(np.concatenate([orc.formula_params(wd, 1), [0.0]]).astype(np.float32)).cuda()
+    hw.load_params(pw)
+    xw = torch.rand((131072, 900), dtype=torch.float32, device="cuda")
+    gw = torch.zeros_like(pw)
+    t_we = _ms(lambda: hw.encode(xw, out_dtype=torch.float32), 5)
+    t_wt = _ms(lambda: hw.fwd_bwd(xw, gw), 3)
+    print(f"AE(900,9) wide class: encode {t_we:.3f} ms, fwd_bwd {t_wt:.3f} ms per 131072 rows")
+    assert t_we < lim(0.50) and t_wt < lim(2.60), "wide class on 900 columns (round 5: 0.50 / 2.60 ms per 131072 rows; layer-wise 0.97 / 4.3)"
+    h, p = _handle()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    x = torch.rand((51200, 24), dtype=torch.float64, device="cuda")
+    st = {"t": 0}
+
+    def steps24():
+        for i in range(100):
+            st["t"] += 1
+            h.train_step(x[i * 512:(i + 1) * 512], p, m, v, st["t"], 1e-3)
+    t_s = _ms(steps24, 1, samples=5) / 100
+    print(f"AE(24,15) 512-row step: {1e3 * t_s:.1f} us")
+    assert 1e3 * t_s < lim(17.8), "512-row step (round 5: 17.8 us; round 4: 18.2)"
