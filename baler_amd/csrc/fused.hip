@@ -1401,10 +1401,14 @@ __global__ void __launch_bounds__(256) pack_wide_bf16_k(const float *__restrict_
 // double-buffered LDS stage (see wide_bf16_encode_kernel: every load of a wave then has the same lead -- fragments and rows three
 // chunks ahead -- so the in-order vmcnt never makes an L2 hit wait for an HBM miss; fragment traffic through the L1 drops 4x;
 // 32 + 32 fragment registers instead of 104).  All four waves must call it together (one barrier per chunk).
+// [kc0, kc1) (kc1 < 0: all): a RANGE of the full chunks only -- the small-batch training pass splits the wide dimension of one row
+// group over several workgroups (wide_small_in_kernel); `rem`: this call also takes the partial last chunk.
 template <int F, bool IN64, int RT = 1, bool WRT = false>
 __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13], v4 (*wst)[13][64], const WStream &ww, const void *xin,
-                                                    int64_t rrow, int64_t rrow1, int g, int lane, int wave, int fr = F) {
-    const int KC = (WRT ? fr : F) / 16;   // FULL chunks: the loop; the remainder is the epilogue below
+                                                    int64_t rrow, int64_t rrow1, int g, int lane, int wave, int fr = F, int kc0 = 0, int kc1 = -1,
+                                                    bool rem = true) {
+    const int KCA = (WRT ? fr : F) / 16;  // FULL chunks of the model: the loop; the remainder is the epilogue below
+    const int KC = kc1 < 0 ? KCA : kc1;   // end of this call's range
     static_assert(F / 16 >= 3, "at least three full chunks");
     v4 wq[2][4], xr[3], xs[3];            // xs / acc1: the second row tile (RT == 2)
     auto wload = [&](v4 (&w)[4], int kc) {
@@ -1424,15 +1428,15 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
     };
     auto lx = [&](int kc) { return wide_x_chunk<F, true, WRT>(xin, IN64 ? 1 : 0, rrow, kc < KC ? kc : 0, g, fr); };
     auto ly = [&](int kc) { return RT == 2 ? wide_x_chunk<F, true, WRT>(xin, IN64 ? 1 : 0, rrow1, kc < KC ? kc : 0, g, fr) : (v4){0.f, 0.f, 0.f, 0.f}; };
-    wload(wq[0], 0);
-    wload(wq[1], 1);
+    wload(wq[0], kc0);
+    wload(wq[1], kc0 + 1);
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { xr[u] = lx(u); xs[u] = ly(u); }
+    for (int u = 0; u < 3; ++u) { xr[u] = lx(kc0 + u); xs[u] = ly(kc0 + u); }
     __syncthreads();                      // the previous row group's last chunk has been read
     wstore(wq[0], 0);
-    wload(wq[0], 2);
+    wload(wq[0], kc0 + 2);
     auto iter = [&](int kc, auto wsl, auto xsl) {
-        constexpr int WS = decltype(wsl)::value, XS = decltype(xsl)::value;      // kc % 2, kc % 3
+        constexpr int WS = decltype(wsl)::value, XS = decltype(xsl)::value;      // (kc - kc0) % 2, (kc - kc0) % 3
         __syncthreads();                  // fragments of chunk kc visible in stage slot WS; slot WS ^ 1 free
         wstore(wq[WS ^ 1], WS ^ 1);       // chunk kc + 1 (fetched two chunks ago)
         const v4 xv = xr[XS], yv = xs[XS];
@@ -1469,7 +1473,7 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
         __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    int kc = 0;
+    int kc = kc0;
     for (; kc + 6 <= KC; kc += 6) {
         iter(kc, I0(), I0()); iter(kc + 1, I1(), I1()); iter(kc + 2, I0(), I2());
         iter(kc + 3, I1(), I0()); iter(kc + 4, I0(), I1()); iter(kc + 5, I1(), I2());
@@ -1479,8 +1483,8 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
     if (kc + 2 < KC) iter(kc + 2, I0(), I2());
     if (kc + 3 < KC) iter(kc + 3, I1(), I0());
     if (kc + 4 < KC) iter(kc + 4, I0(), I1());
-    if ((WRT ? fr : F) % 16 != 0) {       // the remaining features: one partial chunk, fragments straight from L2
-        const int KL = KC;
+    if (rem && (WRT ? fr : F) % 16 != 0) {       // the remaining features: one partial chunk, fragments straight from L2
+        const int KL = KCA;
         constexpr int ST = WRT ? 4 : tile_steps(F, F / 16);      // (a class chunk is a full tile: padding meets zero weights and a zero x)
         const v4 xv = wide_x_chunk<F, false, WRT>(xin, IN64 ? 1 : 0, rrow, KL, g, fr);
         const v4 yv = RT == 2 ? wide_x_chunk<F, false, WRT>(xin, IN64 ? 1 : 0, rrow1, KL, g, fr) : xv;
@@ -1502,11 +1506,14 @@ __device__ __forceinline__ void wide_in_product_lds(v4 (&acc)[13], v4 (&acc1)[13
 // `emit(o, t, slot, full)` consumes output tile t; full = std::true_type in the main loop, where every tile touched is a full one
 // (no "partial tile?" test in front of the loads and stores), std::false_type for the last tiles.  All four waves together; one
 // barrier per tile.
+// [t0, t1) (t1 < 0: all): a RANGE of the output tiles -- the small-batch training pass deals them to several workgroups per row group
+// (wide_small_out_kernel).
 template <int F, bool WRT = false, class Pre, class Emit>
 __device__ __forceinline__ void wide_out_product_lds(const v4 (&a7)[13], v4 (*wst)[13][64], const WStream &ww, const v4 *bias7, int g,
-                                                     int lane, int wave, Pre pre, Emit emit, int fr = F) {
+                                                     int lane, int wave, Pre pre, Emit emit, int fr = F, int t0 = 0, int t1 = -1) {
     constexpr int KCS = tiles(F);                  // stride of the fragment array [k tile of the 200 side][output tile]
-    const int KC = WRT ? (fr + 15) / 16 : tiles(F), KF = (WRT ? fr : F) / 16;      // all / full output tiles
+    const int KCA = WRT ? (fr + 15) / 16 : tiles(F), KFA = (WRT ? fr : F) / 16;      // all / full output tiles of the model
+    const int KC = t1 < 0 || t1 > KCA ? KCA : t1, KF = KFA < KC ? KFA : KC;          // ... of this call's range
     static_assert(F / 16 >= 3, "at least three full tiles");
     v4 wq[2][4];
     auto wload = [&](v4 (&w)[4], int t) {
@@ -1524,14 +1531,20 @@ __device__ __forceinline__ void wide_out_product_lds(const v4 (&a7)[13], v4 (*ws
             if (q < 13) wst[slot][q][lane] = w[k];
         }
     };
-    wload(wq[0], 0);
-    wload(wq[1], 1);
-    pre(0, std::integral_constant<int, 0>(), std::true_type());
-    pre(1, std::integral_constant<int, 1>(), std::true_type());
-    pre(2, std::integral_constant<int, 2>(), std::true_type());
+    wload(wq[0], t0);
+    wload(wq[1], t0 + 1);
+    if (t0 + 3 <= KF) {
+        pre(t0, std::integral_constant<int, 0>(), std::true_type());
+        pre(t0 + 1, std::integral_constant<int, 1>(), std::true_type());
+        pre(t0 + 2, std::integral_constant<int, 2>(), std::true_type());
+    } else {                                       // (a short range at the end of the row: the general path)
+        pre(t0, std::integral_constant<int, 0>(), std::false_type());
+        pre(t0 + 1, std::integral_constant<int, 1>(), std::false_type());
+        pre(t0 + 2, std::integral_constant<int, 2>(), std::false_type());
+    }
     __syncthreads();
     wstore(wq[0], 0);
-    wload(wq[0], 2);
+    wload(wq[0], t0 + 2);
     auto iter = [&](int t, auto wsl, auto xsl, auto full) {
         constexpr int WS = decltype(wsl)::value;
         __syncthreads();
@@ -1570,7 +1583,7 @@ __device__ __forceinline__ void wide_out_product_lds(const v4 (&a7)[13], v4 (*ws
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using TT = std::true_type;
     using FT = std::false_type;
-    int t = 0;
+    int t = t0;
     for (; t + 9 <= KF; t += 6) {                       // tiles t .. t + 5 and the prefetched t + 3 .. t + 8 are all full
         iter(t, I0(), I0(), TT()); iter(t + 1, I1(), I1(), TT()); iter(t + 2, I0(), I2(), TT());
         iter(t + 3, I1(), I0(), TT()); iter(t + 4, I0(), I1(), TT()); iter(t + 5, I1(), I2(), TT());
@@ -1685,12 +1698,14 @@ __device__ __forceinline__ void load_act(v4 (&a)[tiles(D)], const float *__restr
 // dz8 = 2 (recon - x) / F, loss_part[workgroup] = sum of squared errors (double, fixed order).
 // TRAIN = false is the validation pass (training.py:104-137): no activation stores, `dz8` (may be null) receives the
 // reconstruction itself as float32 / float64.
-template <int F, int Z, bool TRAIN, bool WRT = false>
+// MID (the small-batch pass, see wide_small_in_kernel): en1's sums arrive as `nsplit` partial accumulator sets per wave in `part`
+// ([split][row group][wave][tile][lane], added in split order), the launch ends with y7 -- de4, the loss and dz8 are wide_small_out_kernel's.
+template <int F, int Z, bool TRAIN, bool WRT = false, bool MID = false>
 __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, const float *__restrict__ x, int64_t n, float *__restrict__ y1,
                                                              float *__restrict__ y2, float *__restrict__ y3, float *__restrict__ y4,
                                                              float *__restrict__ y5, float *__restrict__ y6, float *__restrict__ y7,
                                                              void *__restrict__ dz8, int out_f64, double *__restrict__ loss_part,
-                                                             int fr = F, int zr = Z) {
+                                                             int fr = F, int zr = Z, const v4 *__restrict__ part = nullptr, int nsplit = 0) {
     using N = Net<F, Z>;
     using S = StreamWideMid<N>;
     const int KC = WRT ? (fr + 15) / 16 : tiles(F);
@@ -1714,7 +1729,15 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
         {
             v4 a1[13];
             init_bias(a1, bias_lds, lane);
-            wide_in_product_lds<F, false, 1, WRT>(a1, a1, wst, w0, x, rrow, 0, g, lane, wave, fr);
+            if constexpr (MID) {
+                for (int sp = 0; sp < nsplit; ++sp) {
+                    const v4 *pp = part + (((int64_t)sp * ngroup + grp) * 4 + wave) * (13 * 64) + lane;
+#pragma unroll
+                    for (int t = 0; t < 13; ++t) a1[t] += pp[t * 64];
+                }
+            } else {
+                wide_in_product_lds<F, false, 1, WRT>(a1, a1, wst, w0, x, rrow, 0, g, lane, wave, fr);
+            }
             lrelu(a1);
             if (TRAIN) store_rows<200>(a1, y1, 0, row, valid, lane, nullptr, nullptr);
             Ring ring;
@@ -1733,6 +1756,7 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
             fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
             if (TRAIN) store_rows<200>(a7, y7, 0, row, valid, lane, nullptr, nullptr);
         }
+        if constexpr (MID) continue;
         // de4 + loss: the x tiles are re-read three tiles ahead of the tile being multiplied, like the fragments (HBM again:
         // 327 MB of rows do not stay in the 256-MB MALL between the two passes)
         v4 xr[3];
@@ -1753,6 +1777,7 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
                 }
             }, fr);
     }
+    if constexpr (MID) return;
     sh[threadIdx.x] = lacc;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -1762,9 +1787,85 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
     if (threadIdx.x == 0) loss_part[blockIdx.x] = sh[0];
 }
 
+// ---- wide models, SMALL training batches (the reference's own: CFD_project_still trains with batch_size = 60, exafel 1 .. 36, hurricane
+// 85, CFD_project_animation 6000) ------------------------------------------------------------------------------------------------
+// wide_train_fwd / bwd_kernel give 16 rows to a wave that walks the whole wide dimension: 8,164 MFMAs for en1 and as many for de4 and for
+// de4's input-gradient product, whatever the batch -- 0.3 + 0.16 ms per pass for 1 .. 4,096 rows.  Here the three wide products of a row
+// group are SPLIT over workgroups: en1 and de4's input-gradient product over the wide (contraction) dimension -- partial accumulator sets,
+// added in split order by the MID launches above and below --, de4 over its output tiles (with the loss and dz8).  Five launches instead of
+// two, the same row-major activations / gradients for the weight-gradient kernels, the same arithmetic per element except for the order in
+// which en1's and the input-gradient product's chunks are added (a fixed order).
+template <int F, bool WRT = false>
+__global__ void __launch_bounds__(256) wide_small_in_kernel(const v4 *wfrag /* [wide chunk][tile of the 200 side] */, int wcount_f4,
+                                                            const float *__restrict__ src, int64_t n, v4 *__restrict__ part, int cps, int fr) {
+    __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 63) / 64;
+    const int sp = blockIdx.x;                             // split of the wide dimension: full chunks [sp cps, (sp + 1) cps)
+    const int64_t grp = blockIdx.y;
+    const int KCA = (WRT ? fr : F) / 16;
+    const int kc0 = sp * cps, kc1 = kc0 + cps < KCA ? kc0 + cps : KCA;
+    const WStream ww = make_stream(wfrag, wcount_f4 * 16, lane);
+    const int64_t row = (grp * 4 + wave) * 16 + (lane & 15);
+    const int64_t rrow = row < n ? row : 0;
+    v4 acc[13];
+    zero_tiles(acc);
+    wide_in_product_lds<F, false, 1, WRT>(acc, acc, wst, ww, src, rrow, 0, g, lane, wave, fr, kc0, kc1, sp == (int)gridDim.x - 1);
+    v4 *pp = part + (((int64_t)sp * ngroup + grp) * 4 + wave) * (13 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < 13; ++t) pp[t * 64] = acc[t];
+}
+// de4 + loss + dz8 of output tiles [blockIdx.x tps, ..) of row group blockIdx.y (y7 from the MID forward launch)
+template <int F, int Z, bool WRT = false>
+__global__ void __launch_bounds__(256) wide_small_out_kernel(const v4 *packed, const float *__restrict__ x, int64_t n, const float *__restrict__ y7,
+                                                             float *__restrict__ dz8, double *__restrict__ loss_part, int tps, int fr) {
+    using N = Net<F, Z>;
+    const int KC = WRT ? (fr + 15) / 16 : tiles(F);
+    __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
+    __shared__ __attribute__((aligned(16))) v4 bias7[tiles(F) * 4];
+    __shared__ double sh[256];
+    for (int i = threadIdx.x; i < tiles(F) * 4; i += 256) bias7[i] = packed[N::bf_off(7) + i];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t grp = blockIdx.y;
+    const int t0 = blockIdx.x * tps, t1 = t0 + tps < KC ? t0 + tps : KC;
+    const WStream w7 = make_stream(packed + N::wf_off(7), N::wcount(7) * 16, lane);
+    const int64_t row = (grp * 4 + wave) * 16 + (lane & 15);
+    const bool valid = row < n;
+    const int64_t rrow = valid ? row : 0;
+    const float gscale = 2.0f / (float)(WRT ? fr : F);
+    double lacc = 0.0;
+    v4 a7[13];
+    load_act<200>(a7, y7, rrow, g);
+    __syncthreads();                                       // the bias tile table
+    v4 xr[3];
+    wide_out_product_lds<F, WRT>(a7, wst, w7, bias7, g, lane, wave,
+        [&](int t, auto slot, auto full) {
+            constexpr int SL = decltype(slot)::value;
+            if (decltype(full)::value) xr[SL] = wide_x_chunk<F, true, WRT>(x, 0, rrow, t, g, fr);
+            else xr[SL] = wide_x_chunk<F, false, WRT>(x, 0, rrow, t < KC ? t : 0, g, fr);
+        },
+        [&](const v4 &o, int t, auto slot, auto full) {
+            constexpr int SL = decltype(slot)::value;
+            constexpr bool FL = decltype(full)::value;
+            const v4 d = o - xr[SL];
+            if (valid) {
+                lacc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
+                wide_store_tile<F, FL, WRT>(d * gscale, dz8, 0, row, t, g, fr);
+            }
+        }, fr, t0, t1);
+    sh[threadIdx.x] = lacc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_part[blockIdx.y * gridDim.x + blockIdx.x] = sh[0];
+}
+
 // the input-gradient chain of 16 rows per wave: dZ_6 = (dZ_7 W_7) * lrelu'(y7) streamed over the wide dimension, then layers 6..1
 // chained in registers; every dZ_l (dL/d pre-activation of layer l) is stored for the weight-gradient GEMMs.
-template <int F, int Z, bool WRT = false>
+// MID (small batches): d6 starts from the partial sums of wide_small_in_kernel (as the forward launch's MID mode)
+template <int F, int Z, bool WRT = false, bool MID = false>
 __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, const float *__restrict__ dz7, int64_t n,
                                                              const float *__restrict__ y1, const float *__restrict__ y2,
                                                              const float *__restrict__ y3, const float *__restrict__ y5,
@@ -1772,7 +1873,7 @@ __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, c
                                                              float *__restrict__ dz0, float *__restrict__ dz1, float *__restrict__ dz2,
                                                              float *__restrict__ dz3, float *__restrict__ dz4, float *__restrict__ dz5,
                                                              float *__restrict__ dz6, const float *__restrict__ dz_latent,
-                                                             int fr = F, int zr = Z) {
+                                                             int fr = F, int zr = Z, const v4 *__restrict__ part = nullptr, int nsplit = 0) {
     using N = Net<F, Z>;
     using S = StreamWideMidBwd<N>;
     __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
@@ -1787,7 +1888,15 @@ __global__ void __launch_bounds__(256) wide_train_bwd_kernel(const v4 *packed, c
         asm volatile("" : "+v"(ws.voff), "+v"(w7.voff));
         v4 d6[13];
         zero_tiles(d6);
-        wide_in_product_lds<F, false, 1, WRT>(d6, d6, wst, w7, dz7, rrow, 0, g, lane, wave, fr);
+        if constexpr (MID) {
+            for (int sp = 0; sp < nsplit; ++sp) {
+                const v4 *pp = part + (((int64_t)sp * ngroup + grp) * 4 + wave) * (13 * 64) + lane;
+#pragma unroll
+                for (int t = 0; t < 13; ++t) d6[t] += pp[t * 64];
+            }
+        } else {
+            wide_in_product_lds<F, false, 1, WRT>(d6, d6, wst, w7, dz7, rrow, 0, g, lane, wave, fr);
+        }
         Ring ring;
         ring_prime<S::total>(ring, ws);
         {
@@ -3474,6 +3583,7 @@ struct FusedState {
     bool dz16 = false;                 // this pass stores dL/drecon as bfloat16 (set per pass by the layer-wise driver: fused_wide_set_dz16)
     DevBuf imgs;                       // X^T / dZ^T images of the small-batch path: 104 KiB per 16-row block
     DevBuf dwpart;                     // partial weight-gradient tiles of the small-batch path when a tile's blocks are split over workgroups
+    DevBuf wpart;                      // wide models, small training batches: partial sums of the split wide products (wide_small_in_kernel)
     bool tail_split = true;            // short remainder of the persistent loop on the small-batch kernels (BALER_AMD_TAIL_SPLIT=0: off)
 };
 
@@ -3937,9 +4047,42 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
         return BAMD_OK;
     }
     // y[l] = activations entering layer l (row-major float32, y[0] unused), dz[l] = dL/d(pre-activation of layer l)
+    // Small training batches (up to BALER_AMD_WIDE_SMALL_ROWS rows, default 8192): how many workgroups share the wide dimension of one
+    // 64-row group (wide_small_in_kernel / wide_small_out_kernel); 1 = the one-launch kernels.  At least three chunks / tiles per
+    // workgroup, at most 16 splits (the MID launches add the partial sums of every split), ~384 workgroups per launch.
+    static int small_splits(const bamd_handle *h, int64_t rows, int units, int *per) {
+        static const int64_t lim = getenv("BALER_AMD_WIDE_SMALL_ROWS") ? atoll(getenv("BALER_AMD_WIDE_SMALL_ROWS")) : 8192;
+        *per = units;
+        if (rows > lim) return 1;
+        const int64_t ngroup = (rows + 63) / 64;
+        int64_t sp = 384 / ngroup;
+        sp = sp > 16 ? 16 : sp;
+        if (sp < 2) return 1;
+        int p = (int)((units + sp - 1) / sp);
+        p = p < 3 ? 3 : p;
+        *per = p;
+        return (units + p - 1) / p;
+    }
     static int wide_fwd(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
                         hipStream_t s) {
         const int grid = grid_for(rows);
+        int cps = 0, tps = 0;
+        const int fr = Fr(h), ngroup = (int)((rows + 63) / 64);
+        const int s_in = small_splits(h, rows, fr / 16, &cps), s_out = small_splits(h, rows, (fr + 15) / 16, &tps);
+        if (s_in > 1 && s_out > 1 && fr / 16 >= 3) {
+            FusedState *st = state_of(h);
+            int rc = st->wpart.ensure((size_t)s_in * ngroup * 4 * 13 * 64 * sizeof(v4));
+            if (rc) return rc;
+            hipLaunchKernelGGL((wide_small_in_kernel<F, WRT>), dim3(s_in, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p + N::wf_off(0), N::wcount(0), x, rows,
+                               (v4 *)st->wpart.p, cps, fr);
+            hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, true, WRT, true>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, y[1], y[2],
+                               y[3], y[4], y[5], y[6], y[7], (void *)dz_last, 0, loss_part, fr, Zr(h), (const v4 *)st->wpart.p, s_in);
+            hipLaunchKernelGGL((wide_small_out_kernel<F, Z, WRT>), dim3(s_out, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, (const float *)y[7],
+                               dz_last, loss_part, tps, fr);
+            *nblk = s_out * ngroup;
+            BAMD_HIP(hipGetLastError());
+            return BAMD_OK;
+        }
         hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, true, WRT>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, y[1], y[2], y[3],
                            y[4], y[5], y[6], y[7], (void *)dz_last, 0, loss_part, Fr(h), Zr(h));
         *nblk = grid;
@@ -3979,6 +4122,22 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
         return BAMD_OK;
     }
     static int wide_bwd(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, const float *dz_latent, hipStream_t s) {
+        int cps = 0;
+        const int fr = Fr(h), ngroup = (int)((rows + 63) / 64);
+        const int s_in = small_splits(h, rows, fr / 16, &cps);
+        if (s_in > 1 && fr / 16 >= 3) {      // small batches: de4's input-gradient product split over the wide dimension (see wide_fwd)
+            FusedState *st = state_of(h);
+            int rc = st->wpart.ensure((size_t)s_in * ngroup * 4 * 13 * 64 * sizeof(v4));
+            if (rc) return rc;
+            hipLaunchKernelGGL((wide_small_in_kernel<F, WRT>), dim3(s_in, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p + N::wb_off(7), N::wcount(7),
+                               (const float *)dz[7], rows, (v4 *)st->wpart.p, cps, fr);
+            hipLaunchKernelGGL((wide_train_bwd_kernel<F, Z, WRT, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                               (const float *)dz[7], rows, (const float *)y[1], (const float *)y[2], (const float *)y[3], (const float *)y[5],
+                               (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz_latent, fr, Zr(h),
+                               (const v4 *)st->wpart.p, s_in);
+            BAMD_HIP(hipGetLastError());
+            return BAMD_OK;
+        }
         hipLaunchKernelGGL((wide_train_bwd_kernel<F, Z, WRT>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
                            (const float *)dz[7], rows, (const float *)y[1], (const float *)y[2], (const float *)y[3], (const float *)y[5],
                            (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz_latent, Fr(h), Zr(h));
@@ -4359,6 +4518,7 @@ static void release_state(FusedState *st) {
     st->dz.release();
     st->imgs.release();
     st->dwpart.release();
+    st->wpart.release();
     for (int k = 0; k < 6; ++k) { st->wb_src[k].release(); st->wb[k].release(); }
     st->sc_off.release();
     st->sc_idx.release();

@@ -227,3 +227,36 @@ def test_mid_width_two_state_handle_follows_the_optimiser(F, Z, monkeypatch):
     assert rel(two[0], orc.encode(dims, st.params, xl[:777].cpu().numpy())) < 2 * TOL32
     lo, g1 = orc.fwd_bwd(dims, st.params, xl.cpu().numpy())
     assert rel(two[1][:-1], g1) < 2 * TOL32 and abs(two[1][-1] - lo) < TOL32 * lo
+
+
+@pytest.mark.parametrize("shape", [(2500, 25), (625, 7), (900, 9), (100, 40)])
+def test_wide_models_small_training_batches(shape, monkeypatch):
+    """The reference trains its wide models with SMALL batches (CFD_project_still: batch_size = 60, exafel 1 .. 36, hurricane_isabel 85,
+    CFD_project_animation 6000).  Up to 8192 rows the three wide products of a row group are split over workgroups (wide_small_in_kernel:
+    en1 and de4's input-gradient product over the wide dimension, partial sums added in split order; wide_small_out_kernel: de4 over its
+    output tiles): against the oracle, against the one-launch kernels (BALER_AMD_WIDE_SMALL_ROWS=0 is read once per process: compared
+    through the oracle instead), bitwise repeatable, and a training step through it."""
+    F, Z = shape
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 900 + F)
+    h, p = make_handle(dims, flat, "fp32")
+    for n in (1, 60, 85, 700, 6000):
+        if F > 1000 and n > 1000:
+            continue
+        x = off_the_kink(dims, flat, n, n).astype(np.float32)
+        lo, go = orc.fwd_bwd(dims, flat, x.astype(np.float64))
+        g, g2 = torch.full_like(p, 5.0), torch.zeros_like(p)
+        h.fwd_bwd(dev(x, torch.float32), g)
+        h.fwd_bwd(dev(x, torch.float32), g2)
+        assert torch.equal(g, g2)
+        gh = g.cpu().numpy().astype(np.float64)
+        assert rel(gh[:-1], go) < 2 * TOL32 and abs(gh[-1] - lo) < TOL32 * lo, (F, n, rel(gh[:-1], go))
+    x = dev(off_the_kink(dims, flat, 60, 7), torch.float32)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    h.train_step(x, p, m, v, 1, 1e-3)
+    lo, go = orc.fwd_bwd(dims, flat, x.cpu().numpy().astype(np.float64))
+    pn, mm, vv = flat.copy(), np.zeros_like(flat), np.zeros_like(flat)
+    orc.adam_step(pn, go, mm, vv, 1, 1e-3)
+    live = np.abs(go) > 1e-6 * np.abs(go).max()
+    assert rel((p.cpu().numpy().astype(np.float64)[:-1] - flat)[live], (pn - flat)[live]) < 1e-3
+    assert rel(h.encode(x, out_dtype=torch.float32).cpu().numpy(), orc.encode(dims, pn, x.cpu().numpy().astype(np.float64))) < 1e-4
