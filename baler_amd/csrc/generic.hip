@@ -1278,6 +1278,65 @@ static void run_dw_short(const ShortPlan &pl, int l, const float *dz, const floa
     }
 }
 
+// ---- all weight gradients of a SMALL float32 batch in one launch ----------------------------------------------------------------------
+// The reference trains its wide models with batches of 1 .. 85 rows (CFD_project_still: 60): eight split-K GEMM launches + a slab
+// reduction for ~0.3 GFLOP were 101 + 5 of the step's 220 us.  Here ONE wave owns a 16 x 16 tile of [dW | db] = dZ^T [X | 1] of one
+// layer and contracts over ALL rows of the batch (operands in MFMA layout straight from the row-major matrices, as dw_short_k: the
+// reduction index of v_mfma_f32_16x16x4_f32 is the row); results go straight to the canonical gradient vector (= or +=).
+struct SmallDwPlan {
+    const float *dz[8], *x[8];
+    int N[8], K[8], kt[8], tile0[9];       // tiles of layer l: [tile0[l], tile0[l + 1]) = nt(l) x kt(l), index = nt * kt(l) + kt
+    int64_t w_off[8], b_off[8];
+    int L;
+};
+__global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan pl, int64_t rows, float *__restrict__ grads, int accumulate) {
+    using v4 = MF<float>::v4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= pl.tile0[pl.L]) return;
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) if (j < pl.L && tile >= pl.tile0[j]) l = j;
+    const int N = pl.N[l], K = pl.K[l], KT = pl.kt[l];
+    const int t = tile - pl.tile0[l], nt = t / KT, kt = t - nt * KT;
+    const int ncol = 16 * nt + i, kcol = 16 * kt + i;                 // this lane's dZ column (A operand) / X column (B operand)
+    const float *pa = pl.dz[l] + (ncol < N ? ncol : N - 1);
+    const float *pb = pl.x[l] + (kcol < K ? kcol : K - 1);
+    const bool a_live = ncol < N, b_live = kcol < K, b_one = kcol == K;
+    v4 acc = (v4){0.f, 0.f, 0.f, 0.f};
+    float a[4], b[4];
+    auto load = [&](int64_t r0) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int64_t r = r0 + 4 * s4 + g;
+            const bool ok = r < rows;
+            const int64_t rr = ok ? r : rows - 1;
+            const float av = pa[rr * N], bv = pb[rr * K];
+            a[s4] = (ok && a_live) ? av : 0.f;
+            b[s4] = b_one ? 1.0f : (b_live ? bv : 0.f);
+        }
+    };
+    load(0);
+    for (int64_t r0 = 0; r0 < rows; r0 += 16) {
+        float a0[4], b0[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { a0[s4] = a[s4]; b0[s4] = b[s4]; }
+        if (r0 + 16 < rows) load(r0 + 16);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = MF<float>::mma(a0[s4], b0[s4], acc);
+    }
+    // C map: register r of lane (i, g) = [dZ column 16 nt + 4 g + r][X column 16 kt + i]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 16 * nt + 4 * g + r;
+        if (n >= N) continue;
+        float *dst = nullptr;
+        if (kcol < K) dst = grads + pl.w_off[l] + (int64_t)n * K + kcol;
+        else if (kcol == K) dst = grads + pl.b_off[l] + n;
+        if (dst) *dst = accumulate ? *dst + acc[r] : acc[r];
+    }
+}
+
 template <typename T>
 static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
                      void *grads_v, const void *latent_grad, hipStream_t s) {
@@ -1357,7 +1416,31 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                                            latent_grad ? (const float *)latent_grad + r0 * h->dims[h->L / 2] : nullptr, s);
             if (rc) return rc;
         }
-        for (int l = h->L - 1; l >= 0; --l) {
+        // small float32 batches of a model on the fused row-local launches: every weight gradient in ONE launch, straight into `grads`
+        bool dw_small = false;
+        if constexpr (sizeof(T) == 4) {
+            static const int64_t lim = getenv("BALER_AMD_DW_SMALL_ROWS") ? atoll(getenv("BALER_AMD_DW_SMALL_ROWS")) : 1024;
+            const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
+            const bool bf16 = h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0');
+            if (wide && !bf16 && rows <= lim && h->L <= 8) {
+                SmallDwPlan pl{};
+                pl.L = h->L;
+                int t0 = 0;
+                for (int l = 0; l < h->L; ++l) {
+                    pl.dz[l] = (const float *)wk.dz[l];
+                    pl.x[l] = l == 0 ? (const float *)x0 : (const float *)wk.y[l];
+                    pl.N[l] = h->dims[l + 1]; pl.K[l] = h->dims[l];
+                    pl.kt[l] = (h->dims[l] + 1 + 15) / 16;
+                    pl.tile0[l] = t0;
+                    t0 += ((h->dims[l + 1] + 15) / 16) * pl.kt[l];
+                    pl.w_off[l] = h->w_off[l]; pl.b_off[l] = h->b_off[l];
+                }
+                pl.tile0[h->L] = t0;
+                hipLaunchKernelGGL(dw_small_all_k, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, pl, rows, (float *)grads, chunk_i > 0 ? 1 : 0);
+                dw_small = true;
+            }
+        }
+        for (int l = h->L - 1; l >= 0 && !dw_small; --l) {
             int K = h->dims[l], N = h->dims[l + 1];
             const T *dz = wk.dz[l];
             // [dW | db] = dZ^T [X | 1], reduced over this chunk's rows in nsplit fixed slabs
@@ -1386,7 +1469,8 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 launch_gemm<T, EPI_DX, true, false>(A, B, (int64_t)N, e, rows, K, 1, s);
             }
         }
-        if (sp.ok) {
+        if (dw_small) {
+        } else if (sp.ok) {
             if constexpr (sizeof(T) == 4)
                 hipLaunchKernelGGL(reduce_layers_k, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const float *)slabs, sp.rp, grads,
                                    chunk_i > 0 ? 1 : 0);
