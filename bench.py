@@ -734,8 +734,22 @@ def other_configs(dev):
         "frames": n, "encode_rows_per_s": n / ms_e * 1e3, "encode_frac_of_mfma_peak": FLOP_C4_ENCODE * n / ms_e / 1e9 / PEAK_TFLOPS["fp32"],
         "decode_rows_per_s": n / ms_d * 1e3, "decode_frac_of_mfma_peak": FLOP_C4_ENCODE * n / ms_d / 1e9 / PEAK_TFLOPS["fp32"],
         "train_fwd_bwd_rows_per_s": n / ms_t * 1e3, "train_frac_of_mfma_peak": FLOP_C4_TRAIN * n / ms_t / 1e9 / PEAK_TFLOPS["fp32"]}
+    # the reference's own batch sizes for this model (CFD_project_still: batch_size = 60, CFD_project_animation: 6000): optimiser steps
+    pc, mo_, vo_ = mc.flat.clone(), torch.zeros_like(mc.flat), torch.zeros_like(mc.flat)
+    stc = {"t": 0}
+    by = {}
+    for bs in (60, 6000):
+        def csteps():
+            for i in range(20):
+                stc["t"] += 1
+                hc.train_step(xc[(i % 5) * bs:(i % 5 + 1) * bs], pc, mo_, vo_, stc["t"], 1e-3)
+        csteps()
+        by[str(bs)] = {"us_per_step": event_ms(csteps, 3) * 1e3 / 20}
+        by[str(bs)]["rows_per_s"] = bs / by[str(bs)]["us_per_step"] * 1e6
+    res["c4_cfd_dense_2500_25"]["train_step_by_reference_batch_size"] = by
+    hc.load_params(mc.flat)
     hc.close()
-    del gc
+    del gc, pc, mo_, vo_
     # the same model in the bf16 mode: en1 / de4 on the bf16 MFMA, HBM-bound (10 KB of float32 per frame)
     from baler_amd import native
     hb = native.Handle([2500, 200, 100, 50, 25, 50, 100, 200, 2500], "bf16")
