@@ -3721,6 +3721,7 @@ struct FusedOps {
     int (*wide_bwd)(bamd_handle *, int64_t, float *const *, float *const *, const float *, hipStream_t);
     int (*pack_extra)(bamd_handle *, FusedState *, hipStream_t);    // further packed copies of the parameters (bf16 fragments)
     bool throughput_training = true;      // false: large-batch training of this shape runs on generic.hip (bamd_path_of: FUSED_INFER)
+    bool (*wide_small)(const bamd_handle *, int64_t) = nullptr;     // wide models: this batch size takes the split launches
 };
 
 static FusedState *state_of(bamd_handle *h) { return (FusedState *)h->fused_state; }
@@ -4063,6 +4064,10 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
         *per = p;
         return (units + p - 1) / p;
     }
+    static bool small_pass(const bamd_handle *h, int64_t rows) {      // this batch runs on the split launches
+        int per = 0;
+        return Fr(h) / 16 >= 3 && small_splits(h, rows, Fr(h) / 16, &per) > 1 && small_splits(h, rows, (Fr(h) + 15) / 16, &per) > 1;
+    }
     static int wide_fwd(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
                         hipStream_t s) {
         const int grid = grid_for(rows);
@@ -4145,7 +4150,7 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
         return BAMD_OK;
     }
     static const FusedOps *ops() {
-        static const FusedOps o = {setup, encode, decode, forward_loss, nullptr, nullptr, wide_fwd, wide_bwd};
+        static const FusedOps o = {setup, encode, decode, forward_loss, nullptr, nullptr, wide_fwd, wide_bwd, nullptr, true, small_pass};
         return &o;
     }
 };
@@ -4330,7 +4335,8 @@ template <int F, int Z> struct ImplWideBf16 {
     }
     static int wide_fwd(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
                         hipStream_t s) {
-        if (!bf16_train_on()) return W::wide_fwd(h, x, rows, y, dz_last, loss_part, nblk, s);
+        // (small batches: the float32 split launches -- the bf16 launches give 32 rows to a wave that walks the whole wide dimension)
+        if (!bf16_train_on() || W::small_pass(h, rows)) return W::wide_fwd(h, x, rows, y, dz_last, loss_part, nblk, s);
         FusedState *st = state_of(h);
         if (st->wb_stale) { int rc = pack_extra(h, st, s); if (rc) return rc; }
         const int grid = grid_for(rows);
@@ -4351,7 +4357,7 @@ template <int F, int Z> struct ImplWideBf16 {
         return BAMD_OK;
     }
     static int wide_bwd(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, const float *dz_latent, hipStream_t s) {
-        if (!bf16_train_on()) return W::wide_bwd(h, rows, y, dz, dz_latent, s);
+        if (!bf16_train_on() || W::small_pass(h, rows)) return W::wide_bwd(h, rows, y, dz, dz_latent, s);
         FusedState *st = state_of(h);
         if (st->wb_stale) { int rc = pack_extra(h, st, s); if (rc) return rc; }
         if constexpr (F % 4 == 0) {
@@ -4372,7 +4378,7 @@ template <int F, int Z> struct ImplWideBf16 {
         return BAMD_OK;
     }
     static const FusedOps *ops() {
-        static const FusedOps o = {setup, encode, decode, W::forward_loss, nullptr, nullptr, wide_fwd, wide_bwd, pack_extra};
+        static const FusedOps o = {setup, encode, decode, W::forward_loss, nullptr, nullptr, wide_fwd, wide_bwd, pack_extra, true, W::small_pass};
         return &o;
     }
 };
@@ -4607,6 +4613,13 @@ int fused_wide_train_forward(bamd_handle *h, const float *x, int64_t rows, float
 }
 // BF16 handles of a wide model whose last layer's weight gradient runs on dw_wide_bf16_k: dL/drecon (the largest array of the pass)
 // is stored as bfloat16 by the forward launch and read as such by the backward launch and that kernel
+// this batch of a wide model runs on the split (small-batch) float32 launches -- also on a BF16 handle, whose weight-gradient kernels
+// then read float32 activations / gradients
+bool fused_wide_small(const bamd_handle *h, int64_t rows) {
+    if (!fused_wide_train(h)) return false;
+    const FusedOps *o = ((const FusedState *)h->fused_state)->ops;
+    return o->wide_small && o->wide_small(h, rows);
+}
 void fused_wide_set_dz16(bamd_handle *h, bool on) {
     if (h->fused_ok && h->fused_state) ((FusedState *)h->fused_state)->dz16 = on;
 }

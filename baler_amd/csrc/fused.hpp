@@ -31,6 +31,7 @@ bool fused_wide_train(const bamd_handle *h);
 int fused_wide_train_forward(bamd_handle *h, const float *x, int64_t rows, float *const *y, float *dz_last, double *loss_part, int *nblk,
                              hipStream_t s);
 void fused_wide_set_dz16(bamd_handle *h, bool on);
+bool fused_wide_small(const bamd_handle *h, int64_t rows);      // this batch runs on the split float32 launches (also on a BF16 handle)
 int fused_wide_train_backward(bamd_handle *h, int64_t rows, float *const *y, float *const *dz, const float *dz_latent, hipStream_t s);
 // fp64 small-batch step (fused64.hip): chain + weight-gradient tiles on v_mfma_f64_16x16x4_f64 for BAMD_MODE_F64 handles
 int fused64_setup(bamd_handle *h);               // leaves h->fused64_state null for shapes without an instantiation

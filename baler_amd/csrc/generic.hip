@@ -1375,10 +1375,11 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
         const bool wide = sizeof(T) == 4 && fused_wide_train(h);
         // BF16 handles: dL/drecon stored as bfloat16 when its two readers take it that way (BALER_AMD_BF16_DZ16=0: float32)
         bool dz16 = false;
+        const bool small_wide = wide && fused_wide_small(h, rows);      // (a BF16 handle's small batches run the float32 split launches)
         if constexpr (sizeof(T) == 4) {
             const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN"), *e16 = getenv("BALER_AMD_BF16_DZ16");
             const int ll = h->L - 1;
-            dz16 = wide && h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0') && !(e16 && e16[0] == '0') && sp.ok && sp.wide[ll] &&
+            dz16 = wide && !small_wide && h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0') && !(e16 && e16[0] == '0') && sp.ok && sp.wide[ll] &&
                    !sp.p_is_n[ll] && h->dims[ll + 1] % 4 == 0;
             if (wide) fused_wide_set_dz16(h, dz16);
         }
@@ -1421,7 +1422,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
         if constexpr (sizeof(T) == 4) {
             static const int64_t lim = getenv("BALER_AMD_DW_SMALL_ROWS") ? atoll(getenv("BALER_AMD_DW_SMALL_ROWS")) : 768;      // (C4: 512 rows 226 -> 180 us, 1024 rows 235 -> 237)
             const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
-            const bool bf16 = h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0');
+            const bool bf16 = h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0') && !small_wide;
             if (wide && !bf16 && rows <= lim && h->L <= 8) {
                 SmallDwPlan pl{};
                 pl.L = h->L;
@@ -1447,7 +1448,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
             if (sp.ok) {
                 if constexpr (sizeof(T) == 4) {
                     const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
-                    const bool bf16 = wide && h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0');
+                    const bool bf16 = wide && !small_wide && h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0');
                     run_dw_short(sp, l, dz, l == 0 ? x0 : wk.y[l], N, K, rows, slabs, bf16, dz16 && l == h->L - 1, s);
                 }
             } else {
