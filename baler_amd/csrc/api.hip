@@ -351,6 +351,13 @@ int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, 
         if (rc) return rc;
         grads = h->gscratch.p;
     }
+    if (n_rows > 0 && h->fused_ok && h->mode != BAMD_MODE_F64) {      // wide models, small batches: Adam inside the weight-gradient launch
+        int rc = generic_small_train_step(h, x, x_dtype, n_rows, features, grads, params, m, v, *hp, loss_accum, s);
+        if (rc != BAMD_ERR_UNSUPPORTED) {
+            if (rc == BAMD_OK) fused_params_changed(h);
+            return rc;
+        }
+    }
     int rc = bamd_fwd_bwd(h, x, x_dtype, n_rows, features, grads, stream);
     if (rc) return rc;
     return bamd_adam_step(h, params, grads, m, v, hp, loss_accum, stream);

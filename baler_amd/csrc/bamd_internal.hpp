@@ -105,7 +105,9 @@ int generic_forward_loss(bamd_handle *h, const void *x, int x_dtype, int64_t n,
                          hipStream_t s);
 int generic_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
                     void *grads, hipStream_t s,
-                    const void *latent_grad = nullptr);   // latent_grad: (n, z_dim) of the compute type, added to dL/dz
+                    const void *latent_grad = nullptr);
+int generic_small_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, void *params,
+                             void *m, void *v, const bamd_adam &hp, double *loss_accum, hipStream_t s);   // latent_grad: (n, z_dim) of the compute type, added to dL/dz
 int generic_activation_means(bamd_handle *h, const void *x, int x_dtype, int64_t n,
                              const double *features, double *out, int max_nodes, hipStream_t s);
 

@@ -1283,13 +1283,27 @@ static void run_dw_short(const ShortPlan &pl, int l, const float *dz, const floa
 // reduction for ~0.3 GFLOP were 101 + 5 of the step's 220 us.  Here ONE wave owns a 16 x 16 tile of [dW | db] = dZ^T [X | 1] of one
 // layer and contracts over ALL rows of the batch (operands in MFMA layout straight from the row-major matrices, as dw_short_k: the
 // reduction index of v_mfma_f32_16x16x4_f32 is the row); results go straight to the canonical gradient vector (= or +=).
+static int64_t dw_small_rows() {      // BALER_AMD_DW_SMALL_ROWS (C4: 512 rows 226 -> 180 us, 1024 rows 235 -> 237 with the one launch)
+    static const int64_t lim = getenv("BALER_AMD_DW_SMALL_ROWS") ? atoll(getenv("BALER_AMD_DW_SMALL_ROWS")) : 768;
+    return lim;
+}
 struct SmallDwPlan {
     const float *dz[8], *x[8];
     int N[8], K[8], kt[8], tile0[9];       // tiles of layer l: [tile0[l], tile0[l + 1]) = nt(l) x kt(l), index = nt * kt(l) + kt
     int64_t w_off[8], b_off[8];
     int L;
 };
-__global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan pl, int64_t rows, float *__restrict__ grads, int accumulate) {
+// `ad.on`: the optimiser step of exactly these parameters in the same launch (elementwise.hip adam_k's arithmetic, operation for
+// operation: bamd_train_step == bamd_fwd_bwd + bamd_adam_step to the last bit), the refresh of their packed copies included
+struct SmallAdam {
+    float *p, *pcopy, *m, *v, *packed;
+    const int *sc_off, *sc_idx;
+    double *loss_accum;
+    double b1, b2, eps, step_size, bc2_sqrt;
+    int64_t np;
+    int on;
+};
+__global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan pl, int64_t rows, float *__restrict__ grads, int accumulate, SmallAdam ad) {
     using v4 = MF<float>::v4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x * 4 + wave;
@@ -1326,23 +1340,52 @@ __global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan pl, int64_t ro
         for (int s4 = 0; s4 < 4; ++s4) acc = MF<float>::mma(a0[s4], b0[s4], acc);
     }
     // C map: register r of lane (i, g) = [dZ column 16 nt + 4 g + r][X column 16 kt + i]
+    int64_t pidx[4];
+    float gv[4], pm[4], pv[4], pp[4];
+    int so0[4], so1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {      // every load of the four elements first (the optimiser state is four dependent round trips otherwise)
+        const int n = 16 * nt + 4 * g + r;
+        pidx[r] = -1;
+        if (n < N && kcol < K) pidx[r] = pl.w_off[l] + (int64_t)n * K + kcol;
+        else if (n < N && kcol == K) pidx[r] = pl.b_off[l] + n;
+        const int64_t q = pidx[r] < 0 ? 0 : pidx[r];
+        gv[r] = accumulate ? grads[q] + acc[r] : acc[r];
+        if (ad.on) {
+            pm[r] = ad.m[q]; pv[r] = ad.v[q]; pp[r] = ad.p[q];
+            so0[r] = ad.packed ? ad.sc_off[q] : 0; so1[r] = ad.packed ? ad.sc_off[q + 1] : 0;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int n = 16 * nt + 4 * g + r;
-        if (n >= N) continue;
-        float *dst = nullptr;
-        if (kcol < K) dst = grads + pl.w_off[l] + (int64_t)n * K + kcol;
-        else if (kcol == K) dst = grads + pl.b_off[l] + n;
-        if (dst) *dst = accumulate ? *dst + acc[r] : acc[r];
+        if (pidx[r] < 0) continue;
+        grads[pidx[r]] = gv[r];
+        if (ad.on) {
+            const double gi = (double)gv[r];
+            double mi = (double)pm[r], vi = (double)pv[r];
+            mi = mi + (gi - mi) * (1.0 - ad.b1);
+            vi = vi * ad.b2 + (1.0 - ad.b2) * gi * gi;
+            const double denom = sqrt(vi) / ad.bc2_sqrt + ad.eps;
+            const double pn = (double)pp[r] - ad.step_size * (mi / denom);
+            ad.m[pidx[r]] = (float)mi;
+            ad.v[pidx[r]] = (float)vi;
+            ad.p[pidx[r]] = (float)pn;
+            if (ad.pcopy) ad.pcopy[pidx[r]] = (float)pn;
+            for (int k = so0[r]; k < so1[r]; ++k) ad.packed[ad.sc_idx[k]] = (float)pn;
+        }
     }
+    if (ad.on && ad.loss_accum && tile == 0 && lane == 0) *ad.loss_accum += (double)grads[ad.np];      // (loss_final_k ran before this launch)
 }
 
 template <typename T>
 static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
-                     void *grads_v, const void *latent_grad, hipStream_t s) {
+                     void *grads_v, const void *latent_grad, hipStream_t s, const SmallAdam *adam = nullptr) {
     Work<T> wk;
     int rc = carve<T>(h, n, true, wk);
     if (rc) return rc;
+    // `adam`: the caller wants the optimiser step in the weight-gradient launch: one chunk of a small float32 batch only
+    if (adam && !(sizeof(T) == 4 && wk.chunk >= n && fused_wide_train(h) && fused_wide_small(h, n) && n <= dw_small_rows() && h->L <= 8))
+        return BAMD_ERR_UNSUPPORTED;
     const T *P = (const T *)h->params.p;
     T *grads = (T *)grads_v;
     int c = h->dims[0];
@@ -1420,7 +1463,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
         // small float32 batches of a model on the fused row-local launches: every weight gradient in ONE launch, straight into `grads`
         bool dw_small = false;
         if constexpr (sizeof(T) == 4) {
-            static const int64_t lim = getenv("BALER_AMD_DW_SMALL_ROWS") ? atoll(getenv("BALER_AMD_DW_SMALL_ROWS")) : 768;      // (C4: 512 rows 226 -> 180 us, 1024 rows 235 -> 237)
+            const int64_t lim = dw_small_rows();
             const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
             const bool bf16 = h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0') && !small_wide;
             if (wide && !bf16 && rows <= lim && h->L <= 8) {
@@ -1437,7 +1480,9 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                     pl.w_off[l] = h->w_off[l]; pl.b_off[l] = h->b_off[l];
                 }
                 pl.tile0[h->L] = t0;
-                hipLaunchKernelGGL(dw_small_all_k, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, pl, rows, (float *)grads, chunk_i > 0 ? 1 : 0);
+                SmallAdam sa{};
+                if (adam) sa = *adam;
+                hipLaunchKernelGGL(dw_small_all_k, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, pl, rows, (float *)grads, chunk_i > 0 ? 1 : 0, sa);
                 dw_small = true;
             }
         }
@@ -1488,6 +1533,27 @@ int generic_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const
                     void *grads, hipStream_t s, const void *latent_grad) {
     if (h->esize == 8) return fwd_bwd_T<double>(h, x, x_dtype, n, features, grads, latent_grad, s);
     return fwd_bwd_T<float>(h, x, x_dtype, n, features, grads, latent_grad, s);
+}
+
+// bamd_train_step of a small float32 batch of a wide model: forward + loss + backward + weight gradients + Adam, the optimiser step inside
+// the one weight-gradient launch (BAMD_ERR_UNSUPPORTED: not such a batch -- the caller runs fwd_bwd and the Adam kernel)
+int generic_small_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, void *params,
+                             void *m, void *v, const bamd_adam &hp, double *loss_accum, hipStream_t s) {
+    if (h->esize != 4) return BAMD_ERR_UNSUPPORTED;
+    static const bool on = !(getenv("BALER_AMD_SMALL_ADAM") && getenv("BALER_AMD_SMALL_ADAM")[0] == '0');
+    if (!on) return BAMD_ERR_UNSUPPORTED;
+    SmallAdam sa{};
+    sa.p = (float *)params; sa.pcopy = (float *)h->params.p; sa.m = (float *)m; sa.v = (float *)v;
+    void *packed = nullptr;
+    fused_scatter(h, &sa.sc_off, &sa.sc_idx, &packed);
+    sa.packed = (float *)packed;
+    sa.loss_accum = loss_accum;
+    sa.b1 = hp.beta1; sa.b2 = hp.beta2; sa.eps = hp.eps;                    // the scalars of launch_adam (elementwise.hip)
+    sa.step_size = hp.lr / (1.0 - pow(hp.beta1, (double)hp.step));
+    sa.bc2_sqrt = sqrt(1.0 - pow(hp.beta2, (double)hp.step));
+    sa.np = h->nparams;
+    sa.on = 1;
+    return fwd_bwd_T<float>(h, x, x_dtype, n, features, grads, nullptr, s, &sa);
 }
 
 template <typename T>

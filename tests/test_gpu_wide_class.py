@@ -253,6 +253,19 @@ def test_wide_models_small_training_batches(shape, monkeypatch):
         assert rel(gh[:-1], go) < 2 * TOL32 and abs(gh[-1] - lo) < TOL32 * lo, (F, n, rel(gh[:-1], go))
     x = dev(off_the_kink(dims, flat, 60, 7), torch.float32)
     m, v = torch.zeros_like(p), torch.zeros_like(p)
+    # the one-call step (Adam inside the weight-gradient launch) == fwd_bwd + adam_step, bit for bit, over two steps, loss sum included
+    h2, p2 = make_handle(dims, flat, "fp32")
+    m2, v2, g2 = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+    la, lb = torch.zeros(1, dtype=torch.float64, device="cuda"), torch.zeros(1, dtype=torch.float64, device="cuda")
+    pa, ma, va = p.clone(), m.clone(), v.clone()
+    for t in (1, 2):
+        h.train_step(x, pa, ma, va, t, 1e-3, loss_accum=la)
+        h2.fwd_bwd(x, g2)
+        h2.adam_step(p2, g2, m2, v2, t, 1e-3, loss_accum=lb)
+    assert torch.equal(pa, p2) and torch.equal(ma, m2) and torch.equal(va, v2) and torch.equal(la, lb)
+    assert rel(h.encode(x, out_dtype=torch.float32).cpu().numpy(), h2.encode(x, out_dtype=torch.float32).cpu().numpy()) == 0.0
+    h2.close()
+    h.load_params(p)
     h.train_step(x, p, m, v, 1, 1e-3)
     lo, go = orc.fwd_bwd(dims, flat, x.cpu().numpy().astype(np.float64))
     pn, mm, vv = flat.copy(), np.zeros_like(flat), np.zeros_like(flat)
