@@ -1754,7 +1754,7 @@ __global__ void __launch_bounds__(256) wide_train_fwd_kernel(const v4 *packed, c
             fwd_layer<N, S, 5>(a5, a6, ring, ws, bias_lds, lane);
             if (TRAIN) store_rows<100>(a6, y6, 0, row, valid, lane, nullptr, nullptr);
             fwd_layer<N, S, 6>(a6, a7, ring, ws, bias_lds, lane);
-            if (TRAIN) store_rows<200>(a7, y7, 0, row, valid, lane, nullptr, nullptr);
+            if (TRAIN || MID) store_rows<200>(a7, y7, 0, row, valid, lane, nullptr, nullptr);      // (MID: wide_small_out_kernel reads it)
         }
         if constexpr (MID) continue;
         // de4 + loss: the x tiles are re-read three tiles ahead of the tile being multiplied, like the fragments (HBM again:
@@ -1816,9 +1816,10 @@ __global__ void __launch_bounds__(256) wide_small_in_kernel(const v4 *wfrag /* [
     for (int t = 0; t < 13; ++t) pp[t * 64] = acc[t];
 }
 // de4 + loss + dz8 of output tiles [blockIdx.x tps, ..) of row group blockIdx.y (y7 from the MID forward launch)
-template <int F, int Z, bool WRT = false>
+// TRAIN = false (the validation pass): `dz8` (may be null) receives the reconstruction itself as float32 / float64
+template <int F, int Z, bool WRT = false, bool TRAIN = true>
 __global__ void __launch_bounds__(256) wide_small_out_kernel(const v4 *packed, const float *__restrict__ x, int64_t n, const float *__restrict__ y7,
-                                                             float *__restrict__ dz8, double *__restrict__ loss_part, int tps, int fr) {
+                                                             void *__restrict__ dz8, double *__restrict__ loss_part, int tps, int fr, int out_f64 = 0) {
     using N = Net<F, Z>;
     const int KC = WRT ? (fr + 15) / 16 : tiles(F);
     __shared__ __attribute__((aligned(16))) v4 wst[2][13][64];
@@ -1850,7 +1851,8 @@ __global__ void __launch_bounds__(256) wide_small_out_kernel(const v4 *packed, c
             const v4 d = o - xr[SL];
             if (valid) {
                 lacc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
-                wide_store_tile<F, FL, WRT>(d * gscale, dz8, 0, row, t, g, fr);
+                if (TRAIN) wide_store_tile<F, FL, WRT>(d * gscale, dz8, 0, row, t, g, fr);
+                else if (dz8) wide_store_tile<F, FL, WRT>(o, dz8, out_f64, row, t, g, fr);
             }
         }, fr, t0, t1);
     sh[threadIdx.x] = lacc;
@@ -4083,7 +4085,7 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
             hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, true, WRT, true>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, y[1], y[2],
                                y[3], y[4], y[5], y[6], y[7], (void *)dz_last, 0, loss_part, fr, Zr(h), (const v4 *)st->wpart.p, s_in);
             hipLaunchKernelGGL((wide_small_out_kernel<F, Z, WRT>), dim3(s_out, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, (const float *)y[7],
-                               dz_last, loss_part, tps, fr);
+                               (void *)dz_last, loss_part, tps, fr, 0);
             *nblk = s_out * ngroup;
             BAMD_HIP(hipGetLastError());
             return BAMD_OK;
@@ -4116,9 +4118,28 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
                 src = h->work.p;
             }
             const int grid = grid_for(rows);
+            void *rdst = recon ? (void *)((char *)recon + (size_t)r0 * fr * oes) : nullptr;
+            if (small_pass(h, rows)) {      // validation batches of the reference's sizes (60 rows ...): the split launches (see wide_fwd)
+                FusedState *st = state_of(h);
+                int cps = 0, tps = 0;
+                const int ngroup = (int)((rows + 63) / 64);
+                const int s_in = small_splits(h, rows, fr / 16, &cps), s_out = small_splits(h, rows, (fr + 15) / 16, &tps);
+                rc = st->wpart.ensure((size_t)s_in * ngroup * 4 * 13 * 64 * sizeof(v4) + (size_t)ngroup * 64 * 200 * sizeof(float));
+                if (rc) return rc;
+                float *y7 = (float *)((char *)st->wpart.p + (size_t)s_in * ngroup * 4 * 13 * 64 * sizeof(v4));
+                hipLaunchKernelGGL((wide_small_in_kernel<F, WRT>), dim3(s_in, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p + N::wf_off(0), N::wcount(0),
+                                   (const float *)src, rows, (v4 *)st->wpart.p, cps, fr);
+                hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, false, WRT, true>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
+                                   rows, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, y7,
+                                   (void *)nullptr, 0, (double *)nullptr, fr, zr, (const v4 *)st->wpart.p, s_in);
+                hipLaunchKernelGGL((wide_small_out_kernel<F, Z, WRT, false>), dim3(s_out, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
+                                   rows, (const float *)y7, rdst, (double *)h->lossp.p + nblk, tps, fr, recon_dtype == BAMD_F64 ? 1 : 0);
+                nblk += s_out * ngroup;
+                continue;
+            }
             hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, false, WRT>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
                                rows, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr,
-                               (float *)nullptr, (float *)nullptr, recon ? (void *)((char *)recon + (size_t)r0 * fr * oes) : nullptr,
+                               (float *)nullptr, (float *)nullptr, rdst,
                                recon_dtype == BAMD_F64, (double *)h->lossp.p + nblk, fr, zr);
             nblk += grid;
         }

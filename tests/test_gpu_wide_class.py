@@ -251,6 +251,12 @@ def test_wide_models_small_training_batches(shape, monkeypatch):
         assert torch.equal(g, g2)
         gh = g.cpu().numpy().astype(np.float64)
         assert rel(gh[:-1], go) < 2 * TOL32 and abs(gh[-1] - lo) < TOL32 * lo, (F, n, rel(gh[:-1], go))
+        # the validation pass of the same batch (training.py:104-137) on the split launches: reconstruction (float32 / float64) and loss
+        want = orc.forward(dims, flat, x.astype(np.float64))
+        for od in (torch.float32, torch.float64):      # (the reconstruction has the rows' type)
+            recon, loss = h.forward_loss(dev(x, od))
+            assert recon.dtype == od and rel(recon.cpu().numpy(), want) < TOL32, (F, n, od)
+            assert abs(loss.item() - ((want - x) ** 2).sum() / F) < TOL32 * max(1.0, ((want - x) ** 2).sum() / F)
     x = dev(off_the_kink(dims, flat, 60, 7), torch.float32)
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     # the one-call step (Adam inside the weight-gradient launch) == fwd_bwd + adam_step, bit for bit, over two steps, loss sum included
