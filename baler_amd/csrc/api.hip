@@ -351,7 +351,7 @@ int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, 
         if (rc) return rc;
         grads = h->gscratch.p;
     }
-    if (n_rows > 0 && h->fused_ok && h->mode != BAMD_MODE_F64) {      // wide models, small batches: Adam inside the weight-gradient launch
+    if (n_rows > 0 && h->mode != BAMD_MODE_F64 && !bf16_kernels_train(h, n_rows)) {      // small batches on the layer-wise / wide launches: Adam inside the weight-gradient launch
         int rc = generic_small_train_step(h, x, x_dtype, n_rows, features, grads, params, m, v, *hp, loss_accum, s);
         if (rc != BAMD_ERR_UNSUPPORTED) {
             if (rc == BAMD_OK) fused_params_changed(h);

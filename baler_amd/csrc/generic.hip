@@ -377,6 +377,49 @@ __global__ void fill_nan_k(double *p, int n) {
     if (i < n) p[i] = NAN;
 }
 
+// ---- few rows (the reference's batch sizes on the layer-wise path: CFD configs 1 .. 85 rows in float64) -----------------------------
+// The tiled kernels above give a 64 x 64 / 128 x 128 output tile to a workgroup that walks the whole contraction: a 60 x 200 product
+// over K = 2500 is FOUR workgroups on a 256-CU chip (~40 us per launch, 35 launches per step).  Here a workgroup owns ONE 16 x 16 output
+// tile, its four waves take a quarter of the contraction each (operands in MFMA layout straight from memory, `kSmallPF` steps of loads
+// ahead of the MFMAs) and add their partial tiles through LDS in wave order (fixed: reproducible); FWD / FWD_LOSS / DX epilogues as above.
+constexpr int kSmallPF = 8;
+template <typename T, int EPI>
+__global__ void __launch_bounds__(256) gemm_small_k(Opnd<T> A, Opnd<T> B, int64_t kred, Epi<T> e) {
+    using v4 = typename MF<T>::v4;
+    __shared__ __attribute__((aligned(16))) v4 red[3][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, o = lane & 15, kg = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.y * 16, j0 = (int64_t)blockIdx.x * 16;
+    const int64_t steps = (kred + 3) / 4, per = (steps + 3) / 4;               // contraction steps of four; this wave's range
+    const int64_t s_lo = w * per, s_hi = s_lo + per < steps ? s_lo + per : steps;
+    v4 acc = (v4){0, 0, 0, 0};
+    T a[kSmallPF], b[kSmallPF];
+    for (int64_t st = s_lo; st < s_hi; st += kSmallPF) {
+#pragma unroll
+        for (int u = 0; u < kSmallPF; ++u) {
+            const int64_t k = (st + u) * 4 + kg;
+            const bool ok = st + u < s_hi;
+            a[u] = ok ? A.get(i0 + o, k, kred) : (T)0;
+            b[u] = ok ? B.get(j0 + o, k, kred) : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < kSmallPF; ++u) acc = MF<T>::mma(a[u], b[u], acc);
+    }
+    if (w > 0) red[w - 1][lane] = acc;
+    __syncthreads();
+    double lsum = 0.0;
+    if (w == 0) {
+        acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) epilogue<T, EPI>(e, i0 + MF<T>::crow(reg, lane), j0 + o, acc[reg], lsum);
+    }
+    if (EPI == EPI_FWD_LOSS) block_loss(lsum, e.loss_part);
+}
+static int64_t gemm_small_rows() {      // BALER_AMD_GEMM_SMALL_ROWS: most rows for the one-tile-per-workgroup kernel (0: off)
+    // (C4 in float32, layer-wise step: 256 rows 965 -> 195 us, 512: 1004 -> 281, 1024: 1052 -> 477)
+    static const int64_t lim = getenv("BALER_AMD_GEMM_SMALL_ROWS") ? atoll(getenv("BALER_AMD_GEMM_SMALL_ROWS")) : 1024;
+    return lim;
+}
+
 // pick the tile: 128 x 128 (double-buffered) when both outer extents are large enough, else 64 x 64
 template <typename T, int EPI, bool AK, bool BK>
 static void launch_gemm(const Opnd<T> &A, const Opnd<T> &B, int64_t kred, const Epi<T> &e, int64_t outer_a, int64_t outer_b,
@@ -385,6 +428,13 @@ static void launch_gemm(const Opnd<T> &A, const Opnd<T> &B, int64_t kred, const 
     // kernel's element-wise K-slow loads made them the slowest launches of a CFD_dense_AE step (103 us each for 0.2 GFLOP);
     // the big-tile kernel skips its dead 16-wide sub-tiles and loads 16 bytes per lane
     const bool long_dw = EPI == EPI_DW && kred >= 4096 && outer_a >= 16 && outer_b >= 16;
+    if constexpr (EPI != EPI_DW) {
+        if (outer_a <= gemm_small_rows()) {      // (outer_a = the rows of the batch in the forward and input-gradient products)
+            dim3 grid((unsigned)((outer_b + 15) / 16), (unsigned)((outer_a + 15) / 16), 1);
+            hipLaunchKernelGGL((gemm_small_k<T, EPI>), grid, dim3(256), 0, s, A, B, kred, e);
+            return;
+        }
+    }
     if ((outer_a >= 96 && outer_b >= 96) || long_dw) {
         const int lds = 4 * 128 * 20 * (int)sizeof(T);
         static bool attr_set = false;
@@ -1287,24 +1337,26 @@ static int64_t dw_small_rows() {      // BALER_AMD_DW_SMALL_ROWS (C4: 512 rows 2
     static const int64_t lim = getenv("BALER_AMD_DW_SMALL_ROWS") ? atoll(getenv("BALER_AMD_DW_SMALL_ROWS")) : 768;
     return lim;
 }
-struct SmallDwPlan {
-    const float *dz[8], *x[8];
+template <typename T> struct SmallDwPlan {
+    const T *dz[8], *x[8];
     int N[8], K[8], kt[8], tile0[9];       // tiles of layer l: [tile0[l], tile0[l + 1]) = nt(l) x kt(l), index = nt * kt(l) + kt
     int64_t w_off[8], b_off[8];
     int L;
 };
 // `ad.on`: the optimiser step of exactly these parameters in the same launch (elementwise.hip adam_k's arithmetic, operation for
 // operation: bamd_train_step == bamd_fwd_bwd + bamd_adam_step to the last bit), the refresh of their packed copies included
-struct SmallAdam {
-    float *p, *pcopy, *m, *v, *packed;
+template <typename T> struct SmallAdamT {
+    T *p, *pcopy, *m, *v, *packed;
     const int *sc_off, *sc_idx;
     double *loss_accum;
     double b1, b2, eps, step_size, bc2_sqrt;
     int64_t np;
     int on;
 };
-__global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan pl, int64_t rows, float *__restrict__ grads, int accumulate, SmallAdam ad) {
-    using v4 = MF<float>::v4;
+using SmallAdam = SmallAdamT<float>;
+template <typename T>
+__global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan<T> pl, int64_t rows, T *__restrict__ grads, int accumulate, SmallAdamT<T> ad) {
+    using v4 = typename MF<T>::v4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= pl.tile0[pl.L]) return;
@@ -1314,38 +1366,38 @@ __global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan pl, int64_t ro
     const int N = pl.N[l], K = pl.K[l], KT = pl.kt[l];
     const int t = tile - pl.tile0[l], nt = t / KT, kt = t - nt * KT;
     const int ncol = 16 * nt + i, kcol = 16 * kt + i;                 // this lane's dZ column (A operand) / X column (B operand)
-    const float *pa = pl.dz[l] + (ncol < N ? ncol : N - 1);
-    const float *pb = pl.x[l] + (kcol < K ? kcol : K - 1);
+    const T *pa = pl.dz[l] + (ncol < N ? ncol : N - 1);
+    const T *pb = pl.x[l] + (kcol < K ? kcol : K - 1);
     const bool a_live = ncol < N, b_live = kcol < K, b_one = kcol == K;
-    v4 acc = (v4){0.f, 0.f, 0.f, 0.f};
-    float a[4], b[4];
+    v4 acc = (v4){0, 0, 0, 0};
+    T a[4], b[4];
     auto load = [&](int64_t r0) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int64_t r = r0 + 4 * s4 + g;
             const bool ok = r < rows;
             const int64_t rr = ok ? r : rows - 1;
-            const float av = pa[rr * N], bv = pb[rr * K];
-            a[s4] = (ok && a_live) ? av : 0.f;
-            b[s4] = b_one ? 1.0f : (b_live ? bv : 0.f);
+            const T av = pa[rr * N], bv = pb[rr * K];
+            a[s4] = (ok && a_live) ? av : (T)0;
+            b[s4] = b_one ? (T)1 : (b_live ? bv : (T)0);
         }
     };
     load(0);
     for (int64_t r0 = 0; r0 < rows; r0 += 16) {
-        float a0[4], b0[4];
+        T a0[4], b0[4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) { a0[s4] = a[s4]; b0[s4] = b[s4]; }
         if (r0 + 16 < rows) load(r0 + 16);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc = MF<float>::mma(a0[s4], b0[s4], acc);
+        for (int s4 = 0; s4 < 4; ++s4) acc = MF<T>::mma(a0[s4], b0[s4], acc);
     }
-    // C map: register r of lane (i, g) = [dZ column 16 nt + 4 g + r][X column 16 kt + i]
+    // C map: register r of lane (i, g) = [dZ column 16 nt + crow(r)][X column 16 kt + i] (crow: 4 g + r in float32, g + 4 r in float64)
     int64_t pidx[4];
-    float gv[4], pm[4], pv[4], pp[4];
+    T gv[4], pm[4], pv[4], pp[4];
     int so0[4], so1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {      // every load of the four elements first (the optimiser state is four dependent round trips otherwise)
-        const int n = 16 * nt + 4 * g + r;
+        const int n = 16 * nt + MF<T>::crow(r, lane);
         pidx[r] = -1;
         if (n < N && kcol < K) pidx[r] = pl.w_off[l] + (int64_t)n * K + kcol;
         else if (n < N && kcol == K) pidx[r] = pl.b_off[l] + n;
@@ -1367,11 +1419,11 @@ __global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan pl, int64_t ro
             vi = vi * ad.b2 + (1.0 - ad.b2) * gi * gi;
             const double denom = sqrt(vi) / ad.bc2_sqrt + ad.eps;
             const double pn = (double)pp[r] - ad.step_size * (mi / denom);
-            ad.m[pidx[r]] = (float)mi;
-            ad.v[pidx[r]] = (float)vi;
-            ad.p[pidx[r]] = (float)pn;
-            if (ad.pcopy) ad.pcopy[pidx[r]] = (float)pn;
-            for (int k = so0[r]; k < so1[r]; ++k) ad.packed[ad.sc_idx[k]] = (float)pn;
+            ad.m[pidx[r]] = (T)mi;
+            ad.v[pidx[r]] = (T)vi;
+            ad.p[pidx[r]] = (T)pn;
+            if (ad.pcopy) ad.pcopy[pidx[r]] = (T)pn;
+            for (int k = so0[r]; k < so1[r]; ++k) ad.packed[ad.sc_idx[k]] = (T)pn;
         }
     }
     if (ad.on && ad.loss_accum && tile == 0 && lane == 0) *ad.loss_accum += (double)grads[ad.np];      // (loss_final_k ran before this launch)
@@ -1380,12 +1432,15 @@ __global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan pl, int64_t ro
 template <typename T>
 static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
                      void *grads_v, const void *latent_grad, hipStream_t s, const SmallAdam *adam = nullptr) {
+    // `adam`: the caller wants the optimiser step in the weight-gradient launch: one chunk of a small float32 batch only
+    // (checked before the workspace is carved: a large batch of a fused shape only asks)
+    if (adam && !(sizeof(T) == 4 && n <= dw_small_rows() && h->L <= 8 &&
+                  !(h->mode == BAMD_MODE_BF16 && fused_wide_train(h) && !fused_wide_small(h, n))))
+        return BAMD_ERR_UNSUPPORTED;
     Work<T> wk;
     int rc = carve<T>(h, n, true, wk);
     if (rc) return rc;
-    // `adam`: the caller wants the optimiser step in the weight-gradient launch: one chunk of a small float32 batch only
-    if (adam && !(sizeof(T) == 4 && wk.chunk >= n && fused_wide_train(h) && fused_wide_small(h, n) && n <= dw_small_rows() && h->L <= 8))
-        return BAMD_ERR_UNSUPPORTED;
+    if (adam && wk.chunk < n) return BAMD_ERR_UNSUPPORTED;
     const T *P = (const T *)h->params.p;
     T *grads = (T *)grads_v;
     int c = h->dims[0];
@@ -1415,7 +1470,10 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
             if (rc) return rc;
         }
         // wide models in float32: the row-local work (forward, loss, input-gradient chain) as two fused launches (fused.hip)
-        const bool wide = sizeof(T) == 4 && fused_wide_train(h);
+        // (BALER_AMD_WIDE_LAYERWISE_ROWS, default 0 = never: up to that many rows the one-tile-per-workgroup kernels of this file would take
+        // every layer of a wide model too -- measured: C4 optimiser step at 60 rows 148 us against 125 on the split launches of fused.hip)
+        static const int64_t lw_rows = getenv("BALER_AMD_WIDE_LAYERWISE_ROWS") ? atoll(getenv("BALER_AMD_WIDE_LAYERWISE_ROWS")) : 0;
+        const bool wide = sizeof(T) == 4 && fused_wide_train(h) && !(rows <= lw_rows && rows <= gemm_small_rows() && h->mode != BAMD_MODE_BF16);
         // BF16 handles: dL/drecon stored as bfloat16 when its two readers take it that way (BALER_AMD_BF16_DZ16=0: float32)
         bool dz16 = false;
         const bool small_wide = wide && fused_wide_small(h, rows);      // (a BF16 handle's small batches run the float32 split launches)
@@ -1440,7 +1498,7 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 // loss pass re-read r and x and wrote dz: 1 GB for 32k CFD frames)
                 const int l = h->L - 1, K = h->dims[l], N = h->dims[l + 1];
                 const bool big = rows >= 96 && N >= 96;
-                const int64_t tile = big ? 128 : 64;
+                const int64_t tile = rows <= gemm_small_rows() ? 16 : (big ? 128 : 64);      // (as launch_gemm picks)
                 nblk = (int)(((N + tile - 1) / tile) * ((rows + tile - 1) / tile));
                 rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk > 1024 ? nblk : 1024));
                 if (rc) return rc;
@@ -1462,35 +1520,17 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
         }
         // small float32 batches of a model on the fused row-local launches: every weight gradient in ONE launch, straight into `grads`
         bool dw_small = false;
-        if constexpr (sizeof(T) == 4) {
-            const int64_t lim = dw_small_rows();
+        {
             const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
             const bool bf16 = h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0') && !small_wide;
-            if (wide && !bf16 && rows <= lim && h->L <= 8) {
-                SmallDwPlan pl{};
-                pl.L = h->L;
-                int t0 = 0;
-                for (int l = 0; l < h->L; ++l) {
-                    pl.dz[l] = (const float *)wk.dz[l];
-                    pl.x[l] = l == 0 ? (const float *)x0 : (const float *)wk.y[l];
-                    pl.N[l] = h->dims[l + 1]; pl.K[l] = h->dims[l];
-                    pl.kt[l] = (h->dims[l] + 1 + 15) / 16;
-                    pl.tile0[l] = t0;
-                    t0 += ((h->dims[l + 1] + 15) / 16) * pl.kt[l];
-                    pl.w_off[l] = h->w_off[l]; pl.b_off[l] = h->b_off[l];
-                }
-                pl.tile0[h->L] = t0;
-                SmallAdam sa{};
-                if (adam) sa = *adam;
-                hipLaunchKernelGGL(dw_small_all_k, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, pl, rows, (float *)grads, chunk_i > 0 ? 1 : 0, sa);
-                dw_small = true;
-            }
+            dw_small = !bf16 && rows <= dw_small_rows() && h->L <= 8;      // every weight gradient in ONE launch, behind the input-gradient chain
         }
-        for (int l = h->L - 1; l >= 0 && !dw_small; --l) {
+        for (int l = h->L - 1; l >= 0; --l) {
             int K = h->dims[l], N = h->dims[l + 1];
             const T *dz = wk.dz[l];
             // [dW | db] = dZ^T [X | 1], reduced over this chunk's rows in nsplit fixed slabs
-            if (sp.ok) {
+            if (dw_small) {
+            } else if (sp.ok) {
                 if constexpr (sizeof(T) == 4) {
                     const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
                     const bool bf16 = wide && !small_wide && h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0');
@@ -1514,6 +1554,24 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 if (latent_grad && l == h->L / 2) { e.add = (const T *)latent_grad + r0 * K; e.ld_add = K; }   // dL/dz of the caller's regulariser
                 launch_gemm<T, EPI_DX, true, false>(A, B, (int64_t)N, e, rows, K, 1, s);
             }
+        }
+        if (dw_small) {      // (any model on this path: the row-major activations / gradients are the same)
+            SmallDwPlan<T> pl{};
+            pl.L = h->L;
+            int t0 = 0;
+            for (int l = 0; l < h->L; ++l) {
+                pl.dz[l] = (const T *)wk.dz[l];
+                pl.x[l] = l == 0 ? (const T *)x0 : (const T *)wk.y[l];
+                pl.N[l] = h->dims[l + 1]; pl.K[l] = h->dims[l];
+                pl.kt[l] = (h->dims[l] + 1 + 15) / 16;
+                pl.tile0[l] = t0;
+                t0 += ((h->dims[l + 1] + 15) / 16) * pl.kt[l];
+                pl.w_off[l] = h->w_off[l]; pl.b_off[l] = h->b_off[l];
+            }
+            pl.tile0[h->L] = t0;
+            SmallAdamT<T> sa{};
+            if constexpr (sizeof(T) == 4) { if (adam) sa = *adam; }
+            hipLaunchKernelGGL(dw_small_all_k<T>, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, pl, rows, grads, chunk_i > 0 ? 1 : 0, sa);
         }
         if (dw_small) {
         } else if (sp.ok) {
