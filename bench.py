@@ -749,6 +749,22 @@ def other_configs(dev):
     res["c4_cfd_dense_2500_25"]["train_step_by_reference_batch_size"] = by
     hc.load_params(mc.flat)
     hc.close()
+    # ... and in the reference's own arithmetic (float64: the layer-wise kernels, one 16 x 16 tile per workgroup at these sizes)
+    from baler_amd import native as _native
+    h64 = _native.Handle([2500, 200, 100, 50, 25, 50, 100, 200, 2500], "fp64")
+    p64 = mc.flat.double()
+    h64.load_params(p64)
+    m64, v64 = torch.zeros_like(p64), torch.zeros_like(p64)
+    x64 = xc[:300].double()
+
+    def c64steps():
+        for i in range(10):
+            stc["t"] += 1
+            h64.train_step(x64[(i % 5) * 60:(i % 5 + 1) * 60], p64, m64, v64, stc["t"], 1e-3)
+    c64steps()
+    res["c4_cfd_dense_2500_25"]["train_step_by_reference_batch_size"]["60_float64"] = {"us_per_step": event_ms(c64steps, 3) * 1e3 / 10}
+    h64.close()
+    del p64, m64, v64, x64
     del gc, pc, mo_, vo_
     # the same model in the bf16 mode: en1 / de4 on the bf16 MFMA, HBM-bound (10 KB of float32 per frame)
     from baler_amd import native
