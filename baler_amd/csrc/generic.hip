@@ -1354,9 +1354,30 @@ template <typename T> struct SmallAdamT {
     int on;
 };
 using SmallAdam = SmallAdamT<float>;
+// The LAST workgroup is loss_final_k: the fixed-order sum of the forward launch's loss partials -> grads[np] (and the caller's running
+// loss when the optimiser step rides along): one launch fewer per step.
 template <typename T>
-__global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan<T> pl, int64_t rows, T *__restrict__ grads, int accumulate, SmallAdamT<T> ad) {
+__global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan<T> pl, int64_t rows, T *__restrict__ grads, int accumulate, SmallAdamT<T> ad,
+                                                      const double *__restrict__ loss_part, int nloss, double loss_scale, int64_t np) {
     using v4 = typename MF<T>::v4;
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ double sh[256];
+        double s = 0.0;
+        for (int k = threadIdx.x; k < nloss; k += 256) s += loss_part[k];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            s = sh[0] * loss_scale;
+            const T lv = accumulate ? (T)((double)grads[np] + s) : (T)s;
+            grads[np] = lv;
+            if (ad.on && ad.loss_accum) *ad.loss_accum += (double)lv;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= pl.tile0[pl.L]) return;
@@ -1426,7 +1447,6 @@ __global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan<T> pl, int64_t
             for (int k = so0[r]; k < so1[r]; ++k) ad.packed[ad.sc_idx[k]] = (T)pn;
         }
     }
-    if (ad.on && ad.loss_accum && tile == 0 && lane == 0) *ad.loss_accum += (double)grads[ad.np];      // (loss_final_k ran before this launch)
 }
 
 template <typename T>
@@ -1511,20 +1531,21 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 launch_gemm<T, EPI_FWD_LOSS, true, true>(A, B, (int64_t)K, e, rows, N, 1, s);
             }
         }
-        hipLaunchKernelGGL(loss_final_k<T>, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk, 1.0 / c,
-                           grads + np, chunk_i > 0 ? 1 : 0);
-        if (wide) {
-            rc = fused_wide_train_backward(h, rows, (float *const *)wk.y.data(), (float *const *)wk.dz.data(),
-                                           latent_grad ? (const float *)latent_grad + r0 * h->dims[h->L / 2] : nullptr, s);
-            if (rc) return rc;
-        }
-        // small float32 batches of a model on the fused row-local launches: every weight gradient in ONE launch, straight into `grads`
         bool dw_small = false;
         {
             const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
             const bool bf16 = h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0') && !small_wide;
             dw_small = !bf16 && rows <= dw_small_rows() && h->L <= 8;      // every weight gradient in ONE launch, behind the input-gradient chain
         }
+        if (!dw_small)      // (that launch also sums the loss partials)
+            hipLaunchKernelGGL(loss_final_k<T>, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk, 1.0 / c,
+                               grads + np, chunk_i > 0 ? 1 : 0);
+        if (wide) {
+            rc = fused_wide_train_backward(h, rows, (float *const *)wk.y.data(), (float *const *)wk.dz.data(),
+                                           latent_grad ? (const float *)latent_grad + r0 * h->dims[h->L / 2] : nullptr, s);
+            if (rc) return rc;
+        }
+        // small float32 batches of a model on the fused row-local launches: every weight gradient in ONE launch, straight into `grads`
         for (int l = h->L - 1; l >= 0; --l) {
             int K = h->dims[l], N = h->dims[l + 1];
             const T *dz = wk.dz[l];
@@ -1571,7 +1592,8 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
             pl.tile0[h->L] = t0;
             SmallAdamT<T> sa{};
             if constexpr (sizeof(T) == 4) { if (adam) sa = *adam; }
-            hipLaunchKernelGGL(dw_small_all_k<T>, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, pl, rows, grads, chunk_i > 0 ? 1 : 0, sa);
+            hipLaunchKernelGGL(dw_small_all_k<T>, dim3((unsigned)((t0 + 3) / 4 + 1)), dim3(256), 0, s, pl, rows, grads, chunk_i > 0 ? 1 : 0, sa,
+                               (const double *)h->lossp.p, nblk, 1.0 / c, (int64_t)np);
         }
         if (dw_small) {
         } else if (sp.ok) {
