@@ -279,3 +279,33 @@ def test_wide_models_small_training_batches(shape, monkeypatch):
     live = np.abs(go) > 1e-6 * np.abs(go).max()
     assert rel((p.cpu().numpy().astype(np.float64)[:-1] - flat)[live], (pn - flat)[live]) < 1e-3
     assert rel(h.encode(x, out_dtype=torch.float32).cpu().numpy(), orc.encode(dims, pn, x.cpu().numpy().astype(np.float64))) < 1e-4
+
+
+@pytest.mark.parametrize("shape,n", [((2500, 25), 60), ((625, 7), 1), ((625, 7), 36), ((40, 40), 512), ((900, 9), 85), ((100, 70), 300)])
+def test_layerwise_path_at_the_references_batch_sizes_fp64(shape, n):
+    """The reference's own arithmetic (float64) at its own batch sizes on the models without fp64 fused kernels: the layer-wise path on the
+    one-tile-per-workgroup kernels (gemm_small_k for the forward / loss / input-gradient products, dw_small_all_k for every weight gradient)
+    against the oracle at the float64 bar; two optimiser steps follow the oracle's."""
+    F, Z = shape
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 50 + F)
+    h = native.Handle(dims, "fp64")
+    p = torch.from_numpy(np.concatenate([flat, [0.0]])).cuda()
+    h.load_params(p)
+    x = np.random.default_rng(n).random((n, F))
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    g = torch.full_like(p, 3.0)
+    h.fwd_bwd(dev(x), g)
+    gh = g.cpu().numpy()
+    assert rel(gh[:-1], go) < 1e-11 and abs(gh[-1] - lo) < 1e-11 * lo
+    assert rel(h.encode(dev(x)).cpu().numpy(), orc.encode(dims, flat, x)) < 1e-11
+    rec, loss = h.forward_loss(dev(x))
+    assert rel(rec.cpu().numpy(), orc.forward(dims, flat, x)) < 1e-11
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    st = orc.FitState(dims, flat)
+    for t in (1, 2):
+        h.train_step(dev(x), p, m, v, t, 1e-3)
+        _, gt = orc.fwd_bwd(dims, st.params, x)
+        orc.adam_step(st.params, gt, st.m, st.v, t, 1e-3)
+    assert rel(p.cpu().numpy()[:-1], st.params) < 1e-9
+    h.close()
