@@ -1815,6 +1815,56 @@ __global__ void __launch_bounds__(256) wide_small_in_kernel(const v4 *wfrag /* [
 #pragma unroll
     for (int t = 0; t < 13; ++t) pp[t * 64] = acc[t];
 }
+// The same partial sets for FEW rows (up to 128: the reference's 1 .. 85-row batches): a workgroup takes ONE 16-row tile and split, its
+// four waves every fourth chunk of the split's range (fragments straight from L2: nothing to share, every wave is on its own chunk) and
+// add their accumulators through LDS in wave order; 4 x as many waves on the product: 12.7 -> ~6 us per launch at 60 rows.
+template <int F, bool WRT = false>
+__global__ void __launch_bounds__(256) wide_small_in16_kernel(const v4 *wfrag, int wcount_f4, const float *__restrict__ src, int64_t n,
+                                                              v4 *__restrict__ part, int cps, int fr) {
+    __shared__ __attribute__((aligned(16))) v4 red[3][13][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int64_t ngroup = (n + 63) / 64;
+    const int sp = blockIdx.x;
+    const int64_t rt = blockIdx.y;                         // 16-row tile
+    const int KCA = (WRT ? fr : F) / 16;
+    const int kc0 = sp * cps, kc1 = kc0 + cps < KCA ? kc0 + cps : KCA;
+    const WStream ww = make_stream(wfrag, wcount_f4 * 16, lane);
+    const int64_t row = rt * 16 + (lane & 15);
+    const int64_t rrow = row < n ? row : 0;
+    v4 acc[13];
+    zero_tiles(acc);
+    for (int kc = kc0 + wave; kc < kc1; kc += 4) {
+        const v4 xv = wide_x_chunk<F, true, WRT>(src, 0, rrow, kc, g, fr);
+        v4 wt[13];
+#pragma unroll
+        for (int t = 0; t < 13; ++t) wt[t] = frag_rt(ww, kc * 13 + t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 13; ++t) acc[t] = mfma(wt[t][r], xv[r], acc[t]);
+    }
+    if (wave == 3 && sp == (int)gridDim.x - 1 && (WRT ? fr : F) % 16 != 0) {      // the partial last chunk (as wide_in_product_lds)
+        constexpr int ST = WRT ? 4 : tile_steps(F, F / 16);
+        const v4 xv = wide_x_chunk<F, false, WRT>(src, 0, rrow, KCA, g, fr);
+        v4 wt[13];
+#pragma unroll
+        for (int t = 0; t < 13; ++t) wt[t] = frag_rt(ww, KCA * 13 + t);
+#pragma unroll
+        for (int r = 0; r < ST; ++r)
+#pragma unroll
+            for (int t = 0; t < 13; ++t) acc[t] = mfma(wt[t][r], xv[r], acc[t]);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 13; ++t) red[wave - 1][t][lane] = acc[t];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        v4 *pp = part + ((int64_t)sp * ngroup * 4 + rt) * (13 * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < 13; ++t) pp[t * 64] = ((acc[t] + red[0][t][lane]) + red[1][t][lane]) + red[2][t][lane];
+    }
+}
 // de4 + loss + dz8 of output tiles [blockIdx.x tps, ..) of row group blockIdx.y (y7 from the MID forward launch)
 // TRAIN = false (the validation pass): `dz8` (may be null) receives the reconstruction itself as float32 / float64
 template <int F, int Z, bool WRT = false, bool TRAIN = true>
@@ -4074,6 +4124,10 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
         *per = p;
         return (units + p - 1) / p;
     }
+    static int64_t in16_rows() {      // BALER_AMD_WIDE_IN16_ROWS: most rows whose contraction-split products take one 16-row tile per workgroup
+        static const int64_t lim = getenv("BALER_AMD_WIDE_IN16_ROWS") ? atoll(getenv("BALER_AMD_WIDE_IN16_ROWS")) : 512;
+        return lim;
+    }
     static bool small_pass(const bamd_handle *h, int64_t rows) {      // this batch runs on the split launches
         int per = 0;
         return Fr(h) / 16 >= 3 && small_splits(h, rows, Fr(h) / 16, &per) > 1 && small_splits(h, rows, (Fr(h) + 15) / 16, &per) > 1;
@@ -4088,8 +4142,12 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
             FusedState *st = state_of(h);
             int rc = st->wpart.ensure((size_t)s_in * ngroup * 4 * 13 * 64 * sizeof(v4));
             if (rc) return rc;
-            hipLaunchKernelGGL((wide_small_in_kernel<F, WRT>), dim3(s_in, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p + N::wf_off(0), N::wcount(0), x, rows,
-                               (v4 *)st->wpart.p, cps, fr);
+            if (rows <= in16_rows())
+                hipLaunchKernelGGL((wide_small_in16_kernel<F, WRT>), dim3(s_in, (unsigned)(4 * ngroup)), dim3(256), 0, s, (const v4 *)h->packed.p + N::wf_off(0),
+                                   N::wcount(0), x, rows, (v4 *)st->wpart.p, cps, fr);
+            else
+                hipLaunchKernelGGL((wide_small_in_kernel<F, WRT>), dim3(s_in, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p + N::wf_off(0), N::wcount(0), x, rows,
+                                   (v4 *)st->wpart.p, cps, fr);
             hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, true, WRT, true>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, y[1], y[2],
                                y[3], y[4], y[5], y[6], y[7], (void *)dz_last, 0, loss_part, fr, Zr(h), (const v4 *)st->wpart.p, s_in);
             hipLaunchKernelGGL((wide_small_out_kernel<F, Z, WRT>), dim3(s_out, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, (const float *)y[7],
@@ -4135,8 +4193,12 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
                 rc = st->wpart.ensure((size_t)s_in * ngroup * 4 * 13 * 64 * sizeof(v4) + (size_t)ngroup * 64 * 200 * sizeof(float));
                 if (rc) return rc;
                 float *y7 = (float *)((char *)st->wpart.p + (size_t)s_in * ngroup * 4 * 13 * 64 * sizeof(v4));
-                hipLaunchKernelGGL((wide_small_in_kernel<F, WRT>), dim3(s_in, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p + N::wf_off(0), N::wcount(0),
-                                   (const float *)src, rows, (v4 *)st->wpart.p, cps, fr);
+                if (rows <= in16_rows())
+                    hipLaunchKernelGGL((wide_small_in16_kernel<F, WRT>), dim3(s_in, (unsigned)(4 * ngroup)), dim3(256), 0, s,
+                                       (const v4 *)h->packed.p + N::wf_off(0), N::wcount(0), (const float *)src, rows, (v4 *)st->wpart.p, cps, fr);
+                else
+                    hipLaunchKernelGGL((wide_small_in_kernel<F, WRT>), dim3(s_in, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p + N::wf_off(0), N::wcount(0),
+                                       (const float *)src, rows, (v4 *)st->wpart.p, cps, fr);
                 hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, false, WRT, true>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
                                    rows, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, y7,
                                    (void *)nullptr, 0, (double *)nullptr, fr, zr, (const v4 *)st->wpart.p, s_in);
@@ -4163,8 +4225,12 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
             FusedState *st = state_of(h);
             int rc = st->wpart.ensure((size_t)s_in * ngroup * 4 * 13 * 64 * sizeof(v4));
             if (rc) return rc;
-            hipLaunchKernelGGL((wide_small_in_kernel<F, WRT>), dim3(s_in, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p + N::wb_off(7), N::wcount(7),
-                               (const float *)dz[7], rows, (v4 *)st->wpart.p, cps, fr);
+            if (rows <= in16_rows())
+                hipLaunchKernelGGL((wide_small_in16_kernel<F, WRT>), dim3(s_in, (unsigned)(4 * ngroup)), dim3(256), 0, s, (const v4 *)h->packed.p + N::wb_off(7),
+                                   N::wcount(7), (const float *)dz[7], rows, (v4 *)st->wpart.p, cps, fr);
+            else
+                hipLaunchKernelGGL((wide_small_in_kernel<F, WRT>), dim3(s_in, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p + N::wb_off(7), N::wcount(7),
+                                   (const float *)dz[7], rows, (v4 *)st->wpart.p, cps, fr);
             hipLaunchKernelGGL((wide_train_bwd_kernel<F, Z, WRT, true>), dim3(grid_for(rows)), dim3(256), 0, s, (const v4 *)h->packed.p,
                                (const float *)dz[7], rows, (const float *)y[1], (const float *)y[2], (const float *)y[3], (const float *)y[5],
                                (const float *)y[6], (const float *)y[7], dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz_latent, fr, Zr(h),
