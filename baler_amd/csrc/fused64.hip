@@ -704,66 +704,108 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     }
 }
 
-// Weight-gradient tiles in 2 x 4 BLOCKS for large fp64 batches.  dw64_kernel's one-tile workgroups each read their two image slices of
+// Weight-gradient tiles in BLOCKS for large fp64 batches.  dw64_kernel's one-tile workgroups each read their two image slices of
 // every 16-row block: at 262,144 rows that is 19.5 GB through L2 / fabric (3.6 of the step's 3.9 ms, MFMA busy 14 %).  Here a workgroup
-// owns 2 output tiles x 4 input tiles of one layer: 6 slices per block feed 8 tiles (0.49x the reads), over `nsplit` block ranges
-// (blockIdx.y); partial tiles go to `part`, dw64_kernel(nsplit) finishes.  Tiles beyond a layer's edge run on a clamped slice and are not
-// stored: uniform code.  (The fp32 twin of this kernel gained 1-5 % at <= 12,288 rows, where unique image bytes bound the step:
-// fused.hip history / DESIGN.md section 4.1; fp64 batches run this decomposition up to 262,144 rows, where the re-reads dominate.)
-// Tile blocks of the weight-gradient product: a workgroup owns MN output x MK input tiles of ONE layer and walks a range of 16-row
-// blocks; per block it loads MN + MK image slices (32 bytes per lane each) for 4 MN MK MFMAs.  The kernel is bound by those loads
-// (12 per 64 MFMAs with 2 x 4 blocks: 48 B/clk/CU), so the blocks are 16 tiles where the layer has them, and their ORIENTATION is
-// chosen per layer to waste the fewest padded tiles: 13 x 2 tiles -> 8 x 2, 7 x 13 -> 8 x 2, 13 x 7 -> 2 x 8, 2 x 13 -> 2 x 8,
-// 4 x 7 / 7 x 4 -> 4 x 4, the two latent layers 2 x 4 / 4 x 2: 368 tile slots for the 298 tiles (2 x 4 everywhere: 416), 8-10 loads
-// per 64 MFMAs.  Measured at 262,144 rows (bamd_fwd_bwd): 2 x 4 everywhere 3.26 ms, 4 x 4 everywhere 3.08, per-layer shapes: see DESIGN 4.8.
+// owns MN output x MK input tiles of ONE layer and walks a range of 16-row blocks (wave w: blocks w, w + 4, ..): per block a wave loads
+// MN + MK image slices (32 bytes per lane each) for 4 MN MK MFMAs; the four waves' accumulators meet in LDS in wave order, the range
+// partial goes to `part`, dw64_kernel(nsplit) adds the ranges in order and finishes.
+//   * below 16,384 rows (Dwm64, dw64m_kernel): 2 x 4 blocks everywhere (52 blocks x 8 ranges fill the chip; tiles beyond a layer's edge
+//     run on a clamped slice and are not stored: uniform code), the blocks of a layer on one XCD.
+//   * from 16,384 rows on (Dwx64, dw64x_kernel): the kernel is bound by the image bytes it pulls from HBM (3.4 GB of images per 262,144
+//     rows, every slice wanted by 2-13 tile blocks) and by padded tiles.  Blocks are EXACT: the smaller tile dimension of a layer stays
+//     whole, the other one is dealt out in balanced pieces of <= 16 tiles per block (13 x 2 tiles -> 7 x 2 + 6 x 2, 7 x 13 -> six 7 x 2 +
+//     one 7 x 1, 4 x 7 -> 4 x 4 + 4 x 3, ..: 24 blocks, 298 tile slots for 298 tiles; round 4's padded shapes had 368), and ONE XCD runs
+//     all blocks of a block range side by side (workgroup b of the launch sits on XCD b & 7 and takes range 8 (j / 24) + XCD, block
+//     j % 24 with j = b >> 3), one workgroup per CU, each wave with the slices of its next two blocks in flight (~330 registers).
+//     Measured at 262,144 rows: the launch 1.30 -> 0.85 ms.  What the counters say about sharing: the XCD's L2 turns over
+//     within about one block time (256 waves x 18 KB per block against 4 MB), so tile blocks that drift a block apart share nothing --
+//     42 M lines missed per launch = 1.58 x the images with either mapping (loading the slices only one tile block wants non-temporal:
+//     slower; one wave per tile block with a barrier per block: 1.12 x, and slower -- the launch is bound by latency, not by HBM bytes).
+constexpr int kDw64Ahead = 2;      // dw64x_kernel: blocks whose slices are in flight ahead of a wave's MFMAs
 struct DwShape { int mn, mk; };
-template <class N, bool BIG> struct Dwm64 {      // BIG: batches of >= 16,384 rows (below, 2 x 4 blocks over 8 ranges fill the chip better)
-    __host__ __device__ static constexpr DwShape shape(int l) {
-        if (!BIG) return DwShape{2, 4};
-        const int nt = tiles(N::dim(l + 1)), kt = tiles(N::dim(l) + 1);
-        const DwShape cand[5] = {{4, 4}, {8, 2}, {2, 8}, {2, 4}, {4, 2}};      // 16-tile blocks first: ties go to them, then to fewer loads
-        int best = 0, best_slots = 1 << 30;
-        for (int c = 0; c < 5; ++c) {
-            const int slots = ((nt + cand[c].mn - 1) / cand[c].mn) * cand[c].mn * (((kt + cand[c].mk - 1) / cand[c].mk) * cand[c].mk);
-            if (slots < best_slots) { best_slots = slots; best = c; }
-        }
-        return cand[best];
-    }
+template <class N> struct Dwm64 {
+    __host__ __device__ static constexpr DwShape shape(int) { return DwShape{2, 4}; }
     __host__ __device__ static constexpr int mn(int l) { return (tiles(N::dim(l + 1)) + shape(l).mn - 1) / shape(l).mn; }
     __host__ __device__ static constexpr int mk(int l) { return (tiles(N::dim(l) + 1) + shape(l).mk - 1) / shape(l).mk; }
     __host__ __device__ static constexpr int off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += mn(j) * mk(j); return s; }
     static constexpr int total = off(N::L);
     static constexpr int per_xcd = (total + 7) / 8;
 };
-// one tile block of layer l (compile-time shape): accumulate over this workgroup's block range, sum the four waves' accumulators
-// through LDS in a fixed order, store the range partial
-template <class N, bool BIG, int l>
-__device__ __forceinline__ void dw64m_block(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total, int accumulate,
-                                            int idx, d4 *red) {
-    using D = Dwm64<N, BIG>;
-    constexpr int MN = D::shape(l).mn, MK = D::shape(l).mk, NA = MN * MK, U = NA >= 16 ? 1 : 2, HALF = NA / 2;
-    constexpr int ntc = tiles(N::dim(l + 1)), ktc = tiles(N::dim(l) + 1), mnc = D::mn(l), soff = N::slab_off(l), xo = N::x_off(l), zo = N::z_off(l);
-    const int nsplit = (int)gridDim.y;
-    const int mkt = idx / mnc, mnt = idx - mkt * mnc;
+struct DwDeal { bool keep_n; int cnt, base, rem; };      // the dealt dimension in `cnt` pieces: `rem` of base + 1 tiles, then base tiles
+template <class N> struct Dwx64 {
+    __host__ __device__ static constexpr DwDeal deal(int l) {
+        const int nt = tiles(N::dim(l + 1)), kt = tiles(N::dim(l) + 1);
+        const bool keep_n = nt <= kt;
+        const int a = keep_n ? nt : kt, b = keep_n ? kt : nt;
+        const int mx = 16 / a > 0 ? 16 / a : 1, cnt = (b + mx - 1) / mx;
+        return DwDeal{keep_n, cnt, b / cnt, b % cnt};
+    }
+    __host__ __device__ static constexpr int off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += deal(j).cnt; return s; }
+    static constexpr int total = off(N::L);
+};
+// one tile block (compile-time shape MN x MK of layer l, first tiles n0 / k0; CLAMP: tiles beyond the layer's edge run on a clamped slice
+// and are not stored): accumulate over block range `range` of `nsplit`, sum the four waves' accumulators through LDS in wave order, store
+// the range partial
+template <class N, int l, int MN, int MK, bool CLAMP>
+__device__ __forceinline__ void dw64_tile_block(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total, int accumulate,
+                                                int n0, int k0, d4 *red, int range, int nsplit) {
+    constexpr int NA = MN * MK, U = NA >= 12 ? 1 : 2, H0 = (NA + 1) / 2;
+    constexpr int ntc = tiles(N::dim(l + 1)), ktc = tiles(N::dim(l) + 1), soff = N::slab_off(l), xo = N::x_off(l), zo = N::z_off(l);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
     const double *pz[MN], *px[MK];
     int nt[MN], kt[MK];
 #pragma unroll
     for (int a = 0; a < MN; ++a) {
-        nt[a] = MN * mnt + a;
-        const int c = nt[a] < ntc ? nt[a] : ntc - 1;
+        nt[a] = n0 + a;
+        const int c = !CLAMP || nt[a] < ntc ? nt[a] : ntc - 1;
         pz[a] = imgs + ((zo + 16 * c + i) * 16 + 4 * g);
     }
 #pragma unroll
     for (int b = 0; b < MK; ++b) {
-        kt[b] = MK * mkt + b;
-        const int c = kt[b] < ktc ? kt[b] : ktc - 1;
+        kt[b] = k0 + b;
+        const int c = !CLAMP || kt[b] < ktc ? kt[b] : ktc - 1;
         px[b] = imgs + ((xo + 16 * c + i) * 16 + 4 * g);
     }
     d4 acc[NA];
 #pragma unroll
     for (int t = 0; t < NA; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int per = (nblk + nsplit - 1) / nsplit, blo = (int)blockIdx.y * per, bhi = blo + per < nblk ? blo + per : nblk;
+    const int per = (nblk + nsplit - 1) / nsplit, blo = range * per, bhi = blo + per < nblk ? blo + per : nblk;
+    if constexpr (!CLAMP) {
+        // the slices of a wave's next D blocks are on their way while it multiplies: D + 1 register sets, filled in turn (loads retire in
+        // order, so waiting for a set leaves the D younger ones in flight; ~330 registers, one wave per SIMD); a set beyond the range is
+        // loaded from the range's first block and not multiplied
+        constexpr int D = kDw64Ahead;
+        d4 za[D + 1][MN], xa[D + 1][MK];
+        int b = blo + wave;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int bb = b + 4 * k;
+            const int64_t o = (int64_t)(bb < bhi ? bb : blo) * N::img_doubles;
+#pragma unroll
+            for (int a = 0; a < MN; ++a) za[k][a] = *(const d4 *)(pz[a] + o);
+#pragma unroll
+            for (int c = 0; c < MK; ++c) xa[k][c] = *(const d4 *)(px[c] + o);
+        }
+        for (; b < bhi; b += 4 * (D + 1)) {
+#pragma unroll
+            for (int p = 0; p <= D; ++p) {
+                const int bb = b + 4 * (p + D);
+                const int64_t o = (int64_t)(bb < bhi ? bb : blo) * N::img_doubles;
+#pragma unroll
+                for (int a = 0; a < MN; ++a) za[(p + D) % (D + 1)][a] = *(const d4 *)(pz[a] + o);
+#pragma unroll
+                for (int c = 0; c < MK; ++c) xa[(p + D) % (D + 1)][c] = *(const d4 *)(px[c] + o);
+                if (b + 4 * p < bhi) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < MK; ++c)
+#pragma unroll
+                            for (int a = 0; a < MN; ++a) acc[c * MN + a] = mfma(za[p][a][r], xa[p][c][r], acc[c * MN + a]);
+                }
+            }
+        }
+    } else
     for (int b0 = blo + wave; b0 < bhi; b0 += 4 * U) {
         d4 za[U][MN], xa[U][MK];
 #pragma unroll
@@ -789,40 +831,78 @@ __device__ __forceinline__ void dw64m_block(const double *__restrict__ imgs, int
     const int e = threadIdx.x;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+        const int cnt = h ? NA - H0 : H0;       // the accumulators pass through LDS in two halves (<= 8 tiles x 4 waves x 2 KB)
         if (h) __syncthreads();
 #pragma unroll
-        for (int t = 0; t < HALF; ++t) red[(t * 4 + wave) * 64 + lane] = acc[h * HALF + t];
+        for (int t = 0; t < H0; ++t)
+            if (t < cnt) red[(t * 4 + wave) * 64 + lane] = acc[h * H0 + t];
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < HALF; ++t) {
-            const int ta = h * HALF + t, c = ta / MN, a = ta % MN;
-            if (nt[a] >= ntc || kt[c] >= ktc) continue;
+        for (int t = 0; t < H0; ++t) {
+            if (t >= cnt) continue;
+            const int ta = h * H0 + t, c = ta / MN, a = ta % MN;
+            if (CLAMP && (nt[a] >= ntc || kt[c] >= ktc)) continue;
             const double *q = rf + t * 1024;
             const double gsum = ((q[e] + q[256 + e]) + q[512 + e]) + q[768 + e];
             const int tile = soff + kt[c] * ntc + nt[a];
-            double *dst = part + ((int64_t)tile * nsplit_total + blockIdx.y) * 256 + e;
+            double *dst = part + ((int64_t)tile * nsplit_total + range) * 256 + e;
             *dst = accumulate ? *dst + gsum : gsum;      // chunks after the first add to the range's running sum (chunk order: one stream)
         }
     }
 }
-template <class N, bool BIG>
+// Both launches cover block ranges 0 .. nsplit - 1 of the nsplit_total ranges the finishing launch adds up.  A batch beyond
+// State64::chunk_rows runs chunk after chunk over the same image buffer, one launch per chunk: every chunk after the first ADDS its
+// range partials to the first chunk's (`accumulate`; the launches are ordered on one stream, so the sum has a fixed order: chunk
+// after chunk per range, then range after range in dw64_kernel) -- the partial buffer and the finishing launch do not grow with the batch
+template <class N>
 __global__ void __launch_bounds__(256) dw64m_kernel(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total,
                                                     int accumulate) {
-    // this launch covers block ranges 0 .. gridDim.y - 1 of the nsplit_total ranges the finishing launch adds up.  A batch beyond
-    // State64::chunk_rows runs chunk after chunk over the same image buffer, one launch of this kernel per chunk: every chunk after
-    // the first ADDS its range partials to the first chunk's (`accumulate`; the launches are ordered on one stream, so the sum has
-    // a fixed order: chunk after chunk per range, then range after range in dw64_kernel) -- the partial buffer and the finishing
-    // launch do not grow with the batch
-    using D = Dwm64<N, BIG>;
-    __shared__ __attribute__((aligned(32))) d4 red[(BIG ? 8 : 4) * 4 * 64];      // half of a block's accumulators from four waves: 64 / 32 KB
+    using D = Dwm64<N>;
+    __shared__ __attribute__((aligned(32))) d4 red[4 * 4 * 64];      // half of a block's accumulators from four waves: 32 KB
     const int mac = (blockIdx.x & 7) * D::per_xcd + (blockIdx.x >> 3);
     if (mac >= D::total) return;
     static_assert(N::L == 8, "one case per layer below");
-#define BAMD_DW64M_CASE(l_) \
-    if (mac >= D::off(l_) && mac < D::off(l_ + 1)) { dw64m_block<N, BIG, l_>(imgs, nblk, part, nsplit_total, accumulate, mac - D::off(l_), red); return; }
+#define BAMD_DW64M_CASE(l_)                                                                                                               \
+    if (mac >= D::off(l_) && mac < D::off(l_ + 1)) {                                                                                      \
+        const int idx = mac - D::off(l_), mkt = idx / D::mn(l_), mnt = idx - mkt * D::mn(l_);                                             \
+        dw64_tile_block<N, l_, 2, 4, true>(imgs, nblk, part, nsplit_total, accumulate, 2 * mnt, 4 * mkt, red, (int)blockIdx.y, (int)gridDim.y); \
+        return;                                                                                                                           \
+    }
     BAMD_DW64M_CASE(0) BAMD_DW64M_CASE(1) BAMD_DW64M_CASE(2) BAMD_DW64M_CASE(3)
     BAMD_DW64M_CASE(4) BAMD_DW64M_CASE(5) BAMD_DW64M_CASE(6) BAMD_DW64M_CASE(7)
 #undef BAMD_DW64M_CASE
+}
+// the blocks of layer l: the `rem` larger pieces, then the others (two shapes per layer at most)
+template <class N, int l>
+__device__ __forceinline__ void dw64x_layer(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total, int accumulate,
+                                            int idx, d4 *red, int range, int nsplit) {
+    constexpr DwDeal d = Dwx64<N>::deal(l);
+    constexpr int nt = tiles(N::dim(l + 1)), kt = tiles(N::dim(l) + 1);
+    if constexpr (d.rem > 0) {
+        if (idx < d.rem) {
+            const int at = idx * (d.base + 1);
+            if constexpr (d.keep_n) dw64_tile_block<N, l, nt, d.base + 1, false>(imgs, nblk, part, nsplit_total, accumulate, 0, at, red, range, nsplit);
+            else dw64_tile_block<N, l, d.base + 1, kt, false>(imgs, nblk, part, nsplit_total, accumulate, at, 0, red, range, nsplit);
+            return;
+        }
+    }
+    const int at = d.rem * (d.base + 1) + (idx - d.rem) * d.base;
+    if constexpr (d.keep_n) dw64_tile_block<N, l, nt, d.base, false>(imgs, nblk, part, nsplit_total, accumulate, 0, at, red, range, nsplit);
+    else dw64_tile_block<N, l, d.base, kt, false>(imgs, nblk, part, nsplit_total, accumulate, at, 0, red, range, nsplit);
+}
+template <class N>
+__global__ void __launch_bounds__(256) dw64x_kernel(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total,
+                                                    int accumulate, int nsplit) {
+    using D = Dwx64<N>;
+    __shared__ __attribute__((aligned(32))) d4 red[8 * 4 * 64];      // half of a block's accumulators from four waves: 64 KB
+    const int j = (int)(blockIdx.x >> 3), range = (j / D::total) * 8 + (int)(blockIdx.x & 7), mac = j % D::total;
+    if (range >= nsplit) return;
+    static_assert(N::L == 8, "one case per layer below");
+#define BAMD_DW64X_CASE(l_) \
+    if (mac >= D::off(l_) && mac < D::off(l_ + 1)) { dw64x_layer<N, l_>(imgs, nblk, part, nsplit_total, accumulate, mac - D::off(l_), red, range, nsplit); return; }
+    BAMD_DW64X_CASE(0) BAMD_DW64X_CASE(1) BAMD_DW64X_CASE(2) BAMD_DW64X_CASE(3)
+    BAMD_DW64X_CASE(4) BAMD_DW64X_CASE(5) BAMD_DW64X_CASE(6) BAMD_DW64X_CASE(7)
+#undef BAMD_DW64X_CASE
 }
 
 __global__ void __launch_bounds__(256) pack64_k(const double *__restrict__ params, const int *__restrict__ src, int count,
@@ -965,15 +1045,17 @@ template <int F, int Z, bool RT = false> struct Impl64 {
         // 4,096: 0.068 / 0.094, 16,384: 0.227 / 0.341, 65,536: 0.85 / 1.32, 262,144: 3.22 / 5.51 (0.37 / 0.22 of the fp64 MFMA peak)
         static const int macro_blks = getenv("BALER_AMD_DW64_MACRO_BLKS") ? atoi(getenv("BALER_AMD_DW64_MACRO_BLKS")) : 64;
         const bool macro = nchunk > 1 || (macro_blks > 0 && nblk_all >= macro_blks);
-        // tile-block shape by batch size; block ranges per chunk (tile blocks x ranges = workgroups): per-layer 16-tile blocks (24 of them)
-        // over 32 ranges from 4,096 blocks on, over 16 from 1,024; below that 2 x 4 blocks (52) over 8 ranges, at least 4 blocks per range.
-        // Every chunk but the last is a full one
+        // tile-block shape by batch size; block ranges per chunk (tile blocks x ranges = workgroups): from 1,024 blocks on the exact
+        // per-layer blocks (24 of them, one workgroup per CU) over 32 ranges = three full rounds of the chip (BALER_AMD_DW64_RANGES;
+        // measured at 262,144 rows 32 / 64 / 128 ranges: 2.11 / 2.15 / 2.21 ms per bamd_fwd_bwd); below that 2 x 4 blocks (52) over 8
+        // ranges, at least 4 blocks per range.  Every chunk but the last is a full one
         const bool big = nblk_all >= 1024;
-        auto splits_of = [big](int64_t blks) { return (int)std::min<int64_t>(big ? (blks >= 4096 ? 32 : 16) : 8, std::max<int64_t>(1, blks / 4)); };
+        static const int big_ranges = getenv("BALER_AMD_DW64_RANGES") ? std::max(1, atoi(getenv("BALER_AMD_DW64_RANGES"))) : 32;
+        auto splits_of = [big](int64_t blks) { return (int)std::min<int64_t>(big ? big_ranges : 8, std::max<int64_t>(1, blks / 4)); };
         int nsplit = 0;
         if (macro) {
-            // the first chunk is the largest (every chunk but the last is a full one): its range count is the buffer's; 32 ranges at most,
-            // i.e. (tiles + 1) x 32 x 2 KB = 19.6 MB whatever the batch
+            // the first chunk is the largest (every chunk but the last is a full one): its range count is the buffer's; 32 ranges by
+            // default, i.e. (tiles + 1) x 32 x 2 KB = 19.6 MB whatever the batch
             nsplit = splits_of((std::min(n, chunk) + 15) / 16);
             rc = st->dwpart.ensure((size_t)(N::slab_off(N::L) + 1) * nsplit * 256 * sizeof(double));
             if (rc) return rc;
@@ -998,10 +1080,10 @@ template <int F, int Z, bool RT = false> struct Impl64 {
             if (macro) {
                 const int ns = splits_of(nblk);
                 if (big)
-                    hipLaunchKernelGGL((dw64m_kernel<N, true>), dim3(8 * Dwm64<N, true>::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
-                                       (double *)st->dwpart.p, nsplit, k > 0);
+                    hipLaunchKernelGGL((dw64x_kernel<N>), dim3(8 * ((ns + 7) / 8) * Dwx64<N>::total), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
+                                       (double *)st->dwpart.p, nsplit, k > 0, ns);
                 else
-                    hipLaunchKernelGGL((dw64m_kernel<N, false>), dim3(8 * Dwm64<N, false>::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
+                    hipLaunchKernelGGL((dw64m_kernel<N>), dim3(8 * Dwm64<N>::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
                                        (double *)st->dwpart.p, nsplit, k > 0);
             }
         }
