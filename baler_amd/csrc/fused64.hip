@@ -663,18 +663,23 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     double pm = 0.0, pv = 0.0, pp = 0.0;
     int s0 = 0, s1 = 0;
     if (MODE == DW_ADAM && p >= 0) { pm = ad.m[p]; pv = ad.v[p]; pp = ad.params[p]; s0 = ad.sc_off[p]; s1 = ad.sc_off[p + 1]; }
+    // the first two packed slots of the parameter (its forward and its transposed fragment) are looked up now, not behind the reduction
+    int sc0 = -1, sc1 = -1;
+    if (MODE == DW_ADAM && s1 > s0) sc0 = ad.sc_idx[s0];
+    if (MODE == DW_ADAM && s1 > s0 + 1) sc1 = ad.sc_idx[s0 + 1];
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int b0 = wave; b0 < (nsplit > 0 ? 0 : nblk); b0 += 16) {   // 4 blocks per wave in flight
-        d4 a[4], x[4];
+    constexpr int UB = 8;                                            // blocks per wave in flight (a 512-row batch: all of a wave's blocks)
+    for (int b0 = wave; b0 < (nsplit > 0 ? 0 : nblk); b0 += 4 * UB) {
+        d4 a[UB], x[UB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UB; ++u) {
             const int b = b0 + 4 * u;
             const bool ok = b < nblk;
             a[u] = ok ? *(const d4 *)(pz + (int64_t)b * N::img_doubles) : (d4){0.0, 0.0, 0.0, 0.0};
             x[u] = ok ? *(const d4 *)(px + (int64_t)b * N::img_doubles) : (d4){0.0, 0.0, 0.0, 0.0};
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < UB; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = mfma(a[u][r], x[u][r], acc);
     }
@@ -686,7 +691,16 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     double gsum = ((rf[e] + rf[256 + e]) + rf[512 + e]) + rf[768 + e];
     if (nsplit > 0) {
         gsum = 0.0;
-        for (int k = 0; k < nsplit; ++k) gsum += part[((int64_t)tile * nsplit + k) * 256 + e];
+        const double *q = part + (int64_t)tile * nsplit * 256 + e;
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {      // eight range partials on their way at a time, added in range order
+            double t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = q[(k + j) * 256];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gsum += t[j];
+        }
+        for (; k < nsplit; ++k) gsum += q[k * 256];
     }
     if (p < 0) return;
     if (grads) grads[p] = gsum;
@@ -700,7 +714,9 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
         ad.v[p] = vi;
         ad.params[p] = pn;
         if (ad.pcopy) ad.pcopy[p] = pn;
-        for (int k = s0; k < s1; ++k) ad.packed[ad.sc_idx[k]] = pn;
+        if (sc0 >= 0) ad.packed[sc0] = pn;
+        if (sc1 >= 0) ad.packed[sc1] = pn;
+        for (int k = s0 + 2; k < s1; ++k) ad.packed[ad.sc_idx[k]] = pn;
     }
 }
 

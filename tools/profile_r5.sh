@@ -29,8 +29,7 @@ unset BALER_AMD_BF16_TRAIN_V2
 prof c python3 $R/tools/bench_c4.py 32768                         # CFD_dense_AE(2500, 25), exact instantiation
 prof k python3 $R/tools/prof_wide_class.py                        # the run-time-width wide class on CFD_dense_AE(900, 9)
 prof s python3 $R/tools/bench_one_batch.py 512 400                # the reference's own regime: 512-row optimiser steps
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/fstats -o run -- python3 $R/tools/prof_fp64.py > $O/fstats.log 2>&1
-$T rocprofv3 --kernel-trace --pmc $PM --output-format csv -d $O/fpmc_m -o run -- python3 $R/tools/prof_fp64.py > $O/fpmc_m.log 2>&1
+prof f python3 $R/tools/prof_fp64.py                              # the fp64 kernels (262,144-row launches; 512-row steps)
 prof i python3 $R/tools/bench_bf16_infer.py                       # bf16 inference of the 24-column model (scalar LeakyReLU multiplies)
 # per-phase shader-clock timeline of the register-chain pair (a -DBAMD_BF16_TRACE build in .abl/) and the instruction-cost probe
 if [ -f $R/.abl/btrace.so ]; then BALER_AMD_LIB=$R/.abl/btrace.so timeout 200 python3 $R/tools/bf16_trace2.py > $O/regchain_trace.txt 2>&1; fi

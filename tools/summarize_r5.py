@@ -17,7 +17,7 @@ R = os.path.join(REPO, "gpurun_out", "r5p")
 KEYS = (("train_dec_kernel", "train_dec"), ("train_enc_kernel", "train_enc"), ("reduce_slabs_k", "reduce_slabs"),
         ("lat2_chain_kernel", "lat2_chain"), ("lat4_chain_kernel", "lat4_chain"), ("lat2_dw_kernel", "lat2_dw"), ("adam_k", "adam_k"),
         ("infer64_kernel<ENCODE>", "infer64_kernel<24, 15, 0>"), ("infer64_kernel<DECODE>", "infer64_kernel<24, 15, 1>"),
-        ("infer64_kernel<FORWARD>", "infer64_kernel<24, 15, 2>"), ("chain64_kernel", "chain64_kernel<"), ("chain64r_kernel", "chain64r_kernel"), ("dw64m_kernel", "dw64m_kernel"), ("dw64_kernel", "dw64_kernel"),
+        ("infer64_kernel<FORWARD>", "infer64_kernel<24, 15, 2>"), ("chain64_kernel", "chain64_kernel<"), ("chain64r_kernel", "chain64r_kernel"), ("dw64m_kernel", "dw64m_kernel"), ("dw64x_kernel", "dw64x_kernel"), ("dw64_kernel", "dw64_kernel"),
         ("bf16_train_kernel<PART 0>", "bf16_train_kernel<24, 15, 0>"), ("bf16_train_kernel<PART 1>", "bf16_train_kernel<24, 15, 1>"),
         ("reduce_tiles_k", "reduce_tiles_k"),
         ("bf16_train2_kernel<PART 0> (register chain)", "bf16_train2_kernel<24, 15, 0>"), ("bf16_train2_kernel<PART 1> (register chain)", "bf16_train2_kernel<24, 15, 1>"),
@@ -71,14 +71,7 @@ quad = merge("q")
 wclass = merge("k")
 small = merge("s")
 infer16 = merge("i")
-f64 = {k: v for k, v in load(f"{R}/fpmc_m/**/*counter_collection.csv").items()}
-for k, e in f64.items():
-    if e.get("GRBM_GUI_ACTIVE"):
-        e["mfma_busy"] = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * e["GRBM_GUI_ACTIVE"] / 8)
-    if e.get("SQ_INSTS_MFMA"):
-        e["valu_per_mfma"] = (e["SQ_INSTS_VALU"] - e["SQ_INSTS_MFMA"]) / e["SQ_INSTS_MFMA"]
-    if e.get("SQ_WAVE_CYCLES"):
-        e["wait_any_frac"] = e.get("SQ_WAIT_ANY", 0) / e["SQ_WAVE_CYCLES"]
+f64 = merge("f")
 lds = load(f"{R}/rpmc_l/**/*counter_collection.csv")
 for k, v in lds.items():
     regchain.setdefault(k, {}).update(v)
@@ -96,7 +89,7 @@ out = {
     "wide_class_note": "the run-time-width wide class on CFD_dense_AE(900, 9), 131,072 float32 rows per launch, `python3 tools/prof_wide_class.py`", "wide_class_kernels": wclass,
     "bf16_infer_note": "bf16 encode / decode of AE(24, 15), `python3 tools/bench_bf16_infer.py` (4M rows, float64 and float32 rows)", "bf16_infer_kernels": infer16,
     "bs512_note": "512-row bamd_train_step, `python3 tools/bench_one_batch.py 512 400`", "bs512_kernels": small,
-    "fp64_note": "fp64 handle, 262,144 rows per launch (512 rows for chain64 / dw64), SQ counters only, `python3 tools/prof_fp64.py`", "fp64_kernels": f64,
+    "fp64_note": "fp64 handle, 262,144 rows per launch (512 rows for chain64 / dw64; dw64_kernel averages the finishing launches of both), `python3 tools/prof_fp64.py`", "fp64_kernels": f64,
     "fwd_bwd_hbm_bytes_per_launch": sum(fp32[k]["hbm_bytes"] for k in ("train_dec_kernel", "train_enc_kernel", "reduce_slabs_k") if k in fp32),
     "bf16_fwd_bwd_hbm_bytes_per_launch": sum(bf16[k]["hbm_bytes"] for k in ("bf16_train_kernel<PART 0>", "bf16_train_kernel<PART 1>", "reduce_tiles_k") if k in bf16),
 }
