@@ -1914,6 +1914,65 @@ __global__ void __launch_bounds__(256) wide_small_out_kernel(const v4 *packed, c
     if (threadIdx.x == 0) loss_part[blockIdx.y * gridDim.x + blockIdx.x] = sh[0];
 }
 
+// The same for FEW rows (<= in16_rows()): ONE 16-row tile per workgroup (blockIdx.y), its four waves deal the tiles of the range among
+// themselves (wave w: t0 + w, t0 + w + 4, ..) -- a 64-row group of a 60-row batch did the full work on its padding tiles.  A wave
+// fetches the 13 fragments of its output tile itself (no stage, no barrier); the products of a tile are added in wide_out_product_lds's
+// order (k tiles in groups of four, even / odd k tiles on two accumulators).
+template <int F, int Z, bool WRT = false, bool TRAIN = true>
+__global__ void __launch_bounds__(256) wide_small_out16_kernel(const v4 *packed, const float *__restrict__ x, int64_t n, const float *__restrict__ y7,
+                                                               void *__restrict__ dz8, double *__restrict__ loss_part, int tps, int fr, int out_f64 = 0) {
+    using N = Net<F, Z>;
+    constexpr int KCS = tiles(F);
+    const int KC = WRT ? (fr + 15) / 16 : tiles(F), KF = (WRT ? fr : F) / 16;
+    __shared__ __attribute__((aligned(16))) v4 bias7[tiles(F) * 4];
+    __shared__ double sh[256];
+    for (int i = threadIdx.x; i < tiles(F) * 4; i += 256) bias7[i] = packed[N::bf_off(7) + i];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+    const int t0 = blockIdx.x * tps, t1 = t0 + tps < KC ? t0 + tps : KC;
+    const WStream w7 = make_stream(packed + N::wf_off(7), N::wcount(7) * 16, lane);
+    const int64_t row = (int64_t)blockIdx.y * 16 + (lane & 15);
+    const bool valid = row < n;
+    const int64_t rrow = valid ? row : 0;
+    const float gscale = 2.0f / (float)(WRT ? fr : F);
+    double lacc = 0.0;
+    v4 a7[13];
+    load_act<200>(a7, y7, rrow, g);
+    __syncthreads();                                       // the bias tile table
+    for (int t = t0 + wave; t < t1; t += 4) {
+        v4 w[13];
+#pragma unroll
+        for (int q = 0; q < 13; ++q) w[q] = frag_rt(w7, q * KCS + t);
+        const bool full = t < KF;
+        const v4 xr = full ? wide_x_chunk<F, true, WRT>(x, 0, rrow, t, g, fr) : wide_x_chunk<F, false, WRT>(x, 0, rrow, t, g, fr);
+        v4 o0 = bias7[t * 4 + g], o1 = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q0 = 0; q0 < 16; q0 += 4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (q0 + k < 13 && r < tile_steps(200, q0 + k)) {
+                        if (k & 1) o1 = mfma(w[q0 + k][r], a7[q0 + k][r], o1); else o0 = mfma(w[q0 + k][r], a7[q0 + k][r], o0);
+                    }
+        const v4 o = o0 + o1, d = o - xr;
+        if (valid) {
+            lacc += (double)(d[0] * d[0] + d[1] * d[1]) + (double)(d[2] * d[2] + d[3] * d[3]);
+            if (TRAIN) {
+                if (full) wide_store_tile<F, true, WRT>(d * gscale, dz8, 0, row, t, g, fr); else wide_store_tile<F, false, WRT>(d * gscale, dz8, 0, row, t, g, fr);
+            } else if (dz8) {
+                if (full) wide_store_tile<F, true, WRT>(o, dz8, out_f64, row, t, g, fr); else wide_store_tile<F, false, WRT>(o, dz8, out_f64, row, t, g, fr);
+            }
+        }
+    }
+    sh[threadIdx.x] = lacc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_part[blockIdx.y * gridDim.x + blockIdx.x] = sh[0];
+}
+
 // the input-gradient chain of 16 rows per wave: dZ_6 = (dZ_7 W_7) * lrelu'(y7) streamed over the wide dimension, then layers 6..1
 // chained in registers; every dZ_l (dL/d pre-activation of layer l) is stored for the weight-gradient GEMMs.
 // MID (small batches): d6 starts from the partial sums of wide_small_in_kernel (as the forward launch's MID mode)
@@ -4128,6 +4187,10 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
         static const int64_t lim = getenv("BALER_AMD_WIDE_IN16_ROWS") ? atoll(getenv("BALER_AMD_WIDE_IN16_ROWS")) : 512;
         return lim;
     }
+    static int64_t out16_rows() {     // BALER_AMD_WIDE_OUT16_ROWS: most rows whose tile-split product (de4) takes one 16-row tile per workgroup
+        static const int64_t lim = getenv("BALER_AMD_WIDE_OUT16_ROWS") ? atoll(getenv("BALER_AMD_WIDE_OUT16_ROWS")) : 512;
+        return lim;
+    }
     static bool small_pass(const bamd_handle *h, int64_t rows) {      // this batch runs on the split launches
         int per = 0;
         return Fr(h) / 16 >= 3 && small_splits(h, rows, Fr(h) / 16, &per) > 1 && small_splits(h, rows, (Fr(h) + 15) / 16, &per) > 1;
@@ -4150,9 +4213,14 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
                                    (v4 *)st->wpart.p, cps, fr);
             hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, true, WRT, true>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, y[1], y[2],
                                y[3], y[4], y[5], y[6], y[7], (void *)dz_last, 0, loss_part, fr, Zr(h), (const v4 *)st->wpart.p, s_in);
-            hipLaunchKernelGGL((wide_small_out_kernel<F, Z, WRT>), dim3(s_out, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, (const float *)y[7],
-                               (void *)dz_last, loss_part, tps, fr, 0);
-            *nblk = s_out * ngroup;
+            const bool out16 = rows <= out16_rows();
+            if (out16)
+                hipLaunchKernelGGL((wide_small_out16_kernel<F, Z, WRT>), dim3(s_out, (unsigned)(4 * ngroup)), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows,
+                                   (const float *)y[7], (void *)dz_last, loss_part, tps, fr, 0);
+            else
+                hipLaunchKernelGGL((wide_small_out_kernel<F, Z, WRT>), dim3(s_out, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p, x, rows, (const float *)y[7],
+                                   (void *)dz_last, loss_part, tps, fr, 0);
+            *nblk = s_out * ngroup * (out16 ? 4 : 1);
             BAMD_HIP(hipGetLastError());
             return BAMD_OK;
         }
@@ -4202,9 +4270,14 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
                 hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, false, WRT, true>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
                                    rows, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, y7,
                                    (void *)nullptr, 0, (double *)nullptr, fr, zr, (const v4 *)st->wpart.p, s_in);
-                hipLaunchKernelGGL((wide_small_out_kernel<F, Z, WRT, false>), dim3(s_out, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
-                                   rows, (const float *)y7, rdst, (double *)h->lossp.p + nblk, tps, fr, recon_dtype == BAMD_F64 ? 1 : 0);
-                nblk += s_out * ngroup;
+                const bool out16 = rows <= out16_rows();
+                if (out16)
+                    hipLaunchKernelGGL((wide_small_out16_kernel<F, Z, WRT, false>), dim3(s_out, (unsigned)(4 * ngroup)), dim3(256), 0, s, (const v4 *)h->packed.p,
+                                       (const float *)src, rows, (const float *)y7, rdst, (double *)h->lossp.p + nblk, tps, fr, recon_dtype == BAMD_F64 ? 1 : 0);
+                else
+                    hipLaunchKernelGGL((wide_small_out_kernel<F, Z, WRT, false>), dim3(s_out, ngroup), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
+                                       rows, (const float *)y7, rdst, (double *)h->lossp.p + nblk, tps, fr, recon_dtype == BAMD_F64 ? 1 : 0);
+                nblk += s_out * ngroup * (out16 ? 4 : 1);
                 continue;
             }
             hipLaunchKernelGGL((wide_train_fwd_kernel<F, Z, false, WRT>), dim3(grid), dim3(256), 0, s, (const v4 *)h->packed.p, (const float *)src,
