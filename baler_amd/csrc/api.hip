@@ -221,6 +221,17 @@ static int bf16_sync(bamd_handle *h, hipStream_t s) {
     return bf16_pack(h, s);
 }
 
+// Every path that has just written h->params / h->packed (the Adam kernel, or Adam inside a weight-gradient launch) ends here: lazily
+// refreshed float32 copies are stale, and a BF16 handle's bf16 fragments are re-rounded (on demand where the handle has both sets).
+static int params_stepped(bamd_handle *h, hipStream_t s) {
+    fused_params_changed(h);
+    if (h->mode == BAMD_MODE_BF16 && h->bf16_state) {
+        if (bf16_train_ok(h)) { h->bf16_infer_stale = true; h->bf16_train_stale = true; }
+        else return bf16_pack(h, s);
+    }
+    return BAMD_OK;
+}
+
 #define BAMD_CHECK_MODEL(h)                                                        \
     BAMD_REQUIRE(h, "null handle");                                                \
     BAMD_REQUIRE((h)->params_loaded, "bamd_load_params() has not been called");    \
@@ -321,12 +332,7 @@ int bamd_adam_step(bamd_handle *h, void *params, const void *grads, void *m, voi
     fused_scatter(h, &sc_off, &sc_idx, &packed);   // Adam also refreshes the packed weight copy (one launch)
     if (h->mode == BAMD_MODE_F64) fused64_scatter(h, &sc_off, &sc_idx, &packed);
     int rc = launch_adam(params, h->params.p, grads, m, v, h->nparams, h->esize, *hp, loss_accum, sc_off, sc_idx, packed, s);
-    if (rc == BAMD_OK) fused_params_changed(h);
-    if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16 && h->bf16_state) {
-        if (bf16_train_ok(h)) { h->bf16_infer_stale = true; h->bf16_train_stale = true; }   // both sets of bf16 fragments on demand
-        else rc = bf16_pack(h, s);
-    }
-    return rc;
+    return rc == BAMD_OK ? params_stepped(h, s) : rc;
 }
 
 int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, const double *features, void *params,
@@ -338,7 +344,7 @@ int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, 
     if (n_rows > 0 && !bf16_kernels_train(h, n_rows)) {
         int rc = fused_train_step(h, x, x_dtype, n_rows, features, grads, params, m, v, *hp, loss_accum, s);
         if (rc != BAMD_ERR_UNSUPPORTED) {
-            if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16) { h->bf16_infer_stale = true; h->bf16_train_stale = true; fused_params_changed(h); }
+            if (rc == BAMD_OK && h->mode == BAMD_MODE_BF16) rc = params_stepped(h, s);
             return rc;
         }
         if (h->mode == BAMD_MODE_F64) {
@@ -351,10 +357,13 @@ int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, 
         if (rc) return rc;
         grads = h->gscratch.p;
     }
-    if (n_rows > 0 && h->mode != BAMD_MODE_F64 && !bf16_kernels_train(h, n_rows)) {      // small batches on the layer-wise / wide launches: Adam inside the weight-gradient launch
+    // small batches on the layer-wise / wide launches: Adam inside the weight-gradient launch.  Only for models whose training runs on
+    // generic.hip anyway (no fused state, or the wide launches): a fused narrow handle that declined above (BALER_AMD_LATENCY_ROWS below
+    // the batch) keeps its throughput pair, as README says of that knob.
+    if (n_rows > 0 && h->mode != BAMD_MODE_F64 && !bf16_kernels_train(h, n_rows) && (!h->fused_ok || fused_wide_train(h))) {
         int rc = generic_small_train_step(h, x, x_dtype, n_rows, features, grads, params, m, v, *hp, loss_accum, s);
         if (rc != BAMD_ERR_UNSUPPORTED) {
-            if (rc == BAMD_OK) fused_params_changed(h);
+            if (rc == BAMD_OK) rc = params_stepped(h, s);
             return rc;
         }
     }

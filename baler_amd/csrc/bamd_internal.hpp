@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,16 @@ void set_error(const std::string &msg);
             return BAMD_ERR_INVALID;                                                        \
         }                                                                                   \
     } while (0)
+
+// Tuning knobs are read on EVERY call (a getenv is nothing beside a launch; tests and A/B runs toggle them inside one process)
+inline long long env_ll(const char *name, long long dflt) {
+    const char *e = getenv(name);
+    return e && e[0] ? atoll(e) : dflt;
+}
+inline bool env_off(const char *name) {      // "NAME=0" switches a default-on path off
+    const char *e = getenv(name);
+    return e && e[0] == '0';
+}
 
 struct DevBuf {
     void *p = nullptr;

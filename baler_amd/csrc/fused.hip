@@ -4163,7 +4163,7 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
     // 64-row group (wide_small_in_kernel / wide_small_out_kernel); 1 = the one-launch kernels.  At least three chunks / tiles per
     // workgroup, at most 16 splits (the MID launches add the partial sums of every split).
     static int small_splits(const bamd_handle *h, int64_t rows, int units, int *per) {
-        static const int64_t lim = getenv("BALER_AMD_WIDE_SMALL_ROWS") ? atoll(getenv("BALER_AMD_WIDE_SMALL_ROWS")) : 8192;
+        const int64_t lim = env_ll("BALER_AMD_WIDE_SMALL_ROWS", 8192);
         *per = units;
         if (rows > lim) return 1;
         const int64_t ngroup = (rows + 63) / 64;
@@ -4184,12 +4184,10 @@ template <int F, int Z, bool WRT = false> struct ImplWide {
         return (units + p - 1) / p;
     }
     static int64_t in16_rows() {      // BALER_AMD_WIDE_IN16_ROWS: most rows whose contraction-split products take one 16-row tile per workgroup
-        static const int64_t lim = getenv("BALER_AMD_WIDE_IN16_ROWS") ? atoll(getenv("BALER_AMD_WIDE_IN16_ROWS")) : 512;
-        return lim;
+        return env_ll("BALER_AMD_WIDE_IN16_ROWS", 512);
     }
     static int64_t out16_rows() {     // BALER_AMD_WIDE_OUT16_ROWS: most rows whose tile-split product (de4) takes one 16-row tile per workgroup
-        static const int64_t lim = getenv("BALER_AMD_WIDE_OUT16_ROWS") ? atoll(getenv("BALER_AMD_WIDE_OUT16_ROWS")) : 512;
-        return lim;
+        return env_ll("BALER_AMD_WIDE_OUT16_ROWS", 512);
     }
     static bool small_pass(const bamd_handle *h, int64_t rows) {      // this batch runs on the split launches
         int per = 0;

@@ -1059,15 +1059,21 @@ template <int F, int Z, bool RT = false> struct Impl64 {
         // from 64 blocks (1,024 rows) on: 2 x 4 tile blocks over block ranges + the finishing launch (BALER_AMD_DW64_MACRO_BLKS, 0 = off).
         // Measured ms per bamd_fwd_bwd, blocks / one tile per workgroup: 512 rows 0.045 / 0.040, 1,024: 0.046 / 0.049, 2,048: 0.054 / 0.064,
         // 4,096: 0.068 / 0.094, 16,384: 0.227 / 0.341, 65,536: 0.85 / 1.32, 262,144: 3.22 / 5.51 (0.37 / 0.22 of the fp64 MFMA peak)
-        static const int macro_blks = getenv("BALER_AMD_DW64_MACRO_BLKS") ? atoi(getenv("BALER_AMD_DW64_MACRO_BLKS")) : 64;
+        const int macro_blks = (int)env_ll("BALER_AMD_DW64_MACRO_BLKS", 64);
         const bool macro = nchunk > 1 || (macro_blks > 0 && nblk_all >= macro_blks);
         // tile-block shape by batch size; block ranges per chunk (tile blocks x ranges = workgroups): from 1,024 blocks on the exact
         // per-layer blocks (24 of them, one workgroup per CU) over 32 ranges = three full rounds of the chip (BALER_AMD_DW64_RANGES;
         // measured at 262,144 rows 32 / 64 / 128 ranges: 2.11 / 2.15 / 2.21 ms per bamd_fwd_bwd); below that 2 x 4 blocks (52) over 8
         // ranges, at least 4 blocks per range.  Every chunk but the last is a full one
         const bool big = nblk_all >= 1024;
-        static const int big_ranges = getenv("BALER_AMD_DW64_RANGES") ? std::max(1, atoi(getenv("BALER_AMD_DW64_RANGES"))) : 32;
-        auto splits_of = [big](int64_t blks) { return (int)std::min<int64_t>(big ? big_ranges : 8, std::max<int64_t>(1, blks / 4)); };
+        const int big_ranges = (int)std::max<long long>(1, env_ll("BALER_AMD_DW64_RANGES", 32));
+        // every range must own at least one block: the kernels prefetch block `range * ceil(blks / ranges)` unconditionally, which an
+        // empty trailing range would read past the images (e.g. 128 ranges of 1,025 blocks: 9 blocks each, range 114 starts at 1,026)
+        auto splits_of = [big, big_ranges](int64_t blks) {
+            int64_t ns = std::min<int64_t>(big ? big_ranges : 8, std::max<int64_t>(1, blks / 4));
+            while (ns > 1 && (ns - 1) * ((blks + ns - 1) / ns) >= blks) --ns;
+            return (int)ns;
+        };
         int nsplit = 0;
         if (macro) {
             // the first chunk is the largest (every chunk but the last is a full one): its range count is the buffer's; 32 ranges by

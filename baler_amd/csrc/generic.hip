@@ -416,8 +416,7 @@ __global__ void __launch_bounds__(256) gemm_small_k(Opnd<T> A, Opnd<T> B, int64_
 }
 static int64_t gemm_small_rows() {      // BALER_AMD_GEMM_SMALL_ROWS: most rows for the one-tile-per-workgroup kernel (0: off)
     // (C4 in float32, layer-wise step: 256 rows 965 -> 195 us, 512: 1004 -> 281, 1024: 1052 -> 477)
-    static const int64_t lim = getenv("BALER_AMD_GEMM_SMALL_ROWS") ? atoll(getenv("BALER_AMD_GEMM_SMALL_ROWS")) : 1024;
-    return lim;
+    return env_ll("BALER_AMD_GEMM_SMALL_ROWS", 1024);
 }
 
 // pick the tile: 128 x 128 (double-buffered) when both outer extents are large enough, else 64 x 64
@@ -1334,8 +1333,7 @@ static void run_dw_short(const ShortPlan &pl, int l, const float *dz, const floa
 // layer and contracts over ALL rows of the batch (operands in MFMA layout straight from the row-major matrices, as dw_short_k: the
 // reduction index of v_mfma_f32_16x16x4_f32 is the row); results go straight to the canonical gradient vector (= or +=).
 static int64_t dw_small_rows() {      // BALER_AMD_DW_SMALL_ROWS (C4: 512 rows 226 -> 180 us, 1024 rows 235 -> 237 with the one launch)
-    static const int64_t lim = getenv("BALER_AMD_DW_SMALL_ROWS") ? atoll(getenv("BALER_AMD_DW_SMALL_ROWS")) : 768;
-    return lim;
+    return env_ll("BALER_AMD_DW_SMALL_ROWS", 768);
 }
 template <typename T> struct SmallDwPlan {
     const T *dz[8], *x[8];
@@ -1449,14 +1447,33 @@ __global__ void __launch_bounds__(256) dw_small_all_k(SmallDwPlan<T> pl, int64_t
     }
 }
 
+// Which launches a chunk of `rows` rows takes.  ONE definition: the optimiser-step precheck of fwd_bwd_T and its body must agree, or a
+// step whose weight gradients do not run on dw_small_all_k would return BAMD_OK without having applied Adam.
+struct ChunkRoute {
+    bool wide;        // row-local work on the two fused wide launches of fused.hip
+    bool small_wide;  // ... on their split float32 forms (also on a BF16 handle)
+    bool bf16_dw;     // BF16 handle whose weight gradients keep the per-layer launches (bf16 operands where the layer is wide)
+    bool dw_small;    // every weight gradient (+ the loss sum, + Adam when asked) in ONE launch: dw_small_all_k
+};
+template <typename T>
+static ChunkRoute route_chunk(const bamd_handle *h, int64_t rows) {
+    ChunkRoute r{};
+    // (BALER_AMD_WIDE_LAYERWISE_ROWS, default 0 = never: up to that many rows the one-tile-per-workgroup kernels of this file would take
+    // every layer of a wide model too -- measured: C4 optimiser step at 60 rows 148 us against 125 on the split launches of fused.hip)
+    const int64_t lw_rows = env_ll("BALER_AMD_WIDE_LAYERWISE_ROWS", 0);
+    r.wide = sizeof(T) == 4 && fused_wide_train(h) && !(rows <= lw_rows && rows <= gemm_small_rows() && h->mode != BAMD_MODE_BF16);
+    r.small_wide = r.wide && fused_wide_small(h, rows);      // (a BF16 handle's small batches run the float32 split launches)
+    r.bf16_dw = h->mode == BAMD_MODE_BF16 && !env_off("BALER_AMD_BF16_WIDE_TRAIN") && !r.small_wide;
+    r.dw_small = !r.bf16_dw && rows <= dw_small_rows() && h->L <= 8;
+    return r;
+}
+
 template <typename T>
 static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,
                      void *grads_v, const void *latent_grad, hipStream_t s, const SmallAdam *adam = nullptr) {
-    // `adam`: the caller wants the optimiser step in the weight-gradient launch: one chunk of a small float32 batch only
-    // (checked before the workspace is carved: a large batch of a fused shape only asks)
-    if (adam && !(sizeof(T) == 4 && n <= dw_small_rows() && h->L <= 8 &&
-                  !(h->mode == BAMD_MODE_BF16 && fused_wide_train(h) && !fused_wide_small(h, n))))
-        return BAMD_ERR_UNSUPPORTED;
+    // `adam`: the caller wants the optimiser step in the weight-gradient launch: one chunk of a small float32 batch whose weight
+    // gradients run on dw_small_all_k (checked before the workspace is carved: a large batch of a fused shape only asks)
+    if (adam && !(sizeof(T) == 4 && route_chunk<T>(h, n).dw_small)) return BAMD_ERR_UNSUPPORTED;
     Work<T> wk;
     int rc = carve<T>(h, n, true, wk);
     if (rc) return rc;
@@ -1490,13 +1507,10 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
             if (rc) return rc;
         }
         // wide models in float32: the row-local work (forward, loss, input-gradient chain) as two fused launches (fused.hip)
-        // (BALER_AMD_WIDE_LAYERWISE_ROWS, default 0 = never: up to that many rows the one-tile-per-workgroup kernels of this file would take
-        // every layer of a wide model too -- measured: C4 optimiser step at 60 rows 148 us against 125 on the split launches of fused.hip)
-        static const int64_t lw_rows = getenv("BALER_AMD_WIDE_LAYERWISE_ROWS") ? atoll(getenv("BALER_AMD_WIDE_LAYERWISE_ROWS")) : 0;
-        const bool wide = sizeof(T) == 4 && fused_wide_train(h) && !(rows <= lw_rows && rows <= gemm_small_rows() && h->mode != BAMD_MODE_BF16);
+        const ChunkRoute route = route_chunk<T>(h, rows);
+        const bool wide = route.wide, small_wide = route.small_wide;
         // BF16 handles: dL/drecon stored as bfloat16 when its two readers take it that way (BALER_AMD_BF16_DZ16=0: float32)
         bool dz16 = false;
-        const bool small_wide = wide && fused_wide_small(h, rows);      // (a BF16 handle's small batches run the float32 split launches)
         if constexpr (sizeof(T) == 4) {
             const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN"), *e16 = getenv("BALER_AMD_BF16_DZ16");
             const int ll = h->L - 1;
@@ -1531,12 +1545,8 @@ static int fwd_bwd_T(bamd_handle *h, const void *x, int x_dtype, int64_t n, cons
                 launch_gemm<T, EPI_FWD_LOSS, true, true>(A, B, (int64_t)K, e, rows, N, 1, s);
             }
         }
-        bool dw_small = false;
-        {
-            const char *e = getenv("BALER_AMD_BF16_WIDE_TRAIN");
-            const bool bf16 = h->mode == BAMD_MODE_BF16 && !(e && e[0] == '0') && !small_wide;
-            dw_small = !bf16 && rows <= dw_small_rows() && h->L <= 8;      // every weight gradient in ONE launch, behind the input-gradient chain
-        }
+        const bool dw_small = route.dw_small;      // every weight gradient in ONE launch, behind the input-gradient chain
+        if (adam && !dw_small) { set_error("fwd_bwd_T: optimiser step asked of a chunk that is not on dw_small_all_k"); return BAMD_ERR_UNSUPPORTED; }
         if (!dw_small)      // (that launch also sums the loss partials)
             hipLaunchKernelGGL(loss_final_k<T>, dim3(1), dim3(256), 0, s, (const double *)h->lossp.p, nblk, 1.0 / c,
                                grads + np, chunk_i > 0 ? 1 : 0);
@@ -1620,8 +1630,7 @@ int generic_fwd_bwd(bamd_handle *h, const void *x, int x_dtype, int64_t n, const
 int generic_small_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features, void *grads, void *params,
                              void *m, void *v, const bamd_adam &hp, double *loss_accum, hipStream_t s) {
     if (h->esize != 4) return BAMD_ERR_UNSUPPORTED;
-    static const bool on = !(getenv("BALER_AMD_SMALL_ADAM") && getenv("BALER_AMD_SMALL_ADAM")[0] == '0');
-    if (!on) return BAMD_ERR_UNSUPPORTED;
+    if (env_off("BALER_AMD_SMALL_ADAM")) return BAMD_ERR_UNSUPPORTED;
     SmallAdam sa{};
     sa.p = (float *)params; sa.pcopy = (float *)h->params.p; sa.m = (float *)m; sa.v = (float *)v;
     void *packed = nullptr;

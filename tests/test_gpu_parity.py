@@ -1229,6 +1229,46 @@ def test_train_step_empty_batch_and_generic_fallback():
     assert torch.equal(pa, pb)
 
 
+@pytest.mark.parametrize("case", ["bf16-wide-layerwise", "bf16-ae24-no-latency", "fp32-ae24-no-latency", "bf16-wide-split"])
+def test_train_step_under_routing_knobs(case, monkeypatch):
+    """bamd_train_step never returns OK without having stepped: under the documented routing knobs that take a handle off its default
+    launches (BALER_AMD_WIDE_TRAIN=0 on a BF16 wide handle: weight gradients on the per-layer launches, no in-kernel Adam;
+    BALER_AMD_LATENCY_ROWS=0 on a narrow handle: the throughput pair for every batch) the one-call step equals bamd_fwd_bwd +
+    bamd_adam_step bit for bit, the parameters MOVE, and the next encode of a BF16 handle sees the new weights (round-5 advisor
+    finding: the precheck and the body of fwd_bwd_T disagreed and the optimiser step was dropped)."""
+    if case.startswith("bf16-wide"):
+        shape, n, mode = (512, 6), 60, "bf16"
+        if case == "bf16-wide-layerwise":
+            monkeypatch.setenv("BALER_AMD_WIDE_TRAIN", "0")
+    else:
+        shape, n, mode = (24, 15), 512, case[:4]
+        monkeypatch.setenv("BALER_AMD_LATENCY_ROWS", "0")      # read at bamd_create
+    dims = orc.ae_dims(*shape)
+    p0 = orc.formula_params(dims, 19)
+    x = off_the_kink(dims, p0, n, 5)
+    xd = dev(x, torch.float32)
+    runs = []
+    for one_call in (False, True):
+        h, flat = make_handle(dims, p0, mode)
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        grads = torch.zeros_like(flat)
+        for t in range(1, 4):
+            if one_call:
+                h.train_step(xd, flat, m, v, t, 1e-2, grads=grads if t % 2 else None)
+            else:
+                h.fwd_bwd(xd, grads)
+                h.adam_step(flat, grads, m, v, t, 1e-2)
+        runs.append((flat.clone(), m.clone(), v.clone(), h.encode(xd, out_dtype=torch.float32)))
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
+    got = runs[1][0][:-1].double().cpu().numpy()
+    assert np.abs(got - p0).max() > 5e-3                       # three steps of lr 1e-2 moved the parameters
+    assert float(runs[1][1].abs().max()) > 0 and float(runs[1][2].abs().max()) > 0
+    z_new = orc.encode(dims, got, x)
+    assert rel_l2(runs[1][3].cpu().numpy(), z_new) < (BF16_TOL if mode == "bf16" else TOL32)
+    assert rel_l2(orc.encode(dims, p0, x), z_new) > 5e-2       # ... by far more than the tolerance the encode is held to
+
+
 def test_bf16_mode_unsupported_shape():
     with pytest.raises(native.NativeError):
         native.Handle(orc.ae_dims(100, 10), "bf16")
