@@ -103,13 +103,21 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
     }
     h->nparams = off;
     for (int l = 0; l <= n_layers; ++l) h->max_dim = dims[l] > h->max_dim ? dims[l] : h->max_dim;
+    // BAMD_MODE_BF16 of a shape without bf16 kernels (any AE / CFD_dense_AE(n_features, z_dim) the reference builds, models.py:122-139,
+    // 192-209, other than the instantiated ones): the handle computes in float32 on whatever serves the shape there (run-time-width
+    // classes, layer-wise kernels) and says so; bamd_mode_of() then reports BAMD_MODE_F32.  A slower path, not an error.
+    bool demoted = false;
+    if (mode == BAMD_MODE_BF16 && !bf16_has_kernels(h) && !fused_has_bf16_kernels(h)) {
+        h->mode = BAMD_MODE_F32;
+        demoted = true;
+    }
     int rc = h->params.ensure((size_t)(h->nparams + 1) * h->esize);
     if (rc) { delete h; return rc; }
     rc = fused_setup(h);
     if (rc) { bamd_destroy(h); return rc; }
     rc = fused64_setup(h);
     if (rc) { bamd_destroy(h); return rc; }
-    if (mode == BAMD_MODE_BF16 && !fused_serves_bf16_inference(h)) {   // (wide models in the bf16 mode are served by fused.hip)
+    if (h->mode == BAMD_MODE_BF16 && !fused_serves_bf16_inference(h)) {   // (wide models in the bf16 mode are served by fused.hip)
         rc = bf16_setup(h);
         if (rc) { bamd_destroy(h); return rc; }
         rc = bf16_train_setup(h);
@@ -117,6 +125,16 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
     }
     *out = h;
     const int path = bamd_path_of(h);
+    if (demoted) {
+        const char *q = getenv("BALER_AMD_QUIET");
+        if (!(q && q[0] == '1')) {
+            std::string d;
+            for (int l = 0; l <= n_layers; ++l) d += (l ? "-" : "") + std::to_string(dims[l]);
+            fprintf(stderr, "[baler_amd] model %s: BAMD_MODE_BF16 has kernels for the 24-column AE and the 2500-25 / 625-7 / 512-6 wide models only; "
+                            "this handle computes in float32 (%s)\n", d.c_str(),
+                    path == BAMD_PATH_GENERIC ? "layer-wise kernels" : "fused run-time-width kernels");
+        }
+    }
     if (path == BAMD_PATH_GENERIC || path == BAMD_PATH_FUSED_INFER) {
         const char *q = getenv("BALER_AMD_QUIET");
         if (!(q && q[0] == '1')) {
@@ -125,7 +143,7 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
             const std::string infer_only = "throughput training kernels (encode / decode / validation and training steps of up to " +
                                            std::to_string((long long)fused_latency_rows(h)) + " rows are fused)";
             fprintf(stderr, "[baler_amd] model %s (%s) has no fused %s: %s run layer by layer (generic.hip, activations through HBM)\n",
-                    d.c_str(), mode == BAMD_MODE_F64 ? "fp64" : mode == BAMD_MODE_BF16 ? "bf16" : "fp32",
+                    d.c_str(), h->mode == BAMD_MODE_F64 ? "fp64" : h->mode == BAMD_MODE_BF16 ? "bf16" : "fp32",
                     path == BAMD_PATH_GENERIC ? "kernel instantiation" : infer_only.c_str(),
                     path == BAMD_PATH_GENERIC ? "encode / decode / training" : "larger training batches");
         }
@@ -148,6 +166,7 @@ void bamd_destroy(bamd_handle *h) {
     fused64_teardown(h);
     bf16_teardown(h);
     bf16_train_teardown(h);
+    comm_teardown(h);
     h->params.release();
     h->packed.release();
     h->work.release();
@@ -341,6 +360,18 @@ int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, 
     BAMD_REQUIRE(params && m && v && hp && n_rows >= 0 && (x || n_rows == 0), "bad arguments");
     BAMD_REQUIRE(hp->step >= 1, "step must be >= 1");
     hipStream_t s = (hipStream_t)stream;
+    if (h->comm) {      // data parallel: this rank's rows -> [grads | loss] summed over the ranks -> the replicated Adam step
+        if (!grads) {
+            int rc = h->gscratch.ensure((size_t)(h->nparams + 1) * h->esize);
+            if (rc) return rc;
+            grads = h->gscratch.p;
+        }
+        int rc = bamd_fwd_bwd(h, x, x_dtype, n_rows, features, grads, stream);
+        if (rc) return rc;
+        rc = comm_allreduce_sum(h, grads, h->esize == 8 ? BAMD_F64 : BAMD_F32, h->nparams + 1, s);
+        if (rc) return rc;
+        return bamd_adam_step(h, params, grads, m, v, hp, loss_accum, stream);
+    }
     if (n_rows > 0 && !bf16_kernels_train(h, n_rows)) {
         int rc = fused_train_step(h, x, x_dtype, n_rows, features, grads, params, m, v, *hp, loss_accum, s);
         if (rc != BAMD_ERR_UNSUPPORTED) {
@@ -388,6 +419,26 @@ int bamd_train_epoch(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows,
         if (rc) return rc;
     }
     if (steps_out) *steps_out = steps;
+    return BAMD_OK;
+}
+
+int bamd_train_epoch_dp(bamd_handle *h, const void *x, int x_dtype, const int64_t *batch_rows, int64_t n_batches, const double *features,
+                        void *params, void *grads, void *m, void *v, const bamd_adam *hp, double *loss_accum, void *stream) {
+    BAMD_REQUIRE(h && hp, "null argument");
+    BAMD_REQUIRE(n_batches >= 0 && (batch_rows || n_batches == 0), "bad arguments");
+    BAMD_REQUIRE(x_dtype == BAMD_F32 || x_dtype == BAMD_F64, "bad dtype");
+    const size_t row_bytes = (size_t)h->dims[0] * (x_dtype == BAMD_F64 ? 8 : 4);
+    bamd_adam step_hp = *hp;
+    int64_t r0 = 0;
+    for (int64_t b = 0; b < n_batches; ++b) {
+        const int64_t rows = batch_rows[b];
+        BAMD_REQUIRE(rows >= 0 && (x || rows == 0), "bad batch_rows entry");
+        step_hp.step = hp->step + b;
+        const int rc = bamd_train_step(h, (const char *)x + (size_t)r0 * row_bytes, x_dtype, rows, features, params, grads, m, v, &step_hp,
+                                       loss_accum, stream);
+        if (rc) return rc;
+        r0 += rows;
+    }
     return BAMD_OK;
 }
 

@@ -80,6 +80,9 @@ struct bamd_handle {
     void *bf16_train_state = nullptr;   // packed bf16 weights + maps of the bf16 training kernels (bf16_train.hip)
     bool bf16_infer_stale = false;  // the inference fragments lag h->params (re-packed lazily by the next inference call)
     bool bf16_train_stale = false;  // the bf16 TRAINING fragments lag h->params (re-packed by the next bf16 training launch)
+    void *comm = nullptr;           // ncclComm_t of data-parallel training (comm.hip); null: single process
+    bool comm_owned = false;        // created by bamd_comm_init (destroyed with the handle) vs attached by the caller
+    int comm_world = 0;
 
     bool has_act(int l) const { return !(l == L / 2 - 1 || l == L - 1); }
 };
@@ -106,6 +109,10 @@ int launch_apply_deltas(void *out, int dtype, int n_cols, const int64_t *rows, c
 int launch_adam(void *params, void *params_copy, const void *grads, void *m, void *v, int64_t np,
                 size_t esize, const bamd_adam &hp, double *loss_accum, const int *sc_off, const int *sc_idx,
                 void *packed, hipStream_t s);
+
+// ---- comm.hip (RCCL resolved at run time) -----------------------------------------------------------
+int comm_allreduce_sum(bamd_handle *h, void *buf, int dtype, int64_t count, hipStream_t s);
+void comm_teardown(bamd_handle *h);
 
 // ---- generic.hip (layer-by-layer MFMA path, any dims) -------------------------------------------
 int generic_forward(bamd_handle *h, const void *x, int x_dtype, int64_t n, const double *features,

@@ -26,8 +26,14 @@ namespace {
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 using v4 = float __attribute__((ext_vector_type(4)));
-constexpr int kMB = 4;        // 16-row batch tiles per wave per pass
-constexpr int kWaves = 8;     // waves per workgroup
+#ifndef BAMD_BF16_KMB
+#define BAMD_BF16_KMB 4
+#endif
+#ifndef BAMD_BF16_WAVES
+#define BAMD_BF16_WAVES 8
+#endif
+constexpr int kMB = BAMD_BF16_KMB;        // 16-row batch tiles per wave per pass
+constexpr int kWaves = BAMD_BF16_WAVES;   // waves per workgroup
 constexpr int kRowsPerPass = 16 * kMB;
 
 template <int F, int Z> struct BNet {
@@ -575,6 +581,8 @@ const Bf16Ops *find_bf16(const bamd_handle *h) {
 }
 
 }  // namespace
+
+bool bf16_has_kernels(const bamd_handle *h) { return find_bf16(h) != nullptr; }
 
 int bf16_setup(bamd_handle *h) {
     const Bf16Ops *ops = find_bf16(h);

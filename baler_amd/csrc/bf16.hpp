@@ -3,6 +3,7 @@
 #include "bamd_internal.hpp"
 
 namespace bamd {
+bool bf16_has_kernels(const bamd_handle *h);     // this shape has a bf16 inference instantiation in bf16.hip
 int bf16_setup(bamd_handle *h);                  // BAMD_ERR_UNSUPPORTED for shapes without an instantiation
 int bf16_pack(bamd_handle *h, hipStream_t s);    // h->params (fp32) -> bf16 fragments + fp32 bias fragments
 void bf16_teardown(bamd_handle *h);

@@ -4755,6 +4755,9 @@ int64_t fused_latency_rows(const bamd_handle *h) {   // the handle's small-batch
     if (h->fused_ok && h->fused_small) return ((const FusedState *)h->fused_small)->latency_max_rows;
     return h->fused_ok ? ((const FusedState *)h->fused_state)->latency_max_rows : 0;
 }
+bool fused_has_bf16_kernels(const bamd_handle *h) {
+    return ImplWide<2500, 25>::matches(h) || ImplWide<625, 7>::matches(h) || ImplWide<512, 6>::matches(h);
+}
 bool fused_serves_bf16_inference(const bamd_handle *h) {   // wide models in the bf16 mode: encode / decode live in fused.hip
     return h->fused_ok && ((const FusedState *)h->fused_state)->ops->pack_extra != nullptr;
 }

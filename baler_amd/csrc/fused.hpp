@@ -9,6 +9,7 @@ void fused_teardown(bamd_handle *h);
 bool fused_trains(const bamd_handle *h);                   // false: inference-only class, training runs on generic.hip
 int64_t fused_latency_rows(const bamd_handle *h);          // rows up to which training steps run on the small-batch kernels (0: no fused path)
 bool fused_serves_bf16_inference(const bamd_handle *h);   // BF16 handle of a wide model (no bf16.hip state)
+bool fused_has_bf16_kernels(const bamd_handle *h);        // the shape is one of the wide models with bf16 kernels in fused.hip (before setup)
 void fused_params_changed(bamd_handle *h);       // an optimiser step changed h->params / h->packed: lazily refreshed copies are stale
 // scatter lists (CSR over parameters) into h->packed for the fused Adam+pack kernel; all null when !fused_ok
 void fused_scatter(bamd_handle *h, const int **sc_off, const int **sc_idx, void **packed);

@@ -14,6 +14,7 @@ N x batch_size: the run equals the single-process reference run with ``batch_siz
 for N = 8), and a step keeps one GPU as busy as it is in the single-GPU run.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as td
@@ -70,6 +71,29 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def lib_comm_wanted():
+    """Should the library run the data-parallel step itself (fwd_bwd -> ncclAllReduce -> Adam in one host call)?  Yes on RCCL
+    ("nccl" backend, one GPU per rank); BALER_AMD_LIB_COMM=0 keeps the three-call Python sequence.  The gloo test set-ups (several
+    ranks sharing one GPU) always keep it: an RCCL communicator needs one device per rank."""
+    return (collectives_on() and td.get_backend() == "nccl" and os.environ.get("BALER_AMD_LIB_COMM", "1") != "0")
+
+
+def attach_comm(handle):
+    """Give `handle` its own RCCL communicator over the ranks of the default group: rank 0's ncclGetUniqueId travels through the
+    existing process group (a 128-byte broadcast), then every rank joins with ncclCommInitRank inside the library.  Idempotent."""
+    from . import native
+    if handle.comm_world:
+        return handle
+    rank, world = rank_world()
+    box = [native.comm_unique_id() if rank == 0 else None]
+    td.broadcast_object_list(box, src=0)
+    handle.comm_init(box[0], rank, world)
+    if rank == 0 and os.environ.get("BALER_AMD_QUIET") != "1":
+        print(f"[baler_amd] data-parallel step inside the library: RCCL communicator of {world} rank(s) "
+              "(bamd_train_epoch_dp: fwd_bwd -> ncclAllReduce -> Adam per batch, one host call per epoch)", file=sys.stderr, flush=True)
+    return handle
+
+
 def allreduce_sum(t):
     """In-place SUM all-reduce on the current stream (RCCL: one ncclAllReduce(ncclSum))."""
     if collectives_on():
@@ -82,6 +106,23 @@ def broadcast(t, src=0):
     if collectives_on():
         td.broadcast(t, src=src)
     return t
+
+
+def all_gather_rows(local, counts):
+    """Rank-ordered concatenation of per-rank row blocks ON EVERY RANK (counts[r] = rows of rank r; they differ by at most one in the
+    batch split, so the blocks travel padded to the largest).  The sliced-Wasserstein loss sorts the latent codes of ONE global batch."""
+    world = len(counts)
+    if world == 1 or not is_dist():
+        return local
+    pad = max(counts)
+    send = local.contiguous()
+    if local.shape[0] != pad:
+        send = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[:local.shape[0]] = local
+    recv = torch.empty((world, pad) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    td.all_gather_into_tensor(recv.view((world * pad,) + tuple(local.shape[1:])), send) if td.get_backend() == "nccl" \
+        else td.all_gather(list(recv.unbind(0)), send)
+    return torch.cat([recv[r, :counts[r]] for r in range(world)], dim=0)
 
 
 def barrier():

@@ -43,7 +43,7 @@ class Adam:
     def zero_grad(self):
         """No work: bamd_fwd_bwd overwrites the gradient buffer (reference training.py:68)."""
 
-    def train_step(self, handle, batch, world=1, swae_latent_dim=None):
+    def train_step(self, handle, batch, world=1, swae_latent_dim=None, global_counts=None):
         """forward+loss+backward -> [all-reduce] -> Adam, all asynchronous on the current stream.  A single process
         issues ONE native call per batch (bamd_train_step: for small batches the Adam update is fused into the
         weight-gradient kernel); data-parallel ranks need the all-reduce between the two halves."""
@@ -51,19 +51,37 @@ class Adam:
         if swae_latent_dim is not None:
             # loss = mse + sliced-Wasserstein(z) (training.py:73-80, utils.py:27-77): encode, regulariser forward +
             # backward on the latent batch, then the usual backward with dL/dz injected at the bottleneck
-            if world > 1:
-                raise NotImplementedError("loss_function_swae sorts the latent codes across ONE batch; it is not "
-                                          "defined for a batch split over ranks")
             z = handle.encode(batch, out_dtype=self.model.flat.dtype)
-            reg_weight = 100 / (batch.shape[0] * (batch.shape[0] - 1))
-            swd, dz = utils.compute_swd(z, 2.0, reg_weight, swae_latent_dim, 2000, "normal")
-            handle.fwd_bwd_latent(batch, dz, self.grads)
+            if world > 1:
+                # the regulariser sorts the latent codes of the WHOLE global batch: all-gather them (rank order = row order), draw
+                # the prior sample and the projections once (rank 0) for everybody, evaluate the small kernel replicated, and inject
+                # this rank's rows of dL/dz; the weight gradients then sum over the ranks like the reconstruction term's
+                rank = bdist.rank_world()[0]
+                counts = global_counts if global_counts is not None else [batch.shape[0]] * world
+                n_glob = sum(counts)
+                z_all = bdist.all_gather_rows(z, counts)
+                draws = list(utils.swae_draws(z_all, swae_latent_dim, 2000, "normal"))
+                for d in draws:
+                    bdist.broadcast(d, src=0)
+                swd, dz_all = utils.compute_swd(z_all, 2.0, 100 / (n_glob * (n_glob - 1)), swae_latent_dim, 2000, "normal", draws=tuple(draws))
+                lo = sum(counts[:rank])
+                if batch.shape[0] > 0:
+                    handle.fwd_bwd_latent(batch, dz_all[lo:lo + batch.shape[0]].contiguous(), self.grads)
+                else:
+                    self.grads.zero_()          # no rows of this global batch here
+                bdist.allreduce_sum(self.grads)
+            else:
+                reg_weight = 100 / (batch.shape[0] * (batch.shape[0] - 1))
+                swd, dz = utils.compute_swd(z, 2.0, reg_weight, swae_latent_dim, 2000, "normal")
+                handle.fwd_bwd_latent(batch, dz, self.grads)
             self.grads[-1:] += swd.to(self.grads.dtype)          # running loss = mse + swd, like loss.item()
             self.step_count += 1
             handle.adam_step(self.model.flat, self.grads, self.m, self.v, self.step_count, g["lr"], g["betas"][0],
                              g["betas"][1], g["eps"], loss_accum=self.loss_accum)
             return
-        if world == 1 and not bdist.collectives_on():       # (BALER_AMD_FORCE_PG=1 keeps the all-reduce at one rank)
+        if (world == 1 and not bdist.collectives_on()) or handle.comm_world:
+            # single process -- or a handle with its own RCCL communicator: the library runs fwd_bwd -> all-reduce -> Adam itself
+            # (BALER_AMD_FORCE_PG=1 keeps the all-reduce at one rank)
             self.step_count += 1
             handle.train_step(batch, self.model.flat, self.m, self.v, self.step_count, g["lr"], g["betas"][0],
                               g["betas"][1], g["eps"], loss_accum=self.loss_accum, grads=self.grads)
@@ -82,9 +100,17 @@ def _epoch_in_one_call(world, swae_latent_dim):
             and os.environ.get("BALER_AMD_EPOCH_CALL", "1") != "0")
 
 
-def _run_batches(optimizer, h, rows, spans, bs, world, swae_latent_dim):
+def _run_batches(optimizer, h, rows, spans, bs, world, swae_latent_dim, global_spans=None):
     """The optimiser steps of the batches `spans` (consecutive local row ranges of `rows`)."""
     if not spans:
+        return
+    if h.comm_world and swae_latent_dim is None and os.environ.get("BALER_AMD_EPOCH_CALL", "1") != "0":
+        # data parallel with the communicator inside the library: the epoch's batch loop is ONE native call per rank
+        a, b = spans[0][0], spans[-1][1]
+        g = optimizer.param_groups[0]
+        optimizer.step_count += h.train_epoch_dp(rows[a:b], [hi - lo for lo, hi in spans], optimizer.model.flat, optimizer.m,
+                                                 optimizer.v, optimizer.step_count + 1, g["lr"], g["betas"][0], g["betas"][1],
+                                                 g["eps"], loss_accum=optimizer.loss_accum, grads=optimizer.grads)
         return
     if _epoch_in_one_call(world, swae_latent_dim):
         a, b = spans[0][0], spans[-1][1]
@@ -93,8 +119,12 @@ def _run_batches(optimizer, h, rows, spans, bs, world, swae_latent_dim):
                                               optimizer.step_count + 1, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                               loss_accum=optimizer.loss_accum, grads=optimizer.grads)
         return
-    for a, b in spans:
-        optimizer.train_step(h, rows[a:b], world, swae_latent_dim=swae_latent_dim)
+    for i, (a, b) in enumerate(spans):
+        counts = None
+        if world > 1 and swae_latent_dim is not None:      # rows of every rank in this global batch (the latent all-gather)
+            glo, ghi = global_spans[i]
+            counts = [hi - lo for lo, hi in (_rank_slice(glo, ghi, r, world) for r in range(world))]
+        optimizer.train_step(h, rows[a:b], world, swae_latent_dim=swae_latent_dim, global_counts=counts)
 
 
 def _swae_dim(config, model):
@@ -156,7 +186,7 @@ def fit(config, model, train_dl, model_children, regular_param, optimizer, laten
     h = model.handle()
     optimizer.loss_accum.zero_()
     rows, spans = _local_batches(data, bs, rank, world)
-    _run_batches(optimizer, h, rows, spans, bs, world, _swae_dim(config, model))
+    _run_batches(optimizer, h, rows, spans, bs, world, _swae_dim(config, model), _batches(data.shape[0], bs))
     # one device->host read per epoch (the reference does one per step)
     last = float(optimizer.grads[model.nparams].item())
     epoch_loss = float(optimizer.loss_accum.item()) / len(spans)
@@ -220,6 +250,8 @@ def train(model, variables, train_data, test_data, project_path, config):
     # different initial weights -- rank 0's are broadcast once, after which the replicated Adam keeps ranks identical
     bdist.broadcast(model.flat, src=0)
     model.mark_params_changed()
+    if bdist.lib_comm_wanted():      # RCCL: the handle gets its own communicator and runs the data-parallel step itself
+        bdist.attach_comm(model.handle())
 
     train_ds = _to_device_dataset(train_data, config, device)
     valid_ds = train_ds if test_data is train_data else _to_device_dataset(test_data, config, device)
@@ -323,10 +355,11 @@ def _fit_with_capture(config, model, train_dl, model_children, optimizer, want_a
     model.train()
     h = model.handle()
     optimizer.loss_accum.zero_()
-    _run_batches(optimizer, h, rows, spans[:-1], bs, world, _swae_dim(config, model))
+    gspans = _batches(data.shape[0], bs)
+    _run_batches(optimizer, h, rows, spans[:-1], bs, world, _swae_dim(config, model), gspans[:-1])
     model._dirty = False      # the native Adam kept the handle's packed weights in step with model.flat
     _capture(model, rows, spans[-1], world)
-    _run_batches(optimizer, h, rows, spans[-1:], bs, world, _swae_dim(config, model))
+    _run_batches(optimizer, h, rows, spans[-1:], bs, world, _swae_dim(config, model), gspans[-1:])
     last = float(optimizer.grads[model.nparams].item())
     epoch_loss = float(optimizer.loss_accum.item()) / len(spans)
     model._dirty = False

@@ -24,7 +24,8 @@ SYMBOLS = (
     "bamd_renormalize", "bamd_encode", "bamd_decode", "bamd_forward_loss", "bamd_fwd_bwd",
     "bamd_adam_step", "bamd_train_step", "bamd_emd_rows", "bamd_activation_means",
     "bamd_error_deltas", "bamd_apply_deltas", "bamd_fwd_bwd_latent", "bamd_swd", "bamd_col_minmax", "bamd_path_of",
-    "bamd_train_epoch",
+    "bamd_train_epoch", "bamd_comm_unique_id", "bamd_comm_init", "bamd_comm_attach", "bamd_comm_release", "bamd_comm_world",
+    "bamd_allreduce_sum", "bamd_train_epoch_dp",
 )
 
 
@@ -62,6 +63,7 @@ def lib():
     L.bamd_param_count.argtypes = [vp]
     L.bamd_param_count.restype = i64
     L.bamd_mode_of.argtypes = [vp]
+    L.bamd_mode_of.restype = ci
     L.bamd_load_params.argtypes = [vp, vp, ci, vp]
     L.bamd_minmax.argtypes = [vp, ci, i64, ci, vp, vp]
     L.bamd_col_minmax.argtypes = [vp, ci, i64, ci, vp, vp]
@@ -75,6 +77,13 @@ def lib():
     L.bamd_adam_step.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, vp]
     L.bamd_train_step.argtypes = [vp, vp, ci, i64, vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, vp]
     L.bamd_train_epoch.argtypes = [vp, vp, ci, i64, i64, vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, ctypes.POINTER(i64), vp]
+    L.bamd_comm_unique_id.argtypes = [vp]
+    L.bamd_comm_init.argtypes = [vp, vp, ci, ci]
+    L.bamd_comm_attach.argtypes = [vp, vp, ci]
+    L.bamd_comm_release.argtypes = [vp]
+    L.bamd_comm_world.argtypes = [vp]
+    L.bamd_allreduce_sum.argtypes = [vp, vp, ci, i64, vp]
+    L.bamd_train_epoch_dp.argtypes = [vp, vp, ci, ctypes.POINTER(i64), i64, vp, vp, vp, vp, vp, ctypes.POINTER(AdamHP), vp, vp]
     L.bamd_emd_rows.argtypes = [vp, vp, ci, i64, ci, vp, vp]
     L.bamd_activation_means.argtypes = [vp, vp, ci, i64, vp, vp, ci, vp]
     L.bamd_error_deltas.argtypes = [vp, vp, ci, i64, dbl, vp, vp, vp]
@@ -131,6 +140,13 @@ def require_gpu():
     if n <= 0 or not torch.cuda.is_available():
         raise NativeError("no MI355X (gfx950) device visible: the baler_amd hot path has no CPU fallback")
     return n
+
+
+def comm_unique_id():
+    """128 bytes identifying a new RCCL communicator (ncclGetUniqueId); rank 0 creates it and sends it to the other ranks."""
+    buf = ctypes.create_string_buffer(128)
+    _check(lib().bamd_comm_unique_id(buf), "bamd_comm_unique_id")
+    return buf.raw
 
 
 # ---- handle-free kernels --------------------------------------------------------------------------
@@ -251,6 +267,8 @@ class Handle:
         self._h = h
         self.nparams = int(lib().bamd_param_count(h))
         self.param_dtype = torch.float64 if self.mode == MODE_F64 else torch.float32
+        # the mode the library computes in: "bf16" asked of a shape without bf16 kernels is served in float32 (notice on stderr)
+        self.compute_mode = int(lib().bamd_mode_of(h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -390,6 +408,52 @@ class Handle:
                                       _ptr(grads), _ptr(m), _ptr(v), ctypes.byref(hp), _ptr(loss_accum), ctypes.byref(steps),
                                       self._s()), "bamd_train_epoch")
         return int(steps.value)
+
+    # ---- data-parallel training inside the library (RCCL resolved at run time by the library) -----------------------------
+    def comm_init(self, unique_id, rank, world):
+        """Collective: ncclCommInitRank(world, unique_id, rank) on the handle's device; afterwards train_step / train_epoch_dp run
+        fwd_bwd -> ncclAllReduce(sum) -> Adam inside the library.  `unique_id`: the 128 bytes of comm_unique_id() of rank 0."""
+        if len(unique_id) != 128:
+            raise NativeError("unique_id must be the 128 bytes of comm_unique_id()")
+        buf = (ctypes.c_char * 128).from_buffer_copy(bytes(unique_id))
+        with torch.cuda.device(self.device):
+            _check(lib().bamd_comm_init(self._h, buf, int(rank), int(world)), "bamd_comm_init")
+
+    def comm_release(self):
+        _check(lib().bamd_comm_release(self._h), "bamd_comm_release")
+
+    @property
+    def comm_world(self):
+        """Ranks of the communicator attached to this handle (0: none, the handle trains single-process)."""
+        return int(lib().bamd_comm_world(self._h))
+
+    def allreduce_sum(self, t):
+        """In-place SUM all-reduce of a float32 / float64 tensor over the handle's communicator, on the current stream."""
+        t = _dev_tensor(t)
+        self._mine(t)
+        _check(lib().bamd_allreduce_sum(self._h, _ptr(t), _dt(t), t.numel(), self._s()), "bamd_allreduce_sum")
+        return t
+
+    def train_epoch_dp(self, x, batch_rows, params, m, v, first_step, lr, beta1=0.9, beta2=0.999, eps=1e-8, loss_accum=None,
+                       grads=None, features=None):
+        """One epoch of the data-parallel batch loop in ONE native call: `x` = this rank's rows of every global batch back to back,
+        batch_rows[i] = its rows of global batch i (bamd_train_epoch_dp).  Returns the number of steps."""
+        x = _dev_tensor(x)
+        self._mine(x, params, m, v, grads, loss_accum, features)
+        for t in (params, m, v):
+            _dev_tensor(t)
+            if t.dtype != self.param_dtype:
+                raise NativeError("optimizer tensors must have the handle's parameter type")
+        if grads is not None and (grads.dtype != self.param_dtype or grads.numel() < self.nparams + 1):
+            raise NativeError("grads must hold param_count+1 elements of the handle's parameter type")
+        counts = [int(c) for c in batch_rows]
+        if sum(counts) != x.shape[0] or any(c < 0 for c in counts):
+            raise NativeError("batch_rows must be non-negative and sum to the number of rows of x")
+        arr = (ctypes.c_int64 * len(counts))(*counts)
+        hp = AdamHP(int(first_step), float(lr), float(beta1), float(beta2), float(eps))
+        _check(lib().bamd_train_epoch_dp(self._h, _ptr(x), _dt(x), arr, len(counts), _ptr(features), _ptr(params), _ptr(grads),
+                                         _ptr(m), _ptr(v), ctypes.byref(hp), _ptr(loss_accum), self._s()), "bamd_train_epoch_dp")
+        return len(counts)
 
     def activation_means(self, x, features=None, max_nodes=200):
         x = _dev_tensor(x)

@@ -533,6 +533,54 @@ def main():
                 by_global[str(bs)] = {"rows_per_s": bs * nb / tg_, "us_per_step": 1e6 * tg_ / nb, "rows_per_gpu_per_step": per,
                                       "steps_timed": nb}
             out["train_rows_per_s_by_global_batch"] = by_global
+        if coll and torch.distributed.get_backend() == "nccl" and os.environ.get("BALER_AMD_LIB_COMM", "1") != "0":
+            # ---- what a data-parallel optimiser step costs, as the three-call Python sequence (bamd_fwd_bwd -> torch all-reduce ->
+            # bamd_adam_step) and with the communicator INSIDE the library (bamd_train_epoch_dp: the same three stages per batch, one
+            # host call per epoch), at 64 and 512 rows per rank.  gpu_us = wall time per step with the stream drained; host_us = the
+            # host thread's time per step until its last enqueue returns.  A failure to build the library's own RCCL communicator is
+            # reported, never fatal: the run's other numbers do not depend on it.
+            dp = {}
+            try:
+                h2 = native.Handle(model.dims, a.mode, dev.index)
+                f2 = flat.clone(); h2.load_params(f2)
+                m2, v2, g2 = torch.zeros_like(f2), torch.zeros_like(f2), torch.zeros_like(f2)
+                bdist.attach_comm(h2)
+                for _ in range(10):
+                    h2.allreduce_sum(g2)
+                dp["lib_allreduce_us"] = 1e6 * timed(lambda: h2.allreduce_sum(g2), 200, world, dev) / 200
+                for per in (64, 512):
+                    nb = max(2, min(400, a.rows // per))
+                    t2 = {"t": 0}
+
+                    def py_steps():
+                        for i in range(nb):
+                            t2["t"] += 1
+                            h.fwd_bwd(x[i * per:(i + 1) * per], grads)
+                            bdist.allreduce_sum(grads)
+                            h.adam_step(flat, grads, m, v, state["t"] + t2["t"], 1e-3, loss_accum=loss_acc)
+
+                    def lib_steps():
+                        t2["t"] += h2.train_epoch_dp(x[:nb * per], [per] * nb, f2, m2, v2, t2["t"] + 1, 1e-3, loss_accum=loss_acc, grads=g2)
+                    rec = {"rows_per_rank": per, "steps_timed": nb}
+                    for tag, fn in (("python_3_calls", py_steps), ("library_1_call", lib_steps)):
+                        fn(); fn()
+                        torch.cuda.synchronize()
+                        if world > 1:
+                            torch.distributed.barrier()
+                        t0 = time.perf_counter()
+                        fn()
+                        t_host = time.perf_counter() - t0
+                        torch.cuda.synchronize()
+                        t_all = time.perf_counter() - t0
+                        rec[tag] = {"gpu_us": 1e6 * t_all / nb, "host_us": 1e6 * t_host / nb}
+                    state["t"] += t2["t"]
+                    dp[str(per)] = rec
+                h2.comm_release()
+                h2.close()
+            except Exception as e:      # noqa: BLE001 -- reported on the line
+                dp["error"] = f"{type(e).__name__}: {e}"
+            out["dp_step"] = dp
+            log("dp step: " + json.dumps(dp))
         if world == 1 and not coll and a.rows >= 2 * 512:
             # ---- the reference's epoch (training.fit, training.py:64-97: sequential batches of 512 rows) as ONE host call: bamd_train_epoch,
             # the batch loop inside the library.  host_us_per_step = the host thread's time inside the call (the enqueue of two

@@ -67,7 +67,8 @@ typedef enum bamd_dtype { BAMD_F32 = 0, BAMD_F64 = 1 } bamd_dtype;
  * partial sums; only the six narrow layers, the loss, the masks and the narrow layers' weight gradients stay fp32 on the
  * activations the pass stores -- dL/drecon as bfloat16 where both of its readers take it that way: one-step gradients within
  * ~1e-3 rel-L2, which is the rounding of those wide operands; BALER_AMD_BF16_WIDE_TRAIN=0: the F32 launches); validation of such a handle runs
- * in fp32; other shapes of a BF16 handle are rejected by bamd_create.  bamd_activation_means of a BF16 handle runs on the fp32
+ * in fp32; any OTHER shape asked for in BAMD_MODE_BF16 is created as a float32 handle (run-time-width fused classes or the layer-wise
+ * kernels, whatever serves the shape in BAMD_MODE_F32) with a notice on stderr -- bamd_mode_of() then returns BAMD_MODE_F32.  bamd_activation_means of a BF16 handle runs on the fp32
  * layer-wise kernels. */
 typedef enum bamd_mode { BAMD_MODE_F32 = 0, BAMD_MODE_F64 = 1, BAMD_MODE_BF16 = 2 } bamd_mode;
 
@@ -120,7 +121,7 @@ typedef enum bamd_path {
 } bamd_path;
 int bamd_path_of(const bamd_handle *h);   /* a bamd_path, or BAMD_ERR_INVALID for a null handle */
 int64_t bamd_param_count(const bamd_handle *h);
-int bamd_mode_of(const bamd_handle *h);
+int bamd_mode_of(const bamd_handle *h);    /* the mode the handle COMPUTES in (BAMD_MODE_BF16 asked of a shape without bf16 kernels: BAMD_MODE_F32) */
 
 /* (Re)build the handle's MFMA-fragment-packed weight copy from the caller's flat parameter vector
  * (device pointer; dtype F32 or F64).  Call after loading a checkpoint or changing params outside
@@ -219,10 +220,41 @@ int bamd_train_step(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, 
  * bamd_train_step() calls it replaces.  x: (n_rows, n_features) row-major, x_dtype.  *loss_accum += every batch's loss
  * (running_loss of training.py:97); grads (may be NULL) holds the LAST batch's gradient and loss afterwards (the "Training Loss"
  * training.py:100 prints).  *steps_out (host, may be NULL) receives the number of optimiser steps taken = ceil(n_rows / batch_size).
- * For single-process training; data-parallel runs keep the per-step sequence (the all-reduce sits between the two halves). */
+ * Single-process form (uniform batch size); the data-parallel epoch is bamd_train_epoch_dp() below. */
 int bamd_train_epoch(bamd_handle *h, const void *x, int x_dtype, int64_t n_rows, int64_t batch_size, const double *features,
                      void *params, void *grads, void *m, void *v, const bamd_adam *hp, double *loss_accum, int64_t *steps_out,
                      void *stream);
+
+/* ---- data-parallel training inside the library ("bmi_allreduce_init/... or pass ncclComm_t"; 8(e)) ----------
+ * The reference is single-process; its batch loop (training.py:64-97) becomes data parallel by summing the [grads | loss] vector over
+ * the ranks between loss.backward() (:92) and optimizer.step() (:93).  With a communicator attached to the handle, bamd_train_step()
+ * and bamd_train_epoch_dp() run that sequence -- bamd_fwd_bwd on this rank's rows, ONE ncclAllReduce(ncclSum) of nparams + 1 elements
+ * in place on `grads`, bamd_adam_step -- inside the library on the caller's stream: one host call per step / per epoch instead of three
+ * Python -> C -> RCCL round trips per step.  RCCL is resolved at run time (dlopen of the librccl the process already has, else
+ * librccl.so.1): the library has no link-time dependency on it, and handles without a communicator never touch it.
+ *
+ * bamd_comm_unique_id: rank 0 fills `id128` (128 bytes, ncclGetUniqueId) and hands it to the other ranks by any means (the Python
+ *   host broadcasts it over its torch.distributed group).
+ * bamd_comm_init: every rank, collectively: ncclCommInitRank(world, id, rank) on the handle's device; the handle owns the communicator
+ *   (bamd_destroy / bamd_comm_release destroy it).  world = 1 is valid (RCCL on one GPU: the sum over one rank is the identity).
+ * bamd_comm_attach: use an EXISTING ncclComm_t (`comm`, e.g. the caller's own) instead; the caller keeps ownership.
+ * bamd_comm_release: detach (and destroy an owned communicator); the handle is single-process again.
+ * bamd_allreduce_sum: the collective alone, in place on `buf` (count elements of dtype BAMD_F32 / BAMD_F64) -- for callers that keep
+ *   the three-call sequence (e.g. the sliced-Wasserstein step) and for timing it. */
+int bamd_comm_unique_id(void *id128);
+int bamd_comm_init(bamd_handle *h, const void *id128, int rank, int world);
+int bamd_comm_attach(bamd_handle *h, void *comm, int world);
+int bamd_comm_release(bamd_handle *h);
+int bamd_comm_world(const bamd_handle *h);      /* ranks of the attached communicator; 0 without one */
+int bamd_allreduce_sum(bamd_handle *h, void *buf, int dtype, int64_t count, void *stream);
+/* One epoch of the data-parallel batch loop in ONE call: `x` holds THIS rank's rows of every global batch back to back (the
+ * block-cyclic shard of SURVEY 8(e)), batch_rows[i] (host array, n_batches entries, each >= 0: an empty slice contributes a zero
+ * gradient) = this rank's rows of global batch i.  Every batch runs fwd_bwd -> all-reduce -> Adam as described above (hp->step for the
+ * first, +1 per batch); without a communicator it is the single-process loop with explicit batch sizes (each batch exactly
+ * bamd_train_step).  *loss_accum += every GLOBAL batch's loss; grads (may be NULL) holds the last batch's summed gradient and loss. */
+int bamd_train_epoch_dp(bamd_handle *h, const void *x, int x_dtype, const int64_t *batch_rows, int64_t n_batches,
+                        const double *features, void *params, void *grads, void *m, void *v, const bamd_adam *hp,
+                        double *loss_accum, void *stream);
 
 /* ---- diagnostics -------------------------------------------------------------------------------
  * Replaces: the EMD term of utils.mse_loss_emd_l1 (utils.py:112-119): sum over rows of the 1-D

@@ -319,6 +319,46 @@ def test_cli_cfd_dense_2d_bf16_mode(tmp_path, monkeypatch):
     assert rel(dec.reshape(60, 2500), orc.decode(dims, final, comp["data"].astype(np.float64))) < 6e-3
 
 
+@pytest.mark.parametrize("compute_mode", ["fp32", "bf16"])
+def test_cli_cfd_dense_2d_class_shape(tmp_path, monkeypatch, compute_mode, capfd):
+    """A 2-D field of a size that has NO exact instantiation (30 x 30 -> CFD_dense_AE(900, 9), models.py:192-209; three shipped configs
+    feed un-blocked 2-D data of whatever size the file has) end to end on the run-time-width wide class: train (ragged last batch:
+    45 + 45 + 10 frames) -> compress -> decompress against the oracle replaying the same run.  With BALER_AMD_MODE=bf16 the same project
+    runs too -- in float32 with a notice (no bf16 kernels for this shape), same bars."""
+    from baler_amd import baler
+    from baler_amd.modules import helper, models
+    field = synth.cfd_field(100, 30, 30)
+    cfg = _CFD_CONFIG.replace("c.batch_size = 6000", "c.batch_size = 45").replace("c.epochs = 3", "c.epochs = 2")
+    out = _write_project(tmp_path, monkeypatch, "CFD", "anim", cfg, field, np.array([]))
+    models.set_default_mode(compute_mode)
+    try:
+        dims = orc.ae_dims(900, 9)
+        init = orc.formula_params(dims, 80)
+        monkeypatch.setattr(helper, "model_init",
+                            lambda name: (lambda n_features, z_dim: getattr(models, name)(n_features, z_dim).load_flat(init)))
+        for mode in ("train", "compress", "decompress"):
+            baler.main(["--project", "CFD", "anim", "--mode", mode])
+    finally:
+        models.set_default_mode("fp32")
+    if compute_mode == "bf16":
+        assert "computes in float32" in capfd.readouterr().err
+    loss = np.load(out / "training" / "loss_data.npy")
+    x = field.astype(np.float32).astype(np.float64).reshape(100, 900)
+    st = orc.FitState(dims, init.astype(np.float32).astype(np.float64))
+    want = [orc.fit_epoch(st, x, 45, 1e-3)[0] for _ in range(2)]
+    assert rel(loss[0], want) < 1e-4          # the reference model itself is float32 here
+    sd = torch.load(out / "compressed_output" / "model.pt")
+    assert tuple(sd["en1.weight"].shape) == (200, 900) and tuple(sd["en4.weight"].shape) == (9, 50)
+    comp = np.load(out / "compressed_output" / "compressed.npz")
+    assert comp["data"].shape == (100, 9) and comp["data"].dtype == np.float32
+    final = np.concatenate([v.numpy().ravel().astype(np.float64) for v in sd.values()])
+    assert rel(final, st.params) < 1e-3       # two epochs of Adam from the same start (float32 moves of 1e-3 per step)
+    assert rel(comp["data"], orc.encode(dims, final, x)) < 1e-5
+    dec = np.load(out / "decompressed_output" / "decompressed.npz")["data"]
+    assert dec.shape == (100, 30, 30) and dec.dtype == np.float32
+    assert rel(dec.reshape(100, 900), orc.decode(dims, final, comp["data"].astype(np.float64))) < 1e-5
+
+
 def test_cli_blocks_2d_with_validation_split(tmp_path, monkeypatch):
     """The reference's exafel1/exafel2 shape of run (public_datasets/exafel1 config): 2-D frames cut into 25x25
     blocks (convert_to_blocks = [1, 25, 25], data_processing.py:26-34), CFD_dense_AE(625, 7) in float32,

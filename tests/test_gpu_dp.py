@@ -330,10 +330,12 @@ def test_rccl_world1_bench_step_is_bit_identical():
 
 def test_rccl_world1_cli_train_is_bit_identical(tmp_path):
     """`python -m baler_amd --mode train` under a one-rank RCCL group (fwd_bwd -> ncclAllReduce -> adam_step per batch) writes the
-    same loss curve and model as the plain single-process run (one fused bamd_train_step per batch)."""
+    same loss curve and model as the plain single-process run (one fused bamd_train_step per batch): with the communicator INSIDE
+    the library (default on RCCL: one bamd_train_epoch_dp call per epoch, `[baler_amd] data-parallel step inside the library` on
+    stderr) and with the three-call Python sequence (BALER_AMD_LIB_COMM=0)."""
     import torch
     outs = {}
-    for tag in ("plain", "rccl"):
+    for tag in ("plain", "rccl", "rccl-python"):
         base = tmp_path / tag
         os.makedirs(base)
         out = _dp_workspace(base, epochs=3)
@@ -342,16 +344,129 @@ def test_rccl_world1_cli_train_is_bit_identical(tmp_path):
         env = dict(os.environ, REPO=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0")
         for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BALER_AMD_DIST_BACKEND", "BALER_AMD_FORCE_DEVICE", "BALER_AMD_FORCE_PG"):
             env.pop(k, None)
+        env.pop("BALER_AMD_LIB_COMM", None)
         if tag == "plain":
             cmd = [sys.executable, str(script)]
         else:
             env["BALER_AMD_FORCE_PG"] = "1"
+            if tag == "rccl-python":
+                env["BALER_AMD_LIB_COMM"] = "0"
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                    "--master-port", str(free_port()), str(script)]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(base))
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         sd = torch.load(out / "compressed_output" / "model.pt")
         outs[tag] = (np.load(out / "training" / "loss_data.npy"), np.concatenate([v.numpy().ravel() for v in sd.values()]))
+        outs[tag] += (r.stderr,)
     assert outs["plain"][0].shape == (2, 3)
-    assert np.array_equal(outs["plain"][0], outs["rccl"][0])          # bamd_train_step == bamd_fwd_bwd + identity + bamd_adam_step
-    assert np.array_equal(outs["plain"][1], outs["rccl"][1])
+    for tag in ("rccl", "rccl-python"):
+        assert np.array_equal(outs["plain"][0], outs[tag][0]), tag    # bamd_train_step == bamd_fwd_bwd + identity + bamd_adam_step
+        assert np.array_equal(outs["plain"][1], outs[tag][1]), tag
+    assert "data-parallel step inside the library" in outs["rccl"][2]
+    assert "data-parallel step inside the library" not in outs["rccl-python"][2]
+
+
+_LIBCOMM_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch
+from baler_amd import native, synth
+from oracle import c_oracle as orc
+mode = os.environ["MODE"]
+dt = torch.float64 if mode == "fp64" else torch.float32
+dims = orc.ae_dims(24, 15)
+p0 = torch.from_numpy(np.concatenate([orc.formula_params(dims, 5), [0.0]])).to(dt).cuda()
+x = torch.from_numpy(orc.normalize(synth.cms_rows(2000))).cuda()
+counts = [512, 0, 300, 512, 64, 1, 611]                  # ragged, with an empty slice (a rank without rows of a batch)
+res = []
+for dp in (False, True):
+    h = native.Handle(dims, mode)
+    p = p0.clone(); h.load_params(p)
+    if dp:
+        h.comm_init(native.comm_unique_id(), 0, 1)       # RCCL communicator of ONE rank, created inside the library
+        assert h.comm_world == 1
+    m, v, g = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+    la = torch.zeros(1, dtype=torch.float64, device="cuda")
+    if dp:
+        h.train_epoch_dp(x, counts, p, m, v, 1, 1e-3, loss_accum=la, grads=g)
+        t = torch.arange(8, dtype=dt, device="cuda")
+        assert torch.equal(h.allreduce_sum(t.clone()), t)
+        h.comm_release()
+        assert h.comm_world == 0
+    else:
+        r0 = 0
+        for i, c in enumerate(counts):
+            h.fwd_bwd(x[r0:r0 + c], g)
+            h.adam_step(p, g, m, v, i + 1, 1e-3, loss_accum=la)
+            r0 += c
+    torch.cuda.synchronize()
+    res.append((p.clone(), m.clone(), v.clone(), g.clone(), la.item()))
+for a, b in zip(res[0], res[1]):
+    assert (torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b)
+print("LIBCOMM_OK", res[0][4])
+'''
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp64", "bf16"])
+def test_lib_comm_world1_epoch_equals_the_three_call_sequence(tmp_path, mode):
+    """bamd_comm_unique_id / bamd_comm_init / bamd_train_epoch_dp / bamd_allreduce_sum / bamd_comm_release on RCCL with ONE rank
+    (no torch.distributed at all: the library resolves and drives RCCL itself): the data-parallel epoch in one host call is
+    bit-identical to bamd_fwd_bwd + bamd_adam_step per batch, ragged batch sizes and an empty slice included."""
+    script = tmp_path / "w.py"
+    script.write_text(_LIBCOMM_WORKER)
+    env = dict(os.environ, REPO=REPO, MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BALER_AMD_DIST_BACKEND", "BALER_AMD_FORCE_DEVICE", "BALER_AMD_FORCE_PG"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "LIBCOMM_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+_SWAE_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch
+from baler_amd import dist as bdist, synth
+from baler_amd.modules import models, training
+from oracle import c_oracle as orc
+rank, world, local = bdist.init_from_env()
+torch.cuda.set_device(local)
+class Cfg: pass
+c = Cfg()
+c.deterministic_algorithm = False; c.test_size = 0; c.batch_size = 64; c.epochs = 2; c.lr = 1e-3
+c.early_stopping = False; c.lr_scheduler = False; c.reg_param = 0.001; c.data_dimension = 1
+c.activation_extraction = False; c.intermittent_model_saving = False; c.intermittent_saving_patience = 100
+c.custom_loss_function = "loss_function_swae"
+data = orc.normalize(synth.cms_rows(151))                # batches of 64, 64, 23 rows: 32+32, 32+32, 12+11 per rank
+model = models.AE(24, 15, mode="fp64").load_flat(orc.formula_params(orc.ae_dims(24, 15), 5))
+out = os.environ["OUT"] + f"/w{world}r{rank}"
+os.makedirs(out, exist_ok=True)
+torch.manual_seed(1234 + 77 * rank)                       # rank 0 draws what the single process draws; rank 1's draws are never used
+training.train(model, 24, data, data, out, c)
+np.save(os.environ["OUT"] + f"/swae_params_w{world}r{rank}.npy", model.flat.cpu().numpy())
+bdist.barrier()
+'''
+
+
+def test_dp_swae_equals_single_process(tmp_path):
+    """config.custom_loss_function = "loss_function_swae" under data parallelism (training.py:73-80 sorts the latent codes of ONE
+    batch): the latent codes of the global batch are all-gathered in row order, rank 0's prior sample and projections are broadcast,
+    the regulariser is evaluated replicated and every rank injects its rows of dL/dz -- loss curve and parameters equal the
+    single-process run with the same draws (fp64; the weight-gradient sums are re-associated across ranks)."""
+    script = tmp_path / "w.py"
+    script.write_text(_SWAE_DP_WORKER)
+    for world in (1, 2):
+        env = dict(os.environ, REPO=REPO, OUT=str(tmp_path), BALER_AMD_FORCE_DEVICE="0", BALER_AMD_DIST_BACKEND="gloo")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BALER_AMD_FORCE_PG"):
+            env.pop(k, None)
+        cmd = [sys.executable, str(script)] if world == 1 else \
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+             "--master-port", str(free_port()), str(script)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    l1 = np.load(tmp_path / "w1r0" / "loss_data.npy")
+    l2 = np.load(tmp_path / "w2r0" / "loss_data.npy")
+    assert l1.shape == (2, 2) and np.all(np.isfinite(l1)) and np.allclose(l2, l1, rtol=1e-9, atol=0)
+    p1 = np.load(tmp_path / "swae_params_w1r0.npy")
+    p20, p21 = np.load(tmp_path / "swae_params_w2r0.npy"), np.load(tmp_path / "swae_params_w2r1.npy")
+    assert np.array_equal(p20, p21)
+    assert np.linalg.norm(p20 - p1) / np.linalg.norm(p1) < 1e-9

@@ -1269,9 +1269,32 @@ def test_train_step_under_routing_knobs(case, monkeypatch):
     assert rel_l2(orc.encode(dims, p0, x), z_new) > 5e-2       # ... by far more than the tolerance the encode is held to
 
 
-def test_bf16_mode_unsupported_shape():
-    with pytest.raises(native.NativeError):
-        native.Handle(orc.ae_dims(100, 10), "bf16")
+@pytest.mark.parametrize("dims,path", [(orc.ae_dims(100, 10), "fused"), (orc.ae_dims(900, 9), "fused"), (orc.ae_dims(30, 7), "fused"),
+                                       ([400, 120, 60, 30, 9, 30, 60, 120, 400], "generic")])
+def test_bf16_mode_of_a_shape_without_bf16_kernels_runs_in_fp32(dims, path, capfd):
+    """models.py:122-139, 192-209 build AE / CFD_dense_AE(n_features, z_dim) for any width; `BALER_AMD_MODE=bf16` on such a model is a
+    slower path, not an error: the handle computes in float32 on whatever serves the shape there (fp32 bar, 1e-5), says so on stderr,
+    and bamd_mode_of() reports fp32."""
+    flat = orc.formula_params(dims, 23)
+    h, p = make_handle(dims, flat, "bf16")
+    assert "computes in float32" in capfd.readouterr().err
+    assert h.compute_mode == native.MODE_NAMES["fp32"] and h.path == path
+    x = off_the_kink(dims, flat, 77, 3)
+    z_ref = orc.encode(dims, flat, x)
+    assert rel(h.encode(dev(x), out_dtype=torch.float32).cpu().numpy(), z_ref) < TOL32
+    assert rel(h.decode(dev(z_ref, torch.float32)).cpu().numpy(), orc.decode(dims, flat, z_ref)) < TOL32
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    g = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), g)
+    gh = g.cpu().numpy().astype(np.float64)
+    assert rel(gh[:-1], go) < TOL32 and abs(gh[-1] - lo) < TOL32 * lo
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    h.train_step(dev(x), p, m, v, 1, 1e-2)
+    pn, mo, vo = flat.copy(), np.zeros_like(flat), np.zeros_like(flat)
+    orc.adam_step(pn, go, mo, vo, 1, 1e-2)
+    live = np.abs(go) > 1e-6 * np.abs(go).max()
+    assert rel((p.cpu().numpy().astype(np.float64)[:-1] - flat)[live], (pn - flat)[live]) < 1e-3
+    assert rel(h.encode(dev(x), out_dtype=torch.float32).cpu().numpy(), orc.encode(dims, p.cpu().numpy().astype(np.float64)[:-1], x)) < TOL32
 
 
 @pytest.mark.parametrize("shape,n", [((2500, 25), 1), ((2500, 25), 33), ((2500, 25), 1000), ((625, 7), 129), ((512, 6), 17), ((512, 6), 4100)])

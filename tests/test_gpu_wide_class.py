@@ -106,6 +106,58 @@ def test_wide_class_vs_oracle(F, Z):
     assert np.array_equal(out[:, m1][~edge], np.trunc(pre[:, m1])[~edge])
 
 
+@pytest.mark.parametrize("F,Z,n", [(128, 13, 9001), (900, 9, 9001), (1024, 11, 9001), (4096, 41, 2100)])
+def test_wide_class_throughput_launches_vs_oracle(F, Z, n, monkeypatch):
+    """The class's THROUGHPUT launches (wide_train_fwd / bwd_kernel<..., WRT = true>, the split-K weight-gradient kernels, the
+    two-tile encode) under an oracle assertion: batches above BALER_AMD_WIDE_SMALL_ROWS (8192) with default knobs -- the sizes
+    `bench.py`'s wide_class numbers are measured at run the same launches -- and, for the 4096-column shape whose oracle pass costs
+    9 MFLOP per row, the same launches forced onto a smaller batch (the limit is read per call).  Gradients per tensor."""
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 500 + F)
+    h, p = make_handle(dims, flat, "fp32")
+    assert h.path == "fused"
+    if n <= 8192:
+        monkeypatch.setenv("BALER_AMD_WIDE_SMALL_ROWS", "0")
+    _check(dims, flat, h, p, (n,), F + 1)
+    # one optimiser step from these weights: the move of every live parameter
+    x = off_the_kink(dims, flat, n, F + 1 + n)
+    lo, go = orc.fwd_bwd(dims, flat, x.astype(np.float32).astype(np.float64))
+    pn, mm, vv = flat.copy(), np.zeros_like(flat), np.zeros_like(flat)
+    orc.adam_step(pn, go, mm, vv, 1, 1e-3)
+    p1, m1, v1 = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    h.train_step(dev(x, torch.float32), p1, m1, v1, 1, 1e-3)
+    live = np.abs(go) > 1e-6 * np.abs(go).max()
+    assert rel((p1.cpu().numpy().astype(np.float64)[:-1] - flat)[live], (pn - flat)[live]) < 1e-3
+
+
+def test_wide_class_fuzz():
+    """Seeded random wide-class shapes (128 .. 4096 columns, latent 1 .. 63) around the small-batch / throughput switch: with
+    BALER_AMD_WIDE_SMALL_ROWS = 600 (read per call) each shape runs a ragged small batch, the last batch on the split launches (600
+    rows) and the first on the throughput launches (601) through encode / decode / forward / fwd_bwd against the oracle."""
+    rng = np.random.default_rng(20241010)
+    old = {k: os.environ.get(k) for k in ("BALER_AMD_QUIET", "BALER_AMD_WIDE_SMALL_ROWS")}
+    os.environ.update({"BALER_AMD_QUIET": "1", "BALER_AMD_WIDE_SMALL_ROWS": "600"})
+    try:
+        for k in range(8):
+            F = int(rng.integers(128, 4097)) if k % 2 else int(rng.integers(128, 1200))
+            Z = int(rng.integers(1, 64))
+            dims = orc.ae_dims(F, Z)
+            flat = orc.formula_params(dims, 7000 + k)
+            h, p = make_handle(dims, flat, "fp32")
+            assert h.path == "fused", (F, Z)
+            sizes = (int(rng.integers(1, 500)), 600, 601) if F <= 1200 else (int(rng.integers(1, 200)), 601)
+            try:
+                _check(dims, flat, h, p, sizes, 100 * k, per_tensor=F <= 1200)
+            finally:
+                h.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("shape", [(625, 7), (2500, 25), (512, 6)])
 def test_wide_class_forced_onto_exact_shapes(shape, monkeypatch):
     """The class kernels on the shapes that also have an exact instantiation: same results to float32 rounding (the class chunk that
