@@ -51,6 +51,20 @@ template <int F, int Z> struct Net64 {
     __host__ __device__ static constexpr int x_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += x_rows(j); return s; }
     __host__ __device__ static constexpr int z_off(int l) { int s = x_off(L); for (int j = 0; j < l; ++j) s += z_rows(j); return s; }
     static constexpr int img_doubles = z_off(L) * 16;
+    // ---- the 4-row chain (chain64q_kernel, v_mfma_f64_4x4x4_4b_f64): a second copy of the weights behind the 16x16x4 fragments.  GEMM g =
+    // forward layer g (g < 8) or the transposed layer 15 - g (g = 8 .. 14); a fragment = 1 KiB = A operand of TWO MFMAs: lane l holds
+    // A[16 grp + (l & 15)][8 k8 + (l >> 4)] and A[..][8 k8 + 4 + (l >> 4)]; fragment (k8, grp) of GEMM g sits at q_frag_off(g) + k8 G + grp.
+    // Behind the fragments: the biases of the 8 layers in natural order, each padded to whole 16-feature groups.
+    __host__ __device__ static constexpr int q_layer(int g) { return g < 8 ? g : 15 - g; }
+    __host__ __device__ static constexpr int q_nout(int g) { return g < 8 ? dim(g + 1) : dim(15 - g); }
+    __host__ __device__ static constexpr int q_kdim(int g) { return g < 8 ? dim(g) : dim(16 - g); }
+    __host__ __device__ static constexpr int q_groups(int g) { return tiles(q_nout(g)); }
+    __host__ __device__ static constexpr int q_ks8(int g) { return (q_kdim(g) + 7) / 8; }
+    __host__ __device__ static constexpr int q_frag_off(int g) { int s = 0; for (int j = 0; j < g; ++j) s += q_groups(j) * q_ks8(j); return s; }
+    __host__ __device__ static constexpr int q_frags() { return q_frag_off(15); }
+    __host__ __device__ static constexpr int qb_off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += 16 * tiles(dim(j + 1)); return s; }
+    __host__ __device__ static constexpr int q_doubles() { return q_frags() * 128 + qb_off(L); }
+    __host__ __device__ static constexpr int packed_all_doubles() { return packed_d4() * 4 + q_doubles(); }
 };
 
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
@@ -443,6 +457,214 @@ __global__ void __launch_bounds__(256) chain64r_kernel(const d4 *packed, const v
     if (lane == 0) loss_part[blk] = lacc;
 }
 
+// ---- the 4-row chain: the reference's own regime (fp64, batch_size = 512: models.py:128-136, CMS_project_v1_config.py:12) -------------
+// chain64_kernel gives a 16-row block to a workgroup: a 512-row batch occupies 32 of the 256 CUs and every workgroup runs 2,110
+// v_mfma_f64_16x16x4 of 64 cycles = 34k cycles per wave whatever the chip size (28.7 us of the step's 41).  v_mfma_f64_4x4x4_4b_f64 computes
+// four independent 4 x 4 x 4 products per instruction at the same FLOP rate (tools/probe/mfma64_4x4_probe.hip: A lane 16 k + 4 b + i,
+// B lane 16 k + 4 b + j, D lane 16 i + 4 b + j; 16.6 - 17.7 cycles per instruction on independent accumulators, 21.7 on one): with
+// A = 16 output features (block b, row i: feature 4 b + i) x 4 contraction indices and B = the FOUR batch rows replicated over the
+// blocks, a workgroup needs only four rows -- 128 workgroups carry the 512-row batch and a workgroup's chain is a quarter of the MFMA
+// work: 606 instructions per wave.  The fp32 twin is lat4_chain_kernel (fused.hip); like there
+//   * what bounds a workgroup is its WEIGHT STREAM (every workgroup reads every weight once, forward and transposed: 1 MB through one
+//     CU's vector-memory path), so all four waves stream in every GEMM: a GEMM's 16-feature groups are dealt to the waves (group w, w + 4,
+//     ..), and a GEMM of one or two groups (en4, de4 and their transposes) splits its contraction over the waves instead and adds the
+//     partial sums through LDS in a fixed order;
+//   * the fragments ([k / 8][group], 1 KiB = two MFMAs) flow through a register ring D fragments ahead of their use, across GEMM
+//     boundaries; groups / contraction steps a wave does not own are requested through an out-of-range offset (zeros, no traffic);
+//   * activations live in LDS as [4 rows][features] (X_l: the next GEMM's B operand and the backward masks; dZ_l: ping-pong), the B
+//     operand of a fragment's two MFMAs is two ds_read_b64 that serve all of the wave's groups of that contraction step;
+//   * results go to the SAME global images as chain64_kernel's ([16-row block][slot][16 rows]; this workgroup fills rows 4 q .. 4 q + 3 of
+//     every slot), so dw64_kernel (weight-gradient tiles + Adam) is unchanged; the loss partial is per workgroup (4 per block).
+template <class N> struct Q4 {
+    static constexpr int NG = 15, D = 24, KB = 3;       // chain GEMMs; fragment ring depth; B operand reads run KB fragments ahead
+    __host__ __device__ static constexpr int G(int g) { return N::q_groups(g); }
+    __host__ __device__ static constexpr int KS8(int g) { return N::q_ks8(g); }
+    __host__ __device__ static constexpr int P(int g) { return G(g) >= 3 ? 1 : (G(g) == 2 ? 2 : 4); }      // contraction parts
+    __host__ __device__ static constexpr int NGM(int g) { return P(g) == 1 ? (G(g) + 3) / 4 : 1; }         // most groups of one wave
+    __host__ __device__ static constexpr int KS8P(int g) { return (KS8(g) + P(g) - 1) / P(g); }             // contraction steps of one wave
+    __host__ __device__ static constexpr int steps(int g) { return KS8P(g) * NGM(g); }                      // fragments of one wave
+    __host__ __device__ static constexpr int pos(int g) { int s = 0; for (int j = 0; j < g; ++j) s += steps(j); return s; }
+    static constexpr int total = pos(NG);
+    __host__ __device__ static constexpr int gemm_at(int S) { int g = 0; for (int j = 0; j < NG; ++j) if (S >= pos(j)) g = j; return g; }
+    // LDS images [4 rows][stride]: stride = 16 x groups rounded up to 32 m + 2 doubles (the four rows of a B read then sit in different
+    // banks); X_0 .. X_7, two dZ buffers, the partial sums [part][group][64 lanes], the biases
+    __host__ __device__ static constexpr int stride_for(int d) { return (16 * tiles(d) + 8 + 31) / 32 * 32 + 2; }
+    __host__ __device__ static constexpr int xs(int l) { return stride_for(N::dim(l)); }
+    __host__ __device__ static constexpr int xo(int l) { int s = 0; for (int j = 0; j < l; ++j) s += 4 * xs(j); return s; }
+    static constexpr int zs = stride_for(200);
+    __host__ __device__ static constexpr int zo(int i) { return xo(8) + i * 4 * zs; }
+    static constexpr int po = zo(2);
+    static constexpr int bo = po + 4 * 64;
+    static constexpr int lds_doubles = bo + N::qb_off(N::L);
+};
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+template <class N, int S_>
+__device__ __forceinline__ void q_issue(d2 (&ring)[Q4<N>::D], __amdgpu_buffer_rsrc_t rs, int lane16, int wave) {
+    using T = Q4<N>;
+    if constexpr (S_ < T::total) {
+        constexpr int g = T::gemm_at(S_), i = S_ - T::pos(g), k8i = i / T::NGM(g), gi = i % T::NGM(g), G = T::G(g), P = T::P(g);
+        const int part = P > 1 ? wave / G : 0;                       // wave-uniform
+        const int grp = P > 1 ? wave % G : wave + 4 * gi;
+        const int k8 = part * T::KS8P(g) + k8i;
+        const int vo = (k8 < T::KS8(g) && grp < G) ? lane16 : 0x7F000000;      // not this wave's: a zero fragment, no traffic
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (N::q_frag_off(g) + k8 * G + grp) * 1024, 0);
+        ring[S_ % T::D] = __builtin_bit_cast(d2, v);
+    }
+}
+template <class N, int... S_>
+__device__ __forceinline__ void q_prologue(d2 (&ring)[Q4<N>::D], __amdgpu_buffer_rsrc_t rs, int lane16, int wave, std::integer_sequence<int, S_...>) {
+    (q_issue<N, S_>(ring, rs, lane16, wave), ...);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class N, int g, int I>
+__device__ __forceinline__ void q_step(double (&acc)[Q4<N>::NGM(g)][2], d2 (&xb)[Q4<N>::KB + 1], const double *brow, d2 (&ring)[Q4<N>::D],
+                                       __amdgpu_buffer_rsrc_t rs, int lane16, int wave) {
+    using T = Q4<N>;
+    constexpr int NGM = T::NGM(g), k8i = I / NGM, gi = I % NGM, S0 = T::pos(g);
+    if constexpr (gi == 0 && k8i + T::KB < T::KS8P(g)) xb[(k8i + T::KB) % (T::KB + 1)] = (d2){brow[8 * (k8i + T::KB)], brow[8 * (k8i + T::KB) + 4]};
+    const d2 a = ring[(S0 + I) % T::D], b = xb[k8i % (T::KB + 1)];
+    acc[gi][0] = mfma4(a[0], b[0], acc[gi][0]);      // two accumulators per group: a dependent 4x4x4 costs 21.7 cycles, not 17
+    acc[gi][1] = mfma4(a[1], b[1], acc[gi][1]);
+    q_issue<N, S0 + I + T::D>(ring, rs, lane16, wave);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class N, int g, int... I>
+__device__ __forceinline__ void q_gemm(double (&out)[Q4<N>::NGM(g)], const double *brow /* this lane's B row at this wave's first step */,
+                                       d2 (&ring)[Q4<N>::D], __amdgpu_buffer_rsrc_t rs, int lane16, int wave, std::integer_sequence<int, I...>) {
+    using T = Q4<N>;
+    double acc[T::NGM(g)][2];
+#pragma unroll
+    for (int i = 0; i < T::NGM(g); ++i) { acc[i][0] = 0.0; acc[i][1] = 0.0; }
+    d2 xb[T::KB + 1];
+#pragma unroll
+    for (int k = 0; k < T::KB && k < T::KS8P(g); ++k) xb[k] = (d2){brow[8 * k], brow[8 * k + 4]};
+    (q_step<N, g, I>(acc, xb, brow, ring, rs, lane16, wave), ...);
+#pragma unroll
+    for (int i = 0; i < T::NGM(g); ++i) out[i] = acc[i][0] + acc[i][1];
+}
+
+template <int F, int Z, bool RT = false>
+__global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict__ qpacked /* the Q region of the packed buffer */,
+                                                       const void *__restrict__ xin, int in_f64, int64_t n, const double *__restrict__ feats,
+                                                       double *__restrict__ imgs, double *__restrict__ loss_part, int fr) {
+    using N = Net64<F, Z>;
+    using T = Q4<N>;
+    static_assert(F % 16 != 0 && F <= 63, "input rows: 64 feature slots x 4 rows = one thread each");
+    __shared__ __attribute__((aligned(16))) double lds[T::lds_doubles];
+    __shared__ double loss_lds[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the four workgroups of a 16-row block share its image lines (32 of the 128 bytes of every slot each): workgroup ids equal mod 8,
+    // i.e. (workgroups are dealt to the XCDs round-robin) the same XCD and L2 -- placement only, nothing depends on it
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    int blk = wg >> 2, quad = wg & 3;
+    if (nwg % 32 == 0) { blk = (wg >> 5) * 8 + (wg & 7); quad = (wg >> 3) & 3; }
+    const int fw = RT ? fr : F;                                    // the table's real width (row stride, valid features, loss scale)
+    double *img = imgs + (int64_t)blk * N::img_doubles + 4 * quad;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)qpacked, 0, N::q_frags() * 1024, 0x00020000);
+    const int lane16 = lane * 16;
+    // ---- request order = order of use: the 4 input rows (HBM), the biases, then the fragment ring
+    const int tj = threadIdx.x & 3, tf = threadIdx.x >> 2;          // input / finalising thread: row tj, feature tf (+ 64 i)
+    const int64_t trow = (int64_t)blk * 16 + 4 * quad + tj;
+    const bool tvalid = trow < n;
+    double xv = 0.0, xmn = 0.0, xrg = 1.0;
+    {
+        const int fc = tf < fw ? tf : 0;                            // padding slots read feature 0 (finite, never used)
+        const int64_t at = (tvalid ? trow : 0) * fw + fc;
+        xv = in_f64 ? ((const double *)xin)[at] : (double)((const float *)xin)[at];
+        if (feats) { xmn = feats[fc]; xrg = feats[fw + fc]; }
+    }
+    for (int i = threadIdx.x; i < N::qb_off(N::L); i += 256) lds[T::bo + i] = qpacked[N::q_frags() * 128 + i];
+    d2 ring[T::D];
+    q_prologue<N>(ring, rs, lane16, wave, std::make_integer_sequence<int, T::D>{});
+    {
+        double v = feats ? (xv - xmn) / xrg : xv;
+        v = tf < fw ? v : 0.0;
+        if (tf == F) v = 1.0;                                        // the ones slot (carries db) sits at the class width
+        if (tf < 16 * tiles(F)) lds[T::xo(0) + tj * T::xs(0) + tf] = v;
+        if (tf < N::x_rows(0)) img[(N::x_off(0) + tf) * 16 + tj] = v;
+    }
+    __syncthreads();
+    // D-operand lane (i, b, j) = lane 16 i + 4 b + j holds feature 16 grp + 4 b + i of row j; B-operand lane (k, b, j): contraction index k of row j
+    const int dj = lane & 3, dfo = ((lane >> 2) & 3) * 4 + (lane >> 4), bk = lane >> 4;
+    const bool dvalid = (int64_t)blk * 16 + 4 * quad + dj < n;
+    double lacc = 0.0;
+    double *pbuf = lds + T::po;
+    // One chain GEMM.  `fin(value without bias, feature, row, row is a real one)` finalises one output element: direct from the
+    // accumulator layout for a GEMM whose groups are dealt to the waves, from the summed partials (thread (tf + 64 i, tj)) for a split one.
+#define Q_GEMM(g, IN_OFF, IN_RS, FIN)                                                                                        \
+    {                                                                                                                        \
+        constexpr int G_ = T::G(g), P_ = T::P(g);                                                                            \
+        const int part_ = P_ > 1 ? wave / G_ : 0;                                                                            \
+        const double *brow = lds + (IN_OFF) + dj * (IN_RS) + bk + 8 * part_ * T::KS8P(g);                                    \
+        double o[T::NGM(g)];                                                                                                 \
+        q_gemm<N, g>(o, brow, ring, rs, lane16, wave, std::make_integer_sequence<int, T::steps(g)>{});                       \
+        if constexpr (P_ == 1) {                                                                                             \
+            _Pragma("unroll") for (int gi = 0; gi < T::NGM(g); ++gi) {                                                       \
+                const int grp = wave + 4 * gi;                                                                               \
+                if (grp < G_) FIN(o[gi], 16 * grp + dfo, dj, dvalid);                                                        \
+            }                                                                                                                \
+        } else {                                                                                                             \
+            pbuf[(part_ * G_ + wave % G_) * 64 + lane] = o[0];                                                               \
+            __syncthreads();                                                                                                 \
+            if ((int)threadIdx.x < 64 * G_) {                                                                                \
+                const int grp = threadIdx.x >> 6;                                                                            \
+                double v = 0.0;                                                                                              \
+                _Pragma("unroll") for (int p = 0; p < P_; ++p) v += pbuf[(p * G_ + grp) * 64 + lane];                        \
+                FIN(v, 16 * grp + dfo, dj, dvalid);                                                                          \
+            }                                                                                                                \
+        }                                                                                                                    \
+        __syncthreads();                                                                                                     \
+    }
+    // ---------------- forward: X_{l+1} = act(W_l X_l + b_l) ----------------
+#define Q_FWD(l)                                                                                                             \
+    {                                                                                                                        \
+        auto fin = [&](double v, int f, int j, bool) {                                                                       \
+            v += lds[T::bo + N::qb_off(l) + f];                                                                              \
+            if (N::act(l)) v = v > 0.0 ? v : v * kSlope;                                                                     \
+            if (f == N::dim((l) + 1)) v = 1.0;                                                                               \
+            lds[T::xo((l) + 1) + j * T::xs((l) + 1) + f] = v;                                                                \
+            img[(N::x_off((l) + 1) + f) * 16 + j] = v;                                                                       \
+        };                                                                                                                   \
+        Q_GEMM(l, T::xo(l), T::xs(l), fin)                                                                                   \
+    }
+    Q_FWD(0) Q_FWD(1) Q_FWD(2) Q_FWD(3) Q_FWD(4) Q_FWD(5) Q_FWD(6)
+#undef Q_FWD
+    {   // de4 (no activation) + loss + dL/drecon = 2 (r - x) / C (utils.py:195-199)
+        auto fin = [&](double v, int f, int j, bool rowok) {
+            v += lds[T::bo + N::qb_off(7) + f];
+            const double d = v - lds[T::xo(0) + j * T::xs(0) + f];
+            const bool live = rowok && f < fw;
+            if (live) lacc += d * d;
+            const double dz = live ? d * (2.0 / (double)fw) : 0.0;
+            lds[T::zo(1) + j * T::zs + f] = dz;
+            img[(N::z_off(7) + f) * 16 + j] = dz;
+        };
+        Q_GEMM(7, T::xo(7), T::xs(7), fin)
+    }
+    // ---------------- backward chain: GEMM 15 - l: dZ_{l-1} = (W_l^T dZ_l) . lrelu'(X_l); dZ_l in buffer l & 1 ----------------
+#define Q_BWD(l)                                                                                                             \
+    {                                                                                                                        \
+        auto fin = [&](double v, int f, int j, bool) {                                                                       \
+            if (N::act((l) - 1)) v = lds[T::xo(l) + j * T::xs(l) + f] > 0.0 ? v : v * kSlope;                                \
+            lds[T::zo(((l) - 1) & 1) + j * T::zs + f] = v;                                                                   \
+            img[(N::z_off((l) - 1) + f) * 16 + j] = v;                                                                       \
+        };                                                                                                                   \
+        Q_GEMM(15 - (l), T::zo((l) & 1), T::zs, fin)                                                                         \
+    }
+    Q_BWD(7) Q_BWD(6) Q_BWD(5) Q_BWD(4) Q_BWD(3) Q_BWD(2) Q_BWD(1)
+#undef Q_BWD
+#undef Q_GEMM
+    // loss partial of these 4 rows: lanes of a wave, then waves 0..3 (fixed order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lacc += __shfl_down(lacc, off);
+    if (lane == 0) loss_lds[wave] = lacc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_part[4 * blk + quad] = ((loss_lds[0] + loss_lds[1]) + loss_lds[2]) + loss_lds[3];
+}
+
 // ---- fp64 throughput inference: encode / decode / forward + loss at any row count ---------------------------------------------
 // The reference computes in fp64 (models.py:128-136); until round 3 bamd_encode / bamd_decode / bamd_forward_loss of an F64 handle
 // ran layer by layer (activations through HBM, LDS-tiled GEMMs).  Here every WAVE pushes its own 16 rows through the layers with
@@ -630,7 +852,7 @@ enum { DW_WRITE = 0, DW_ADAM = 1 };
 template <class N, int MODE>
 __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ imgs, int nblk, const double *__restrict__ loss_part,
                                                    const int *__restrict__ inv_map, double *__restrict__ grads, Adam64 ad,
-                                                   const double *__restrict__ part, int nsplit, int np, double inv_c) {
+                                                   const double *__restrict__ part, int nsplit, int np, double inv_c, int nloss) {
     // nsplit == 0: the whole job.  nsplit > 0: the tiles' partial sums over `nsplit` block ranges are in `part` (dw64m_kernel); this
     // launch adds them in range order and finishes (store / Adam).
     constexpr int T = N::slab_off(N::L);       // (np, inv_c: the handle's real parameter count and 1 / columns -- class instantiations)
@@ -639,7 +861,7 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     const int tile = (blockIdx.x & 7) * kPerXcd + (blockIdx.x >> 3);       // XCD c takes a contiguous tile range (see fused.hip)
     if (tile > T) return;
     if (tile == T) {   // loss: fixed-order sum of the per-block partials, / C
-        const double s = block_sum_fixed(loss_part, nblk, (double *)red);
+        const double s = block_sum_fixed(loss_part, nloss, (double *)red);      // (one partial per block, four with the 4-row chain)
         if (threadIdx.x == 0) {
             const double gl = s * inv_c;
             if (grads) grads[np] = gl;
@@ -663,10 +885,12 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     double pm = 0.0, pv = 0.0, pp = 0.0;
     int s0 = 0, s1 = 0;
     if (MODE == DW_ADAM && p >= 0) { pm = ad.m[p]; pv = ad.v[p]; pp = ad.params[p]; s0 = ad.sc_off[p]; s1 = ad.sc_off[p + 1]; }
-    // the first two packed slots of the parameter (its forward and its transposed fragment) are looked up now, not behind the reduction
-    int sc0 = -1, sc1 = -1;
+    // the packed slots of the parameter (forward and transposed fragment of either chain: up to four) are looked up now, not behind the reduction
+    int sc0 = -1, sc1 = -1, sc2 = -1, sc3 = -1;
     if (MODE == DW_ADAM && s1 > s0) sc0 = ad.sc_idx[s0];
     if (MODE == DW_ADAM && s1 > s0 + 1) sc1 = ad.sc_idx[s0 + 1];
+    if (MODE == DW_ADAM && s1 > s0 + 2) sc2 = ad.sc_idx[s0 + 2];
+    if (MODE == DW_ADAM && s1 > s0 + 3) sc3 = ad.sc_idx[s0 + 3];
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
     constexpr int UB = 8;                                            // blocks per wave in flight (a 512-row batch: all of a wave's blocks)
     for (int b0 = wave; b0 < (nsplit > 0 ? 0 : nblk); b0 += 4 * UB) {
@@ -716,7 +940,9 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
         if (ad.pcopy) ad.pcopy[p] = pn;
         if (sc0 >= 0) ad.packed[sc0] = pn;
         if (sc1 >= 0) ad.packed[sc1] = pn;
-        for (int k = s0 + 2; k < s1; ++k) ad.packed[ad.sc_idx[k]] = pn;
+        if (sc2 >= 0) ad.packed[sc2] = pn;
+        if (sc3 >= 0) ad.packed[sc3] = pn;
+        for (int k = s0 + 4; k < s1; ++k) ad.packed[ad.sc_idx[k]] = pn;
     }
 }
 
@@ -976,7 +1202,26 @@ template <int F, int Z, bool RT = false> struct Impl64 {
         auto dimr = [&](int i) { return h->dims[i]; };
         auto woff = [&](int l) { return (int)h->w_off[l]; };
         auto boff = [&](int l) { return (int)h->b_off[l]; };
-        std::vector<int> src((size_t)N::packed_d4() * 4, -1);
+        std::vector<int> src((size_t)N::packed_all_doubles(), -1);
+        // the 4-row chain's copy (chain64q_kernel): fragment (k8, grp) of GEMM g, lane l, half h = A[16 grp + (l & 15)][8 k8 + 4 h + (l >> 4)]
+        // with A = W_g (forward) or W_{15-g}^T (backward), then the biases in natural order
+        {
+            const size_t q0 = (size_t)N::packed_d4() * 4;
+            for (int g = 0; g < 15; ++g) {
+                const int l = N::q_layer(g), G = N::q_groups(g), Kr = dimr(l), NNr = dimr(l + 1);
+                for (int k8 = 0; k8 < N::q_ks8(g); ++k8)
+                    for (int grp = 0; grp < G; ++grp)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int hh = 0; hh < 2; ++hh) {
+                                const int f = 16 * grp + (lane & 15), k = 8 * k8 + 4 * hh + (lane >> 4);
+                                const size_t o = q0 + ((size_t)(N::q_frag_off(g) + k8 * G + grp) * 64 + lane) * 2 + hh;
+                                if (g < 8) { if (f < NNr && k < Kr) src[o] = woff(l) + f * Kr + k; }          // W_l[f][k]
+                                else if (f < Kr && k < NNr) src[o] = woff(l) + k * Kr + f;                     // W_l[k][f]
+                            }
+            }
+            for (int l = 0; l < N::L; ++l)
+                for (int f = 0; f < dimr(l + 1); ++f) src[q0 + (size_t)N::q_frags() * 128 + N::qb_off(l) + f] = boff(l) + f;
+        }
         for (int l = 0; l < N::L; ++l) {
             const int K = N::dim(l), NN = N::dim(l + 1), KT = tiles(K), NT = tiles(NN), Kr = dimr(l), NNr = dimr(l + 1);
             // forward fragment (q, t): lane (i, g) component r = W[16 t + i][16 q + 4 r + g]
@@ -1053,7 +1298,7 @@ template <int F, int Z, bool RT = false> struct Impl64 {
         const int nblk_max = (int)((std::min(n, chunk) + 15) / 16);
         int rc = st->imgs.ensure((size_t)N::img_doubles * sizeof(double) * (size_t)nblk_max);
         if (rc) return rc;
-        rc = h->lossp.ensure(sizeof(double) * (size_t)(nblk_all > 1024 ? nblk_all : 1024));
+        rc = h->lossp.ensure(sizeof(double) * (size_t)(4 * nblk_all > 1024 ? 4 * nblk_all : 1024));      // (four partials per block with the 4-row chain)
         if (rc) return rc;
         const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
         // from 64 blocks (1,024 rows) on: 2 x 4 tile blocks over block ranges + the finishing launch (BALER_AMD_DW64_MACRO_BLKS, 0 = off).
@@ -1083,6 +1328,7 @@ template <int F, int Z, bool RT = false> struct Impl64 {
             if (rc) return rc;
         }
         const size_t xes = x_dtype == BAMD_F64 ? 8 : 4;
+        bool quad = false;
         for (int k = 0; k < nchunk; ++k) {
             const int64_t r0 = k * chunk, rows = std::min(n - r0, chunk);
             const int nblk = (int)((rows + 15) / 16);
@@ -1091,7 +1337,14 @@ template <int F, int Z, bool RT = false> struct Impl64 {
             // moves the switch (0: always, read per call: the parity tests run both kernels on the same batch)
             const char *re = getenv("BALER_AMD_F64_REGCHAIN_BLKS");
             const int64_t rmin = re ? atoll(re) : 1024;
-            if (nblk_all >= rmin)
+            // up to BALER_AMD_F64_QCHAIN_BLKS blocks (default 96 = 1,536 rows; 0: never): FOUR rows per workgroup on v_mfma_f64_4x4x4
+            // (chain64q_kernel): the reference's 512-row batch on 128 CUs instead of 32
+            quad = nchunk == 1 && nblk_all < rmin && nblk_all <= env_ll("BALER_AMD_F64_QCHAIN_BLKS", 96);
+            if (quad)
+                hipLaunchKernelGGL((chain64q_kernel<F, Z, RT>), dim3(4 * nblk), dim3(256), 0, s,
+                                   (const double *)st->packed.p + (size_t)N::packed_d4() * 4, x, x_dtype == BAMD_F64, rows, features,
+                                   (double *)st->imgs.p, (double *)h->lossp.p, fr(h));
+            else if (nblk_all >= rmin)
                 hipLaunchKernelGGL((chain64r_kernel<F, Z, RT>), dim3((nblk + 3) / 4), dim3(256), kLdsR, s, (const d4 *)st->packed.p,
                                    (const void *)((const char *)x + (size_t)r0 * fr(h) * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
                                    (double *)h->lossp.p + r0 / 16, nblk, fr(h));
@@ -1112,13 +1365,13 @@ template <int F, int Z, bool RT = false> struct Impl64 {
         const double *part = macro ? (const double *)st->dwpart.p : nullptr;
         // the finishing launch: the loss partials of ALL blocks; with `part` the sum over all chunks' block ranges in order, else
         // (one small chunk) the tiles themselves over the images
-        const int nblk_fin = (int)nblk_all;
+        const int nblk_fin = (int)nblk_all, nloss = quad ? 4 * nblk_fin : nblk_fin;
         if (ad)
             hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
-                               (const int *)st->inv_map.p, grads, *ad, part, nsplit, (int)h->nparams, 1.0 / fr(h));
+                               (const int *)st->inv_map.p, grads, *ad, part, nsplit, (int)h->nparams, 1.0 / fr(h), nloss);
         else
             hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
-                               (const int *)st->inv_map.p, grads, Adam64{}, part, nsplit, (int)h->nparams, 1.0 / fr(h));
+                               (const int *)st->inv_map.p, grads, Adam64{}, part, nsplit, (int)h->nparams, 1.0 / fr(h), nloss);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }

@@ -350,8 +350,8 @@ def test_fp64_any_narrow_table_runs_fused(F, Z):
 
 @pytest.mark.parametrize("n", [1, 33, 1000, 16385, 70001])
 def test_fp64_register_chain_equals_exchange_chain(n, monkeypatch):
-    """The two fp64 training chains -- one workgroup per 16-row block exchanging every layer through LDS (chain64_kernel: the 512-row
-    step) and one WAVE per block with the activations in registers and the LeakyReLU signs in bit masks (chain64r_kernel: from 1,024
+    """The fp64 training chains -- one workgroup per 16-row block exchanging every layer through LDS (chain64_kernel), one workgroup
+    per FOUR rows on the 4x4x4 MFMA (chain64q_kernel: the 512-row step, up to 1,536 rows by default) and one WAVE per block with the activations in registers and the LeakyReLU signs in bit masks (chain64r_kernel: from 1,024
     blocks on) -- write the same images bit for bit (every output element accumulates its k blocks in the same order), so the
     gradients are IDENTICAL and only the loss sum (another order over the block's lanes) may differ in its last bits.  Both against
     the oracle at 1e-11; normalise-on-load through both."""
@@ -363,14 +363,18 @@ def test_fp64_register_chain_equals_exchange_chain(n, monkeypatch):
     h, p = make_handle(dims, flat, "fp64")
     lo, go = orc.fwd_bwd(dims, flat, x)
     got = {}
-    for tag, blks in (("registers", "0"), ("exchange", "1000000000")):
+    for tag, blks, qblks in (("registers", "0", "0"), ("exchange", "1000000000", "0"), ("four-rows", "1000000000", "1000000000")):
         monkeypatch.setenv("BALER_AMD_F64_REGCHAIN_BLKS", blks)
+        monkeypatch.setenv("BALER_AMD_F64_QCHAIN_BLKS", qblks)
         g = torch.zeros_like(p)
         h.fwd_bwd(dev(raw), g, features=dev(feats))
         got[tag] = g.cpu().numpy()
         assert rel(got[tag][:-1], go) < TOL64 and abs(got[tag][-1] - lo) < TOL64 * max(lo, 1e-300), tag
     assert np.array_equal(got["registers"][:-1], got["exchange"][:-1])
     assert abs(got["registers"][-1] - got["exchange"][-1]) <= 1e-13 * max(abs(got["exchange"][-1]), 1e-300)
+    # the 4-row chain (chain64q_kernel, v_mfma_f64_4x4x4: four rows per workgroup) sums every contraction in two interleaved chains and
+    # splits en4 / de4 over the waves: the same numbers to rounding, not to the bit
+    assert rel(got["four-rows"], got["exchange"]) < 1e-13
 
 
 @pytest.mark.parametrize("n,chunk", [(70001, 4096), (20000, 16), (300_001, None), (1_000_003, None)])
