@@ -475,8 +475,17 @@ __global__ void __launch_bounds__(256) chain64r_kernel(const d4 *packed, const v
 //     operand of a fragment's two MFMAs is two ds_read_b64 that serve all of the wave's groups of that contraction step;
 //   * results go to the SAME global images as chain64_kernel's ([16-row block][slot][16 rows]; this workgroup fills rows 4 q .. 4 q + 3 of
 //     every slot), so dw64_kernel (weight-gradient tiles + Adam) is unchanged; the loss partial is per workgroup (4 per block).
+#ifdef BAMD_Q4_TRACE   // debug build: shader-clock stamps of workgroup 0, wave 0 at every GEMM boundary (tools/q4_trace.py)
+__device__ unsigned long long g_q4_trace[32];
+#define Q4_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_q4_trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define Q4_T(i) do {} while (0)
+#endif
+#ifndef BAMD_Q4_RING
+#define BAMD_Q4_RING 24
+#endif
 template <class N> struct Q4 {
-    static constexpr int NG = 15, D = 24, KB = 3;       // chain GEMMs; fragment ring depth; B operand reads run KB fragments ahead
+    static constexpr int NG = 15, D = BAMD_Q4_RING, KB = 3;       // chain GEMMs; fragment ring depth; B operand reads run KB fragments ahead
     __host__ __device__ static constexpr int G(int g) { return N::q_groups(g); }
     __host__ __device__ static constexpr int KS8(int g) { return N::q_ks8(g); }
     __host__ __device__ static constexpr int P(int g) { return G(g) >= 3 ? 1 : (G(g) == 2 ? 2 : 4); }      // contraction parts
@@ -561,6 +570,7 @@ __global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict_
     const int wg = blockIdx.x, nwg = gridDim.x;
     int blk = wg >> 2, quad = wg & 3;
     if (nwg % 32 == 0) { blk = (wg >> 5) * 8 + (wg & 7); quad = (wg >> 3) & 3; }
+    Q4_T(0);
     const int fw = RT ? fr : F;                                    // the table's real width (row stride, valid features, loss scale)
     double *img = imgs + (int64_t)blk * N::img_doubles + 4 * quad;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)qpacked, 0, N::q_frags() * 1024, 0x00020000);
@@ -576,9 +586,18 @@ __global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict_
         xv = in_f64 ? ((const double *)xin)[at] : (double)((const float *)xin)[at];
         if (feats) { xmn = feats[fc]; xrg = feats[fw + fc]; }
     }
-    for (int i = threadIdx.x; i < N::qb_off(N::L); i += 256) lds[T::bo + i] = qpacked[N::q_frags() * 128 + i];
+    // (the biases wait in registers until the ring is requested: written to LDS first, they held the ring's requests behind the rows'
+    // HBM round trip -- 4,100 cycles in front of the first GEMM, tools/q4_trace.py)
+    constexpr int kNB = N::qb_off(N::L), kNBI = (kNB + 255) / 256;
+    double bv[kNBI];
+#pragma unroll
+    for (int i = 0; i < kNBI; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        bv[i] = qpacked[N::q_frags() * 128 + (idx < kNB ? idx : 0)];
+    }
     d2 ring[T::D];
     q_prologue<N>(ring, rs, lane16, wave, std::make_integer_sequence<int, T::D>{});
+    Q4_T(1);
     {
         double v = feats ? (xv - xmn) / xrg : xv;
         v = tf < fw ? v : 0.0;
@@ -586,7 +605,13 @@ __global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict_
         if (tf < 16 * tiles(F)) lds[T::xo(0) + tj * T::xs(0) + tf] = v;
         if (tf < N::x_rows(0)) img[(N::x_off(0) + tf) * 16 + tj] = v;
     }
+#pragma unroll
+    for (int i = 0; i < kNBI; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (idx < kNB) lds[T::bo + idx] = bv[i];
+    }
     __syncthreads();
+    Q4_T(2);
     // D-operand lane (i, b, j) = lane 16 i + 4 b + j holds feature 16 grp + 4 b + i of row j; B-operand lane (k, b, j): contraction index k of row j
     const int dj = lane & 3, dfo = ((lane >> 2) & 3) * 4 + (lane >> 4), bk = lane >> 4;
     const bool dvalid = (int64_t)blk * 16 + 4 * quad + dj < n;
@@ -629,6 +654,7 @@ __global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict_
             img[(N::x_off((l) + 1) + f) * 16 + j] = v;                                                                       \
         };                                                                                                                   \
         Q_GEMM(l, T::xo(l), T::xs(l), fin)                                                                                   \
+        Q4_T(3 + (l));                                                                                                       \
     }
     Q_FWD(0) Q_FWD(1) Q_FWD(2) Q_FWD(3) Q_FWD(4) Q_FWD(5) Q_FWD(6)
 #undef Q_FWD
@@ -643,6 +669,7 @@ __global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict_
             img[(N::z_off(7) + f) * 16 + j] = dz;
         };
         Q_GEMM(7, T::xo(7), T::xs(7), fin)
+        Q4_T(10);
     }
     // ---------------- backward chain: GEMM 15 - l: dZ_{l-1} = (W_l^T dZ_l) . lrelu'(X_l); dZ_l in buffer l & 1 ----------------
 #define Q_BWD(l)                                                                                                             \
@@ -653,6 +680,7 @@ __global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict_
             img[(N::z_off((l) - 1) + f) * 16 + j] = v;                                                                       \
         };                                                                                                                   \
         Q_GEMM(15 - (l), T::zo((l) & 1), T::zs, fin)                                                                         \
+        Q4_T(18 - (l));                                                                                                      \
     }
     Q_BWD(7) Q_BWD(6) Q_BWD(5) Q_BWD(4) Q_BWD(3) Q_BWD(2) Q_BWD(1)
 #undef Q_BWD
@@ -663,6 +691,7 @@ __global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict_
     if (lane == 0) loss_lds[wave] = lacc;
     __syncthreads();
     if (threadIdx.x == 0) loss_part[4 * blk + quad] = ((loss_lds[0] + loss_lds[1]) + loss_lds[2]) + loss_lds[3];
+    Q4_T(18);
 }
 
 // ---- fp64 throughput inference: encode / decode / forward + loss at any row count ---------------------------------------------
@@ -892,6 +921,8 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     if (MODE == DW_ADAM && s1 > s0 + 2) sc2 = ad.sc_idx[s0 + 2];
     if (MODE == DW_ADAM && s1 > s0 + 3) sc3 = ad.sc_idx[s0 + 3];
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+    // (requesting the first UB blocks' image slices BEFORE the parameter index and the optimiser state behind it was measured in round 6:
+    // 512-row step 30.1 -> 29.9 us, 1,024 rows 35.6 -> 37.0: not kept)
     constexpr int UB = 8;                                            // blocks per wave in flight (a 512-row batch: all of a wave's blocks)
     for (int b0 = wave; b0 < (nsplit > 0 ? 0 : nblk); b0 += 4 * UB) {
         d4 a[UB], x[UB];
@@ -1497,3 +1528,10 @@ int fused64_infer(bamd_handle *h, int kind, const void *x, int x_dtype, int64_t 
 }
 
 }  // namespace bamd
+
+#ifdef BAMD_Q4_TRACE
+// debug builds only (tools/q4_trace.py): the stamps of the last chain64q_kernel launch.  Not part of the ABI: the shipped library does not export it.
+extern "C" int bamd_debug_q4_trace(unsigned long long *dst, int count) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(bamd::g_q4_trace), sizeof(unsigned long long) * (count < 32 ? count : 32));
+}
+#endif

@@ -470,22 +470,8 @@ def main():
                     t_ = timed(bpass, 1, world, dev)
                     bb[str(bs)] = {"rows_per_s": bs * nb / t_, "us_per_step": 1e6 * t_ / nb}
                 out["bf16_train_rows_per_s_by_batch"] = bb
-                # the two round-5 rewrites of the bf16 training kernels, measured beside the shipped pair (both correct, both slower:
-                # DESIGN.md section 4.6): the register-chain pair and the four launches with eight waves per workgroup
-                alt = {}
-                for tag, ver in (("register_chain_pair", "1"), ("quad_launches_two_waves_per_simd", "3")):
-                    os.environ["BALER_AMD_BF16_TRAIN_V2"] = ver
-                    try:
-                        ha = native.Handle(model.dims, "bf16")
-                        ha.load_params(flat.clone())
-                        ga = torch.zeros_like(flat)
-                        warm(lambda: ha.fwd_bwd(x, ga))
-                        ms_a = event_ms(lambda: ha.fwd_bwd(x, ga), 10)
-                        alt[tag] = {"launch_ms": ms_a, "frac": FLOP_TRAIN_ROW * a.rows / ms_a / 1e9 / PEAK_TFLOPS["bf16"]}
-                        ha.close()
-                    finally:
-                        os.environ.pop("BALER_AMD_BF16_TRAIN_V2", None)
-                extra_roof["train_bf16"]["other_kernel_versions"] = alt
+                # (the two round-5 rewrites that rode this line in round 5 -- 0.833 / 0.984 ms against the pair's 0.744 -- were removed
+                # in round 6: profiles/r5_bench.json, profiles/r5_bf16_regchain_kernel_stats.csv, profiles/r5_bf16_quad_kernel_stats.csv)
             hb.close()
         # ---- the reference's batching regime and the curve up to the benchmarked batch: sequential optimizer steps ----
         by_batch = {}

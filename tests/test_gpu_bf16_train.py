@@ -289,32 +289,3 @@ def test_wide_model_large_batches(shape, n):
     a, b = res["bf16"], res["fp32"]
     assert np.isfinite(a).all()
     assert abs(a[-1] - b[-1]) < 1e-4 * b[-1] and rel(a[:-1], b[:-1]) < 5e-3
-
-
-@pytest.mark.parametrize("version", ["1", "3"])
-@pytest.mark.parametrize("n", [1, 65, 1000, 20000])
-def test_register_chain_pair(n, version, data, monkeypatch):
-    """BALER_AMD_BF16_TRAIN_V2=1 (read at handle creation): the round-5 pair -- per-wave register chain through all layers, weight
-    fragments through an LDS ring fed by direct-to-LDS loads, cut at the bottleneck, epilogues dealt between the next tile group's
-    MFMAs -- against the oracle at the mode's bar and against the default pair (both round every operand to bfloat16 once, in
-    different places: the gradients agree to rounding noise).  Measured slower than the default pair."""
-    raw, x = data
-    flat = orc.formula_params(DIMS, 7)
-    h1, p = handle(flat)
-    g1 = torch.zeros_like(p)
-    h1.fwd_bwd(torch.as_tensor(x[:n]).cuda(), g1)
-    monkeypatch.setenv("BALER_AMD_BF16_TRAIN_V2", version)     # "3": the quad launches (four launches, eight waves per workgroup)
-    h2, _ = handle(flat)
-    g2, g3 = torch.zeros_like(p), torch.zeros_like(p)
-    h2.fwd_bwd(torch.as_tensor(x[:n]).cuda(), g2)
-    h2.fwd_bwd(torch.as_tensor(x[:n]).cuda(), g3)
-    assert torch.equal(g2, g3)                                  # fixed-order reductions
-    loss_ref, g_ref = orc.fwd_bwd(DIMS, flat, x[:n])
-    a, b = g1.cpu().numpy().astype(np.float64), g2.cpu().numpy().astype(np.float64)
-    assert abs(b[-1] - loss_ref) < 2e-3 * loss_ref
-    if n >= 64:
-        assert rel(b[:-1], g_ref) < 2e-2 and rel(b[:-1], a[:-1]) < 2e-2
-    feats = torch.as_tensor(np.stack([raw.min(0), raw.max(0) - raw.min(0)])).cuda()
-    g4 = torch.zeros_like(p)
-    h2.fwd_bwd(torch.as_tensor(raw[:n]).cuda(), g4, features=feats)      # normalise-on-load: the same bits
-    assert torch.equal(g4, g2)

@@ -12,7 +12,7 @@ h.load_params(p)
 m, v = torch.zeros_like(p), torch.zeros_like(p)
 x = torch.from_numpy(orc.normalize(synth.cms_rows(8192))).cuda()
 print("rows   four-row chain   exchange chain   (us per bamd_train_step)")
-for n in (16, 64, 256, 512, 768, 1024, 1536, 2048, 4096):
+for n in ([int(a) for a in sys.argv[1:]] or [16, 64, 256, 512, 768, 1024, 1536, 2048, 4096]):
     row = []
     for q in ("1000000", "0"):
         os.environ["BALER_AMD_F64_QCHAIN_BLKS"] = q
