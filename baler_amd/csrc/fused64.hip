@@ -10,6 +10,9 @@
 // closes with NATURAL feature order (slot s = feature s; no g-major / r-major distinction between full and partial tiles).
 // Batches above FusedState64::max_rows stay on the layer-wise kernels (generic.hip); the inference entry points run on
 // infer64_kernel below (every wave its own 16 rows, register chain, no exchange).
+// Three chains write the same images for the weight-gradient kernels: chain64q_kernel (FOUR rows per workgroup on v_mfma_f64_4x4x4: up
+// to 1,536 rows, the reference's 512-row step), chain64_kernel (one workgroup per 16-row block, tiles exchanged through LDS) and
+// chain64r_kernel (one wave per block, activations in registers: from 16,384 rows on).
 #include "fused.hpp"
 
 #include <algorithm>
@@ -889,6 +892,12 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     __shared__ __attribute__((aligned(32))) d4 red[4 * 64];
     const int tile = (blockIdx.x & 7) * kPerXcd + (blockIdx.x >> 3);       // XCD c takes a contiguous tile range (see fused.hip)
     if (tile > T) return;
+#ifdef BAMD_Q4_TRACE
+#define DW_T(i) do { if (tile == 150 && threadIdx.x == 0) g_q4_trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DW_T(i) do {} while (0)
+#endif
+    DW_T(20);
     if (tile == T) {   // loss: fixed-order sum of the per-block partials, / C
         const double s = block_sum_fixed(loss_part, nloss, (double *)red);      // (one partial per block, four with the 4-row chain)
         if (threadIdx.x == 0) {
@@ -920,9 +929,12 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
     if (MODE == DW_ADAM && s1 > s0 + 1) sc1 = ad.sc_idx[s0 + 1];
     if (MODE == DW_ADAM && s1 > s0 + 2) sc2 = ad.sc_idx[s0 + 2];
     if (MODE == DW_ADAM && s1 > s0 + 3) sc3 = ad.sc_idx[s0 + 3];
+    DW_T(21);
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
     // (requesting the first UB blocks' image slices BEFORE the parameter index and the optimiser state behind it was measured in round 6:
-    // 512-row step 30.1 -> 29.9 us, 1,024 rows 35.6 -> 37.0: not kept)
+    // 512-row step 30.1 -> 29.9 us, 1,024 rows 35.6 -> 37.0: not kept; so was a per-thread table of the parameter's packed slots that cuts
+    // the dependent index chain to one round trip behind the images: 30.3 -> 30.3 us.  tools/q4_trace.py: the image slices are what this
+    // kernel waits for -- 16k - 19k of its 23k cycles at 512 rows, whatever is requested first)
     constexpr int UB = 8;                                            // blocks per wave in flight (a 512-row batch: all of a wave's blocks)
     for (int b0 = wave; b0 < (nsplit > 0 ? 0 : nblk); b0 += 4 * UB) {
         d4 a[UB], x[UB];
@@ -938,8 +950,10 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = mfma(a[u][r], x[u][r], acc);
     }
+    DW_T(22);
     red[wave * 64 + lane] = acc;
     __syncthreads();
+    DW_T(23);
     // thread e = 4 lane' + r' owns D[n slot = g' + 4 r'][k slot = lane' & 15]  (f64 C/D map)
     const double *rf = (const double *)red;
     const int e = threadIdx.x;
@@ -975,7 +989,9 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
         if (sc3 >= 0) ad.packed[sc3] = pn;
         for (int k = s0 + 4; k < s1; ++k) ad.packed[ad.sc_idx[k]] = pn;
     }
+    DW_T(24);
 }
+#undef DW_T
 
 // Weight-gradient tiles in BLOCKS for large fp64 batches.  dw64_kernel's one-tile workgroups each read their two image slices of
 // every 16-row block: at 262,144 rows that is 19.5 GB through L2 / fabric (3.6 of the step's 3.9 ms, MFMA busy 14 %).  Here a workgroup

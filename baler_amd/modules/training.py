@@ -16,6 +16,7 @@ slices resident (``ShardedRows``: the block-cyclic row shard of SURVEY.md sectio
 """
 import os
 import random
+import sys
 import time
 
 import numpy as np
@@ -251,7 +252,10 @@ def train(model, variables, train_data, test_data, project_path, config):
     bdist.broadcast(model.flat, src=0)
     model.mark_params_changed()
     if bdist.lib_comm_wanted():      # RCCL: the handle gets its own communicator and runs the data-parallel step itself
-        bdist.attach_comm(model.handle())
+        try:
+            bdist.attach_comm(model.handle())
+        except Exception as e:       # noqa: BLE001 -- e.g. a librccl the library cannot resolve: the three-call sequence still works
+            print(f"[baler_amd] data-parallel step stays in Python (no library communicator: {type(e).__name__}: {e})", file=sys.stderr, flush=True)
 
     train_ds = _to_device_dataset(train_data, config, device)
     valid_ds = train_ds if test_data is train_data else _to_device_dataset(test_data, config, device)

@@ -315,6 +315,36 @@ def main():
         state["t"] += 1
         h.adam_step(flat, grads, m, v, state["t"], 1e-3, loss_accum=loss_acc)
 
+    # The library's own RCCL communicator (bamd_comm_init: fwd_bwd -> ncclAllReduce -> Adam in ONE host call), built in a helper thread
+    # with a deadline: should ncclCommInitRank not return on some node (it never failed on the boxes this was developed on), the run says
+    # so on the line and measures every data-parallel loop as three Python calls, as rounds 1-5 did.  `value` never depends on it.
+    lib_dp, lib_dp_error = False, None
+    if coll and torch.distributed.get_backend() == "nccl" and os.environ.get("BALER_AMD_LIB_COMM", "1") != "0":
+        import threading
+        att = {}
+
+        def _attach():
+            try:
+                bdist.attach_comm(h)
+                att["ok"] = True
+            except Exception as e:      # noqa: BLE001
+                att["err"] = f"{type(e).__name__}: {e}"
+        th = threading.Thread(target=_attach, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("BALER_AMD_COMM_INIT_TIMEOUT", "90")))
+        if th.is_alive():
+            state["hard_exit"] = True      # a thread stuck inside RCCL: leave through os._exit after the JSON line
+            lib_dp_error = "timeout building the library's RCCL communicator"
+        elif "err" in att:
+            lib_dp_error = att["err"]
+        else:
+            lib_dp = True
+        if world > 1:      # every rank must take the same path through the data-parallel loops
+            okf = torch.tensor([1.0 if lib_dp else 0.0], device=torch.device("cuda", local))
+            torch.distributed.all_reduce(okf, op=torch.distributed.ReduceOp.MIN)
+            if lib_dp and float(okf.item()) == 0.0:
+                lib_dp, lib_dp_error = False, "another rank could not build the library's communicator"
+        rank_diag("library communicator " + ("up" if lib_dp else f"NOT available ({lib_dp_error})"), local)
     log("data resident, model ready")
     # clocks and caches to their steady state before the W warm-up steps (forward + backward only: the gradient buffer is rewritten by
     # every step, nothing else is touched); see warm()
@@ -431,7 +461,13 @@ def main():
                 "bound": "hbm", "kernel": "bamd_encode (bf16_infer_kernel)", "launch_ms": ms, "unit": "GB/s",
                 "achieved": BYTES_ENCODE_ROW * a.rows / ms / 1e6, "peak": PEAK_HBM_GBS,
                 "frac": BYTES_ENCODE_ROW * a.rows / ms / 1e6 / PEAK_HBM_GBS,
-                "mfma_tflops": FLOP_ENCODE_ROW * a.rows / ms / 1e9, "mfma_frac": FLOP_ENCODE_ROW * a.rows / ms / 1e9 / PEAK_TFLOPS["bf16"]}
+                "mfma_tflops": FLOP_ENCODE_ROW * a.rows / ms / 1e9, "mfma_frac": FLOP_ENCODE_ROW * a.rows / ms / 1e9 / PEAK_TFLOPS["bf16"],
+                # what actually bounds this kernel: the SIMD's issue port, not HBM.  Its layers issue 1.34 x the
+                # algorithmic MACs (K padded to 32) beside 3.4 VALU instructions per MFMA (LeakyReLU = multiply + maximum + half a conversion per
+                # activation value: gfx950 has no packed-bf16 arithmetic); tools/probe/mfma_shape_probe.hip issues 1,033 - 1,219 TFLOP/s at
+                # 3.75 - 2.5 VALU per MFMA (profiles/r3_mfma_shape_probe.txt), i.e. ~1,085 at this kernel's ratio
+                "issued_tflops": 1.34 * FLOP_ENCODE_ROW * a.rows / ms / 1e9, "issue_ceiling_tflops": 1085.0,
+                "frac_of_issue_ceiling": 1.34 * FLOP_ENCODE_ROW * a.rows / ms / 1e9 / 1085.0}
             # bf16 MFMA TRAINING (BASELINE configs[1] names bf16): fp32 master weights + fp32 Adam, bf16 kernels
             fb = flat.clone()
             gb, mb, vb = torch.zeros_like(fb), torch.zeros_like(fb), torch.zeros_like(fb)
@@ -454,7 +490,12 @@ def main():
                 "launch_ms": ms, "unit": "TFLOP/s", "achieved": FLOP_TRAIN_ROW * a.rows / ms / 1e9, "peak": PEAK_TFLOPS["bf16"],
                 "frac": FLOP_TRAIN_ROW * a.rows / ms / 1e9 / PEAK_TFLOPS["bf16"],
                 "hbm_gbs_algorithmic": BYTES_TRAIN_ROW * a.rows / ms / 1e6, "hbm_frac": BYTES_TRAIN_ROW * a.rows / ms / 1e6 / PEAK_HBM_GBS,
-                "last_batch_loss": float(gb[-1].item())}
+                "last_batch_loss": float(gb[-1].item()),
+                # issued MACs are 1.38 x the algorithmic ones (K padded to 32); the pair's main-loop instruction multiset replayed with every
+                # dependency removed (tools/isa_mix.py, profiles/r6_bf16_train_mix_replay.txt) takes 12.1 - 12.7 us per 64-row iteration of
+                # both launches: the schedulable ceiling of THIS multiset
+                "issued_frac": 1.38 * FLOP_TRAIN_ROW * a.rows / ms / 1e9 / PEAK_TFLOPS["bf16"],
+                "us_per_64_row_iteration": 1e3 * (ms - 0.017) / (a.rows / 64 / 256), "mix_replay_us_per_iteration": [12.1, 12.7]}
             if world == 1:      # the bf16 handle's optimizer steps by batch size (<= 3072 rows: the fp32 small-batch kernels)
                 bb = {}
                 for bs in (512, 8192, 32768):
@@ -481,6 +522,9 @@ def main():
                 continue
 
             def batch_pass():
+                if lib_dp:          # what training.fit issues under RCCL: ONE bamd_train_epoch_dp per epoch and rank
+                    state["t"] += h.train_epoch_dp(x[:nb * bs], [bs] * nb, flat, m, v, state["t"] + 1, 1e-3, loss_accum=loss_acc, grads=grads)
+                    return
                 for i in range(nb):
                     state["t"] += 1
                     xb = x[i * bs:(i + 1) * bs]
@@ -497,6 +541,8 @@ def main():
                                  "tflops": FLOP_TRAIN_ROW * world * bs * nb / tb_ / 1e12,
                                  "frac_of_mfma_peak": FLOP_TRAIN_ROW * bs * nb / tb_ / 1e12 / PEAK_TFLOPS[a.mode]}
         out["train_rows_per_s_by_batch"] = by_batch
+        if coll:
+            out["dp_steps_run_by"] = "library (bamd_train_epoch_dp)" if lib_dp else "python (fwd_bwd, torch all-reduce, adam_step)"
         if world > 1:
             # the numbers above take bs rows PER GPU per step (dp_batch = "per_gpu": global batch = N x bs); the reference's
             # config means the GLOBAL batch (dist.batch_policy's default): every rank computes bs / N rows of each step
@@ -509,6 +555,9 @@ def main():
                 nb = max(2, min(400, a.rows // per))
 
                 def gpass():
+                    if lib_dp:
+                        state["t"] += h.train_epoch_dp(x[:nb * per], [per] * nb, flat, m, v, state["t"] + 1, 1e-3, loss_accum=loss_acc, grads=grads)
+                        return
                     for i in range(nb):
                         state["t"] += 1
                         h.fwd_bwd(x[i * per:(i + 1) * per], grads)
@@ -523,30 +572,27 @@ def main():
             # ---- what a data-parallel optimiser step costs, as the three-call Python sequence (bamd_fwd_bwd -> torch all-reduce ->
             # bamd_adam_step) and with the communicator INSIDE the library (bamd_train_epoch_dp: the same three stages per batch, one
             # host call per epoch), at 64 and 512 rows per rank.  gpu_us = wall time per step with the stream drained; host_us = the
-            # host thread's time per step until its last enqueue returns.  A failure to build the library's own RCCL communicator is
-            # reported, never fatal: the run's other numbers do not depend on it.
+            # host thread's time per step until its last enqueue returns.
             dp = {}
-            try:
-                h2 = native.Handle(model.dims, a.mode, dev.index)
-                f2 = flat.clone(); h2.load_params(f2)
-                m2, v2, g2 = torch.zeros_like(f2), torch.zeros_like(f2), torch.zeros_like(f2)
-                bdist.attach_comm(h2)
+            if not lib_dp:
+                dp["error"] = lib_dp_error
+            else:
+                g2 = torch.zeros_like(flat)
                 for _ in range(10):
-                    h2.allreduce_sum(g2)
-                dp["lib_allreduce_us"] = 1e6 * timed(lambda: h2.allreduce_sum(g2), 200, world, dev) / 200
+                    h.allreduce_sum(g2)
+                dp["lib_allreduce_us"] = 1e6 * timed(lambda: h.allreduce_sum(g2), 200, world, dev) / 200
                 for per in (64, 512):
                     nb = max(2, min(400, a.rows // per))
-                    t2 = {"t": 0}
 
                     def py_steps():
                         for i in range(nb):
-                            t2["t"] += 1
+                            state["t"] += 1
                             h.fwd_bwd(x[i * per:(i + 1) * per], grads)
                             bdist.allreduce_sum(grads)
-                            h.adam_step(flat, grads, m, v, state["t"] + t2["t"], 1e-3, loss_accum=loss_acc)
+                            h.adam_step(flat, grads, m, v, state["t"], 1e-3, loss_accum=loss_acc)
 
                     def lib_steps():
-                        t2["t"] += h2.train_epoch_dp(x[:nb * per], [per] * nb, f2, m2, v2, t2["t"] + 1, 1e-3, loss_accum=loss_acc, grads=g2)
+                        state["t"] += h.train_epoch_dp(x[:nb * per], [per] * nb, flat, m, v, state["t"] + 1, 1e-3, loss_accum=loss_acc, grads=grads)
                     rec = {"rows_per_rank": per, "steps_timed": nb}
                     for tag, fn in (("python_3_calls", py_steps), ("library_1_call", lib_steps)):
                         fn(); fn()
@@ -559,12 +605,7 @@ def main():
                         torch.cuda.synchronize()
                         t_all = time.perf_counter() - t0
                         rec[tag] = {"gpu_us": 1e6 * t_all / nb, "host_us": 1e6 * t_host / nb}
-                    state["t"] += t2["t"]
                     dp[str(per)] = rec
-                h2.comm_release()
-                h2.close()
-            except Exception as e:      # noqa: BLE001 -- reported on the line
-                dp["error"] = f"{type(e).__name__}: {e}"
             out["dp_step"] = dp
             log("dp step: " + json.dumps(dp))
         if world == 1 and not coll and a.rows >= 2 * 512:
@@ -644,7 +685,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.cpu_rows)
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if state.get("hard_exit"):
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
     if world > 1:
         import torch.distributed as td
         td.barrier()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The run-time-width wide class for rocprofv3: CFD_dense_AE(900, 9), 131,072 rows: encode / decode / fwd_bwd, 10 passes."""
+"""The run-time-width wide class for rocprofv3: CFD_dense_AE(900, 9), 131,072 rows: encode / decode / fwd_bwd, 6 untimed + 30 launches each."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +13,9 @@ assert h.path == "fused"
 x = torch.rand((131072, 900), dtype=torch.float32, device="cuda")
 g = torch.zeros_like(p)
 z = h.encode(x)
-for _ in range(10):
-    z = h.encode(x); y = h.decode(z); h.fwd_bwd(x, g)
-torch.cuda.synchronize()
+y = torch.empty_like(x)
+for fn in (lambda: h.encode(x, out=z), lambda: h.decode(z, out=y), lambda: h.fwd_bwd(x, g)):
+    for _ in range(36):
+        fn()
+    torch.cuda.synchronize()
 print("done")

@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Write the round-6 section at the top of profiles/README.md from profiles/r6_bench.json, profiles/pmc_summary.json and the
+r6_*_kernel_stats.csv files (after tools/profile_r6.sh + tools/summarize_r6.py):  python tools/profiles_readme_r6.py
+Older rounds' sections stay below it."""
+import csv
+import json
+import os
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = f"{R}/profiles"
+b = json.load(open(f"{P}/r6_bench.json"))
+b5 = json.load(open(f"{P}/r5_bench.json"))
+d = json.load(open(f"{P}/pmc_summary.json"))
+rx, rx5 = b["roofline_extra"], b5["roofline_extra"]
+oc, oc5 = b["other_configs"], b5["other_configs"]
+c4, c45 = oc["c4_cfd_dense_2500_25"], oc5["c4_cfd_dense_2500_25"]
+
+
+def stats(name):
+    f = f"{P}/{name}"
+    return {r["Name"]: (int(r["Calls"]), float(r["AverageNs"]) / 1e3) for r in csv.DictReader(open(f))} if os.path.exists(f) else {}
+
+
+def avg(tab, *needles):
+    """(calls, average us) of the first kernel whose name holds every needle."""
+    for name, v in tab.items():
+        if all(n in name for n in needles):
+            return v
+    return (0, float("nan"))
+
+
+def pct(x):
+    return f"{100 * x:.1f} %"
+
+
+def row(tab, name):
+    e = tab.get(name)
+    if not e:
+        return "— | — | — | —"
+    return f"{pct(e.get('mfma_busy', 0))} | {e.get('valu_per_mfma', 0):.2f} | {pct(e.get('wait_any_frac', 0))} | {e.get('hbm_bytes', 0) / 1e6:.1f} MB"
+
+
+c4s, wcs, ifs, q64, f64 = (stats(n) for n in ("r6_c4_kernel_stats.csv", "r6_wide_class_kernel_stats.csv", "r6_bf16_infer_kernel_stats.csv",
+                                              "r6_fp64_bs512_kernel_stats.csv", "r6_fp64_kernel_stats.csv"))
+FLOP_C4_ENC, FLOP_C4_TRAIN, NC4 = 1052500, 5315000, 32768
+enc_k = avg(c4s, "wide_encode_lds_kernel<2500, 25")
+if enc_k[0] == 0:
+    enc_k = avg(c4s, "wide_encode2_kernel<2500, 25")
+dec_k = avg(c4s, "wide_decode_lds_kernel<2500, 25")
+if dec_k[0] == 0:
+    dec_k = avg(c4s, "wide_infer_kernel<2500, 25, 1")
+benc_k, bdec_k = avg(c4s, "wide_bf16_encode_dma_kernel<2500, 25"), avg(c4s, "wide_bf16_decode_kernel<2500, 25")
+
+
+def frac_mfma(us, flop, n):
+    return flop * n / us / 1e6 / 157.3 if us == us and us > 0 else float("nan")
+
+
+def frac_hbm(us, nbytes):
+    return nbytes / us / 1e6 / 8.0 if us == us and us > 0 else float("nan")
+
+
+dp = b.get("dp_step") or {}
+if not dp and os.path.exists(f"{P}/r6_bench_forced_pg.json"):
+    dp = json.load(open(f"{P}/r6_bench_forced_pg.json")).get("dp_step", {})
+k, bk, fk, sk, qk = (d.get(x, {}) for x in ("kernels", "bf16_kernels", "fp64_kernels", "bs512_kernels", "fp64_bs512_kernels"))
+eb = rx["encode_bf16"]
+tb = rx["train_bf16"]
+sec = f"""# profiles — round 6 (1×MI355X; 1,000,000 synthetic CMS rows resident in HBM)
+
+All numbers from the GPU box via `gpurun` (`tools/profile_r6.sh`, `tools/summarize_r6.py`, this section by `tools/profiles_readme_r6.py`; raw
+rocprofv3 CSVs are scratch, `gpurun_out/r6p`). Committed here: `r6_bench.json` (the bench line), `r6_bench_forced_pg.json` (the same program under
+a one-rank RCCL group, `BALER_AMD_FORCE_PG=1`: carries `dp_step`), the `rocprofv3 --kernel-trace --stats` summaries `r6_kernel_stats.csv`
+(`python3 bench.py --no-cpu-baseline --no-extras`), `r6_bf16_kernel_stats.csv` (`tools/bench_bf16_train.py 1000000 40`), `r6_c4_kernel_stats.csv`
+(`tools/prof_c4_r6.py 32768`: fp32 and bf16 handles, **36 launches per entry point**), `r6_wide_class_kernel_stats.csv` (`tools/prof_wide_class.py`,
+36 launches each), `r6_bs512_kernel_stats.csv` (`tools/bench_one_batch.py 512 400`), `r6_fp64_kernel_stats.csv` (`tools/prof_fp64.py`),
+`r6_fp64_bs512_kernel_stats.csv` (`tools/prof_fp64_bs512.py`: the 4-row fp64 chain), `r6_bf16_infer_kernel_stats.csv` (`tools/prof_bf16_infer_r6.py`:
+1M / 4M rows and C5, 36 launches each) and `pmc_summary.json` (FETCH_SIZE, WRITE_SIZE and the SQ counters each in their own `--pmc` run with
+`--kernel-trace` only; stamped with the hash of the kernel sources, `{d['source_hash']}`: `bench.py` quotes `roofline.traffic` from it only when
+the hash matches; `hbm_bytes = 2·FETCH_SIZE + WRITE_SIZE` is exact for kernels whose loads are 16-B-per-lane streams — the throughput pair, the
+inference kernels, the wide kernels — and an UPPER bound for the small-batch kernels, whose 4-/8-byte image stores and gathers are not calibrated).
+Measurements that are not profiles: `r6_bf16_train_mix_replay.txt` (the bf16 training pair's instruction multiset replayed without
+dependencies: the ceiling of DESIGN §4.6), `r6_mfma64_4x4_probe.txt` (`v_mfma_f64_4x4x4_4b_f64`: lane maps, rate), `r6_fp64_small_steps.txt`
+(fp64 optimiser step by batch size, 4-row chain vs exchange chain), `r6_fp64_chain_trace.txt` (per-GEMM shader-clock timeline of `chain64q_kernel`
+and of one `dw64_kernel` workgroup), `r6_bf16_infer_rows_sweep.txt` / `r6_bf16_infer_tile_wave_ab.txt` (bf16 inference: time against rows for
+every dtype pair; rows per wave × waves per workgroup), `r6_fp64_chunk_rows.txt` (fp64 1M-row step against the chunk size), `r6_wide_class_bench.txt`.
+
+| quantity (`r6_bench.json`, steady state: DESIGN.md §5) | round 6 | round 5 |
+|---|---|---|
+| fp32 train, one 1M-row step — `value` | **{b['value'] / 1e6:.1f} M rows/s**, {b['ms_per_step']:.3f} ms/step; `bamd_fwd_bwd` {b['roofline']['launch_ms']:.3f} ms = **{b['roofline']['frac']:.3f} of the fp32 MFMA peak** (kernels unchanged) | {b5['value'] / 1e6:.1f} M, {b5['roofline']['frac']:.3f} |
+| fp32 encode / decode | {b['encode_rows_per_s'] / 1e9:.2f} / {b['decode_rows_per_s'] / 1e9:.2f} G rows/s | {b5['encode_rows_per_s'] / 1e9:.2f} / {b5['decode_rows_per_s'] / 1e9:.2f} |
+| **fp64 `batch_size = 512` step** (`roofline_extra.train_bs512_f64`: the reference's dtype and batch size) | **{rx['train_bs512_f64']['launch_us']:.1f} µs** (`chain64q_kernel` {avg(q64, 'chain64q_kernel')[1]:.1f} + `dw64_kernel<adam>` {avg(q64, 'dw64_kernel')[1]:.1f} µs under rocprofv3) | {rx5['train_bs512_f64']['launch_us']:.1f} µs (`chain64_kernel` 28.7 + 12.7) |
+| fp32 `batch_size = 512` step · by batch | {b['train_bs512_us_per_step']:.1f} µs; one host call per epoch {b['train_bs512_epoch_call']['us_per_step']:.2f} µs per step, host {b['train_bs512_epoch_call']['host_us_per_step']:.1f} µs · 4,096: {b['train_rows_per_s_by_batch']['4096']['us_per_step']:.1f} · 32,768: {b['train_rows_per_s_by_batch']['32768']['us_per_step']:.0f} · 262,144: {b['train_rows_per_s_by_batch']['262144']['us_per_step']:.0f} | {b5['train_bs512_us_per_step']:.1f} · 44.1 · 150 · 905 |
+| **data-parallel step, world-1 RCCL** (`r6_bench_forced_pg.json: dp_step`) | 512 rows per rank: three Python calls {dp.get('512', {}).get('python_3_calls', {}).get('gpu_us', float('nan')):.1f} µs (host {dp.get('512', {}).get('python_3_calls', {}).get('host_us', float('nan')):.1f}) → library, one call per epoch **{dp.get('512', {}).get('library_1_call', {}).get('gpu_us', float('nan')):.1f} µs** (host {dp.get('512', {}).get('library_1_call', {}).get('host_us', float('nan')):.1f}); 64 rows: {dp.get('64', {}).get('python_3_calls', {}).get('gpu_us', float('nan')):.1f} → {dp.get('64', {}).get('library_1_call', {}).get('gpu_us', float('nan')):.1f} µs; all-reduce alone {dp.get('lib_allreduce_us', float('nan')):.1f} µs | not on a record |
+| bf16 training (`roofline_extra.train_bf16`) | {b['bf16_train_rows_per_s'] / 1e9:.2f} G rows/s through the step; pair {tb['launch_ms']:.3f} ms = {tb['frac']:.3f} of the bf16 peak ({tb.get('issued_frac', float('nan')):.3f} issued); {tb.get('us_per_64_row_iteration', float('nan')):.1f} µs per 64-row iteration against **12.1–12.7 µs for its dependency-free replay** | 0.744 ms = 0.192; two rewrites 0.833 / 0.984 ms |
+| bf16 encode / decode, 24 columns, 1M float64 rows | {b['bf16_encode_rows_per_s'] / 1e9:.1f} / {b['bf16_decode_rows_per_s'] / 1e9:.1f} G rows/s; event-timed launch {eb['launch_ms'] * 1e3:.0f} µs = {eb['frac']:.2f} of HBM, {eb.get('issued_tflops', float('nan')):.0f} TFLOP/s issued = **{eb.get('frac_of_issue_ceiling', float('nan')):.2f} of the issue ceiling** of its VALU-per-MFMA ratio | 10.9 / 8.7 G |
+| fp64 large batches (`roofline_extra`) | encode {rx['encode_f64']['frac']:.2f}; training at 1M rows {rx['train_f64']['launch_ms']:.2f} ms = {rx['train_f64']['frac']:.3f} (unchanged kernels) | {rx5['train_f64']['launch_ms']:.2f} ms = {rx5['train_f64']['frac']:.3f} |
+| C4 `CFD_dense_AE(2500,25)`, 32,768 frames | fp32 encode / decode / training {c4['encode_frac_of_mfma_peak']:.2f} / {c4['decode_frac_of_mfma_peak']:.2f} / {c4['train_frac_of_mfma_peak']:.2f}; bf16 encode / decode {c4['bf16_encode_frac_of_hbm']:.2f} / {c4['bf16_decode_frac_of_hbm']:.2f} of HBM | {c45['encode_frac_of_mfma_peak']:.2f} / {c45['decode_frac_of_mfma_peak']:.2f} / {c45['train_frac_of_mfma_peak']:.2f}; {c45['bf16_encode_frac_of_hbm']:.2f} / {c45['bf16_decode_frac_of_hbm']:.2f} |
+| C5 512 columns, 262,144 rows | encode {oc['c5_encode_512col']['encode_frac_of_mfma_peak']:.2f} of the fp32 peak; bf16 encode {oc['c5_encode_512col']['bf16_encode_frac_of_hbm']:.2f} of HBM | {oc5['c5_encode_512col']['encode_frac_of_mfma_peak']:.2f}; {oc5['c5_encode_512col']['bf16_encode_frac_of_hbm']:.2f} |
+| PCIe-inclusive, 10 M-row file | compress {b['pcie']['compress_rows_per_s'] / 1e6:.0f} M rows/s, decompress {b['pcie']['decompress_rows_per_s'] / 1e6:.0f} M | {b5['pcie']['compress_rows_per_s'] / 1e6:.0f} / {b5['pcie']['decompress_rows_per_s'] / 1e6:.0f} |
+| CPU baseline (plain-PyTorch fp64 port of `training.fit`, bs 512, 1M rows) | {b['cpu_baseline']['value'] / 1e3:.0f} k rows/s on {b['cpu_baseline']['cores']} of 256 threads (the calibration's best) of an EPYC 9575F | {b5['cpu_baseline']['value'] / 1e3:.0f} k on {b5['cpu_baseline']['cores']} |
+
+## Do the profiles reproduce the line's side fractions? (round-5 review, weak #8)
+
+Kernel averages of the 36-launch profiles (rocprofv3 serialises every launch: 3–10 % longer than the event times of `bench.py`) against the bench line:
+
+| C4, 32,768 frames | kernel average under rocprofv3 | fraction from the profile | fraction on the bench line |
+|---|---|---|---|
+| fp32 encode | {enc_k[1]:.0f} µs × {enc_k[0]} | {frac_mfma(enc_k[1], FLOP_C4_ENC, NC4):.2f} of the fp32 peak | {c4['encode_frac_of_mfma_peak']:.2f} |
+| fp32 decode | {dec_k[1]:.0f} µs × {dec_k[0]} | {frac_mfma(dec_k[1], FLOP_C4_ENC, NC4):.2f} | {c4['decode_frac_of_mfma_peak']:.2f} |
+| bf16 encode | {benc_k[1]:.0f} µs × {benc_k[0]} | {frac_hbm(benc_k[1], 10100 * NC4):.2f} of HBM | {c4['bf16_encode_frac_of_hbm']:.2f} |
+| bf16 decode | {bdec_k[1]:.0f} µs × {bdec_k[0]} | {frac_hbm(bdec_k[1], 10100 * NC4):.2f} of HBM | {c4['bf16_decode_frac_of_hbm']:.2f} |
+
+(The training pass of C4 is several kernels: `r6_c4_kernel_stats.csv`; the 24-column bf16 encode at 1M float64 rows:
+{avg(ifs, 'bf16_infer_kernel<24, 15, false, true>')[1]:.0f} µs averaged over the 1M- and 4M-row launches of `r6_bf16_infer_kernel_stats.csv`.)
+
+## Counters (`pmc_summary.json`, round 6)
+
+| kernel | MFMA busy | VALU per MFMA | `SQ_WAIT_ANY` | HBM bytes per launch (2·FETCH + WRITE) |
+|---|---|---|---|---|
+| `train_dec_kernel` (fp32, 1M rows) | {row(k, 'train_dec_kernel')} |
+| `train_enc_kernel` | {row(k, 'train_enc_kernel')} |
+| `bf16_train_kernel<PART 0>` | {row(bk, 'bf16_train_kernel<PART 0>')} |
+| `bf16_train_kernel<PART 1>` | {row(bk, 'bf16_train_kernel<PART 1>')} |
+| **`chain64q_kernel`** (fp64, 512 rows, four rows per workgroup) | {row(qk, 'chain64q_kernel (4 rows per workgroup)')} |
+| `dw64_kernel<adam>` (fp64, 512 rows) | {row(qk, 'dw64_kernel')} |
+| `dw64x_kernel` (fp64 weight-gradient tile blocks, 262,144 rows) | {row(fk, 'dw64x_kernel')} |
+| `chain64r_kernel` (fp64 chain, 262,144 rows) | {row(fk, 'chain64r_kernel')} |
+| `lat4_chain_kernel` (fp32, 512 rows) | {row(sk, 'lat4_chain_kernel')} |
+| `lat2_dw_kernel<adam>` (fp32, 512 rows) | {row(sk, 'lat2_dw_kernel')} |
+
+The wide class, the C4 kernels (fp32 and bf16) and the bf16 inference kernels: `wide_class_kernels`, `c4_kernels`, `bf16_infer_kernels` in the same file.
+
+---
+
+"""
+p = f"{P}/README.md"
+s = open(p).read()
+mark5 = "# profiles — round 5 ("
+mark6 = "# profiles — round 6 ("
+if mark6 in s:
+    s = s[s.index("# round 5 (kept for the history"):]
+else:
+    s = s.replace(mark5, "# round 5 (kept for the history; superseded where round 6 re-measured) — profiles (", 1)
+open(p, "w").write(sec + s)
+print("profiles/README.md: round-6 section written")

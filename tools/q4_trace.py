@@ -20,6 +20,7 @@ names = ["start", "rows + biases + ring issued", "X_0 published", "L0 (13 groups
          "L4 (4, K 15)", "L5 (7, K 50)", "L6 (13, K 100)", "L7 + loss (2, K 200, split 2)", "B7 (13, K 24)", "B6 (7, K 200)", "B5 (4, K 100)",
          "B4 (1, K 50, split 4)", "B3 (4, K 15)", "B2 (7, K 50)", "B1 (13, K 100)", "loss partial"]
 acc = np.zeros(19)
+dw = np.zeros(5)
 reps = 20
 for i in range(60):
     k = i % 20
@@ -30,7 +31,13 @@ for i in range(60):
         L.bamd_debug_q4_trace(buf, 32)
         t = np.array(buf[:19], dtype=np.int64)
         acc += (t - t[0])
+        d = np.array(buf[20:25], dtype=np.int64)
+        dw += np.concatenate([[d[0] - t[18]], np.diff(d)])
 acc /= reps
 print(f"chain64q_kernel, {R} rows per step, workgroup 0 wave 0, mean of {reps} steps: total {acc[18]:.0f} cycles (s_memtime ticks)")
 for i in range(1, 19):
     print(f"  {names[i]:34s} {acc[i] - acc[i - 1]:8.0f}")
+dw /= reps
+print("dw64_kernel<adam>, the workgroup of tile 150, thread 0 (cycles): starts %.0f after the chain's last stamp of workgroup 0;" % dw[0])
+for nm, v in zip(("map entry, optimiser state and scatter indices requested -> known", "image slices + MFMAs", "LDS hand-over + barrier", "sum, Adam, stores"), dw[1:]):
+    print(f"  {nm:66s} {v:8.0f}")
