@@ -325,6 +325,7 @@ def main():
 
         def _attach():
             try:
+                torch.cuda.set_device(local)      # (the current device is per thread: a new thread starts on device 0)
                 bdist.attach_comm(h)
                 att["ok"] = True
             except Exception as e:      # noqa: BLE001

@@ -72,10 +72,10 @@ All numbers from the GPU box via `gpurun` (`tools/profile_r6.sh`, `tools/summari
 rocprofv3 CSVs are scratch, `gpurun_out/r6p`). Committed here: `r6_bench.json` (the bench line), `r6_bench_forced_pg.json` (the same program under
 a one-rank RCCL group, `BALER_AMD_FORCE_PG=1`: carries `dp_step`), the `rocprofv3 --kernel-trace --stats` summaries `r6_kernel_stats.csv`
 (`python3 bench.py --no-cpu-baseline --no-extras`), `r6_bf16_kernel_stats.csv` (`tools/bench_bf16_train.py 1000000 40`), `r6_c4_kernel_stats.csv`
-(`tools/prof_c4_r6.py 32768`: fp32 and bf16 handles, **36 launches per entry point**), `r6_wide_class_kernel_stats.csv` (`tools/prof_wide_class.py`,
-36 launches each), `r6_bs512_kernel_stats.csv` (`tools/bench_one_batch.py 512 400`), `r6_fp64_kernel_stats.csv` (`tools/prof_fp64.py`),
+(`tools/prof_c4_r6.py 32768`: fp32 and bf16 handles, **100 launches per entry point behind a 150-ms clock warm-up**), `r6_wide_class_kernel_stats.csv` (`tools/prof_wide_class.py`,
+100 launches each behind a 150-ms clock warm-up), `r6_bs512_kernel_stats.csv` (`tools/bench_one_batch.py 512 400`), `r6_fp64_kernel_stats.csv` (`tools/prof_fp64.py`),
 `r6_fp64_bs512_kernel_stats.csv` (`tools/prof_fp64_bs512.py`: the 4-row fp64 chain), `r6_bf16_infer_kernel_stats.csv` (`tools/prof_bf16_infer_r6.py`:
-1M / 4M rows and C5, 36 launches each) and `pmc_summary.json` (FETCH_SIZE, WRITE_SIZE and the SQ counters each in their own `--pmc` run with
+1M / 4M rows and C5, 100 launches each behind a 150-ms clock warm-up) and `pmc_summary.json` (FETCH_SIZE, WRITE_SIZE and the SQ counters each in their own `--pmc` run with
 `--kernel-trace` only; stamped with the hash of the kernel sources, `{d['source_hash']}`: `bench.py` quotes `roofline.traffic` from it only when
 the hash matches; `hbm_bytes = 2·FETCH_SIZE + WRITE_SIZE` is exact for kernels whose loads are 16-B-per-lane streams — the throughput pair, the
 inference kernels, the wide kernels — and an UPPER bound for the small-batch kernels, whose 4-/8-byte image stores and gathers are not calibrated).
@@ -102,7 +102,7 @@ every dtype pair; rows per wave × waves per workgroup), `r6_fp64_chunk_rows.txt
 
 ## Do the profiles reproduce the line's side fractions? (round-5 review, weak #8)
 
-Kernel averages of the 36-launch profiles (rocprofv3 serialises every launch: 3–10 % longer than the event times of `bench.py`) against the bench line:
+Kernel averages of the 100-launch profiles (rocprofv3 serialises every launch: 3–10 % longer than the event times of `bench.py`) against the bench line:
 
 | C4, 32,768 frames | kernel average under rocprofv3 | fraction from the profile | fraction on the bench line |
 |---|---|---|---|

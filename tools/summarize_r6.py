@@ -74,10 +74,10 @@ out = {
             "passes, --kernel-trace only); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half of a wide "
             "coalesced read, MI355X_MICROARCH.md; checked on minmax_partial: 96 MB reported for a 192 MB read)",
     "source_hash": bench.source_hash(), "rows": 1000000, "kernels": fp32, "bf16_kernels": bf16,
-    "c4_note": "CFD_dense_AE(2500, 25), 32768 frames per launch, fp32 and bf16 handles, 36 launches per entry point (6 of them warm-up), `python3 tools/prof_c4_r6.py 32768`", "c4_kernels": c4,
+    "c4_note": "CFD_dense_AE(2500, 25), 32768 frames per launch, fp32 and bf16 handles, 100 launches per entry point behind a 150-ms clock warm-up (6 of them warm-up), `python3 tools/prof_c4_r6.py 32768`", "c4_kernels": c4,
     "fp64_bs512_note": "512-row bamd_train_step of an fp64 handle (chain64q_kernel: four rows per workgroup on v_mfma_f64_4x4x4, + dw64_kernel<adam>), `python3 tools/prof_fp64_bs512.py`, 300 steps", "fp64_bs512_kernels": q64,
-    "wide_class_note": "the run-time-width wide class on CFD_dense_AE(900, 9), 131,072 float32 rows per launch, 36 launches per entry point, `python3 tools/prof_wide_class.py`", "wide_class_kernels": wclass,
-    "bf16_infer_note": "bf16 encode / decode of AE(24, 15) at 1M float64 rows, 4M float64 and 4M float32 rows (36 launches each: the counters are averages over all three), and the C5 bf16 encode at 262,144 rows, `python3 tools/prof_bf16_infer_r6.py`", "bf16_infer_kernels": infer16,
+    "wide_class_note": "the run-time-width wide class on CFD_dense_AE(900, 9), 131,072 float32 rows per launch, 100 launches per entry point behind a 150-ms clock warm-up, `python3 tools/prof_wide_class.py`", "wide_class_kernels": wclass,
+    "bf16_infer_note": "bf16 encode / decode of AE(24, 15) at 1M float64 rows, 4M float64 and 4M float32 rows (100 launches each behind a 150-ms clock warm-up: the counters are averages over all three), and the C5 bf16 encode at 262,144 rows, `python3 tools/prof_bf16_infer_r6.py`", "bf16_infer_kernels": infer16,
     "bs512_note": "512-row bamd_train_step, `python3 tools/bench_one_batch.py 512 400`", "bs512_kernels": small,
     "fp64_note": "fp64 handle, 262,144 rows per launch (512 rows for chain64 / dw64; dw64_kernel averages the finishing launches of both), `python3 tools/prof_fp64.py`", "fp64_kernels": f64,
     "fwd_bwd_hbm_bytes_per_launch": sum(fp32[k]["hbm_bytes"] for k in ("train_dec_kernel", "train_enc_kernel", "reduce_slabs_k") if k in fp32),
