@@ -606,7 +606,8 @@ enum { DW_WRITE = 0, DW_ADAM = 1 };
 template <class N, int MODE>
 __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ imgs, int nblk, const double *__restrict__ loss_part,
                                                    const int *__restrict__ inv_map, double *__restrict__ grads, Adam64 ad,
-                                                   const double *__restrict__ part, int nsplit, int np, double inv_c, int nloss) {
+                                                   const double *__restrict__ part, int nsplit, int np, double inv_c, int nloss, int accum) {
+    // accum (DW_WRITE only): this launch covers one chunk of a larger batch -- gradients and loss are ADDED to what earlier chunks left
     // nsplit == 0: the whole job.  nsplit > 0: the tiles' partial sums over `nsplit` block ranges are in `part` (dw64m_kernel); this
     // launch adds them in range order and finishes (store / Adam).
     constexpr int T = N::slab_off(N::L);       // (np, inv_c: the handle's real parameter count and 1 / columns -- class instantiations)
@@ -624,7 +625,7 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
         const double s = block_sum_fixed(loss_part, nloss, (double *)red);      // (one partial per block, four with the 4-row chain)
         if (threadIdx.x == 0) {
             const double gl = s * inv_c;
-            if (grads) grads[np] = gl;
+            if (grads) grads[np] = accum ? grads[np] + gl : gl;
             if (MODE == DW_ADAM && ad.loss_accum) *ad.loss_accum += gl;
         }
         return;
@@ -694,7 +695,7 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
         for (; k < nsplit; ++k) gsum += q[k * 256];
     }
     if (p < 0) return;
-    if (grads) grads[p] = gsum;
+    if (grads) grads[p] = accum ? grads[p] + gsum : gsum;
     if (MODE == DW_ADAM) {   // elementwise.hip adam_k, on the parameters this tile owns
         double mi = pm, vi = pv;
         mi = mi + (gsum - mi) * (1.0 - ad.b1);
@@ -934,6 +935,7 @@ struct State64 {
     // BALER_AMD_LATENCY_ROWS (as for fp32) caps the rows the fused pair takes at all: larger batches then run layer by layer.
     int64_t chunk_rows = 262144;
     int64_t max_rows = INT64_MAX;
+    bool q_only = false;      // Impl64Q: only the small-batch step is fused
 };
 struct Ops64 {
     int (*setup)(bamd_handle *, State64 *);
@@ -944,6 +946,103 @@ struct Ops64 {
                  double *, hipStream_t);
 };
 State64 *st64(bamd_handle *h) { return (State64 *)h->fused64_state; }
+
+// The maps of a handle: which packed slot (both fragment orders, biases) holds which canonical parameter, which thread of which
+// weight-gradient tile owns which parameter, and the CSR scatter lists the Adam kernels refresh the packed copies through.  Geometry
+// (tiles, fragment order, slot -> feature) from the instantiated Net64; which slots hold a parameter, and its canonical index, from
+// the handle's REAL dimensions (identical for an exact instantiation).
+template <class N>
+int build_maps64(bamd_handle *h, State64 *st) {
+    const int nparams = (int)h->nparams;
+    auto dimr = [&](int i) { return h->dims[i]; };
+    auto woff = [&](int l) { return (int)h->w_off[l]; };
+    auto boff = [&](int l) { return (int)h->b_off[l]; };
+    std::vector<int> src((size_t)N::packed_all_doubles(), -1);
+    // the 4-row chain's copy (chain64q_kernel): fragment (k8, grp) of GEMM g, lane l, half h = A[16 grp + (l & 15)][8 k8 + 4 h + (l >> 4)]
+    // with A = W_g (forward) or W_{15-g}^T (backward), then the biases in natural order
+    {
+        const size_t q0 = (size_t)N::packed_d4() * 4;
+        for (int g = 0; g < 15; ++g) {
+            const int l = N::q_layer(g), G = N::q_groups(g), Kr = dimr(l), NNr = dimr(l + 1);
+            for (int k8 = 0; k8 < N::q_ks8(g); ++k8)
+                for (int grp = 0; grp < G; ++grp)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int f = 16 * grp + (lane & 15), k = 8 * k8 + 4 * hh + (lane >> 4);
+                            const size_t o = q0 + ((size_t)(N::q_frag_off(g) + k8 * G + grp) * 64 + lane) * 2 + hh;
+                            if (g < 8) { if (f < NNr && k < Kr) src[o] = woff(l) + f * Kr + k; }          // W_l[f][k]
+                            else if (f < Kr && k < NNr) src[o] = woff(l) + k * Kr + f;                     // W_l[k][f]
+                        }
+        }
+        for (int l = 0; l < N::L; ++l)
+            for (int f = 0; f < dimr(l + 1); ++f) src[q0 + (size_t)N::q_frags() * 128 + N::qb_off(l) + f] = boff(l) + f;
+    }
+    for (int l = 0; l < N::L; ++l) {
+        const int K = N::dim(l), NN = N::dim(l + 1), KT = tiles(K), NT = tiles(NN), Kr = dimr(l), NNr = dimr(l + 1);
+        // forward fragment (q, t): lane (i, g) component r = W[16 t + i][16 q + 4 r + g]
+        for (int q = 0; q < KT; ++q)
+            for (int t = 0; t < NT; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = 16 * t + (lane & 15), k = creg_feature(K, q, lane >> 4, r);
+                        if (n < NNr && k >= 0 && k < Kr) src[((size_t)N::wf_off(l) + (q * NT + t) * 64 + lane) * 4 + r] = woff(l) + n * Kr + k;
+                    }
+        // backward fragment (tq, tk), l >= 1: lane (i, g) component r = W[16 tq + 4 r + g][16 tk + i]
+        for (int tq = 0; tq < NT && l >= 1; ++tq)
+            for (int tk = 0; tk < KT; ++tk)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = creg_feature(NN, tq, lane >> 4, r), k = 16 * tk + (lane & 15);
+                        if (n >= 0 && n < NNr && k < Kr) src[((size_t)N::wb_off(l) + (tq * KT + tk) * 64 + lane) * 4 + r] = woff(l) + n * Kr + k;
+                    }
+        // bias fragment (t, g) component r = b[16 t + 4 r + g]
+        for (int t = 0; t < NT; ++t)
+            for (int g = 0; g < 4; ++g)
+                for (int r = 0; r < 4; ++r) {
+                    const int n = creg_feature(NN, t, g, r);
+                    if (n >= 0 && n < NNr) src[((size_t)N::bf_off(l) + t * 4 + g) * 4 + r] = boff(l) + n;
+                }
+    }
+    // weight-gradient tile (kt, nt) of layer l: thread e = 4 lane + r holds dW[16 nt + g + 4 r][16 kt + (lane & 15)]; column K = db
+    const int ntiles = N::slab_off(N::L);
+    std::vector<int> inv((size_t)ntiles * 256, -1);
+    for (int l = 0; l < N::L; ++l) {
+        const int K = N::dim(l), NN = N::dim(l + 1), NT = tiles(NN), Kr = dimr(l), NNr = dimr(l + 1);
+        for (int kt = 0; kt < tiles(K + 1); ++kt)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = creg_feature(NN, nt, lane >> 4, r), kc = 16 * kt + (lane & 15);
+                        if (n < 0 || n >= NNr) continue;
+                        const size_t o = ((size_t)(N::slab_off(l) + kt * NT + nt) * 64 + lane) * 4 + r;
+                        if (kc < K) { if (kc < Kr) inv[o] = woff(l) + n * Kr + kc; }
+                        else if (kc == K) inv[o] = boff(l) + n;      // (the ones slot sits at the CLASS width)
+                    }
+    }
+    {
+        std::vector<char> seen(nparams, 0);
+        for (int v : inv) if (v >= 0) seen[v]++;
+        for (char c : seen) if (c != 1) { set_error("fp64 fused step: incomplete gradient map"); return BAMD_ERR_INVALID; }
+    }
+    std::vector<int> off((size_t)nparams + 1, 0), idx;
+    for (int v : src) if (v >= 0) off[v + 1]++;
+    for (int p = 0; p < nparams; ++p) off[p + 1] += off[p];
+    idx.resize(off[nparams]);
+    std::vector<int> cur(off.begin(), off.end() - 1);
+    for (size_t i = 0; i < src.size(); ++i) if (src[i] >= 0) idx[cur[src[i]]++] = (int)i;
+    st->packed_doubles = (int)src.size();
+    int rc = st->pack_src.ensure(src.size() * sizeof(int));
+    if (!rc) rc = st->inv_map.ensure(inv.size() * sizeof(int));
+    if (!rc) rc = st->sc_off.ensure(off.size() * sizeof(int));
+    if (!rc) rc = st->sc_idx.ensure(idx.size() * sizeof(int));
+    if (!rc) rc = st->packed.ensure(src.size() * sizeof(double));
+    if (rc) return rc;
+    BAMD_HIP(hipMemcpy(st->pack_src.p, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
+    BAMD_HIP(hipMemcpy(st->inv_map.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice));
+    BAMD_HIP(hipMemcpy(st->sc_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+    BAMD_HIP(hipMemcpy(st->sc_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    return BAMD_OK;
+}
 
 // RT: the instantiation serves every AE(f <= F, z <= Z) with the reference's hidden widths (as Impl<F, Z, true> in fused.hip): the
 // geometry is the class's, the maps and the row I/O follow the handle's real dimensions
@@ -965,96 +1064,7 @@ template <int F, int Z, bool RT = false> struct Impl64 {
         return true;
     }
     static int setup(bamd_handle *h, State64 *st) {
-        // geometry (tiles, fragment order, slot -> feature) from the instantiated Net64; which slots hold a parameter, and its canonical
-        // index, from the handle's real dimensions (identical for an exact instantiation)
-        const int nparams = (int)h->nparams;
-        auto dimr = [&](int i) { return h->dims[i]; };
-        auto woff = [&](int l) { return (int)h->w_off[l]; };
-        auto boff = [&](int l) { return (int)h->b_off[l]; };
-        std::vector<int> src((size_t)N::packed_all_doubles(), -1);
-        // the 4-row chain's copy (chain64q_kernel): fragment (k8, grp) of GEMM g, lane l, half h = A[16 grp + (l & 15)][8 k8 + 4 h + (l >> 4)]
-        // with A = W_g (forward) or W_{15-g}^T (backward), then the biases in natural order
-        {
-            const size_t q0 = (size_t)N::packed_d4() * 4;
-            for (int g = 0; g < 15; ++g) {
-                const int l = N::q_layer(g), G = N::q_groups(g), Kr = dimr(l), NNr = dimr(l + 1);
-                for (int k8 = 0; k8 < N::q_ks8(g); ++k8)
-                    for (int grp = 0; grp < G; ++grp)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int hh = 0; hh < 2; ++hh) {
-                                const int f = 16 * grp + (lane & 15), k = 8 * k8 + 4 * hh + (lane >> 4);
-                                const size_t o = q0 + ((size_t)(N::q_frag_off(g) + k8 * G + grp) * 64 + lane) * 2 + hh;
-                                if (g < 8) { if (f < NNr && k < Kr) src[o] = woff(l) + f * Kr + k; }          // W_l[f][k]
-                                else if (f < Kr && k < NNr) src[o] = woff(l) + k * Kr + f;                     // W_l[k][f]
-                            }
-            }
-            for (int l = 0; l < N::L; ++l)
-                for (int f = 0; f < dimr(l + 1); ++f) src[q0 + (size_t)N::q_frags() * 128 + N::qb_off(l) + f] = boff(l) + f;
-        }
-        for (int l = 0; l < N::L; ++l) {
-            const int K = N::dim(l), NN = N::dim(l + 1), KT = tiles(K), NT = tiles(NN), Kr = dimr(l), NNr = dimr(l + 1);
-            // forward fragment (q, t): lane (i, g) component r = W[16 t + i][16 q + 4 r + g]
-            for (int q = 0; q < KT; ++q)
-                for (int t = 0; t < NT; ++t)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = 16 * t + (lane & 15), k = creg_feature(K, q, lane >> 4, r);
-                            if (n < NNr && k >= 0 && k < Kr) src[((size_t)N::wf_off(l) + (q * NT + t) * 64 + lane) * 4 + r] = woff(l) + n * Kr + k;
-                        }
-            // backward fragment (tq, tk), l >= 1: lane (i, g) component r = W[16 tq + 4 r + g][16 tk + i]
-            for (int tq = 0; tq < NT && l >= 1; ++tq)
-                for (int tk = 0; tk < KT; ++tk)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = creg_feature(NN, tq, lane >> 4, r), k = 16 * tk + (lane & 15);
-                            if (n >= 0 && n < NNr && k < Kr) src[((size_t)N::wb_off(l) + (tq * KT + tk) * 64 + lane) * 4 + r] = woff(l) + n * Kr + k;
-                        }
-            // bias fragment (t, g) component r = b[16 t + 4 r + g]
-            for (int t = 0; t < NT; ++t)
-                for (int g = 0; g < 4; ++g)
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = creg_feature(NN, t, g, r);
-                        if (n >= 0 && n < NNr) src[((size_t)N::bf_off(l) + t * 4 + g) * 4 + r] = boff(l) + n;
-                    }
-        }
-        // weight-gradient tile (kt, nt) of layer l: thread e = 4 lane + r holds dW[16 nt + g + 4 r][16 kt + (lane & 15)]; column K = db
-        const int ntiles = N::slab_off(N::L);
-        std::vector<int> inv((size_t)ntiles * 256, -1);
-        for (int l = 0; l < N::L; ++l) {
-            const int K = N::dim(l), NN = N::dim(l + 1), NT = tiles(NN), Kr = dimr(l), NNr = dimr(l + 1);
-            for (int kt = 0; kt < tiles(K + 1); ++kt)
-                for (int nt = 0; nt < NT; ++nt)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = creg_feature(NN, nt, lane >> 4, r), kc = 16 * kt + (lane & 15);
-                            if (n < 0 || n >= NNr) continue;
-                            const size_t o = ((size_t)(N::slab_off(l) + kt * NT + nt) * 64 + lane) * 4 + r;
-                            if (kc < K) { if (kc < Kr) inv[o] = woff(l) + n * Kr + kc; }
-                            else if (kc == K) inv[o] = boff(l) + n;      // (the ones slot sits at the CLASS width)
-                        }
-        }
-        {
-            std::vector<char> seen(nparams, 0);
-            for (int v : inv) if (v >= 0) seen[v]++;
-            for (char c : seen) if (c != 1) { set_error("fp64 fused step: incomplete gradient map"); return BAMD_ERR_INVALID; }
-        }
-        std::vector<int> off((size_t)nparams + 1, 0), idx;
-        for (int v : src) if (v >= 0) off[v + 1]++;
-        for (int p = 0; p < nparams; ++p) off[p + 1] += off[p];
-        idx.resize(off[nparams]);
-        std::vector<int> cur(off.begin(), off.end() - 1);
-        for (size_t i = 0; i < src.size(); ++i) if (src[i] >= 0) idx[cur[src[i]]++] = (int)i;
-        st->packed_doubles = (int)src.size();
-        int rc = st->pack_src.ensure(src.size() * sizeof(int));
-        if (!rc) rc = st->inv_map.ensure(inv.size() * sizeof(int));
-        if (!rc) rc = st->sc_off.ensure(off.size() * sizeof(int));
-        if (!rc) rc = st->sc_idx.ensure(idx.size() * sizeof(int));
-        if (!rc) rc = st->packed.ensure(src.size() * sizeof(double));
-        if (rc) return rc;
-        BAMD_HIP(hipMemcpy(st->pack_src.p, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice));
-        BAMD_HIP(hipMemcpy(st->inv_map.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice));
-        BAMD_HIP(hipMemcpy(st->sc_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
-        BAMD_HIP(hipMemcpy(st->sc_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (const int rc = build_maps64<N>(h, st)) return rc;
         BAMD_HIP(hipFuncSetAttribute((const void *)chain64_kernel<F, Z, 4, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
         return BAMD_OK;
     }
@@ -1137,10 +1147,10 @@ template <int F, int Z, bool RT = false> struct Impl64 {
         const int nblk_fin = (int)nblk_all, nloss = quad ? 4 * nblk_fin : nblk_fin;
         if (ad)
             hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
-                               (const int *)st->inv_map.p, grads, *ad, part, nsplit, (int)h->nparams, 1.0 / fr(h), nloss);
+                               (const int *)st->inv_map.p, grads, *ad, part, nsplit, (int)h->nparams, 1.0 / fr(h), nloss, 0);
         else
             hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
-                               (const int *)st->inv_map.p, grads, Adam64{}, part, nsplit, (int)h->nparams, 1.0 / fr(h), nloss);
+                               (const int *)st->inv_map.p, grads, Adam64{}, part, nsplit, (int)h->nparams, 1.0 / fr(h), nloss, 0);
         BAMD_HIP(hipGetLastError());
         return BAMD_OK;
     }
@@ -1175,6 +1185,67 @@ template <int F, int Z, bool RT = false> struct Impl64 {
     }
 };
 
+// 64 .. 127 columns (latent <= 31) in fp64: the SMALL-BATCH step only -- chain64q_kernel (four rows per workgroup; its input rows are two
+// feature slots per thread) + dw64_kernel for EVERY training batch (chunks of 65,536 rows): the reference's batch_size = 512 in the
+// reference's dtype for its wider tables (models.py:128-136 builds AE(n_features, z_dim) in float64 for any table) runs 3.8x, 4,096 rows 6x,
+// 65,536 rows 1.5x faster than on the layer-wise kernels.  The exchange chain, the register chain and the inference kernel give ONE input
+// tile to a wave (<= 63 columns): encode / decode / validation of such a handle stay layer-wise (bamd_path_of says BAMD_PATH_GENERIC).
+template <int F, int FLO, int Z> struct Impl64Q {
+    using N = Net64<F, Z>;
+    static bool matches(const bamd_handle *h) {
+        if (h->L != 8) return false;
+        for (int i = 1; i <= 7; ++i)
+            if (i != 4 && h->dims[i] != N::dim(i)) return false;
+        return h->dims[0] == h->dims[8] && h->dims[0] > FLO && h->dims[0] <= F && h->dims[4] >= 1 && h->dims[4] <= Z;
+    }
+    static int setup(bamd_handle *h, State64 *st) {
+        st->q_only = true;
+        return build_maps64<N>(h, st);
+    }
+    static int step(bamd_handle *h, State64 *st, const void *x, int x_dtype, int64_t n, const double *features, double *grads,
+                    const Adam64 *ad, hipStream_t s) {
+        // Chunks of up to BALER_AMD_F64_QCHAIN_BLKS 16-row blocks (default here 4,096 = 65,536 rows, 15 KB of images per row; 0: the
+        // layer-wise kernels), the chunks' gradients added in order.  Measured us per step, this path / layer-wise, AE(80, 16): 512 rows
+        // 34 / 134, 1,536: 61 / 849, 4,096: 132 / 839, 16,384: 469 / 892, 65,536: 1,820 / 2,780 (tools/bench_fp64_mid_width_step.py)
+        const int64_t lim = env_ll("BALER_AMD_F64_QCHAIN_BLKS", -1);
+        if (lim == 0) return BAMD_ERR_UNSUPPORTED;                                     // the caller runs the layer-wise kernels
+        const int64_t per = lim > 0 ? lim : 4096, nblk_all = (n + 15) / 16, nchunk = (nblk_all + per - 1) / per;
+        if (ad && nchunk > 1) return BAMD_ERR_UNSUPPORTED;                             // (the caller: bamd_fwd_bwd chunk after chunk, then the Adam kernel)
+        const int64_t nblk_max = std::min(nblk_all, per);
+        int rc = st->imgs.ensure((size_t)N::img_doubles * sizeof(double) * (size_t)nblk_max);
+        if (rc) return rc;
+        rc = h->lossp.ensure(sizeof(double) * (size_t)(4 * nblk_max > 1024 ? 4 * nblk_max : 1024));
+        if (rc) return rc;
+        const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
+        const size_t row_bytes = (size_t)h->dims[0] * (x_dtype == BAMD_F64 ? 8 : 4);
+        for (int64_t k = 0; k < nchunk; ++k) {
+            const int64_t r0 = k * per * 16, rows = std::min(n - r0, per * 16);
+            const int nblk = (int)((rows + 15) / 16);
+            rc = fused64q_launch(F, Z, true, 4u * (unsigned)nblk, s, (const double *)st->packed.p + (size_t)N::packed_d4() * 4,
+                                 (const char *)x + (size_t)r0 * row_bytes, x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
+                                 (double *)h->lossp.p, h->dims[0]);
+            if (rc) return rc;
+            if (ad)
+                hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk, (const double *)h->lossp.p,
+                                   (const int *)st->inv_map.p, grads, *ad, (const double *)nullptr, 0, (int)h->nparams, 1.0 / h->dims[0], 4 * nblk, 0);
+            else
+                hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk, (const double *)h->lossp.p,
+                                   (const int *)st->inv_map.p, grads, Adam64{}, (const double *)nullptr, 0, (int)h->nparams, 1.0 / h->dims[0], 4 * nblk,
+                                   k > 0 ? 1 : 0);
+        }
+        BAMD_HIP(hipGetLastError());
+        return BAMD_OK;
+    }
+    static int infer(bamd_handle *, State64 *, int, const void *, int, int64_t, const double *, void *, int, const double *, const uint8_t *,
+                     double *, hipStream_t) {
+        return BAMD_ERR_UNSUPPORTED;
+    }
+    static const Ops64 *ops() {
+        static const Ops64 o = {setup, step, infer};
+        return &o;
+    }
+};
+
 const Ops64 *find64(const bamd_handle *h) {
     if (h->mode != BAMD_MODE_F64) return nullptr;
     if (Impl64<24, 15>::matches(h)) return Impl64<24, 15>::ops();
@@ -1193,6 +1264,11 @@ const Ops64 *find64(const bamd_handle *h) {
     if (Impl64<63, 15, true>::matches(h)) return Impl64<63, 15, true>::ops();
     if (Impl64<31, 31, true>::matches(h)) return Impl64<31, 31, true>::ops();
     if (Impl64<63, 31, true>::matches(h)) return Impl64<63, 31, true>::ops();
+    // 64 .. 127 columns: the small-batch step only (Impl64Q)
+    if (Impl64Q<79, 63, 31>::matches(h)) return Impl64Q<79, 63, 31>::ops();
+    if (Impl64Q<95, 79, 31>::matches(h)) return Impl64Q<95, 79, 31>::ops();
+    if (Impl64Q<111, 95, 31>::matches(h)) return Impl64Q<111, 95, 31>::ops();
+    if (Impl64Q<127, 111, 31>::matches(h)) return Impl64Q<127, 111, 31>::ops();
     return nullptr;
 }
 
@@ -1217,6 +1293,11 @@ void fused64_teardown(bamd_handle *h) {
     st->pack_src.release(); st->inv_map.release(); st->sc_off.release(); st->sc_idx.release(); st->packed.release(); st->imgs.release(); st->dwpart.release();
     delete st;
     h->fused64_state = nullptr;
+}
+
+bool fused64_small_step_only(const bamd_handle *h) {      // 64 .. 127 columns: fused small-batch steps, everything else layer-wise
+    const State64 *st = (const State64 *)h->fused64_state;
+    return st && st->q_only;
 }
 
 int fused64_pack(bamd_handle *h, hipStream_t s) {

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict_
                                                        double *__restrict__ imgs, double *__restrict__ loss_part, int fr) {
     using N = Net64<F, Z>;
     using T = Q4<N>;
-    static_assert(F % 16 != 0 && F <= 63, "input rows: 64 feature slots x 4 rows = one thread each");
+    static_assert(F % 16 != 0 && F <= 127, "input rows: up to two 64-slot halves x 4 rows per thread");
     __shared__ __attribute__((aligned(16))) double lds[T::lds_doubles];
     __shared__ double loss_lds[4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -130,12 +130,16 @@ __global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict_
     const int tj = threadIdx.x & 3, tf = threadIdx.x >> 2;          // input / finalising thread: row tj, feature tf (+ 64 i)
     const int64_t trow = (int64_t)blk * 16 + 4 * quad + tj;
     const bool tvalid = trow < n;
-    double xv = 0.0, xmn = 0.0, xrg = 1.0;
-    {
-        const int fc = tf < fw ? tf : 0;                            // padding slots read feature 0 (finite, never used)
+    constexpr int kXH = (16 * tiles(F) + 63) / 64;                 // 64-slot halves of the input image (1 up to 63 columns, 2 up to 127)
+    double xv[kXH], xmn[kXH], xrg[kXH];
+#pragma unroll
+    for (int hh = 0; hh < kXH; ++hh) {
+        const int f = tf + 64 * hh;
+        const int fc = f < fw ? f : 0;                              // padding slots read feature 0 (finite, never used)
         const int64_t at = (tvalid ? trow : 0) * fw + fc;
-        xv = in_f64 ? ((const double *)xin)[at] : (double)((const float *)xin)[at];
-        if (feats) { xmn = feats[fc]; xrg = feats[fw + fc]; }
+        xv[hh] = in_f64 ? ((const double *)xin)[at] : (double)((const float *)xin)[at];
+        xmn[hh] = 0.0; xrg[hh] = 1.0;
+        if (feats) { xmn[hh] = feats[fc]; xrg[hh] = feats[fw + fc]; }
     }
     // (the biases wait in registers until the ring is requested: written to LDS first, they held the ring's requests behind the rows'
     // HBM round trip -- 4,100 cycles in front of the first GEMM, tools/q4_trace.py)
@@ -149,12 +153,14 @@ __global__ void __launch_bounds__(256) chain64q_kernel(const double *__restrict_
     d2 ring[T::D];
     q_prologue<N>(ring, rs, lane16, wave, std::make_integer_sequence<int, T::D>{});
     Q4_T(1);
-    {
-        double v = feats ? (xv - xmn) / xrg : xv;
-        v = tf < fw ? v : 0.0;
-        if (tf == F) v = 1.0;                                        // the ones slot (carries db) sits at the class width
-        if (tf < 16 * tiles(F)) lds[T::xo(0) + tj * T::xs(0) + tf] = v;
-        if (tf < N::x_rows(0)) img[(N::x_off(0) + tf) * 16 + tj] = v;
+#pragma unroll
+    for (int hh = 0; hh < kXH; ++hh) {
+        const int f = tf + 64 * hh;
+        double v = feats ? (xv[hh] - xmn[hh]) / xrg[hh] : xv[hh];
+        v = f < fw ? v : 0.0;
+        if (f == F) v = 1.0;                                         // the ones slot (carries db) sits at the class width
+        if (f < 16 * tiles(F)) lds[T::xo(0) + tj * T::xs(0) + f] = v;
+        if (f < N::x_rows(0)) img[(N::x_off(0) + f) * 16 + tj] = v;
     }
 #pragma unroll
     for (int i = 0; i < kNBI; ++i) {
@@ -260,6 +266,7 @@ int fused64q_launch(int F, int Z, bool rt, unsigned grid, hipStream_t s, const d
     Q_CASE(24, 15, false) Q_CASE(24, 12, false) Q_CASE(24, 8, false) Q_CASE(24, 6, false) Q_CASE(24, 10, false)
     Q_CASE(24, 5, false) Q_CASE(24, 4, false) Q_CASE(24, 3, false) Q_CASE(24, 2, false)
     Q_CASE(31, 15, true) Q_CASE(47, 15, true) Q_CASE(63, 15, true) Q_CASE(31, 31, true) Q_CASE(63, 31, true)
+    Q_CASE(79, 31, true) Q_CASE(95, 31, true) Q_CASE(111, 31, true) Q_CASE(127, 31, true)      // 64 .. 127 columns: Impl64Q (fused64.hip)
 #undef Q_CASE
     set_error("fp64 4-row chain: no instantiation for this shape");
     return BAMD_ERR_UNSUPPORTED;

@@ -348,6 +348,77 @@ def test_fp64_any_narrow_table_runs_fused(F, Z):
     assert rel(h1.encode(dev(x)).cpu().numpy(), orc.encode(dims, st.params, x)) < 1e-9
 
 
+@pytest.mark.parametrize("F,Z", [(64, 16), (80, 16), (100, 31), (127, 1), (96, 20)])
+def test_fp64_mid_width_small_batch_step_is_fused(F, Z, monkeypatch, capfd):
+    """64 .. 127 columns in the reference's own dtype (models.py:128-136 builds AE(n_features, z_dim) in float64 for any table) at the
+    reference's batch size and beyond: every training batch runs on the 4-row chain (chain64q_kernel, two input slots per thread) +
+    dw64_kernel, chunk after chunk with the gradients added in order -- against the oracle at 1e-11 at ragged sizes and over several
+    chunks, against the layer-wise kernels on the same batch (the switch is read per call), train_step == fwd_bwd + adam_step bit for bit
+    with the packed copies following the step.  Inference of such a handle stays layer-wise (path "generic"; the notice says so)."""
+    dims = orc.ae_dims(F, Z)
+    flat = orc.formula_params(dims, 600 + F)
+    h, p = make_handle(dims, flat, "fp64")
+    assert h.path == "generic" and "training runs fused" in capfd.readouterr().err
+    rng = np.random.default_rng(F)
+    for n in (1, 37, 512, 513, 1536, 1537):
+        x = rng.random((n, F))
+        lo, go = orc.fwd_bwd(dims, flat, x)
+        g = torch.full_like(p, 5.0)
+        h.fwd_bwd(dev(x), g)
+        gh = g.cpu().numpy()
+        assert rel(gh[:-1], go) < TOL64 and abs(gh[-1] - lo) < TOL64 * lo, (F, Z, n)
+        if n in (37, 512):
+            monkeypatch.setenv("BALER_AMD_F64_QCHAIN_BLKS", "0")       # the layer-wise kernels on the same batch
+            g2 = torch.zeros_like(p)
+            h.fwd_bwd(dev(x), g2)
+            monkeypatch.delenv("BALER_AMD_F64_QCHAIN_BLKS")
+            assert rel(g2.cpu().numpy(), gh) < 1e-12 and not np.array_equal(g2.cpu().numpy(), gh)      # two different kernels
+            g3 = torch.zeros_like(p)
+            h.fwd_bwd(dev(x.astype(np.float32)), g3)                   # float32 rows are widened on load
+            _, go32 = orc.fwd_bwd(dims, flat, x.astype(np.float32).astype(np.float64))
+            assert rel(g3.cpu().numpy()[:-1], go32) < TOL64
+    # several chunks (ragged last one), gradients added in chunk order; a batch beyond one chunk through train_step (fwd_bwd + the Adam kernel)
+    monkeypatch.setenv("BALER_AMD_F64_QCHAIN_BLKS", "300")
+    x = rng.random((20001, F))
+    lo, go = orc.fwd_bwd(dims, flat, x)
+    g = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), g)
+    assert rel(g.cpu().numpy()[:-1], go) < TOL64 and abs(g.cpu().numpy()[-1] - lo) < TOL64 * lo
+    pa, ma, va = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    ha, _ = make_handle(dims, flat, "fp64")
+    ha.train_step(dev(x), pa, ma, va, 1, 1e-3)
+    pb, mb_, vb = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    h.adam_step(pb, g, mb_, vb, 1, 1e-3)
+    assert torch.equal(pa[:-1], pb[:-1])
+    h.load_params(p)
+    monkeypatch.delenv("BALER_AMD_F64_QCHAIN_BLKS")
+    # normalise-on-load
+    raw = rng.uniform(-3, 9, size=(300, F))
+    feats = orc.find_minmax(raw)
+    g = torch.zeros_like(p)
+    h.fwd_bwd(dev(raw), g, features=dev(feats))
+    lo, go = orc.fwd_bwd(dims, flat, orc.normalize(raw))
+    assert rel(g.cpu().numpy()[:-1], go) < TOL64
+    # the one-call step == the two-call step, and the next step (and the layer-wise encode) see the new weights
+    x = rng.random((512, F))
+    g = torch.zeros_like(p)
+    h.fwd_bwd(dev(x), g)
+    m1, v1, m2, v2 = (torch.zeros_like(p) for _ in range(4))
+    p1, p2 = p.clone(), p.clone()
+    h1, _ = make_handle(dims, flat, "fp64")
+    h1.train_step(dev(x), p1, m1, v1, 1, 1e-3)
+    h.adam_step(p2, g, m2, v2, 1, 1e-3)
+    assert torch.equal(p1[:-1], p2[:-1]) and torch.equal(m1[:-1], m2[:-1]) and torch.equal(v1[:-1], v2[:-1])
+    g3, g4 = torch.zeros_like(p), torch.zeros_like(p)
+    h1.fwd_bwd(dev(x), g3)
+    h.fwd_bwd(dev(x), g4)
+    assert torch.equal(g3, g4)
+    pn = p2.cpu().numpy()[:-1]
+    _, go2 = orc.fwd_bwd(dims, pn, x)
+    assert rel(g4.cpu().numpy()[:-1], go2) < TOL64
+    assert rel(h1.encode(dev(x)).cpu().numpy(), orc.encode(dims, pn, x)) < TOL64
+
+
 @pytest.mark.parametrize("n", [1, 33, 1000, 16385, 70001])
 def test_fp64_register_chain_equals_exchange_chain(n, monkeypatch):
     """The fp64 training chains -- one workgroup per 16-row block exchanging every layer through LDS (chain64_kernel), one workgroup
