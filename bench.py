@@ -915,7 +915,20 @@ def other_configs(dev):
         res["narrow_tables"][f"ae_{F}_{Z}"] = {"path": hn.path, "encode_rows_per_s": n / ms_e * 1e3, "train_fwd_bwd_rows_per_s": n / ms_t * 1e3,
                                                "train_bs512_us_per_step": ms_s * 1e3}
         hn.close()
-        del xn, gn, mo, vo
+        # the same table in the reference's own dtype at the reference's batch size (fp64 class kernels up to 63 columns; 64 .. 127 columns:
+        # the 4-row chain, round 6 -- layer-wise before: 134 us)
+        m64 = models.AE(F, Z, mode="fp64").to(dev)
+        h64n = m64.handle()
+        mo64, vo64 = torch.zeros_like(m64.flat), torch.zeros_like(m64.flat)
+        st64 = {"t": 0}
+
+        def steps512_64():
+            for i in range(50):
+                st64["t"] += 1
+                h64n.train_step(xn[i * 512:(i + 1) * 512], m64.flat, mo64, vo64, st64["t"], 1e-3)
+        res["narrow_tables"][f"ae_{F}_{Z}"]["fp64_train_bs512_us_per_step"] = event_ms(steps512_64, 1) / 50 * 1e3
+        h64n.close()
+        del xn, gn, mo, vo, mo64, vo64
     # wide models other than the compiled-in shapes (models.py:192-209 builds CFD_dense_AE(n_features, z_dim) for any flattened field):
     # the run-time-width class ImplWide<4096, ZC, true>; on (625, 7) also forced (BALER_AMD_WIDE_CLASS=force at bamd_create) next to
     # the exact instantiation
