@@ -1185,18 +1185,18 @@ template <int F, int Z, bool RT = false> struct Impl64 {
     }
 };
 
-// 64 .. 127 columns (latent <= 31) in fp64: the SMALL-BATCH step only -- chain64q_kernel (four rows per workgroup; its input rows are two
+// 64 .. 127 columns (latent <= 63), and up to 63 columns with a latent of 32 .. 63, in fp64: TRAINING only -- chain64q_kernel (four rows per workgroup; its input rows are two
 // feature slots per thread) + dw64_kernel for EVERY training batch (chunks of 65,536 rows): the reference's batch_size = 512 in the
 // reference's dtype for its wider tables (models.py:128-136 builds AE(n_features, z_dim) in float64 for any table) runs 3.8x, 4,096 rows 6x,
 // 65,536 rows 1.5x faster than on the layer-wise kernels.  The exchange chain, the register chain and the inference kernel give ONE input
 // tile to a wave (<= 63 columns): encode / decode / validation of such a handle stay layer-wise (bamd_path_of says BAMD_PATH_GENERIC).
-template <int F, int FLO, int Z> struct Impl64Q {
+template <int F, int FLO, int Z, int ZLO = 0> struct Impl64Q {
     using N = Net64<F, Z>;
     static bool matches(const bamd_handle *h) {
         if (h->L != 8) return false;
         for (int i = 1; i <= 7; ++i)
             if (i != 4 && h->dims[i] != N::dim(i)) return false;
-        return h->dims[0] == h->dims[8] && h->dims[0] > FLO && h->dims[0] <= F && h->dims[4] >= 1 && h->dims[4] <= Z;
+        return h->dims[0] == h->dims[8] && h->dims[0] > FLO && h->dims[0] <= F && h->dims[4] > ZLO && h->dims[4] <= Z;
     }
     static int setup(bamd_handle *h, State64 *st) {
         st->q_only = true;
@@ -1269,6 +1269,12 @@ const Ops64 *find64(const bamd_handle *h) {
     if (Impl64Q<95, 79, 31>::matches(h)) return Impl64Q<95, 79, 31>::ops();
     if (Impl64Q<111, 95, 31>::matches(h)) return Impl64Q<111, 95, 31>::ops();
     if (Impl64Q<127, 111, 31>::matches(h)) return Impl64Q<127, 111, 31>::ops();
+    // ... and a latent of 32 .. 63 (up to 127 columns) the same way
+    if (Impl64Q<63, 0, 63, 31>::matches(h)) return Impl64Q<63, 0, 63, 31>::ops();
+    if (Impl64Q<79, 63, 63, 31>::matches(h)) return Impl64Q<79, 63, 63, 31>::ops();
+    if (Impl64Q<95, 79, 63, 31>::matches(h)) return Impl64Q<95, 79, 63, 31>::ops();
+    if (Impl64Q<111, 95, 63, 31>::matches(h)) return Impl64Q<111, 95, 63, 31>::ops();
+    if (Impl64Q<127, 111, 63, 31>::matches(h)) return Impl64Q<127, 111, 63, 31>::ops();
     return nullptr;
 }
 

@@ -267,6 +267,7 @@ int fused64q_launch(int F, int Z, bool rt, unsigned grid, hipStream_t s, const d
     Q_CASE(24, 5, false) Q_CASE(24, 4, false) Q_CASE(24, 3, false) Q_CASE(24, 2, false)
     Q_CASE(31, 15, true) Q_CASE(47, 15, true) Q_CASE(63, 15, true) Q_CASE(31, 31, true) Q_CASE(63, 31, true)
     Q_CASE(79, 31, true) Q_CASE(95, 31, true) Q_CASE(111, 31, true) Q_CASE(127, 31, true)      // 64 .. 127 columns: Impl64Q (fused64.hip)
+    Q_CASE(63, 63, true) Q_CASE(79, 63, true) Q_CASE(95, 63, true) Q_CASE(111, 63, true) Q_CASE(127, 63, true)      // a latent of 32 .. 63
 #undef Q_CASE
     set_error("fp64 4-row chain: no instantiation for this shape");
     return BAMD_ERR_UNSUPPORTED;

@@ -348,7 +348,7 @@ def test_fp64_any_narrow_table_runs_fused(F, Z):
     assert rel(h1.encode(dev(x)).cpu().numpy(), orc.encode(dims, st.params, x)) < 1e-9
 
 
-@pytest.mark.parametrize("F,Z", [(64, 16), (80, 16), (100, 31), (127, 1), (96, 20)])
+@pytest.mark.parametrize("F,Z", [(64, 16), (80, 16), (100, 31), (127, 1), (96, 20), (100, 63), (40, 40), (127, 32)])
 def test_fp64_mid_width_small_batch_step_is_fused(F, Z, monkeypatch, capfd):
     """64 .. 127 columns in the reference's own dtype (models.py:128-136 builds AE(n_features, z_dim) in float64 for any table) at the
     reference's batch size and beyond: every training batch runs on the 4-row chain (chain64q_kernel, two input slots per thread) +
