@@ -606,8 +606,7 @@ enum { DW_WRITE = 0, DW_ADAM = 1 };
 template <class N, int MODE>
 __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ imgs, int nblk, const double *__restrict__ loss_part,
                                                    const int *__restrict__ inv_map, double *__restrict__ grads, Adam64 ad,
-                                                   const double *__restrict__ part, int nsplit, int np, double inv_c, int nloss, int accum) {
-    // accum (DW_WRITE only): this launch covers one chunk of a larger batch -- gradients and loss are ADDED to what earlier chunks left
+                                                   const double *__restrict__ part, int nsplit, int np, double inv_c, int nloss) {
     // nsplit == 0: the whole job.  nsplit > 0: the tiles' partial sums over `nsplit` block ranges are in `part` (dw64m_kernel); this
     // launch adds them in range order and finishes (store / Adam).
     constexpr int T = N::slab_off(N::L);       // (np, inv_c: the handle's real parameter count and 1 / columns -- class instantiations)
@@ -625,7 +624,7 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
         const double s = block_sum_fixed(loss_part, nloss, (double *)red);      // (one partial per block, four with the 4-row chain)
         if (threadIdx.x == 0) {
             const double gl = s * inv_c;
-            if (grads) grads[np] = accum ? grads[np] + gl : gl;
+            if (grads) grads[np] = gl;
             if (MODE == DW_ADAM && ad.loss_accum) *ad.loss_accum += gl;
         }
         return;
@@ -695,7 +694,7 @@ __global__ void __launch_bounds__(256) dw64_kernel(const double *__restrict__ im
         for (; k < nsplit; ++k) gsum += q[k * 256];
     }
     if (p < 0) return;
-    if (grads) grads[p] = accum ? grads[p] + gsum : gsum;
+    if (grads) grads[p] = gsum;
     if (MODE == DW_ADAM) {   // elementwise.hip adam_k, on the parameters this tile owns
         double mi = pm, vi = pv;
         mi = mi + (gsum - mi) * (1.0 - ad.b1);
@@ -947,6 +946,78 @@ struct Ops64 {
 };
 State64 *st64(bamd_handle *h) { return (State64 *)h->fused64_state; }
 
+// The fused fp64 training pass of any instantiation: chunks over one image buffer, per chunk the chain launch (`chain`: which of the
+// three chains, decided by the instantiation) and -- from 64 blocks on -- the tile-block launch over block ranges, then ONE finishing
+// launch (the tiles themselves for a small batch; loss, range sums, store or Adam).  fw = the table's real width.
+template <class N, class ChainFn>
+int step64_common(bamd_handle *h, State64 *st, int64_t n, double *grads, const Adam64 *ad, hipStream_t s, int fw, ChainFn chain) {
+    const int64_t nblk_all = (n + 15) / 16;
+    if (nblk_all > (int64_t)1 << 30) { set_error("fp64 fused step: batch too large"); return BAMD_ERR_INVALID; }
+    const int64_t chunk = st->chunk_rows & ~(int64_t)15;
+    const int nchunk = (int)((n + chunk - 1) / chunk);
+    const int nblk_max = (int)((std::min(n, chunk) + 15) / 16);
+    int rc = st->imgs.ensure((size_t)N::img_doubles * sizeof(double) * (size_t)nblk_max);
+    if (rc) return rc;
+    rc = h->lossp.ensure(sizeof(double) * (size_t)(4 * nblk_all > 1024 ? 4 * nblk_all : 1024));      // (four partials per block with the 4-row chain)
+    if (rc) return rc;
+    const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
+    // from 64 blocks (1,024 rows) on: 2 x 4 tile blocks over block ranges + the finishing launch (BALER_AMD_DW64_MACRO_BLKS, 0 = off).
+    // Measured ms per bamd_fwd_bwd, blocks / one tile per workgroup: 512 rows 0.045 / 0.040, 1,024: 0.046 / 0.049, 2,048: 0.054 / 0.064,
+    // 4,096: 0.068 / 0.094, 16,384: 0.227 / 0.341, 65,536: 0.85 / 1.32, 262,144: 3.22 / 5.51 (0.37 / 0.22 of the fp64 MFMA peak)
+    const int macro_blks = (int)env_ll("BALER_AMD_DW64_MACRO_BLKS", 64);
+    const bool macro = nchunk > 1 || (macro_blks > 0 && nblk_all >= macro_blks);
+    // tile-block shape by batch size; block ranges per chunk (tile blocks x ranges = workgroups): from 1,024 blocks on the exact
+    // per-layer blocks (24 of them, one workgroup per CU) over 32 ranges = three full rounds of the chip (BALER_AMD_DW64_RANGES;
+    // measured at 262,144 rows 32 / 64 / 128 ranges: 2.11 / 2.15 / 2.21 ms per bamd_fwd_bwd); below that 2 x 4 blocks (52) over 8
+    // ranges, at least 4 blocks per range.  Every chunk but the last is a full one
+    const bool big = nblk_all >= 1024;
+    const int big_ranges = (int)std::max<long long>(1, env_ll("BALER_AMD_DW64_RANGES", 32));
+    // every range must own at least one block: the kernels prefetch block `range * ceil(blks / ranges)` unconditionally, which an
+    // empty trailing range would read past the images (e.g. 128 ranges of 1,025 blocks: 9 blocks each, range 114 starts at 1,026)
+    auto splits_of = [big, big_ranges](int64_t blks) {
+        int64_t ns = std::min<int64_t>(big ? big_ranges : 8, std::max<int64_t>(1, blks / 4));
+        while (ns > 1 && (ns - 1) * ((blks + ns - 1) / ns) >= blks) --ns;
+        return (int)ns;
+    };
+    int nsplit = 0;
+    if (macro) {
+        // the first chunk is the largest (every chunk but the last is a full one): its range count is the buffer's; 32 ranges by
+        // default, i.e. (tiles + 1) x 32 x 2 KB = 19.6 MB whatever the batch
+        nsplit = splits_of((std::min(n, chunk) + 15) / 16);
+        rc = st->dwpart.ensure((size_t)(N::slab_off(N::L) + 1) * nsplit * 256 * sizeof(double));
+        if (rc) return rc;
+    }
+    bool quad = false;
+    for (int k = 0; k < nchunk; ++k) {
+        const int64_t r0 = k * chunk, rows = std::min(n - r0, chunk);
+        const int nblk = (int)((rows + 15) / 16);
+        const int per_blk = chain(k, r0, rows, nblk, nblk_all, nchunk);      // the chunk's chain launch; loss partials per 16-row block (1 or 4)
+        if (per_blk < 0) return per_blk;
+        quad = per_blk == 4;
+        if (macro) {
+            const int ns = splits_of(nblk);
+            if (big)
+                hipLaunchKernelGGL((dw64x_kernel<N>), dim3(8 * ((ns + 7) / 8) * Dwx64<N>::total), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
+                                   (double *)st->dwpart.p, nsplit, k > 0, ns);
+            else
+                hipLaunchKernelGGL((dw64m_kernel<N>), dim3(8 * Dwm64<N>::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
+                                   (double *)st->dwpart.p, nsplit, k > 0);
+        }
+    }
+    const double *part = macro ? (const double *)st->dwpart.p : nullptr;
+    // the finishing launch: the loss partials of ALL blocks; with `part` the sum over all chunks' block ranges in order, else
+    // (one small chunk) the tiles themselves over the images
+    const int nblk_fin = (int)nblk_all, nloss = quad ? 4 * nblk_fin : nblk_fin;
+    if (ad)
+        hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
+                           (const int *)st->inv_map.p, grads, *ad, part, nsplit, (int)h->nparams, 1.0 / fw, nloss);
+    else
+        hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
+                           (const int *)st->inv_map.p, grads, Adam64{}, part, nsplit, (int)h->nparams, 1.0 / fw, nloss);
+    BAMD_HIP(hipGetLastError());
+    return BAMD_OK;
+}
+
 // The maps of a handle: which packed slot (both fragment orders, biases) holds which canonical parameter, which thread of which
 // weight-gradient tile owns which parameter, and the CSR scatter lists the Adam kernels refresh the packed copies through.  Geometry
 // (tiles, fragment order, slot -> feature) from the instantiated Net64; which slots hold a parameter, and its canonical index, from
@@ -1070,47 +1141,11 @@ template <int F, int Z, bool RT = false> struct Impl64 {
     }
     static int step(bamd_handle *h, State64 *st, const void *x, int x_dtype, int64_t n, const double *features, double *grads,
                     const Adam64 *ad, hipStream_t s) {
-        const int64_t nblk_all = (n + 15) / 16;
-        if (nblk_all > (int64_t)1 << 30) { set_error("fp64 fused step: batch too large"); return BAMD_ERR_INVALID; }
-        const int64_t chunk = st->chunk_rows & ~(int64_t)15;
-        const int nchunk = (int)((n + chunk - 1) / chunk);
-        const int nblk_max = (int)((std::min(n, chunk) + 15) / 16);
-        int rc = st->imgs.ensure((size_t)N::img_doubles * sizeof(double) * (size_t)nblk_max);
-        if (rc) return rc;
-        rc = h->lossp.ensure(sizeof(double) * (size_t)(4 * nblk_all > 1024 ? 4 * nblk_all : 1024));      // (four partials per block with the 4-row chain)
-        if (rc) return rc;
-        const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
-        // from 64 blocks (1,024 rows) on: 2 x 4 tile blocks over block ranges + the finishing launch (BALER_AMD_DW64_MACRO_BLKS, 0 = off).
-        // Measured ms per bamd_fwd_bwd, blocks / one tile per workgroup: 512 rows 0.045 / 0.040, 1,024: 0.046 / 0.049, 2,048: 0.054 / 0.064,
-        // 4,096: 0.068 / 0.094, 16,384: 0.227 / 0.341, 65,536: 0.85 / 1.32, 262,144: 3.22 / 5.51 (0.37 / 0.22 of the fp64 MFMA peak)
-        const int macro_blks = (int)env_ll("BALER_AMD_DW64_MACRO_BLKS", 64);
-        const bool macro = nchunk > 1 || (macro_blks > 0 && nblk_all >= macro_blks);
-        // tile-block shape by batch size; block ranges per chunk (tile blocks x ranges = workgroups): from 1,024 blocks on the exact
-        // per-layer blocks (24 of them, one workgroup per CU) over 32 ranges = three full rounds of the chip (BALER_AMD_DW64_RANGES;
-        // measured at 262,144 rows 32 / 64 / 128 ranges: 2.11 / 2.15 / 2.21 ms per bamd_fwd_bwd); below that 2 x 4 blocks (52) over 8
-        // ranges, at least 4 blocks per range.  Every chunk but the last is a full one
-        const bool big = nblk_all >= 1024;
-        const int big_ranges = (int)std::max<long long>(1, env_ll("BALER_AMD_DW64_RANGES", 32));
-        // every range must own at least one block: the kernels prefetch block `range * ceil(blks / ranges)` unconditionally, which an
-        // empty trailing range would read past the images (e.g. 128 ranges of 1,025 blocks: 9 blocks each, range 114 starts at 1,026)
-        auto splits_of = [big, big_ranges](int64_t blks) {
-            int64_t ns = std::min<int64_t>(big ? big_ranges : 8, std::max<int64_t>(1, blks / 4));
-            while (ns > 1 && (ns - 1) * ((blks + ns - 1) / ns) >= blks) --ns;
-            return (int)ns;
-        };
-        int nsplit = 0;
-        if (macro) {
-            // the first chunk is the largest (every chunk but the last is a full one): its range count is the buffer's; 32 ranges by
-            // default, i.e. (tiles + 1) x 32 x 2 KB = 19.6 MB whatever the batch
-            nsplit = splits_of((std::min(n, chunk) + 15) / 16);
-            rc = st->dwpart.ensure((size_t)(N::slab_off(N::L) + 1) * nsplit * 256 * sizeof(double));
-            if (rc) return rc;
-        }
         const size_t xes = x_dtype == BAMD_F64 ? 8 : 4;
-        bool quad = false;
-        for (int k = 0; k < nchunk; ++k) {
-            const int64_t r0 = k * chunk, rows = std::min(n - r0, chunk);
-            const int nblk = (int)((rows + 15) / 16);
+        auto chain = [&](int k, int64_t r0, int64_t rows, int nblk, int64_t nblk_all, int nchunk) -> int {
+            (void)k;
+            int rc = BAMD_OK;
+            bool quad = false;
             // one wave per 16-row block (register chain) once the blocks fill the chip's wave slots (1,024 blocks = one wave per SIMD:
             // 16,384 rows 0.233 -> 0.201 ms, 8,192 rows 0.123 -> 0.141); one workgroup per block below.  BALER_AMD_F64_REGCHAIN_BLKS
             // moves the switch (0: always, read per call: the parity tests run both kernels on the same batch)
@@ -1131,28 +1166,9 @@ template <int F, int Z, bool RT = false> struct Impl64 {
                 hipLaunchKernelGGL((chain64_kernel<F, Z, 4, RT>), dim3(nblk), dim3(256), kLds, s, (const d4 *)st->packed.p,
                                    (const void *)((const char *)x + (size_t)r0 * fr(h) * xes), x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
                                    (double *)h->lossp.p + r0 / 16, fr(h));
-            if (macro) {
-                const int ns = splits_of(nblk);
-                if (big)
-                    hipLaunchKernelGGL((dw64x_kernel<N>), dim3(8 * ((ns + 7) / 8) * Dwx64<N>::total), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
-                                       (double *)st->dwpart.p, nsplit, k > 0, ns);
-                else
-                    hipLaunchKernelGGL((dw64m_kernel<N>), dim3(8 * Dwm64<N>::per_xcd, ns), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
-                                       (double *)st->dwpart.p, nsplit, k > 0);
-            }
-        }
-        const double *part = macro ? (const double *)st->dwpart.p : nullptr;
-        // the finishing launch: the loss partials of ALL blocks; with `part` the sum over all chunks' block ranges in order, else
-        // (one small chunk) the tiles themselves over the images
-        const int nblk_fin = (int)nblk_all, nloss = quad ? 4 * nblk_fin : nblk_fin;
-        if (ad)
-            hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
-                               (const int *)st->inv_map.p, grads, *ad, part, nsplit, (int)h->nparams, 1.0 / fr(h), nloss, 0);
-        else
-            hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk_fin, (const double *)h->lossp.p,
-                               (const int *)st->inv_map.p, grads, Adam64{}, part, nsplit, (int)h->nparams, 1.0 / fr(h), nloss, 0);
-        BAMD_HIP(hipGetLastError());
-        return BAMD_OK;
+            return quad ? 4 : 1;
+        };
+        return step64_common<N>(h, st, n, grads, ad, s, fr(h), chain);
     }
     static int infer(bamd_handle *h, State64 *st, int kind, const void *x, int x_dtype, int64_t n, const double *features, void *out,
                      int out_dtype, const double *renorm, const uint8_t *imask, double *loss_sum, hipStream_t s) {
@@ -1186,7 +1202,7 @@ template <int F, int Z, bool RT = false> struct Impl64 {
 };
 
 // 64 .. 127 columns (latent <= 63), and up to 63 columns with a latent of 32 .. 63, in fp64: TRAINING only -- chain64q_kernel (four rows per workgroup; its input rows are two
-// feature slots per thread) + dw64_kernel for EVERY training batch (chunks of 65,536 rows): the reference's batch_size = 512 in the
+// feature slots per thread) + the common weight-gradient launches for EVERY training batch (chunks of 65,536 rows): the reference's batch_size = 512 in the
 // reference's dtype for its wider tables (models.py:128-136 builds AE(n_features, z_dim) in float64 for any table) runs 3.8x, 4,096 rows 6x,
 // 65,536 rows 1.5x faster than on the layer-wise kernels.  The exchange chain, the register chain and the inference kernel give ONE input
 // tile to a wave (<= 63 columns): encode / decode / validation of such a handle stay layer-wise (bamd_path_of says BAMD_PATH_GENERIC).
@@ -1204,37 +1220,21 @@ template <int F, int FLO, int Z, int ZLO = 0> struct Impl64Q {
     }
     static int step(bamd_handle *h, State64 *st, const void *x, int x_dtype, int64_t n, const double *features, double *grads,
                     const Adam64 *ad, hipStream_t s) {
-        // Chunks of up to BALER_AMD_F64_QCHAIN_BLKS 16-row blocks (default here 4,096 = 65,536 rows, 15 KB of images per row; 0: the
-        // layer-wise kernels), the chunks' gradients added in order.  Measured us per step, this path / layer-wise, AE(80, 16): 512 rows
-        // 34 / 134, 1,536: 61 / 849, 4,096: 132 / 839, 16,384: 469 / 892, 65,536: 1,820 / 2,780 (tools/bench_fp64_mid_width_step.py)
+        // The common pass (chunks, tile blocks over block ranges from 1,024 rows on, one finishing launch) with the 4-row chain for EVERY
+        // chunk: chunks of BALER_AMD_F64_QCHAIN_BLKS 16-row blocks (default here 4,096 = 65,536 rows, 15 KB of images per row; 0: the
+        // layer-wise kernels).  Measured us per step, this path with one-tile weight gradients / layer-wise, AE(80, 16): 512 rows 34 / 134,
+        // 1,536: 61 / 849, 4,096: 132 / 839, 16,384: 469 / 892, 65,536: 1,820 / 2,780 (profiles/r6_fp64_mid_width_step.txt)
         const int64_t lim = env_ll("BALER_AMD_F64_QCHAIN_BLKS", -1);
         if (lim == 0) return BAMD_ERR_UNSUPPORTED;                                     // the caller runs the layer-wise kernels
-        const int64_t per = lim > 0 ? lim : 4096, nblk_all = (n + 15) / 16, nchunk = (nblk_all + per - 1) / per;
-        if (ad && nchunk > 1) return BAMD_ERR_UNSUPPORTED;                             // (the caller: bamd_fwd_bwd chunk after chunk, then the Adam kernel)
-        const int64_t nblk_max = std::min(nblk_all, per);
-        int rc = st->imgs.ensure((size_t)N::img_doubles * sizeof(double) * (size_t)nblk_max);
-        if (rc) return rc;
-        rc = h->lossp.ensure(sizeof(double) * (size_t)(4 * nblk_max > 1024 ? 4 * nblk_max : 1024));
-        if (rc) return rc;
-        const dim3 grid(8 * ((N::slab_off(N::L) + 1 + 7) / 8));
+        st->chunk_rows = (lim > 0 ? lim : 4096) * 16;
         const size_t row_bytes = (size_t)h->dims[0] * (x_dtype == BAMD_F64 ? 8 : 4);
-        for (int64_t k = 0; k < nchunk; ++k) {
-            const int64_t r0 = k * per * 16, rows = std::min(n - r0, per * 16);
-            const int nblk = (int)((rows + 15) / 16);
-            rc = fused64q_launch(F, Z, true, 4u * (unsigned)nblk, s, (const double *)st->packed.p + (size_t)N::packed_d4() * 4,
-                                 (const char *)x + (size_t)r0 * row_bytes, x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
-                                 (double *)h->lossp.p, h->dims[0]);
-            if (rc) return rc;
-            if (ad)
-                hipLaunchKernelGGL((dw64_kernel<N, DW_ADAM>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk, (const double *)h->lossp.p,
-                                   (const int *)st->inv_map.p, grads, *ad, (const double *)nullptr, 0, (int)h->nparams, 1.0 / h->dims[0], 4 * nblk, 0);
-            else
-                hipLaunchKernelGGL((dw64_kernel<N, DW_WRITE>), grid, dim3(256), 0, s, (const double *)st->imgs.p, nblk, (const double *)h->lossp.p,
-                                   (const int *)st->inv_map.p, grads, Adam64{}, (const double *)nullptr, 0, (int)h->nparams, 1.0 / h->dims[0], 4 * nblk,
-                                   k > 0 ? 1 : 0);
-        }
-        BAMD_HIP(hipGetLastError());
-        return BAMD_OK;
+        auto chain = [&](int, int64_t r0, int64_t rows, int nblk, int64_t, int) -> int {
+            const int rc = fused64q_launch(F, Z, true, 4u * (unsigned)nblk, s, (const double *)st->packed.p + (size_t)N::packed_d4() * 4,
+                                           (const char *)x + (size_t)r0 * row_bytes, x_dtype == BAMD_F64, rows, features, (double *)st->imgs.p,
+                                           (double *)h->lossp.p + 4 * (r0 / 16), h->dims[0]);
+            return rc ? rc : 4;
+        };
+        return step64_common<N>(h, st, n, grads, ad, s, h->dims[0], chain);
     }
     static int infer(bamd_handle *, State64 *, int, const void *, int, int64_t, const double *, void *, int, const double *, const uint8_t *,
                      double *, hipStream_t) {
