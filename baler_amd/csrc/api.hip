@@ -142,13 +142,10 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
             for (int l = 0; l <= n_layers; ++l) d += (l ? "-" : "") + std::to_string(dims[l]);
             const std::string infer_only = "throughput training kernels (encode / decode / validation and training steps of up to " +
                                            std::to_string((long long)fused_latency_rows(h)) + " rows are fused)";
-            const bool qonly = h->mode == BAMD_MODE_F64 && fused64_small_step_only(h);
             fprintf(stderr, "[baler_amd] model %s (%s) has no fused %s: %s run layer by layer (generic.hip, activations through HBM)\n",
                     d.c_str(), h->mode == BAMD_MODE_F64 ? "fp64" : h->mode == BAMD_MODE_BF16 ? "bf16" : "fp32",
-                    qonly ? "inference kernels (training runs fused: chain64q_kernel + dw64_kernel)"
-                          : path == BAMD_PATH_GENERIC ? "kernel instantiation" : infer_only.c_str(),
-                    qonly ? "encode / decode / validation"
-                          : path == BAMD_PATH_GENERIC ? "encode / decode / training" : "larger training batches");
+                    path == BAMD_PATH_GENERIC ? "kernel instantiation" : infer_only.c_str(),
+                    path == BAMD_PATH_GENERIC ? "encode / decode / training" : "larger training batches");
         }
     }
     return BAMD_OK;
@@ -157,7 +154,7 @@ int bamd_create(const int *dims, int n_layers, int mode, int device, bamd_handle
 int bamd_path_of(const bamd_handle *h) {
     BAMD_REQUIRE(h, "null handle");
     if (h->mode == BAMD_MODE_BF16 && h->bf16_state) return BAMD_PATH_BF16;
-    if (h->mode == BAMD_MODE_F64) return h->fused64_state && !fused64_small_step_only(h) ? BAMD_PATH_FUSED : BAMD_PATH_GENERIC;
+    if (h->mode == BAMD_MODE_F64) return h->fused64_state ? BAMD_PATH_FUSED : BAMD_PATH_GENERIC;
     if (!h->fused_ok) return BAMD_PATH_GENERIC;
     return fused_trains(h) ? BAMD_PATH_FUSED : BAMD_PATH_FUSED_INFER;
 }

@@ -37,7 +37,6 @@ int fused_wide_train_backward(bamd_handle *h, int64_t rows, float *const *y, flo
 // fp64 small-batch step (fused64.hip): chain + weight-gradient tiles on v_mfma_f64_16x16x4_f64 for BAMD_MODE_F64 handles
 int fused64_setup(bamd_handle *h);               // leaves h->fused64_state null for shapes without an instantiation
 void fused64_teardown(bamd_handle *h);
-bool fused64_small_step_only(const bamd_handle *h);   // 64 .. 127 columns in fp64: training is fused (4-row chain), inference layer-wise
 int fused64_pack(bamd_handle *h, hipStream_t s); // h->params (fp64) -> fragment-packed fp64 weights
 void fused64_scatter(bamd_handle *h, const int **sc_off, const int **sc_idx, void **packed);   // for the fused Adam + pack kernel
 // fwd + loss + bwd (hp == nullptr) or the whole training step (hp != nullptr) of a small batch; BAMD_ERR_UNSUPPORTED when this

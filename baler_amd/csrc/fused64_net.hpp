@@ -53,8 +53,39 @@ template <int F, int Z> struct Net64 {
     __host__ __device__ static constexpr int packed_all_doubles() { return packed_d4() * 4 + q_doubles(); }
 };
 
-}  // namespace
 
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;   // lane * 32
+};
+// fragment idx of the stream: two 16-byte halves per lane
+__device__ __forceinline__ d4 frag_rt(const WStream &ws, int idx) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const u4 lo = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, idx * 2048, 0);
+    const u4 hi = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff + 16, idx * 2048, 0);
+    const d2 a = __builtin_bit_cast(d2, lo), b = __builtin_bit_cast(d2, hi);
+    return (d4){a[0], a[1], b[0], b[1]};
+}
+
+template <int NL> __device__ __forceinline__ void lrelu(d4 (&a)[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[i][r] = a[i][r] > 0.0 ? a[i][r] : a[i][r] * kSlope;
+}}  // namespace
+
+// fused64i.hip / fused64j.hip: infer64_kernel<F, Z, KIND, RT> (encode / decode / forward + loss of an fp64 handle; kind: 0 / 1 / 2) for the
+// shapes of find64 -- the exact 24-column latents and the classes up to 63 columns in fused64i.hip, the 64 .. 127-column / latent <= 63
+// classes in fused64j.hip (two translation units: 69 fully unrolled kernels would take six minutes in one); BAMD_ERR_UNSUPPORTED for others
+int fused64_infer_launch(int F, int Z, bool rt, bamd_handle *h, const double *packed, int kind, const void *x, int x_dtype, int64_t n,
+                         const double *features, void *out, int out_dtype, const double *renorm, const uint8_t *imask, double *loss_sum,
+                         hipStream_t s);
+int fused64j_infer_launch(int F, int Z, bool rt, bamd_handle *h, const double *packed, int kind, const void *x, int x_dtype, int64_t n,
+                          const double *features, void *out, int out_dtype, const double *renorm, const uint8_t *imask, double *loss_sum,
+                          hipStream_t s);
 // fused64q.hip: chain64q_kernel<F, Z, RT> for the shapes fused64.hip instantiates; BAMD_ERR_UNSUPPORTED for any other (F, Z, RT)
 int fused64q_launch(int F, int Z, bool rt, unsigned grid, hipStream_t s, const double *qpacked, const void *x, int in_f64, int64_t rows,
                     const double *feats, double *imgs, double *loss_part, int fr);

@@ -354,11 +354,12 @@ def test_fp64_mid_width_small_batch_step_is_fused(F, Z, monkeypatch, capfd):
     reference's batch size and beyond: every training batch runs on the 4-row chain (chain64q_kernel, two input slots per thread) +
     dw64_kernel, chunk after chunk with the gradients added in order -- against the oracle at 1e-11 at ragged sizes and over several
     chunks, against the layer-wise kernels on the same batch (the switch is read per call), train_step == fwd_bwd + adam_step bit for bit
-    with the packed copies following the step.  Inference of such a handle stays layer-wise (path "generic"; the notice says so)."""
+    with the packed copies following the step; encode / decode / forward + loss on the register-chained inference kernel (fused64j.hip),
+    normalisation and the int mask fused."""
     dims = orc.ae_dims(F, Z)
     flat = orc.formula_params(dims, 600 + F)
     h, p = make_handle(dims, flat, "fp64")
-    assert h.path == "generic" and "training runs fused" in capfd.readouterr().err
+    assert h.path == "fused" and "layer by layer" not in capfd.readouterr().err
     rng = np.random.default_rng(F)
     for n in (1, 37, 512, 513, 1536, 1537):
         x = rng.random((n, F))
@@ -392,6 +393,24 @@ def test_fp64_mid_width_small_batch_step_is_fused(F, Z, monkeypatch, capfd):
     assert torch.equal(pa[:-1], pb[:-1])
     h.load_params(p)
     monkeypatch.delenv("BALER_AMD_F64_QCHAIN_BLKS")
+    # inference: ragged sizes, float32 rows, fused (un)normalisation and int truncation, the loss of forward + loss
+    for n in (1, 37, 4099):
+        x = rng.random((n, F))
+        z_ref = orc.encode(dims, flat, x)
+        assert rel(h.encode(dev(x)).cpu().numpy(), z_ref) < TOL64, (F, Z, n)
+        assert rel(h.decode(dev(z_ref)).cpu().numpy(), orc.decode(dims, flat, z_ref)) < TOL64
+        recon, loss = h.forward_loss(dev(x))
+        want = orc.forward(dims, flat, x)
+        assert rel(recon.cpu().numpy(), want) < TOL64 and abs(loss.item() - ((want - x) ** 2).sum() / F) < TOL64 * max(1.0, ((want - x) ** 2).sum() / F)
+    raw = rng.uniform(-40, 90, size=(257, F))
+    feats = orc.find_minmax(raw)
+    z1 = h.encode(dev(raw), features=dev(feats)).cpu().numpy()
+    assert rel(z1, orc.encode(dims, flat, orc.normalize(raw))) < TOL64
+    mask = np.zeros(F, dtype=np.uint8)
+    mask[[0, F - 1]] = 1
+    outd = h.decode(dev(z1), features=dev(feats), int_mask=dev(mask)).cpu().numpy()
+    wantd = orc.renormalize(orc.decode(dims, flat, z1), feats[0], feats[1])
+    assert rel(outd[:, mask == 0], wantd[:, mask == 0]) < TOL64 and np.mean(outd[:, mask == 1] == np.trunc(wantd[:, mask == 1])) > 0.99
     # normalise-on-load
     raw = rng.uniform(-3, 9, size=(300, F))
     feats = orc.find_minmax(raw)

@@ -13,7 +13,7 @@ EXTRA=""
 case ${BASE%%__*} in fused*|bf16_train*) EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function $EXTRA -I$C -I$R/include "$@" -c $SRC -o /tmp/abl/$NAME.o
 OBJS=""
-for o in api elementwise generic fused fused64 fused64q swd bf16 bf16_train comm; do
+for o in api elementwise generic fused fused64 fused64q fused64i fused64j swd bf16 bf16_train comm; do
   if [ "$o" = "${BASE%%__*}" ]; then OBJS="$OBJS /tmp/abl/$NAME.o"; else OBJS="$OBJS $C/$o.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $R/.abl/$NAME.so $OBJS
