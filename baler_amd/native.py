@@ -419,7 +419,13 @@ class Handle:
         with torch.cuda.device(self.device):
             _check(lib().bamd_comm_init(self._h, buf, int(rank), int(world)), "bamd_comm_init")
 
+    def comm_attach(self, comm, world=0):
+        """Use a communicator the CALLER made (an ncclComm_t as an integer address, from the same RCCL the library resolves); the
+        handle never destroys it.  world <= 0: ask ncclCommCount."""
+        _check(lib().bamd_comm_attach(self._h, ctypes.c_void_p(int(comm)), int(world)), "bamd_comm_attach")
+
     def comm_release(self):
+        """Detach the communicator (ncclCommDestroy only if comm_init made it); the handle trains single-process again."""
         _check(lib().bamd_comm_release(self._h), "bamd_comm_release")
 
     @property

@@ -403,13 +403,44 @@ for dp in (False, True):
     res.append((p.clone(), m.clone(), v.clone(), g.clone(), la.item()))
 for a, b in zip(res[0], res[1]):
     assert (torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b)
+# bamd_comm_attach: a communicator the CALLER made, with the RCCL the library itself resolved (the copy mapped in this process)
+import ctypes
+paths = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+assert len(paths) == 1, paths
+rccl = ctypes.CDLL(paths[0])
+class Uid(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * 128)]
+uid = Uid()
+assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+comm = ctypes.c_void_p()
+rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, Uid, ctypes.c_int]
+assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0 and comm.value
+h = native.Handle(dims, mode)
+p = p0.clone(); h.load_params(p)
+h.comm_attach(comm.value)                                # world <= 0: the library asks ncclCommCount
+assert h.comm_world == 1
+m, v, g = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+la = torch.zeros(1, dtype=torch.float64, device="cuda")
+h.train_epoch_dp(x, counts, p, m, v, 1, 1e-3, loss_accum=la, grads=g)
+torch.cuda.synchronize()
+for a, b in zip(res[0], (p, m, v, g, la.item())):
+    assert (torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b)
+h.comm_release()
+assert h.comm_world == 0
+n = ctypes.c_int(-1)                                     # the handle did not destroy what it did not make
+rccl.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+assert rccl.ncclCommCount(comm, ctypes.byref(n)) == 0 and n.value == 1
+rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+assert rccl.ncclCommDestroy(comm) == 0
+h.fwd_bwd(x[:512], g)                                    # and it trains single-process again
+torch.cuda.synchronize()
 print("LIBCOMM_OK", res[0][4])
 '''
 
 
 @pytest.mark.parametrize("mode", ["fp32", "fp64", "bf16"])
 def test_lib_comm_world1_epoch_equals_the_three_call_sequence(tmp_path, mode):
-    """bamd_comm_unique_id / bamd_comm_init / bamd_train_epoch_dp / bamd_allreduce_sum / bamd_comm_release on RCCL with ONE rank
+    """bamd_comm_unique_id / bamd_comm_init / bamd_comm_attach / bamd_train_epoch_dp / bamd_allreduce_sum / bamd_comm_release on RCCL with ONE rank
     (no torch.distributed at all: the library resolves and drives RCCL itself): the data-parallel epoch in one host call is
     bit-identical to bamd_fwd_bwd + bamd_adam_step per batch, ragged batch sizes and an empty slice included."""
     script = tmp_path / "w.py"

@@ -209,6 +209,15 @@ parts = [None] * world
 torch.distributed.all_gather_object(parts, z)
 if rank == 0:
     assert np.array_equal(np.concatenate(parts), orc.encode(dims, flat, data))
+# the sliced-Wasserstein exchange: ragged rank blocks (38 + 38, 39 + 38, 1 + 0 rows) gathered in rank order on every rank
+assert not bdist.lib_comm_wanted()                     # gloo: the library-side RCCL step is never chosen
+for lo, hi in ((1024, 1100), (0, 77), (5, 6)):
+    spans = [training._rank_slice(lo, hi, r, world) for r in range(world)]
+    counts = [b - a for a, b in spans]
+    a, b = spans[rank]
+    got = bdist.all_gather_rows(torch.from_numpy(data[a:b, :15].copy()), counts)
+    assert got.shape == (hi - lo, 15) and np.array_equal(got.numpy(), data[lo:hi, :15]), (lo, hi, counts)
+if rank == 0:
     print("DP-OK")
 bdist.barrier()
 '''
