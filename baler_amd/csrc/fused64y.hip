@@ -194,21 +194,25 @@ __global__ void __launch_bounds__(256) dw64y_kernel(const double *__restrict__ i
 //      A: L6 rows 0-2 + (row 12, k 0-3) | L6 rows 3-5 + (row 12, k 4-6) | L6 rows 6-8 + L3 | L6 rows 9-11 + L4          25 24 25 25
 //      B: L1 k 0-2 + (k 12, rows 0-3)   | L1 k 3-5 + (k 12, rows 4-6)   | L1 k 6-8 + (L2, k 6) | L1 k 9-11 + (L5, row 6)  25 24 25 25
 //      C: L0 | L7 | L2 k 0-5 | L5 rows 0-5                                                                               26 26 24 24
+typedef double __attribute__((ext_vector_type(2))) dw2;
+// HALF a block of a rectangle's slices: rows 4 g + 2 h, 4 g + 2 h + 1 of slot i (16 bytes per lane) = the operands of two of the block's
+// four MFMAs per tile.  Four half-sets rotate: one is multiplied while three are in flight (9.6k cycles of MFMA work ahead instead of the
+// 6.4k of two whole-block sets, in the same 240 VGPRs).
 template <class N, class R>
-__device__ __forceinline__ void dww_load(d4 (&za)[R::mn > 0 ? R::mn : 1], d4 (&xa)[R::mk > 0 ? R::mk : 1], const double *__restrict__ base) {
+__device__ __forceinline__ void dww_load(dw2 (&za)[R::mn > 0 ? R::mn : 1], dw2 (&xa)[R::mk > 0 ? R::mk : 1], const double *__restrict__ base) {
     if constexpr (R::mn > 0) {
 #pragma unroll
-        for (int a = 0; a < R::mn; ++a) za[a] = *(const d4 *)(base + (N::z_off(R::l) + 16 * (R::n0 + a)) * 16);
+        for (int a = 0; a < R::mn; ++a) za[a] = *(const dw2 *)(base + (N::z_off(R::l) + 16 * (R::n0 + a)) * 16);
 #pragma unroll
-        for (int c = 0; c < R::mk; ++c) xa[c] = *(const d4 *)(base + (N::x_off(R::l) + 16 * (R::k0 + c)) * 16);
+        for (int c = 0; c < R::mk; ++c) xa[c] = *(const dw2 *)(base + (N::x_off(R::l) + 16 * (R::k0 + c)) * 16);
     }
 }
 template <class R>
-__device__ __forceinline__ void dww_mma(d4 (&acc)[R::mn * R::mk > 0 ? R::mn * R::mk : 1], const d4 (&za)[R::mn > 0 ? R::mn : 1],
-                                        const d4 (&xa)[R::mk > 0 ? R::mk : 1]) {
+__device__ __forceinline__ void dww_mma(d4 (&acc)[R::mn * R::mk > 0 ? R::mn * R::mk : 1], const dw2 (&za)[R::mn > 0 ? R::mn : 1],
+                                        const dw2 (&xa)[R::mk > 0 ? R::mk : 1]) {
     if constexpr (R::mn > 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int c = 0; c < R::mk; ++c)
 #pragma unroll
@@ -228,34 +232,42 @@ __device__ __forceinline__ void dw64w_wave(const double *__restrict__ imgs, int 
     for (int t = 0; t < NA1; ++t) acc1[t] = mfma(zin, zin, (d4){0.0, 0.0, 0.0, 0.0});
 #pragma unroll
     for (int t = 0; t < (NA2 > 0 ? NA2 : 1); ++t) acc2[t] = mfma(zin, zin, (d4){0.0, 0.0, 0.0, 0.0});
-    d4 z1[2][R1::mn], x1[2][R1::mk], z2[2][R2::mn > 0 ? R2::mn : 1], x2[2][R2::mk > 0 ? R2::mk : 1];
-    auto load = [&](int set, int b) {
-        const double *base = lbase + (int64_t)(b < bhi ? b : blo) * N::img_doubles;      // beyond the range: the first block again, not multiplied
+    // NS half-sets rotate through 240 VGPRs: six for a wave of <= 10 slices (2.5 blocks ahead), four up to 15 slices (1.5 blocks)
+    constexpr int SL = R1::mn + R1::mk + R2::mn + R2::mk, NS = SL <= 10 ? 6 : 4;
+    static_assert(SL <= 15, "two whole blocks of slices in 240 VGPRs");
+    dw2 z1[NS][R1::mn], x1[NS][R1::mk], z2[NS][R2::mn > 0 ? R2::mn : 1], x2[NS][R2::mk > 0 ? R2::mk : 1];
+    const int hlo = 2 * blo, hhi = 2 * bhi;
+    auto load = [&](int set, int hb) {      // half-block hb = 2 b + h; beyond the range: the first one again, not multiplied
+        const int q = hb < hhi ? hb : hlo;
+        const double *base = lbase + (int64_t)(q >> 1) * N::img_doubles + 2 * (q & 1);
         dww_load<N, R1>(z1[set], x1[set], base);
         dww_load<N, R2>(z2[set], x2[set], base);
     };
-    load(0, blo);
-    int b = blo;
-    // whole pairs of blocks; sched_barrier: the next block's loads are ISSUED before this block's MFMAs (left free, hipcc sinks them to
-    // their first use and the wave waits a memory round trip per block)
-    for (; b + 1 < bhi; b += 2) {
-        if (SYNC) __syncthreads();
-        load(1, b + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        dww_mma<R1>(acc1, z1[0], x1[0]);
-        dww_mma<R2>(acc2, z2[0], x2[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (SYNC) __syncthreads();
-        load(0, b + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        dww_mma<R1>(acc1, z1[1], x1[1]);
-        dww_mma<R2>(acc2, z2[1], x2[1]);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k) load(k, hlo + k);
+    int hb = hlo;
+    // NS / 2 whole blocks per trip; sched_barrier: the loads are ISSUED before the MFMAs of the half in hand (left free, hipcc sinks
+    // them to their first use and the wave waits a memory round trip per block)
+    for (; hb + NS - 1 < hhi; hb += NS) {
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+            if (SYNC && (p & 1) == 0) __syncthreads();
+            load((p + NS - 1) % NS, hb + p + NS - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            dww_mma<R1>(acc1, z1[p], x1[p]);
+            dww_mma<R2>(acc2, z2[p], x2[p]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
-    if (b < bhi) {      // an odd block count: set 0 holds the last block
-        dww_mma<R1>(acc1, z1[0], x1[0]);
-        dww_mma<R2>(acc2, z2[0], x2[0]);
-    }
+#pragma unroll
+    for (int q = 0; q < NS - 2; q += 2)      // the remaining whole blocks (fewer than NS / 2): their halves sit in sets q, q + 1
+        if (hb + q < hhi) {
+            if (SYNC) __syncthreads();
+            dww_mma<R1>(acc1, z1[q], x1[q]);
+            dww_mma<R2>(acc2, z2[q], x2[q]);
+            dww_mma<R1>(acc1, z1[q + 1], x1[q + 1]);
+            dww_mma<R2>(acc2, z2[q + 1], x2[q + 1]);
+        }
     dwy_store<N, R1>(acc1, part, nsplit_total, accumulate, range, lane);
     dwy_store<N, R2>(acc2, part, nsplit_total, accumulate, range, lane);
 }
@@ -263,25 +275,29 @@ template <class N>
 __global__ void __launch_bounds__(256) dw64w_kernel(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total,
                                                     int accumulate, int nsplit) {
     if constexpr (Dwy64<N>::ok) {
-        const int type = (int)blockIdx.x % 3, range = (int)blockIdx.x / 3;
+        const int type = (int)blockIdx.x & 3, range = (int)blockIdx.x >> 2;
         if (range >= nsplit) return;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int per = (nblk + nsplit - 1) / nsplit, blo = range * per, bhi = blo + per < nblk ? blo + per : nblk;
 #define BAMD_DWW(T_, W_, R1_, R2_, S_) \
         if (type == T_ && wave == W_) { dw64w_wave<N, R1_, R2_, S_>(imgs, blo, bhi, part, nsplit_total, accumulate, range); return; }
 #define BAMD_R(...) DwRect<__VA_ARGS__>
-        BAMD_DWW(0, 0, BAMD_R(6, 0, 3, 0, 7), BAMD_R(6, 12, 1, 0, 4), true)
-        BAMD_DWW(0, 1, BAMD_R(6, 3, 3, 0, 7), BAMD_R(6, 12, 1, 4, 3), true)
-        BAMD_DWW(0, 2, BAMD_R(6, 6, 3, 0, 7), BAMD_R(3, 0, 1, 0, 4), true)
-        BAMD_DWW(0, 3, BAMD_R(6, 9, 3, 0, 7), BAMD_R(4, 0, 4, 0, 1), true)
-        BAMD_DWW(1, 0, BAMD_R(1, 0, 7, 0, 3), BAMD_R(1, 0, 4, 12, 1), true)
-        BAMD_DWW(1, 1, BAMD_R(1, 0, 7, 3, 3), BAMD_R(1, 4, 3, 12, 1), true)
-        BAMD_DWW(1, 2, BAMD_R(1, 0, 7, 6, 3), BAMD_R(2, 0, 4, 6, 1), true)
-        BAMD_DWW(1, 3, BAMD_R(1, 0, 7, 9, 3), BAMD_R(5, 6, 1, 0, 4), true)
-        BAMD_DWW(2, 0, BAMD_R(0, 0, 13, 0, 2), DwNone, false)
-        BAMD_DWW(2, 1, BAMD_R(7, 0, 2, 0, 13), DwNone, false)
-        BAMD_DWW(2, 2, BAMD_R(2, 0, 4, 0, 6), DwNone, false)
-        BAMD_DWW(2, 3, BAMD_R(5, 0, 6, 0, 4), DwNone, false)
+        BAMD_DWW(0, 0, BAMD_R(6, 0, 3, 0, 7), DwNone, true)
+        BAMD_DWW(0, 1, BAMD_R(6, 3, 3, 0, 7), DwNone, true)
+        BAMD_DWW(0, 2, BAMD_R(6, 6, 3, 0, 7), DwNone, true)
+        BAMD_DWW(0, 3, BAMD_R(6, 9, 3, 0, 7), DwNone, true)
+        BAMD_DWW(1, 0, BAMD_R(1, 0, 7, 0, 3), DwNone, true)
+        BAMD_DWW(1, 1, BAMD_R(1, 0, 7, 3, 3), DwNone, true)
+        BAMD_DWW(1, 2, BAMD_R(1, 0, 7, 6, 3), DwNone, true)
+        BAMD_DWW(1, 3, BAMD_R(1, 0, 7, 9, 3), DwNone, true)
+        BAMD_DWW(2, 0, BAMD_R(0, 0, 7, 0, 2), BAMD_R(3, 0, 1, 0, 4), false)
+        BAMD_DWW(2, 1, BAMD_R(0, 7, 6, 0, 2), BAMD_R(4, 0, 4, 0, 1), false)
+        BAMD_DWW(2, 2, BAMD_R(2, 0, 4, 0, 4), DwNone, false)
+        BAMD_DWW(2, 3, BAMD_R(2, 0, 4, 4, 3), BAMD_R(6, 12, 1, 0, 7), false)
+        BAMD_DWW(3, 0, BAMD_R(7, 0, 2, 0, 7), DwNone, false)
+        BAMD_DWW(3, 1, BAMD_R(7, 0, 2, 7, 6), DwNone, false)
+        BAMD_DWW(3, 2, BAMD_R(5, 0, 4, 0, 4), DwNone, false)
+        BAMD_DWW(3, 3, BAMD_R(5, 4, 3, 0, 4), BAMD_R(1, 0, 7, 12, 1), false)
 #undef BAMD_R
 #undef BAMD_DWW
     }
@@ -293,7 +309,7 @@ int dwy_go(int ns, hipStream_t s, const double *imgs, int nblk, double *part, in
                                                        (int)kDwyLdsBytes);
     BAMD_HIP(attr);
     if (env_ll("BALER_AMD_DW64Y_LDS", 0) == 0)
-        hipLaunchKernelGGL((dw64w_kernel<Net64<F, Z>>), dim3(3 * ns), dim3(256), 0, s, imgs, nblk, part, nsplit_total, accumulate, ns);
+        hipLaunchKernelGGL((dw64w_kernel<Net64<F, Z>>), dim3(4 * ns), dim3(256), 0, s, imgs, nblk, part, nsplit_total, accumulate, ns);
     else
     hipLaunchKernelGGL((dw64y_kernel<Net64<F, Z>>), dim3(4 * ns), dim3(256), kDwyLdsBytes, s, imgs, nblk, part, nsplit_total, accumulate, ns);
     BAMD_HIP(hipGetLastError());

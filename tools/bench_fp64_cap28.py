@@ -26,8 +26,8 @@ def ms(fn, reps):
 for n in [int(a) for a in sys.argv[1:]] or [65536, 262144, 1000000]:
     x = torch.from_numpy(orc.normalize(synth.cms_rows(n))).cuda()
     ref = None
-    for name, env in (("16-tile blocks, 32 ranges", {}), ("wave-owned tiles in registers, 85 ranges", {"BALER_AMD_DW64Y_BLKS": "1024", "BALER_AMD_DW64Y_RANGES": "85"}),
-                      ("wave-owned tiles in registers, 170 ranges", {"BALER_AMD_DW64Y_BLKS": "1024", "BALER_AMD_DW64Y_RANGES": "170"}),
+    for name, env in (("16-tile blocks, 32 ranges", {}), ("wave-owned tiles in registers, 64 ranges", {"BALER_AMD_DW64Y_BLKS": "1024", "BALER_AMD_DW64Y_RANGES": "64"}),
+                      ("wave-owned tiles in registers, 128 ranges", {"BALER_AMD_DW64Y_BLKS": "1024", "BALER_AMD_DW64Y_RANGES": "128"}),
                       ("wave-owned tiles, slices via LDS, 64 ranges", {"BALER_AMD_DW64Y_BLKS": "1024", "BALER_AMD_DW64Y_LDS": "1"})):
         for k in ("BALER_AMD_DW64Y_BLKS", "BALER_AMD_DW64Y_RANGES", "BALER_AMD_DW64_CAP28_BLKS", "BALER_AMD_DW64Y_LDS"):
             os.environ.pop(k, None)
