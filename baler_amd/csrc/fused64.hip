@@ -547,12 +547,12 @@ template <class N> struct Dwm64 {
     static constexpr int per_xcd = (total + 7) / 8;
 };
 struct DwDeal { bool keep_n; int cnt, base, rem; };      // the dealt dimension in `cnt` pieces: `rem` of base + 1 tiles, then base tiles
-template <class N, int CAP = 16> struct Dwx64 {      // CAP: tiles per block at most (16: ~330 registers with two blocks ahead; 28: ~440 with one)
+template <class N> struct Dwx64 {
     __host__ __device__ static constexpr DwDeal deal(int l) {
         const int nt = tiles(N::dim(l + 1)), kt = tiles(N::dim(l) + 1);
         const bool keep_n = nt <= kt;
         const int a = keep_n ? nt : kt, b = keep_n ? kt : nt;
-        const int mx = CAP / a > 0 ? CAP / a : 1, cnt = (b + mx - 1) / mx;
+        const int mx = 16 / a > 0 ? 16 / a : 1, cnt = (b + mx - 1) / mx;
         return DwDeal{keep_n, cnt, b / cnt, b % cnt};
     }
     __host__ __device__ static constexpr int off(int l) { int s = 0; for (int j = 0; j < l; ++j) s += deal(j).cnt; return s; }
@@ -561,10 +561,10 @@ template <class N, int CAP = 16> struct Dwx64 {      // CAP: tiles per block at 
 // one tile block (compile-time shape MN x MK of layer l, first tiles n0 / k0; CLAMP: tiles beyond the layer's edge run on a clamped slice
 // and are not stored): accumulate over block range `range` of `nsplit`, sum the four waves' accumulators through LDS in wave order, store
 // the range partial
-template <class N, int l, int MN, int MK, bool CLAMP, int AHEAD = kDw64Ahead>
+template <class N, int l, int MN, int MK, bool CLAMP>
 __device__ __forceinline__ void dw64_tile_block(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total, int accumulate,
                                                 int n0, int k0, d4 *red, int range, int nsplit) {
-    constexpr int NA = MN * MK, U = NA >= 12 ? 1 : 2, H0 = NA <= 16 ? (NA + 1) / 2 : 8, NH = (NA + H0 - 1) / H0;
+    constexpr int NA = MN * MK, U = NA >= 12 ? 1 : 2, H0 = (NA + 1) / 2;
     constexpr int ntc = tiles(N::dim(l + 1)), ktc = tiles(N::dim(l) + 1), soff = N::slab_off(l), xo = N::x_off(l), zo = N::z_off(l);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
     const double *pz[MN], *px[MK];
@@ -589,7 +589,7 @@ __device__ __forceinline__ void dw64_tile_block(const double *__restrict__ imgs,
         // the slices of a wave's next D blocks are on their way while it multiplies: D + 1 register sets, filled in turn (loads retire in
         // order, so waiting for a set leaves the D younger ones in flight; ~330 registers, one wave per SIMD); a set beyond the range is
         // loaded from the range's first block and not multiplied
-        constexpr int D = AHEAD;
+        constexpr int D = kDw64Ahead;
         d4 za[D + 1][MN], xa[D + 1][MK];
         int b = blo + wave;
 #pragma unroll
@@ -645,8 +645,8 @@ __device__ __forceinline__ void dw64_tile_block(const double *__restrict__ imgs,
     const double *rf = (const double *)red;
     const int e = threadIdx.x;
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-        const int cnt = NA - h * H0 < H0 ? NA - h * H0 : H0;       // the accumulators pass through LDS in halves / passes of <= 8 tiles (x 4 waves x 2 KB)
+    for (int h = 0; h < 2; ++h) {
+        const int cnt = h ? NA - H0 : H0;       // the accumulators pass through LDS in two halves (<= 8 tiles x 4 waves x 2 KB)
         if (h) __syncthreads();
 #pragma unroll
         for (int t = 0; t < H0; ++t)
@@ -688,34 +688,33 @@ __global__ void __launch_bounds__(256) dw64m_kernel(const double *__restrict__ i
 #undef BAMD_DW64M_CASE
 }
 // the blocks of layer l: the `rem` larger pieces, then the others (two shapes per layer at most)
-template <class N, int l, int CAP>
+template <class N, int l>
 __device__ __forceinline__ void dw64x_layer(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total, int accumulate,
                                             int idx, d4 *red, int range, int nsplit) {
-    constexpr DwDeal d = Dwx64<N, CAP>::deal(l);
-    constexpr int A = CAP > 16 ? 1 : kDw64Ahead;
+    constexpr DwDeal d = Dwx64<N>::deal(l);
     constexpr int nt = tiles(N::dim(l + 1)), kt = tiles(N::dim(l) + 1);
     if constexpr (d.rem > 0) {
         if (idx < d.rem) {
             const int at = idx * (d.base + 1);
-            if constexpr (d.keep_n) dw64_tile_block<N, l, nt, d.base + 1, false, A>(imgs, nblk, part, nsplit_total, accumulate, 0, at, red, range, nsplit);
-            else dw64_tile_block<N, l, d.base + 1, kt, false, A>(imgs, nblk, part, nsplit_total, accumulate, at, 0, red, range, nsplit);
+            if constexpr (d.keep_n) dw64_tile_block<N, l, nt, d.base + 1, false>(imgs, nblk, part, nsplit_total, accumulate, 0, at, red, range, nsplit);
+            else dw64_tile_block<N, l, d.base + 1, kt, false>(imgs, nblk, part, nsplit_total, accumulate, at, 0, red, range, nsplit);
             return;
         }
     }
     const int at = d.rem * (d.base + 1) + (idx - d.rem) * d.base;
-    if constexpr (d.keep_n) dw64_tile_block<N, l, nt, d.base, false, A>(imgs, nblk, part, nsplit_total, accumulate, 0, at, red, range, nsplit);
-    else dw64_tile_block<N, l, d.base, kt, false, A>(imgs, nblk, part, nsplit_total, accumulate, at, 0, red, range, nsplit);
+    if constexpr (d.keep_n) dw64_tile_block<N, l, nt, d.base, false>(imgs, nblk, part, nsplit_total, accumulate, 0, at, red, range, nsplit);
+    else dw64_tile_block<N, l, d.base, kt, false>(imgs, nblk, part, nsplit_total, accumulate, at, 0, red, range, nsplit);
 }
-template <class N, int CAP = 16>
+template <class N>
 __global__ void __launch_bounds__(256) dw64x_kernel(const double *__restrict__ imgs, int nblk, double *__restrict__ part, int nsplit_total,
                                                     int accumulate, int nsplit) {
-    using D = Dwx64<N, CAP>;
+    using D = Dwx64<N>;
     __shared__ __attribute__((aligned(32))) d4 red[8 * 4 * 64];      // half of a block's accumulators from four waves: 64 KB
     const int j = (int)(blockIdx.x >> 3), range = (j / D::total) * 8 + (int)(blockIdx.x & 7), mac = j % D::total;
     if (range >= nsplit) return;
     static_assert(N::L == 8, "one case per layer below");
 #define BAMD_DW64X_CASE(l_) \
-    if (mac >= D::off(l_) && mac < D::off(l_ + 1)) { dw64x_layer<N, l_, CAP>(imgs, nblk, part, nsplit_total, accumulate, mac - D::off(l_), red, range, nsplit); return; }
+    if (mac >= D::off(l_) && mac < D::off(l_ + 1)) { dw64x_layer<N, l_>(imgs, nblk, part, nsplit_total, accumulate, mac - D::off(l_), red, range, nsplit); return; }
     BAMD_DW64X_CASE(0) BAMD_DW64X_CASE(1) BAMD_DW64X_CASE(2) BAMD_DW64X_CASE(3)
     BAMD_DW64X_CASE(4) BAMD_DW64X_CASE(5) BAMD_DW64X_CASE(6) BAMD_DW64X_CASE(7)
 #undef BAMD_DW64X_CASE
@@ -775,11 +774,7 @@ int step64_common(bamd_handle *h, State64 *st, int64_t n, double *grads, const A
     // measured at 262,144 rows 32 / 64 / 128 ranges: 2.11 / 2.15 / 2.21 ms per bamd_fwd_bwd); below that 2 x 4 blocks (52) over 8
     // ranges, at least 4 blocks per range.  Every chunk but the last is a full one
     const bool big = nblk_all >= 1024;
-    const long long y_blks = env_ll("BALER_AMD_DW64Y_BLKS", 0);
-    const bool ywave = y_blks > 0 && nblk_all >= y_blks && fused64y_has(N::dim(0), N::dim(4));      // a wave owns its tiles: every image slice read by one workgroup
-    const long long cap28_blks = env_ll("BALER_AMD_DW64_CAP28_BLKS", 0);
-    const bool cap28 = cap28_blks > 0 && nblk_all >= cap28_blks;      // tile blocks of up to 28 tiles (one block of slices ahead)
-    const int big_ranges = (int)std::max<long long>(1, ywave ? env_ll("BALER_AMD_DW64Y_RANGES", 64) : env_ll("BALER_AMD_DW64_RANGES", 32));
+    const int big_ranges = (int)std::max<long long>(1, env_ll("BALER_AMD_DW64_RANGES", 32));
     // every range must own at least one block: the kernels prefetch block `range * ceil(blks / ranges)` unconditionally, which an
     // empty trailing range would read past the images (e.g. 128 ranges of 1,025 blocks: 9 blocks each, range 114 starts at 1,026)
     auto splits_of = [big, big_ranges](int64_t blks) {
@@ -804,12 +799,7 @@ int step64_common(bamd_handle *h, State64 *st, int64_t n, double *grads, const A
         quad = per_blk == 4;
         if (macro) {
             const int ns = splits_of(nblk);
-            if (big && ywave)
-                fused64y_launch(N::dim(0), N::dim(4), ns, s, (const double *)st->imgs.p, nblk, (double *)st->dwpart.p, nsplit, k > 0);
-            else if (big && cap28)
-                hipLaunchKernelGGL((dw64x_kernel<N, 28>), dim3(8 * ((ns + 7) / 8) * Dwx64<N, 28>::total), dim3(256), 0, s, (const double *)st->imgs.p,
-                                   nblk, (double *)st->dwpart.p, nsplit, k > 0, ns);
-            else if (big)
+            if (big)
                 hipLaunchKernelGGL((dw64x_kernel<N>), dim3(8 * ((ns + 7) / 8) * Dwx64<N>::total), dim3(256), 0, s, (const double *)st->imgs.p, nblk,
                                    (double *)st->dwpart.p, nsplit, k > 0, ns);
             else
@@ -1043,7 +1033,6 @@ template <int F, int FLO, int Z, int ZLO = 0> struct Impl64Q {
 const Ops64 *find64(const bamd_handle *h) {
     if (h->mode != BAMD_MODE_F64) return nullptr;
     if (Impl64<24, 15>::matches(h)) return Impl64<24, 15>::ops();
-#ifndef BAMD_F64_QUICK      // development builds: the benchmark shape only (fused64.hip takes minutes with every instantiation)
     if (Impl64<24, 12>::matches(h)) return Impl64<24, 12>::ops();
     if (Impl64<24, 8>::matches(h)) return Impl64<24, 8>::ops();
     if (Impl64<24, 6>::matches(h)) return Impl64<24, 6>::ops();
@@ -1070,7 +1059,6 @@ const Ops64 *find64(const bamd_handle *h) {
     if (Impl64Q<95, 79, 63, 31>::matches(h)) return Impl64Q<95, 79, 63, 31>::ops();
     if (Impl64Q<111, 95, 63, 31>::matches(h)) return Impl64Q<111, 95, 63, 31>::ops();
     if (Impl64Q<127, 111, 63, 31>::matches(h)) return Impl64Q<127, 111, 63, 31>::ops();
-#endif
     return nullptr;
 }
 

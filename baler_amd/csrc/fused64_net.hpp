@@ -86,9 +86,6 @@ int fused64_infer_launch(int F, int Z, bool rt, bamd_handle *h, const double *pa
 int fused64j_infer_launch(int F, int Z, bool rt, bamd_handle *h, const double *packed, int kind, const void *x, int x_dtype, int64_t n,
                           const double *features, void *out, int out_dtype, const double *renorm, const uint8_t *imask, double *loss_sum,
                           hipStream_t s);
-// fused64y.hip: weight-gradient tiles of a large batch, one wave per tile set (ns block ranges, 3 workgroups per range)
-bool fused64y_has(int F, int Z);
-int fused64y_launch(int F, int Z, int ns, hipStream_t s, const double *imgs, int nblk, double *part, int nsplit_total, int accumulate);
 // fused64q.hip: chain64q_kernel<F, Z, RT> for the shapes fused64.hip instantiates; BAMD_ERR_UNSUPPORTED for any other (F, Z, RT)
 int fused64q_launch(int F, int Z, bool rt, unsigned grid, hipStream_t s, const double *qpacked, const void *x, int in_f64, int64_t rows,
                     const double *feats, double *imgs, double *loss_part, int fr);
