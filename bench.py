@@ -426,6 +426,15 @@ def main():
         "frac": achieved / PEAK_TFLOPS[a.mode], "traffic": traffic,
         "launch_ms": k_ms, "algorithmic_flop_per_row": FLOP_TRAIN_ROW, "rows_per_launch": a.rows,
     }
+    if a.mode == "fp32":
+        # the pair's instruction multiset replayed with every dependency removed (tools/isa_mix.py, profiles/r6_f32_train_mix_replay.txt):
+        # 39.0 + 15.0 us per 64-row iteration of a workgroup, i.e. what THIS multiset can issue; the shipped iteration beside it
+        iters = a.rows / 64 / 256
+        out["roofline"].update({
+            "issued_over_algorithmic_macs": 1.16,
+            "us_per_64_row_iteration": 1e3 * (k_ms - 0.015) / iters if iters >= 1 else None,
+            "mix_replay_us_per_iteration": 54.0,
+            "frac_at_mix_replay": (FLOP_TRAIN_ROW * a.rows / ((iters * 54.0 + 15.0) * 1e-6) / 1e12 / PEAK_TFLOPS["fp32"]) if iters >= 1 else None})
 
     if not a.no_extras:
         extra_roof = {}

@@ -88,10 +88,12 @@ THREE_SRC = ("v_fma", "v_med3", "v_max3", "v_min3", "v_bfi", "v_perm", "v_lshl_a
              "v_maximum3", "v_minimum3", "v_cndmask")
 
 
-def emit(seq, path, name, drop=()):
+def emit(seq, path, name, drop=(), waves=4):
     """The replay: one asm volatile block, the class sequence of `seq` with independent operands (classes in `drop` left out)."""
     out = []
     k = collections.Counter()
+    nq = 16 if waves <= 4 else 12          # accumulator quads the MFMAs rotate over; v_accvgpr reads come from the registers behind them
+    na = 96 if waves <= 4 else 64          # (8 waves per workgroup = 2 per SIMD: 256 registers per wave, v60..v163 + a0..a63)
     for ins in seq:
         c = classify(ins)
         if c in drop or (c.startswith("valu") and "valu_all" in drop) or (c.startswith("ds_") and "lds" in drop) or \
@@ -100,10 +102,19 @@ def emit(seq, path, name, drop=()):
         i = k[c]
         k[c] += 1
         if c == "mfma":
-            a = 4 * (i % 16)
-            out.append(f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], v[64:67], v[68:71], a[{a}:{a + 3}]")
+            # the kernel's own MFMA shape on independent accumulators (16 quads / 8 octets in turn)
+            op = ins.split()[0]
+            if op.startswith("v_mfma_f64"):
+                a = 8 * (i % (nq // 2))
+                out.append(f"{op} a[{a}:{a + 7}], v[64:65], v[68:69], a[{a}:{a + 7}]")
+            elif op.endswith("_f32") and not op.endswith("bf16"):      # v_mfma_f32_16x16x4_f32, v_mfma_f32_4x4x1_16b_f32: one register per operand
+                a = 4 * (i % nq)
+                out.append(f"{op} a[{a}:{a + 3}], v64, v68, a[{a}:{a + 3}]")
+            else:
+                a = 4 * (i % nq)
+                out.append(f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], v[64:67], v[68:71], a[{a}:{a + 3}]")
         elif c == "acc_mov":
-            out.append(f"v_accvgpr_read_b32 v{72 + i % 24}, a{64 + i % 32}")
+            out.append(f"v_accvgpr_read_b32 v{72 + i % 24}, a{4 * nq + i % (na - 4 * nq)}")
         elif c == "valu_pk":
             d = 72 + 2 * (i % 12)
             out.append(f"v_pk_mul_f32 v[{d}:{d + 1}], v[96:97], v[98:99]")
@@ -138,19 +149,19 @@ def emit(seq, path, name, drop=()):
             out.append("s_add_u32 s20, s20, 1")
         # branches / other: dropped
     body = " \\n\\t\"\n        \"".join(out)
-    clob = ", ".join([f'"v{i}"' for i in range(60, 164)] + [f'"a{i}"' for i in range(0, 96)])
+    clob = ", ".join([f'"v{i}"' for i in range(60, 164)] + [f'"a{i}"' for i in range(0, na)])
     src = f'''// GENERATED by tools/isa_mix.py from the main loop of {name}: the same instruction-class sequence, every dependency removed.
 // hipcc --offload-arch=gfx950 -O3 -o /tmp/mix_replay THIS_FILE && /tmp/mix_replay
-// One workgroup of 4 waves per CU (one wave per SIMD, as the kernel runs); LDS reads / writes at lane * 16, buffer loads from an L2-resident MB.
+// One workgroup of {waves} waves per CU (as the kernel runs); LDS reads / writes at lane * 16, buffer loads from an L2-resident MB.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-__global__ void __launch_bounds__(256) replay(const float *buf, int iters, unsigned long long *out) {{
+__global__ void __launch_bounds__({64 * waves}) replay(const float *buf, int iters, unsigned long long *out) {{
     extern __shared__ float lds[];
     const unsigned long long bp = (unsigned long long)buf;
     const unsigned int r4[4] = {{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bp),
                                 (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(bp >> 32) & 0xffffu)), 1u << 20, 0x00020000u}};
     const int lane = threadIdx.x & 63;
-    lds[threadIdx.x] = 0.f;
+    lds[threadIdx.x & 255] = 0.f;
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {{
@@ -180,12 +191,12 @@ int main() {{
     for (int rep = 0; rep < 3; ++rep) {{
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(replay, dim3(256), dim3(256), 65536, 0, buf, iters, out);
+        hipLaunchKernelGGL(replay, dim3(256), dim3({64 * waves}), 65536, 0, buf, iters, out);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long h[256]; hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
         double s = 0; for (int i = 0; i < 256; ++i) s += (double)h[i];
-        printf("{name}: %.2f us per iteration (wall, 256 workgroups x 4 waves), %.0f shader cycles per iteration (mean over workgroups)\\n",
+        printf("{name}: %.2f us per iteration (wall, 256 workgroups x {waves} waves), %.0f shader cycles per iteration (mean over workgroups)\\n",
                1e3 * ms / iters, s / 256 / iters);
     }}
     return 0;
@@ -209,5 +220,6 @@ if __name__ == "__main__":
               f"LDS writes per MFMA {(cnt['ds_write_b128'] + cnt['ds_write_other']) / nm:.2f}; barriers {cnt['barrier']}")
     if "--emit" in sys.argv:
         drop = tuple(sys.argv[sys.argv.index("--drop") + 1].split(",")) if "--drop" in sys.argv else ()
-        emit(seq, sys.argv[sys.argv.index("--emit") + 1], needle + (" without " + "+".join(drop) if drop else ""), drop)
+        waves = int(sys.argv[sys.argv.index("--waves") + 1]) if "--waves" in sys.argv else 4
+        emit(seq, sys.argv[sys.argv.index("--emit") + 1], needle + (" without " + "+".join(drop) if drop else ""), drop, waves)
         print("wrote", sys.argv[sys.argv.index("--emit") + 1])
