@@ -79,8 +79,11 @@ a one-rank RCCL group, `BALER_AMD_FORCE_PG=1`: carries `dp_step`), the `rocprofv
 `--kernel-trace` only; stamped with the hash of the kernel sources, `{d['source_hash']}`: `bench.py` quotes `roofline.traffic` from it only when
 the hash matches; `hbm_bytes = 2·FETCH_SIZE + WRITE_SIZE` is exact for kernels whose loads are 16-B-per-lane streams — the throughput pair, the
 inference kernels, the wide kernels — and an UPPER bound for the small-batch kernels, whose 4-/8-byte image stores and gathers are not calibrated).
-Measurements that are not profiles: `r6_bf16_train_mix_replay.txt` (the bf16 training pair's instruction multiset replayed without
-dependencies: the ceiling of DESIGN §4.6), `r6_mfma64_4x4_probe.txt` (`v_mfma_f64_4x4x4_4b_f64`: lane maps, rate), `r6_fp64_small_steps.txt`
+Measurements that are not profiles: `r6_f32_train_mix_replay.txt` (THE HEADLINE pair's instruction multiset replayed without dependencies:
+54.0 µs per 64-row iteration against 54.2–54.5 shipped, what each instruction class costs: the ceiling of DESIGN §4.1),
+`r6_bf16_train_mix_replay.txt` (the same for the bf16 training pair: DESIGN §4.6), `r6_bf16_infer_mix_replay.txt` (the bf16 encode kernel:
+9.1–9.5 µs per round issued, 10.3–12 shipped), `r6_fp64_wave_owned_tiles.txt` (fp64 large batches: weight-gradient tiles owned by waves,
+four variants measured and rejected), `r6_mfma64_4x4_probe.txt` (`v_mfma_f64_4x4x4_4b_f64`: lane maps, rate), `r6_fp64_small_steps.txt`
 (fp64 optimiser step by batch size, 4-row chain vs exchange chain), `r6_fp64_chain_trace.txt` (per-GEMM shader-clock timeline of `chain64q_kernel`
 and of one `dw64_kernel` workgroup), `r6_bf16_infer_rows_sweep.txt` / `r6_bf16_infer_tile_wave_ab.txt` (bf16 inference: time against rows for
 every dtype pair; rows per wave × waves per workgroup), `r6_fp64_chunk_rows.txt` (fp64 1M-row step against the chunk size), `r6_wide_class_bench.txt`.
