@@ -81,7 +81,8 @@ the hash matches; `hbm_bytes = 2·FETCH_SIZE + WRITE_SIZE` is exact for kernels 
 inference kernels, the wide kernels — and an UPPER bound for the small-batch kernels, whose 4-/8-byte image stores and gathers are not calibrated).
 Measurements that are not profiles: `r6_f32_train_mix_replay.txt` (THE HEADLINE pair's instruction multiset replayed without dependencies:
 54.0 µs per 64-row iteration against 54.2–54.5 shipped, what each instruction class costs: the ceiling of DESIGN §4.1),
-`r6_bf16_train_mix_replay.txt` (the same for the bf16 training pair: DESIGN §4.6), `r6_bf16_infer_mix_replay.txt` (the bf16 encode kernel:
+`r6_f32_encode_mix_replay.txt` (fp32 encode: 31.2–31.7 µs per round replayed, 34.1 shipped), `r6_bf16_train_mix_replay.txt` (the same for the
+bf16 training pair: DESIGN §4.6), `r6_bf16_infer_mix_replay.txt` (the bf16 encode kernel:
 9.1–9.5 µs per round issued, 10.3–12 shipped), `r6_fp64_wave_owned_tiles.txt` (fp64 large batches: weight-gradient tiles owned by waves,
 four variants measured and rejected), `r6_mfma64_4x4_probe.txt` (`v_mfma_f64_4x4x4_4b_f64`: lane maps, rate), `r6_fp64_small_steps.txt`
 (fp64 optimiser step by batch size, 4-row chain vs exchange chain), `r6_fp64_chain_trace.txt` (per-GEMM shader-clock timeline of `chain64q_kernel`
