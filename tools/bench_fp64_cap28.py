@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""fp64 bamd_fwd_bwd of AE(24, 15) at large batches: weight-gradient tile blocks of <= 16 tiles (two blocks of slices ahead) against
-<= 28 tiles (one block ahead), over 32 / 64 block ranges.  Gradients of the variants are compared bit for bit at equal range counts."""
+"""fp64 bamd_fwd_bwd of AE(24, 15) at large batches: the shipped weight-gradient tile blocks against the wave-owned-tile variants of the
+round-6 experiment (profiles/r6_fp64_wave_owned_tiles.txt).  The variants and their switches (BALER_AMD_DW64Y_BLKS, BALER_AMD_DW64Y_RANGES,
+BALER_AMD_DW64Y_LDS, BALER_AMD_DW64_CAP28_BLKS) exist only in the experiment commits e992b02 / c5eec6f (git checkout <commit> -- baler_amd/csrc,
+make); against the shipped library every line measures the shipped path.  Gradients of the variants are compared with the first line's."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""fp64 bamd_fwd_bwd at 262,144 rows for rocprofv3 (10 launches): weight-gradient kernel chosen by the environment."""
+"""fp64 bamd_fwd_bwd at 262,144 rows for rocprofv3 (10 launches).  Argument `y`: the wave-owned-tile kernel of the round-6 experiment
+(BALER_AMD_DW64Y_BLKS: only in the experiment commits e992b02 / c5eec6f; the shipped library ignores it and runs dw64x_kernel)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
