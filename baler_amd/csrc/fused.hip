@@ -1233,204 +1233,6 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
     }
 }
 
-// ---- EXPERIMENT (round 6, not kept: profiles/r6_bf16_enc256_ab.txt): the same encode with 256 ROWS PER GROUP: eight compute waves (32 rows
-// each), two row loaders, one fragment loader.  A group's 13-KiB fragment chunk then serves 32 KiB of rows instead of 16, 64-96 KiB of
-// rows are in flight per CU instead of 48, and the fragments have a queue of their own.  Eleven waves = three per SIMD: 168 registers, so
-// the narrow layers run one row tile at a time on operands converted to bf16 up front.  Bit-identical to the kernel above; C4 0.48 of
-// HBM against 0.50, C5 0.32 against 0.48.
-#ifndef BAMD_DMA2_RING
-#define BAMD_DMA2_RING 3
-#endif
-#ifndef BAMD_DMA2_STAGE
-#define BAMD_DMA2_STAGE 3
-#endif
-constexpr int kDma2Ring = BAMD_DMA2_RING, kDma2Stage = BAMD_DMA2_STAGE, kDma2Lead = kDma2Ring - 1, kDma2FLead = kDma2Stage - 1, kDma2Chunk = 32768,
-              kDma2Threads = 704;
-template <int KD> __device__ __forceinline__ void to_kblocks(const v4 (&in)[tiles(KD)], bf8 (&q)[(tiles(KD) + 1) / 2]) {
-    constexpr int KT = tiles(KD);
-    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < (KT + 1) / 2; ++c) q[c] = to_bf8(in[2 * c], 2 * c + 1 < KT ? in[2 * c + 1 < KT ? 2 * c + 1 : 0] : zero);
-}
-// one narrow layer of ONE row tile: q = the layer's input as bf16 k blocks, fragments one k block ahead (chain_bf16_pair's order)
-template <class N, int l, int CB>
-__device__ __forceinline__ void fwd_layer_bf16_one(const bf8 (&q)[(tiles(N::dim(l)) + 1) / 2], v4 (&out)[tiles(N::dim(l + 1))], const WStream &wc,
-                                                   const v4 *bias_l, int lane) {
-    constexpr int base = [] { int b = 0; for (int j = CB; j < l; ++j) b += ((tiles(N::dim(j)) + 1) / 2) * tiles(N::dim(j + 1)); return b; }();
-    constexpr int NT = tiles(N::dim(l + 1)), KBK = (tiles(N::dim(l)) + 1) / 2;
-    init_bias(out, bias_l, lane);
-    bf8 w[2][NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) w[0][t] = frag_bf(wc, base + t);
-#pragma unroll
-    for (int c = 0; c < KBK; ++c) {
-        if (c + 1 < KBK) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) w[(c + 1) & 1][t] = frag_bf(wc, base + (c + 1) * NT + t);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) out[t] = mfma_bf(w[c & 1][t], q[c], out[t]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (N::act(l)) lrelu(out);
-}
-template <int F, int Z>
-__global__ void __launch_bounds__(kDma2Threads) wide_bf16_encode_dma256_kernel(const v4 *packed, const v4 *w0p, const v4 *wce, const float *__restrict__ xin,
-                                                                               int64_t n, void *__restrict__ out, int out_f64) {
-    using N = Net<F, Z>;
-    constexpr int KB = F / 32, KBT = (F + 31) / 32;
-    static_assert((F * 4) % 16 == 0 && KB >= kDma2Ring, "16-byte pieces of float32 rows; a row group fills the ring");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char dma_lds[];
-    unsigned char *const ring_b = dma_lds;
-    v4 (*const wst)[13][64] = (v4 (*)[13][64])(dma_lds + kDma2Ring * kDma2Chunk);
-    v4 *const bias_lds = (v4 *)(dma_lds + kDma2Ring * kDma2Chunk + kDma2Stage * 13 * 1024);
-    constexpr int nb = N::bf_off(4) - N::bf_off(0);                      // biases of layers 0..3
-    for (int i = threadIdx.x; i < nb; i += kDma2Threads) bias_lds[i] = packed[N::bf_off(0) + i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
-    const int64_t ngroup = (n + 255) / 256;
-    if (wave == 10) {
-        // ---- fragment loader: the 13 fragments of chunk c + kDma2FLead into the stage slot chunk c - 1 has left, requested at barrier c
-        const unsigned stage0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring_b + (unsigned)(kDma2Ring * kDma2Chunk);
-        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)w0p, 0, KBT * 13 * 1024, 0x00020000);
-        int ci = 0, si = 0;
-        auto issue = [&]() {
-#pragma unroll
-            for (int t = 0; t < 13; ++t)
-                lds_dma_b128(__builtin_amdgcn_readfirstlane(stage0 + (unsigned)(si * 13 + t) * 1024u), lane * 16, wrs, (ci * 13 + t) * 1024);
-            if (++ci == KB) ci = 0;
-            si = si + 1 == kDma2Stage ? 0 : si + 1;
-        };
-        for (int k = 0; k < kDma2FLead; ++k) issue();
-        for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x)
-            for (int c = 0; c < KB; ++c) {
-                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(13 * (kDma2FLead - 1)) : "memory");         // the fragments of chunk c are in their stage slot
-                __builtin_amdgcn_s_barrier();                            // barrier c: the compute waves have finished chunk c - 1
-                issue();
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // nothing may land in LDS after the workgroup has gone
-        return;
-    }
-    if (wave >= 8) {
-        // ---- row loader L: rows 128 L .. 128 L + 127 of every group of this workgroup (compute waves 4 L .. 4 L + 3) --------------
-        const int L = wave - 8;
-        const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring_b + (unsigned)L * 16384u;
-        int64_t gi = blockIdx.x;            // issue cursor: group, chunk, ring slot
-        int ci = 0, pi = 0;
-        auto issue = [&]() {
-            const int64_t gg = gi < ngroup ? gi : ngroup - 1;            // past the end: harmless re-reads keep the DMA count uniform
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xin + (size_t)gg * 256 * F), 0, 0x7fffffff, 0x00020000);
-            const int soff = ci * 128;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {   // (compute wave 4 L + (q >> 1), row tile q & 1)
-                const int rl = 128 * L + 16 * q + (lane & 15);
-                const int voff = (gg * 256 + rl < n ? rl : 0) * (F * 4) + 16 * g;       // rows beyond n read the group's first row
-                const unsigned dst = __builtin_amdgcn_readfirstlane(ring0 + (unsigned)pi * kDma2Chunk + (unsigned)q * 2048u);
-                lds_dma_b128(dst, voff, rs, soff);
-                lds_dma_b128(dst + 1024u, voff, rs, soff + 64);
-            }
-            if (++ci == KB) { ci = 0; gi += gridDim.x; }
-            pi = pi + 1 == kDma2Ring ? 0 : pi + 1;
-        };
-        for (int k = 0; k < kDma2Lead; ++k) issue();
-        for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x)
-            for (int c = 0; c < KB; ++c) {
-                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(16 * (kDma2Lead - 1)) : "memory");    // all but the youngest chunks: chunk c is in LDS
-                __builtin_amdgcn_s_barrier();                            // barrier c
-                issue();                                                 // chunk c + lead into the ring slot of chunk c - 1
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-    // ---- compute waves: wave w owns rows 32 w .. 32 w + 31 of the group (two 16-row tiles) -------------------------------------
-    WStream ww = make_stream(w0p, KBT * 13 * 1024, lane);
-    WStream wc = make_stream(wce, chain_bf16_frags<N, 1>() * 1024, lane);
-    int slot = 0, ws = 0;
-    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
-        const int64_t r0 = (grp * 8 + wave) * 32 + (lane & 15), r1 = r0 + 16;
-        const bool v0 = r0 < n, v1 = r1 < n;
-        asm volatile("" : "+v"(wc.voff), "+v"(ww.voff));
-        v4 a1[13], b1[13];
-        init_bias(a1, bias_lds, lane);
-#pragma unroll
-        for (int t = 0; t < 13; ++t) b1[t] = a1[t];
-        for (int c = 0; c < KB; ++c) {
-            __syncthreads();          // barrier c: rows of chunk c in ring slot `slot`, its fragments in stage slot `ws`
-            const v4 *xs = (const v4 *)(ring_b + slot * kDma2Chunk + wave * 4096) + lane;
-            const v4 (*const wf)[64] = wst[ws];
-            const v4 l0 = xs[0], h0 = xs[64], l1 = xs[128], h1 = xs[192];
-            slot = slot + 1 == kDma2Ring ? 0 : slot + 1;
-            ws = ws + 1 == kDma2Stage ? 0 : ws + 1;
-            const bf8 q0 = to_bf8(l0, h0), q1 = to_bf8(l1, h1);
-            bf8 wl[2][4];
-            auto rd = [&](bf8 (&w)[4], int t0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) w[k] = __builtin_bit_cast(bf8, wf[t0 + k < 13 ? t0 + k : 12][lane]);
-            };
-            auto mm = [&](const bf8 (&w)[4], int t0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (t0 + k < 13) { a1[t0 + k] = mfma_bf(w[k], q0, a1[t0 + k]); b1[t0 + k] = mfma_bf(w[k], q1, b1[t0 + k]); }
-            };
-            rd(wl[0], 0);
-            rd(wl[1], 4);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(wl[0], 0);
-            rd(wl[0], 8);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(wl[1], 4);
-            rd(wl[1], 12);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(wl[0], 8);
-            mm(wl[1], 12);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (F % 32 != 0) {            // the remaining F % 32 features: one partial chunk, rows and fragments straight from L2 (natural k order)
-            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(xin + (size_t)(grp * 256) * F), 0, 0x7fffffff, 0x00020000);
-            const int lr0 = wave * 32 + (lane & 15);
-            const int xo0 = ((v0 ? lr0 : 0) * F + 8 * g) * 4, xo1 = ((v1 ? lr0 + 16 : 0) * F + 8 * g) * 4;
-            const XPair p0 = wide_x_chunk32_buf<F>(xrs, xo0, 0, KB, g), p1 = wide_x_chunk32_buf<F>(xrs, xo1, 0, KB, g);
-            const bf8 q0 = to_bf8(p0.lo, p0.hi), q1 = to_bf8(p1.lo, p1.hi);
-#pragma unroll
-            for (int t = 0; t < 13; ++t) {
-                const bf8 w = frag_bf(ww, KB * 13 + t);
-                a1[t] = mfma_bf(w, q0, a1[t]);
-                b1[t] = mfma_bf(w, q1, b1[t]);
-            }
-        }
-        lrelu(a1);
-        lrelu(b1);
-#ifdef BAMD_DMA2_NOCHAIN      // timing-only build: the group's tail left out (every accumulator folded into one stored tile)
-        {
-            v4 f0[tiles(Z)], f1[tiles(Z)];
-#pragma unroll
-            for (int t = 0; t < tiles(Z); ++t) { f0[t] = a1[t]; f1[t] = b1[t]; }
-#pragma unroll
-            for (int t = tiles(Z); t < 13; ++t) { f0[0] += a1[t]; f1[0] += b1[t]; }
-            store_rows<Z>(f0, out, out_f64, r0, v0, lane, nullptr, nullptr);
-            store_rows<Z>(f1, out, out_f64, r1, v1, lane, nullptr, nullptr);
-            continue;
-        }
-#endif
-        // the narrow layers on the bf16 MFMA, one row tile at a time: both tiles' layer-1 operands converted first (the float32 tiles die)
-        bf8 qa[7], qb[7];
-        to_kblocks<200>(a1, qa);
-        to_kblocks<200>(b1, qb);
-#pragma unroll
-        for (int tile = 0; tile < 2; ++tile) {
-            v4 a2[7], a3[4], a4[tiles(Z)];
-            fwd_layer_bf16_one<N, 1, 1>(tile ? qb : qa, a2, wc, bias_lds + (N::bf_off(1) - N::bf_off(0)), lane);
-            bf8 q2[4];
-            to_kblocks<100>(a2, q2);
-            fwd_layer_bf16_one<N, 2, 1>(q2, a3, wc, bias_lds + (N::bf_off(2) - N::bf_off(0)), lane);
-            bf8 q3[2];
-            to_kblocks<50>(a3, q3);
-            fwd_layer_bf16_one<N, 3, 1>(q3, a4, wc, bias_lds + (N::bf_off(3) - N::bf_off(0)), lane);
-            store_rows<Z>(a4, out, out_f64, tile ? r1 : r0, tile ? v1 : v0, lane, nullptr, nullptr);
-        }
-    }
-}
-
 // Decode.  Two things bound the round-3 kernel (200-236 M frames/s, 0.25-0.30 of HBM; 532 M without its stores): every wave fetched
 // all 7 fragments of an output tile for itself, and -- what mattered -- those loads sat in the same in-order queue as the wave's
 // stores: vector-memory operations of a wave retire in order (vmcnt counts loads AND stores), so every wait for a fragment also
@@ -4532,7 +4334,6 @@ template <int F, int Z> struct ImplWideBf16 {
         const int64_t g = (rows + 127) / 128;
         return (int)(g < 1 ? 1 : (g > 2 * st->nwg_max ? 2 * st->nwg_max : g));
     }
-    static constexpr size_t dma2_lds_bytes() { return (size_t)kDma2Ring * kDma2Chunk + kDma2Stage * 13 * 1024 + (size_t)(N::bf_off(4) - N::bf_off(0)) * 16; }
     static constexpr size_t dma_lds_bytes() { return (size_t)kDmaRing * kDmaChunk + kDmaStage * 13 * 1024 + (size_t)(N::bf_off(4) - N::bf_off(0)) * 16; }
     static int setup(bamd_handle *h, FusedState *st) {
         int rc = build_maps<F, Z, false>(h, st);
@@ -4597,10 +4398,8 @@ template <int F, int Z> struct ImplWideBf16 {
         };
         const std::vector<int> sce = chain_map(1), scd = chain_map(4);
         const std::vector<int> *srcs[6] = {&s0, &s7, &s7t, &s0p, &sce, &scd};
-        if constexpr (kDma) {
+        if constexpr (kDma)
             BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_encode_dma_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes()));
-            BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_encode_dma256_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma2_lds_bytes()));
-        }
         BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_decode_kernel<F, Z, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_lds_bytes()));
         BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_decode_kernel<F, Z, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_lds_bytes()));
         for (int k = 0; k < 6; ++k) {
@@ -4646,15 +4445,6 @@ template <int F, int Z> struct ImplWideBf16 {
             const dim3 grid((unsigned)(ngroup > 2048 ? 2048 : ngroup));
             void *zo = (void *)((char *)z + (size_t)r0 * Z * zes);
             if constexpr (kDma) {
-                // EXPERIMENT: 256-row groups (8 compute + 3 loader waves) from BALER_AMD_BF16_ENC256 rows on (0 = off, the default)
-                const int64_t enc256 = env_ll("BALER_AMD_BF16_ENC256", 0);
-                if (!src_f64 && enc256 > 0 && rows >= enc256) {
-                    const int64_t ng = (rows + 255) / 256;
-                    hipLaunchKernelGGL((wide_bf16_encode_dma256_kernel<F, Z>), dim3((unsigned)(ng > st->nwg_max ? st->nwg_max : ng)), dim3(kDma2Threads),
-                                       dma2_lds_bytes(), s, (const v4 *)h->packed.p, (const v4 *)st->wb[3].p, (const v4 *)st->wb[4].p, (const float *)src, rows,
-                                       zo, z_dtype == BAMD_F64);
-                    continue;
-                }
                 if (!src_f64) {      // persistent: one workgroup (4 compute + 2 loader waves, 150 KiB of LDS) per CU
                     hipLaunchKernelGGL((wide_bf16_encode_dma_kernel<F, Z>), dim3((unsigned)(ngroup > st->nwg_max ? st->nwg_max : ngroup)), dim3(384),
                                        dma_lds_bytes(), s, (const v4 *)h->packed.p, (const v4 *)st->wb[3].p, (const v4 *)st->wb[4].p, (const float *)src, rows, zo,
