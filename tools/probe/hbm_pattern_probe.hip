@@ -1,77 +1,70 @@
-// How does the HBM read rate of a row-panel walk depend on the contiguous run fetched per row?
-// A workgroup (256 threads) owns 128 rows of a row-major float32 table (row = F floats, C4: 2500) and walks along them;
-// every wave-instruction loads 16 bytes per lane, 64 lanes cover RPI rows x RUN contiguous bytes (RPI * RUN = 1024):
-//   RUN =   64: 16 rows x 64 B  (the MFMA-operand-shaped loads of wide_bf16_encode_*: lane (i, g) -> 16 B of row i)
-//   RUN =  128:  8 rows x 128 B (one full cache line per row)
-//   RUN =  256 / 512 / 1024: 4 / 2 / 1 rows per instruction
-// Each wave keeps DEPTH instructions in flight.  Build: hipcc --offload-arch=gfx950 -O3 hbm_pattern_probe.hip -o hbm_pattern_probe
+// HBM read rate against the ADDRESS PATTERN of a wave's 1-KiB load instruction, on a table of float32 rows of F = 2500 columns (10,000 B per
+// row, C4's frames): what the bf16 wide encode's row loaders request (16 rows x 64 B per instruction, the second half of each 128-B line by
+// the next instruction) against contiguous streams and against 2 rows x 512 B / 4 rows x 256 B per instruction.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/hbm_pattern tools/probe/hbm_pattern_probe.hip && /tmp/hbm_pattern
+// Every pattern reads each byte of the table exactly once per pass; 512 workgroups x 256 threads, 8 loads in flight per lane.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include <cstdlib>
+#include <cstdint>
 typedef float v4 __attribute__((ext_vector_type(4)));
-template <int RUN, int DEPTH, bool MFMA_SHAPED = false>
-__global__ void __launch_bounds__(256) walk(const float *__restrict__ x, int64_t n, int F, float *__restrict__ out) {
-    constexpr int RPI = 1024 / RUN;                 // rows per instruction
-    constexpr int LPR = RUN / 16;                   // lanes per row
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t ngroup = n / 128;
-    const int rowbytes = F * 4;
-    const int steps_per_row = rowbytes / RUN;       // full runs only
+constexpr int F = 2500, ROWB = F * 4;
+// MODE 0: contiguous 1 KiB per instruction over the whole table.
+// MODE p > 0: an instruction covers R = 1024 / P rows x P bytes (P = 64, 128, 256, 512, 1024): lane l -> row l / (P / 16), byte 16 (l % (P / 16)).
+// A wave walks a 16-row tile chunk after chunk (P bytes of each row per step, in instructions of R rows), tile after tile.
+template <int P>
+__global__ void __launch_bounds__(256) rd(const char *__restrict__ base, int64_t nrows, float *out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
     v4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
-        // the wave's 32 rows, RPI at a time; per position along the row: 32 / RPI instructions
-        const char *base = (const char *)x + (grp * 128 + wave * 32) * (int64_t)rowbytes;
-        const int total = steps_per_row * (32 / RPI);
-        v4 buf[DEPTH];
-        auto addr = [&](int k) {
-            const int s = k / (32 / RPI), rb = k % (32 / RPI);
-            // MFMA_SHAPED: lane (i, g) = (lane & 15, lane >> 4) -> 16 bytes g of row i: the same 16 rows x 64 B per instruction, but
-            // ADJACENT LANES IN DIFFERENT ROWS (what a B operand of v_mfma_f32_16x16x32 loaded straight from a row-major table looks like)
-            const int row = MFMA_SHAPED ? rb * RPI + (lane & 15) : rb * RPI + lane / LPR;
-            const int piece = MFMA_SHAPED ? (lane >> 4) : lane % LPR;
-            return (const v4 *)(base + (int64_t)row * rowbytes + s * RUN + piece * 16);
-        };
+    if (P == 0) {
+        const int64_t total = nrows * ROWB / 1024;      // 1-KiB pieces
+        for (int64_t i = wave; i + 7 * nwave < total; i += 8 * nwave) {
+            v4 t[8];
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) buf[d] = *addr(d);
-        for (int k = 0; k < total; k += DEPTH) {
+            for (int u = 0; u < 8; ++u) t[u] = *(const v4 *)(base + (i + u * nwave) * 1024 + lane * 16);
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                acc += buf[d];
-                const int kn = k + d + DEPTH;
-                buf[d] = *addr(kn < total ? kn : d);
+            for (int u = 0; u < 8; ++u) acc += t[u];
+        }
+    } else {
+        constexpr int PP = P > 0 ? P : 64, LPR = PP / 16, R = 64 / LPR;      // lanes per row, rows per instruction
+        const int64_t ntile = nrows / 16;
+        constexpr int NCH = ROWB / PP;                   // whole chunks per row (the tail of a row is skipped: < 3 % of the bytes)
+        for (int64_t tile = wave; tile < ntile; tile += nwave) {
+            const char *tb = base + tile * 16 * (int64_t)ROWB + (int64_t)(lane / LPR) * ROWB + (lane % LPR) * 16;
+            for (int c = 0; c + 8 / (16 / R) <= NCH; c += 8 / (16 / R) > 0 ? 8 / (16 / R) : 1) {
+                v4 t[8];
+                // 16 / R instructions cover the tile's 16 rows for one chunk; 8 loads in flight = 8 / (16 / R) chunks (at least one)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ch = c + u / (16 / R), sub = u % (16 / R);
+                    t[u] = *(const v4 *)(tb + (int64_t)sub * R * ROWB + (int64_t)ch * PP);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += t[u];
             }
         }
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) acc += buf[d];
     }
-    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[threadIdx.x] = acc[0];
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) out[0] = acc[0];
 }
-template <int RUN, int DEPTH, bool M = false> void run(const float *x, int64_t n, int F, float *out, int grid) {
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((walk<RUN, DEPTH, M>), dim3(grid), dim3(256), 0, 0, x, n, F, out);
-    hipEventRecord(e0);
-    const int reps = 10;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((walk<RUN, DEPTH, M>), dim3(grid), dim3(256), 0, 0, x, n, F, out);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
-    const double bytes = (double)n * (F * 4 / RUN) * RUN;
-    printf("run %5d B/row%s, %2d loads in flight per wave, grid %4d: %.3f ms  %.2f TB/s\n", RUN, M ? " (lane = row + 16 piece)" : "", DEPTH, grid, ms, bytes / ms / 1e9);
-}
-int main(int argc, char **argv) {
-    const int64_t n = argc > 1 ? atoll(argv[1]) : 131072;
-    const int F = argc > 2 ? atoi(argv[2]) : 2500;
-    float *x, *out;
-    hipMalloc(&x, n * F * 4); hipMalloc(&out, 4096);
-    hipMemset(x, 0, n * F * 4);
-    for (int grid : {256, 512, 1024}) {
-        run<64, 8, true>(x, n, F, out, grid); run<64, 16, true>(x, n, F, out, grid);
-        run<64, 8>(x, n, F, out, grid); run<64, 16>(x, n, F, out, grid);
-        run<128, 8>(x, n, F, out, grid); run<128, 16>(x, n, F, out, grid);
-        run<256, 8>(x, n, F, out, grid); run<256, 16>(x, n, F, out, grid);
-        run<512, 8>(x, n, F, out, grid); run<512, 16>(x, n, F, out, grid);
-        run<1024, 8>(x, n, F, out, grid); run<1024, 16>(x, n, F, out, grid);
+template <int P> void run(const char *buf, int64_t nrows, float *out, const char *name) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(rd<P>, dim3(512), dim3(256), 0, 0, buf, nrows, out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep == 2) printf("%-44s %7.1f us per pass = %5.2f TB/s\n", name, 1e3 * ms / 10, nrows * (double)ROWB / (ms / 10 * 1e-3) / 1e12);
     }
+}
+int main() {
+    const int64_t nrows = 131072;      // 1.31 GB
+    char *buf; float *out;
+    hipMalloc(&buf, nrows * ROWB + 4096); hipMemset(buf, 0, nrows * ROWB + 4096); hipMalloc(&out, 64);
+    run<0>(buf, nrows, out, "contiguous, 1 KiB per instruction");
+    run<1024>(buf, nrows, out, "1 row x 1,024 B per instruction");
+    run<512>(buf, nrows, out, "2 rows x 512 B");
+    run<256>(buf, nrows, out, "4 rows x 256 B");
+    run<128>(buf, nrows, out, "8 rows x 128 B");
+    run<64>(buf, nrows, out, "16 rows x 64 B (the encode kernel's loaders)");
     return 0;
 }
