@@ -28,15 +28,15 @@ for name, F, Z, ns in (("C4 2500-25", 2500, 25, (32768, 65536, 131072, 262144, 1
     for n in ns:
         x = torch.rand((n, F), dtype=torch.float32, device="cuda")
         res = {}
-        for tag, env in (("128-row groups", "0"), ("256-row groups", "1")):
-            os.environ["BALER_AMD_BF16_ENC256"] = env
+        for tag, env in (("loader waves (DMA)", "0"), ("rows in registers", "1")):
+            os.environ["BALER_AMD_BF16_ENC_REG"] = env
             z = torch.empty((n, Z), dtype=torch.float32, device="cuda")
             h.encode(x, out=z); torch.cuda.synchronize()
             reps = max(3, min(50, int(2e9 / (n * F * 4))))
             t = ms(lambda: h.encode(x, out=z), reps)
             res[tag] = (t, z.clone())
         gb = n * (F + Z) * 4 / 1e9
-        d = float((res["256-row groups"][1] - res["128-row groups"][1]).abs().max())
+        d = float((res["rows in registers"][1] - res["loader waves (DMA)"][1]).abs().max())
         print(f"{name} {n:8d} rows: " + "   ".join(f"{k} {v[0] * 1e3:8.1f} us = {gb / v[0] / 8:.3f} of HBM" for k, v in res.items()) + f"   max |diff| {d:.2e}", flush=True)
         del x
     h.close()
