@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""(Experiment of commit b012638: the switch exists only there.)  bf16 encode of the wide models: 128-row groups (wide_bf16_encode_dma_kernel) against 256-row groups (wide_bf16_encode_dma256_kernel,
+"""(Experiments of commits b012638 (BALER_AMD_BF16_ENC256) and beeb36f (BALER_AMD_BF16_ENC_REG, what this version toggles): the switches exist only there.)  bf16 encode of the wide models: 128-row groups (wide_bf16_encode_dma_kernel) against 256-row groups (wide_bf16_encode_dma256_kernel,
 BALER_AMD_BF16_ENC256 = minimum rows, 0 = off), outputs compared."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
