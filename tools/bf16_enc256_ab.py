@@ -28,7 +28,7 @@ for name, F, Z, ns in (("C4 2500-25", 2500, 25, (32768, 65536, 131072, 262144, 1
     for n in ns:
         x = torch.rand((n, F), dtype=torch.float32, device="cuda")
         res = {}
-        for tag, env in (("loader waves (DMA)", "0"), ("rows in registers", "1")):
+        for tag, env in (("loader waves (DMA)", "0"), ("rows in registers", "4"), ("registers, 256-row groups", "8")):
             os.environ["BALER_AMD_BF16_ENC_REG"] = env
             z = torch.empty((n, Z), dtype=torch.float32, device="cuda")
             h.encode(x, out=z); torch.cuda.synchronize()
@@ -36,7 +36,7 @@ for name, F, Z, ns in (("C4 2500-25", 2500, 25, (32768, 65536, 131072, 262144, 1
             t = ms(lambda: h.encode(x, out=z), reps)
             res[tag] = (t, z.clone())
         gb = n * (F + Z) * 4 / 1e9
-        d = float((res["rows in registers"][1] - res["loader waves (DMA)"][1]).abs().max())
+        d = max(float((res[k][1] - res["loader waves (DMA)"][1]).abs().max()) for k in res)
         print(f"{name} {n:8d} rows: " + "   ".join(f"{k} {v[0] * 1e3:8.1f} us = {gb / v[0] / 8:.3f} of HBM" for k, v in res.items()) + f"   max |diff| {d:.2e}", flush=True)
         del x
     h.close()
