@@ -1233,128 +1233,6 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
     }
 }
 
-// ---- bf16 encode of the wide models, rows through REGISTERS at two waves per SIMD (round 6) ------------------------------------------
-// The loaders of the kernel above stream rows at 5.3 TB/s when alone and 3.9-4.0 in the complete kernel, whatever the fragment bytes per
-// row (256-row groups: DESIGN_HISTORY) -- while plain register loads with the SAME 16-rows-x-64-bytes pattern stream at 6.3 TB/s with 64 KiB
-// in flight per CU (tools/probe/hbm_pattern_probe.hip).  Here the four waves of a workgroup load their own rows two chunks ahead
-// (4 x 1 KiB per chunk and wave), only the FRAGMENTS go global -> LDS (each wave requests a quarter of a chunk's 13, two chunks ahead,
-// four stage slots), and the workgroup is small enough for TWO per CU: 54 KiB of LDS, <= 256 registers (amdgpu_waves_per_eu(2, 2)), i.e.
-// eight compute waves and 64 KiB of rows in flight per CU.  Same fragment packing and k order as the kernel above: bit-identical output.
-template <int F, int Z, int W>
-__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2)))
-wide_bf16_encode_reg_kernel(const v4 *packed, const v4 *w0p, const v4 *wce, const float *__restrict__ xin, int64_t n, void *__restrict__ out, int out_f64) {
-    using N = Net<F, Z>;
-    constexpr int KB = F / 32, KBT = (F + 31) / 32, kSt = 4;
-    static_assert((F * 4) % 16 == 0 && KB % 2 == 0 && KB >= 4, "16-byte pieces of float32 rows; chunks in pairs");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char reg_lds[];
-    v4 (*const wst)[13][64] = (v4 (*)[13][64])reg_lds;
-    v4 *const bias_lds = (v4 *)(reg_lds + kSt * 13 * 1024);
-    constexpr int nb = N::bf_off(4) - N::bf_off(0);                      // biases of layers 0..3
-    for (int i = threadIdx.x; i < nb; i += 64 * W) bias_lds[i] = packed[N::bf_off(0) + i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
-    constexpr int GR = 32 * W, FQ = (13 + W - 1) / W;      // rows per group; fragment requests per wave and chunk
-    const int64_t ngroup = (n + GR - 1) / GR;
-    const unsigned stage0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)reg_lds;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)w0p, 0, KBT * 13 * 1024, 0x00020000);
-    // issue cursor, two chunks ahead of the compute cursor: group, chunk, stage slot
-    int64_t gi = blockIdx.x;
-    int ci = 0, si = 0;
-    v4 xr[2][4];      // [chunk parity][tile 0 low / high half, tile 1 low / high half]
-    auto issue = [&](v4 (&x)[4]) {
-        // this wave's quarter of the chunk's 13 fragments (tile 12 is fetched by waves 1..3 again: four loads per wave and chunk) ...
-#pragma unroll
-        for (int k = 0; k < FQ; ++k) {
-            const int t = wave + W * k < 13 ? wave + W * k : 12;
-            lds_dma_b128(__builtin_amdgcn_readfirstlane(stage0 + (unsigned)(si * 13 + t) * 1024u), lane * 16, wrs, (ci * 13 + t) * 1024);
-        }
-        // ... then its own rows of that chunk (past the last group: the last group again, never multiplied into anything stored)
-        const int64_t gg = gi < ngroup ? gi : ngroup - 1;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xin + (size_t)gg * GR * F), 0, 0x7fffffff, 0x00020000);
-        const int rl = wave * 32 + (lane & 15);
-        const int vo0 = (gg * GR + rl < n ? rl : 0) * (F * 4) + 16 * g, vo1 = (gg * GR + rl + 16 < n ? rl + 16 : 0) * (F * 4) + 16 * g;
-        x[0] = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo0, ci * 128, 0));
-        x[1] = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo0 + 64, ci * 128, 0));
-        x[2] = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo1, ci * 128, 0));
-        x[3] = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo1 + 64, ci * 128, 0));
-        if (++ci == KB) { ci = 0; gi += gridDim.x; }
-        si = (si + 1) & (kSt - 1);
-    };
-    issue(xr[0]);
-    issue(xr[1]);
-    WStream ww = make_stream(w0p, KBT * 13 * 1024, lane);
-    WStream wc = make_stream(wce, chain_bf16_frags<N, 1>() * 1024, lane);
-    int ws = 0;
-    for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
-        const int64_t r0 = (grp * W + wave) * 32 + (lane & 15), r1 = r0 + 16;
-        const bool v0 = r0 < n, v1 = r1 < n;
-        asm volatile("" : "+v"(wc.voff), "+v"(ww.voff));
-        v4 a1[13], b1[13];
-        init_bias(a1, bias_lds, lane);
-#pragma unroll
-        for (int t = 0; t < 13; ++t) b1[t] = a1[t];
-        auto step = [&](v4 (&x)[4]) {
-            // everything but the 8 youngest requests of this wave (the next chunk's) has landed: this chunk's rows and fragment quarter
-            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(FQ + 4) : "memory");
-            __syncthreads();          // ... and so has every wave's quarter; the stage slot of two chunks ago is free
-            const v4 (*const wf)[64] = wst[ws];
-            ws = (ws + 1) & (kSt - 1);
-            const bf8 q0 = to_bf8(x[0], x[1]), q1 = to_bf8(x[2], x[3]);
-            issue(x);                 // two chunks ahead, into the registers just converted
-            bf8 wl[2][4];
-            auto rd = [&](bf8 (&w)[4], int t0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) w[k] = __builtin_bit_cast(bf8, wf[t0 + k < 13 ? t0 + k : 12][lane]);
-            };
-            auto mm = [&](const bf8 (&w)[4], int t0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (t0 + k < 13) { a1[t0 + k] = mfma_bf(w[k], q0, a1[t0 + k]); b1[t0 + k] = mfma_bf(w[k], q1, b1[t0 + k]); }
-            };
-            rd(wl[0], 0);
-            rd(wl[1], 4);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(wl[0], 0);
-            rd(wl[0], 8);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(wl[1], 4);
-            rd(wl[1], 12);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(wl[0], 8);
-            mm(wl[1], 12);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        for (int c = 0; c < KB; c += 2) {
-            step(xr[0]);
-            step(xr[1]);
-        }
-        if (F % 32 != 0) {            // the remaining F % 32 features: one partial chunk, rows and fragments straight from L2 (natural k order)
-            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(xin + (size_t)(grp * GR) * F), 0, 0x7fffffff, 0x00020000);
-            const int lr0 = wave * 32 + (lane & 15);
-            const int xo0 = ((v0 ? lr0 : 0) * F + 8 * g) * 4, xo1 = ((v1 ? lr0 + 16 : 0) * F + 8 * g) * 4;
-            const XPair p0 = wide_x_chunk32_buf<F>(xrs, xo0, 0, KB, g), p1 = wide_x_chunk32_buf<F>(xrs, xo1, 0, KB, g);
-            const bf8 q0 = to_bf8(p0.lo, p0.hi), q1 = to_bf8(p1.lo, p1.hi);
-#pragma unroll
-            for (int t = 0; t < 13; ++t) {
-                const bf8 w = frag_bf(ww, KB * 13 + t);
-                a1[t] = mfma_bf(w, q0, a1[t]);
-                b1[t] = mfma_bf(w, q1, b1[t]);
-            }
-        }
-        lrelu(a1);
-        lrelu(b1);
-        {   // the narrow layers on the bf16 MFMA, both row tiles at once (chain_bf16_pair)
-            v4 a2[7], b2[7], a3[4], b3[4], a4[tiles(Z)], b4[tiles(Z)];
-            fwd_layer_bf16_pair<N, 1, 1>(a1, b1, a2, b2, wc, bias_lds + (N::bf_off(1) - N::bf_off(0)), lane);
-            fwd_layer_bf16_pair<N, 2, 1>(a2, b2, a3, b3, wc, bias_lds + (N::bf_off(2) - N::bf_off(0)), lane);
-            fwd_layer_bf16_pair<N, 3, 1>(a3, b3, a4, b4, wc, bias_lds + (N::bf_off(3) - N::bf_off(0)), lane);
-            store_rows<Z>(a4, out, out_f64, r0, v0, lane, nullptr, nullptr);
-            store_rows<Z>(b4, out, out_f64, r1, v1, lane, nullptr, nullptr);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // nothing may land in LDS after the workgroup has gone
-}
-
 // Decode.  Two things bound the round-3 kernel (200-236 M frames/s, 0.25-0.30 of HBM; 532 M without its stores): every wave fetched
 // all 7 fragments of an output tile for itself, and -- what mattered -- those loads sat in the same in-order queue as the wave's
 // stores: vector-memory operations of a wave retire in order (vmcnt counts loads AND stores), so every wait for a fragment also
@@ -4456,7 +4334,6 @@ template <int F, int Z> struct ImplWideBf16 {
         const int64_t g = (rows + 127) / 128;
         return (int)(g < 1 ? 1 : (g > 2 * st->nwg_max ? 2 * st->nwg_max : g));
     }
-    static constexpr size_t reg_lds_bytes() { return (size_t)4 * 13 * 1024 + (size_t)(N::bf_off(4) - N::bf_off(0)) * 16; }
     static constexpr size_t dma_lds_bytes() { return (size_t)kDmaRing * kDmaChunk + kDmaStage * 13 * 1024 + (size_t)(N::bf_off(4) - N::bf_off(0)) * 16; }
     static int setup(bamd_handle *h, FusedState *st) {
         int rc = build_maps<F, Z, false>(h, st);
@@ -4521,11 +4398,8 @@ template <int F, int Z> struct ImplWideBf16 {
         };
         const std::vector<int> sce = chain_map(1), scd = chain_map(4);
         const std::vector<int> *srcs[6] = {&s0, &s7, &s7t, &s0p, &sce, &scd};
-        if constexpr (kDma) {
+        if constexpr (kDma)
             BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_encode_dma_kernel<F, Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dma_lds_bytes()));
-            BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_encode_reg_kernel<F, Z, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_lds_bytes()));
-            BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_encode_reg_kernel<F, Z, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_lds_bytes()));
-        }
         BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_decode_kernel<F, Z, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_lds_bytes()));
         BAMD_HIP(hipFuncSetAttribute((const void *)wide_bf16_decode_kernel<F, Z, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_lds_bytes()));
         for (int k = 0; k < 6; ++k) {
@@ -4571,20 +4445,6 @@ template <int F, int Z> struct ImplWideBf16 {
             const dim3 grid((unsigned)(ngroup > 2048 ? 2048 : ngroup));
             void *zo = (void *)((char *)z + (size_t)r0 * Z * zes);
             if constexpr (kDma) {
-                const long long reg = env_ll("BALER_AMD_BF16_ENC_REG", 8);      // 4: two workgroups of four waves per CU; 8: one of eight (256-row groups)
-                if (!src_f64 && reg == 4) {
-                    hipLaunchKernelGGL((wide_bf16_encode_reg_kernel<F, Z, 4>), dim3((unsigned)(ngroup > 2 * st->nwg_max ? 2 * st->nwg_max : ngroup)), dim3(256),
-                                       reg_lds_bytes(), s, (const v4 *)h->packed.p, (const v4 *)st->wb[3].p, (const v4 *)st->wb[4].p, (const float *)src, rows,
-                                       zo, z_dtype == BAMD_F64);
-                    continue;
-                }
-                if (!src_f64 && reg == 8) {
-                    const int64_t ng = (rows + 255) / 256;
-                    hipLaunchKernelGGL((wide_bf16_encode_reg_kernel<F, Z, 8>), dim3((unsigned)(ng > st->nwg_max ? st->nwg_max : ng)), dim3(512),
-                                       reg_lds_bytes(), s, (const v4 *)h->packed.p, (const v4 *)st->wb[3].p, (const v4 *)st->wb[4].p, (const float *)src, rows,
-                                       zo, z_dtype == BAMD_F64);
-                    continue;
-                }
                 if (!src_f64) {      // persistent: one workgroup (4 compute + 2 loader waves, 150 KiB of LDS) per CU
                     hipLaunchKernelGGL((wide_bf16_encode_dma_kernel<F, Z>), dim3((unsigned)(ngroup > st->nwg_max ? st->nwg_max : ngroup)), dim3(384),
                                        dma_lds_bytes(), s, (const v4 *)h->packed.p, (const v4 *)st->wb[3].p, (const v4 *)st->wb[4].p, (const float *)src, rows, zo,
