@@ -28,8 +28,8 @@ for name, F, Z, ns in (("C4 2500-25", 2500, 25, (32768, 65536, 131072, 262144, 1
     for n in ns:
         x = torch.rand((n, F), dtype=torch.float32, device="cuda")
         res = {}
-        for tag, env in (("loader waves (DMA)", "0"), ("rows in registers", "4"), ("registers, 256-row groups", "8")):
-            os.environ["BALER_AMD_BF16_ENC_REG"] = env
+        for tag, env in (("loader waves (DMA)", "0"), ("loaders, rows in chunk pairs", "1")):
+            os.environ["BALER_AMD_BF16_ENC_PAIR"] = env
             z = torch.empty((n, Z), dtype=torch.float32, device="cuda")
             h.encode(x, out=z); torch.cuda.synchronize()
             reps = max(3, min(50, int(2e9 / (n * F * 4))))
