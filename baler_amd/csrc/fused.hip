@@ -1105,7 +1105,7 @@ __device__ __forceinline__ void lds_dma_b128(unsigned lds_addr, int voff, __amdg
 }
 template <int F, int Z>
 __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *packed, const v4 *w0p, const v4 *wce, const float *__restrict__ xin, int64_t n,
-                                                                   void *__restrict__ out, int out_f64, int pair) {
+                                                                   void *__restrict__ out, int out_f64) {
     using N = Net<F, Z>;
     using S = StreamWideEnc<N>;
     constexpr int KB = F / 32, KBT = (F + 31) / 32;
@@ -1125,26 +1125,20 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
         const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring_b + (unsigned)L * 8192u;
         const unsigned stage0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)ring_b + (unsigned)(kDmaRing * kDmaChunk);
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)w0p, 0, KBT * 13 * 1024, 0x00020000);
-        int ci = 0, si = 0;                 // fragment cursor: chunk, stage slot
-        // rows of the chunk at the ROW cursor (rg, rc, rp) into its ring slot
-        int64_t rg = blockIdx.x;
-        int rc = 0, rp = 0;
-        auto issue_rows = [&]() {
-            const int64_t gg = rg < ngroup ? rg : ngroup - 1;            // past the end: harmless re-reads keep the DMA count uniform
+        int64_t gi = blockIdx.x;            // issue cursor: group, chunk, ring slot, stage slot
+        int ci = 0, pi = 0, si = 0;
+        auto issue = [&]() {
+            const int64_t gg = gi < ngroup ? gi : ngroup - 1;            // past the end: harmless re-reads keep the DMA count uniform
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(xin + (size_t)gg * 128 * F), 0, 0x7fffffff, 0x00020000);
-            const int soff = rc * 128;
+            const int soff = ci * 128;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {   // (compute wave 2 L + (q >> 1), row tile q & 1)
                 const int rl = 64 * L + 16 * q + (lane & 15);
                 const int voff = (gg * 128 + rl < n ? rl : 0) * (F * 4) + 16 * g;       // rows beyond n read the group's first row
-                const unsigned dst = __builtin_amdgcn_readfirstlane(ring0 + (unsigned)rp * kDmaChunk + (unsigned)q * 2048u);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ring0 + (unsigned)pi * kDmaChunk + (unsigned)q * 2048u);
                 lds_dma_b128(dst, voff, rs, soff);
                 lds_dma_b128(dst + 1024u, voff, rs, soff + 64);
             }
-            if (++rc == KB) { rc = 0; rg += gridDim.x; }
-            rp = rp + 1 == kDmaRing ? 0 : rp + 1;
-        };
-        auto issue_frags = [&]() {
             // the chunk's 13 weight fragments (L2-resident, 1 KiB each) into the stage: tiles 0..6 by loader 0, 7..12 by loader 1
             // (which fetches tile 12 twice: both loaders count 15 loads per chunk)
 #pragma unroll
@@ -1153,34 +1147,10 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
                 const unsigned dst = __builtin_amdgcn_readfirstlane(stage0 + (unsigned)(si * 13 + t) * 1024u);
                 lds_dma_b128(dst, lane * 16, wrs, (ci * 13 + t) * 1024);
             }
-            if (++ci == KB) ci = 0;
+            if (++ci == KB) { ci = 0; gi += gridDim.x; }
+            pi = pi + 1 == kDmaRing ? 0 : pi + 1;
             si = (si + 1) & (kDmaStage - 1);
         };
-        auto issue = [&]() { issue_rows(); issue_frags(); };
-        if (pair) {
-            // ROWS IN PAIRS OF CHUNKS: at every second barrier the rows of chunks c + 3 AND c + 4 are requested back to back (four
-            // consecutive 64-byte pieces of every row: HBM streams 5.9 TB/s that way against 5.3 with two, tools/probe/hbm_locality_probe.hip);
-            // the fragments keep their chunk-by-chunk schedule (four stage slots).  Queue of a loader, oldest first, at barrier c:
-            //   .. | rows c-1, rows c, frags c-1 | frags c | rows c+1, rows c+2, frags c+1 | frags c+2 |        (c even)
-            //   .. | rows c, rows c+1, frags c | frags c+1 | rows c+2, rows c+3, frags c+2 |                    (c odd)
-            // chunk c is complete when all but the youngest 30 requests have landed, in both cases; at most 53 are in flight.
-            issue_rows(); issue_frags();          // chunk 0
-            issue_rows(); issue_frags();          // chunk 1
-            issue_rows(); issue_frags();          // chunk 2
-            // (prologue in single chunks: the first barriers find fewer than 30 younger requests and simply wait for a little more)
-            for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
-                for (int c = 0; c < KB; c += 2) {
-                    asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                        // barrier c (even): ring slots of chunks c - 3, c - 2 are free
-                    issue_rows();                                        // chunk c + 3
-                    issue_rows();                                        // chunk c + 4
-                    issue_frags();                                       // chunk c + 3: stage slot of chunk c - 1
-                    asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                        // barrier c + 1
-                    issue_frags();                                       // chunk c + 4: stage slot of chunk c
-                }
-            }
-        } else {
         for (int k = 0; k < kDmaLead; ++k) issue();
         for (int64_t grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
             for (int c = 0; c < KB; ++c) {
@@ -1188,7 +1158,6 @@ __global__ void __launch_bounds__(384) wide_bf16_encode_dma_kernel(const v4 *pac
                 __builtin_amdgcn_s_barrier();                            // barrier c: the compute waves have finished chunk c - 1
                 issue();                                                 // chunk c + 3: ring slot of chunk c - 3, stage slot of chunk c - 1
             }
-        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // nothing may land in LDS after the workgroup has gone
         return;
@@ -4479,7 +4448,7 @@ template <int F, int Z> struct ImplWideBf16 {
                 if (!src_f64) {      // persistent: one workgroup (4 compute + 2 loader waves, 150 KiB of LDS) per CU
                     hipLaunchKernelGGL((wide_bf16_encode_dma_kernel<F, Z>), dim3((unsigned)(ngroup > st->nwg_max ? st->nwg_max : ngroup)), dim3(384),
                                        dma_lds_bytes(), s, (const v4 *)h->packed.p, (const v4 *)st->wb[3].p, (const v4 *)st->wb[4].p, (const float *)src, rows, zo,
-                                       z_dtype == BAMD_F64, (int)(env_ll("BALER_AMD_BF16_ENC_PAIR", 1) != 0 && (F / 32) % 2 == 0));
+                                       z_dtype == BAMD_F64);
                     continue;
                 }
             }
