@@ -85,7 +85,7 @@ Measurements that are not profiles: `r6_f32_train_mix_replay.txt` (THE HEADLINE 
 bf16 training pair: DESIGN §4.6), `r6_bf16_infer_mix_replay.txt` (the bf16 encode kernel:
 9.1–9.5 µs per round issued, 10.3–12 shipped), `r6_fp64_wave_owned_tiles.txt` (fp64 large batches: weight-gradient tiles owned by waves,
 four variants measured and rejected), `r6_bf16_enc256_ab.txt` (bf16 encode of C4 / C5: 256-row groups with dedicated loaders, rows through registers, both together — four
-designs at the same 0.50 — and the HBM locality probe that names the lever), `r6_hbm_pattern_probe.txt` (HBM read rate against the per-instruction address pattern: 6.1–6.4 TB/s whatever the pattern), `r6_mfma64_4x4_probe.txt` (`v_mfma_f64_4x4x4_4b_f64`: lane maps, rate), `r6_fp64_small_steps.txt`
+designs at the same 0.50 — and the HBM locality probe that names the lever), `r6_hbm_pattern_probe.txt` (HBM read rate against the per-instruction address pattern: 6.1–6.4 TB/s whatever the pattern), `r6_hbm_write_probe.txt` (store-only kernels: 4.2–5.6 TB/s; the C4 bf16 decode writes 3.87), `r6_mfma64_4x4_probe.txt` (`v_mfma_f64_4x4x4_4b_f64`: lane maps, rate), `r6_fp64_small_steps.txt`
 (fp64 optimiser step by batch size, 4-row chain vs exchange chain), `r6_fp64_chain_trace.txt` (per-GEMM shader-clock timeline of `chain64q_kernel`
 and of one `dw64_kernel` workgroup), `r6_bf16_infer_rows_sweep.txt` / `r6_bf16_infer_tile_wave_ab.txt` (bf16 inference: time against rows for
 every dtype pair; rows per wave × waves per workgroup), `r6_fp64_chunk_rows.txt` (fp64 1M-row step against the chunk size), `r6_wide_class_bench.txt`.
