@@ -11,14 +11,23 @@ __global__ void __launch_bounds__(256) wr(char *__restrict__ base, int64_t nrows
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
     const v4 val = {1.f, 2.f, 3.f, (float)lane};
-    if (MODE == 0) {
+    if constexpr (MODE == 0) {
         const int64_t total = nrows * ROWB / 1024;
         for (int64_t i = wave; i < total; i += nwave) *(v4 *)(base + i * 1024 + lane * 16) = val;
-    } else {
+    } else if constexpr (MODE == 1) {
         const int64_t ntile = nrows / 16;
         for (int64_t t = wave; t < ntile; t += nwave) {
             char *tb = base + t * 16 * (int64_t)ROWB + (int64_t)(lane >> 2) * ROWB + (lane & 3) * 16;
             for (int c = 0; c < NCH; ++c) *(v4 *)(tb + (int64_t)c * 64) = val;
+        }
+    } else {      // MODE = bytes per row and instruction (256: the aligned decode path's windows -- 4 rows x 256 B; 512: 2 rows x 512 B), a wave owns 32 rows
+        constexpr int LPR = MODE / 16, RPI = 64 / LPR, NW = ROWB / MODE;
+        const int64_t ngrp = nrows / 32;
+        for (int64_t t = wave; t < ngrp; t += nwave) {
+            char *tb = base + t * 32 * (int64_t)ROWB + (int64_t)(lane / LPR) * ROWB + (lane % LPR) * 16;
+            for (int c = 0; c < NW; ++c)
+#pragma unroll
+                for (int k = 0; k < 32 / RPI; ++k) *(v4 *)(tb + (int64_t)k * RPI * ROWB + (int64_t)c * MODE) = val;
         }
     }
 }
@@ -29,7 +38,7 @@ template <int MODE> void run(char *buf, int64_t nrows, const char *name, int wgs
         for (int k = 0; k < 10; ++k) hipLaunchKernelGGL((wr<MODE>), dim3(wgs), dim3(256), 0, 0, buf, nrows);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        if (rep == 2) printf("%-60s %4d workgroups: %7.1f us per pass = %5.2f TB/s\n", name, wgs, 1e3 * ms / 10, nrows * (double)(MODE ? NCH * 64 : ROWB) / (ms / 10 * 1e-3) / 1e12);
+        if (rep == 2) printf("%-60s %4d workgroups: %7.1f us per pass = %5.2f TB/s\n", name, wgs, 1e3 * ms / 10, nrows * (double)(MODE == 0 ? ROWB : MODE == 1 ? NCH * 64 : (ROWB / MODE) * MODE) / (ms / 10 * 1e-3) / 1e12);
     }
 }
 int main() {
@@ -38,7 +47,9 @@ int main() {
     (void)hipMalloc(&buf, nrows * ROWB + 4096);
     for (int wgs : {512, 1024, 2048}) {
         run<0>(buf, nrows, "contiguous 1-KiB stores", wgs);
-        run<1>(buf, nrows, "16 rows x 64 B per store instruction (the decode kernels)", wgs);
+        run<1>(buf, nrows, "16 rows x 64 B per store instruction", wgs);
+        run<256>(buf, nrows, "4 rows x 256 B (the aligned decode path's windows)", wgs);
+        run<512>(buf, nrows, "2 rows x 512 B", wgs);
     }
     return 0;
 }
