@@ -867,6 +867,9 @@ def other_configs(dev):
         "bf16_train_fwd_bwd_rows_per_s": n / ms_bt * 1e3, "bf16_train_vs_fp32": ms_t / ms_bt,
         "bf16_encode_rows_per_s": n / ms_be * 1e3, "bf16_encode_frac_of_hbm": 10100 * n / ms_be / 1e6 / PEAK_HBM_GBS,
         "bf16_decode_rows_per_s": n / ms_bd * 1e3, "bf16_decode_frac_of_hbm": 10100 * n / ms_bd / 1e6 / PEAK_HBM_GBS,
+        # what a kernel that does nothing but store row-strided reaches on this part: 4.1 TB/s (tools/probe/hbm_write_probe.hip,
+        # profiles/r6_hbm_write_probe.txt; contiguous 1-KiB bursts 4.5 - 5.5); the decode writes 10,000 B per frame
+        "bf16_decode_frac_of_store_only_kernel": 10000 * n / ms_bd / 1e6 / 4100.0,
         "bf16_encode_rel_err_vs_fp32": float(torch.linalg.norm(zb.double() - zc.double()) / torch.linalg.norm(zc.double()))})
     hb.close()
     del xc
